@@ -1,0 +1,727 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/*.npz by RUNNING THE REFERENCE (PySDM at
+/root/reference) in its own pure-Python mode (njit == identity; the mode of the reference's
+`nojit_and_codecov` CI job, .github/workflows/tests.yml:56-74).
+
+Only usable in the build container (the reference does not travel); the produced .npz files are
+data (inputs + expected outputs) and are committed.  Run as:
+
+    PYTHONDONTWRITEBYTECODE=1 CI=1 python3 -B tests/golden/gen_golden.py [what ...]
+
+`what` in {micro, traj, breakup, frag} (default: all).  numba/pint/chempy/pyevtk are absent from this
+image, so import-only stand-ins from tests/golden/standins/ are put on sys.path first
+(they hold no reference code, see their docstrings).
+"""
+# pylint: disable=wrong-import-position,import-error,too-many-locals,protected-access
+import os
+import sys
+import warnings
+
+os.environ.setdefault("CI", "1")
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(HERE, "standins"), "/root/reference"]
+
+import numpy as np
+
+from PySDM import Builder, Formulae
+from PySDM.backends import CPU
+from PySDM.dynamics import Coalescence, Collision
+from PySDM.dynamics.collisions.breakup_efficiencies import ConstEb
+from PySDM.dynamics.collisions.breakup_fragmentations import (
+    AlwaysN,
+    Exponential as ExpFrag,
+    Straub2010Nf,
+)
+from PySDM.dynamics.collisions.coalescence_efficiencies import (
+    Berry1967,
+    ConstEc,
+    Straub2010Ec,
+)
+from PySDM.dynamics.collisions.collision_kernels import Geometric, Golovin
+from PySDM.environments import Box
+from PySDM.impl.mesh import Mesh
+from PySDM.initialisation import spectra
+from PySDM.initialisation.sampling.spectral_sampling import ConstantMultiplicity
+from PySDM.physics import si
+
+OUT = HERE
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays")
+
+
+# ------------------------------------------------------------------------------------------
+# micro goldens: one backend method at a time
+# ------------------------------------------------------------------------------------------
+def _storages(backend):
+    # the same factories Particulator uses (particulator.py:38-45)
+    from PySDM.backends.impl_common.index import make_Index
+    from PySDM.backends.impl_common.indexed_storage import make_IndexedStorage
+    from PySDM.backends.impl_common.pair_indicator import make_PairIndicator
+    from PySDM.backends.impl_common.pairwise_storage import make_PairwiseStorage
+
+    return (
+        make_Index(backend),
+        make_IndexedStorage(backend),
+        make_PairIndicator(backend),
+        make_PairwiseStorage(backend),
+    )
+
+
+def random_cells(rng, n_sd, n_cell):
+    """random cell sizes incl. empty and odd cells"""
+    cell_id = np.sort(rng.integers(0, n_cell, size=n_sd)).astype(np.int64)
+    cell_start = np.searchsorted(cell_id, np.arange(n_cell + 1)).astype(np.int64)
+    return cell_id, cell_start
+
+
+def gen_micro():
+    backend = CPU(Formulae())
+    Index, IndexedStorage, PairIndicator, PairwiseStorage = _storages(backend)
+    Storage = backend.Storage
+    out = {}
+    rng = np.random.default_rng(12345)
+
+    # --- PCG64 streams (impl_numba/random.py:13-19)
+    for seed in (44, 256, 0, 2**31 + 7):
+        size = 40
+        sto = Storage.empty(size, dtype=float)
+        rnd = backend.Random(size, seed)
+        rnd(sto)
+        first = sto.to_ndarray()
+        rnd(sto)
+        out[f"pcg64/{seed}/first"] = first
+        out[f"pcg64/{seed}/second"] = sto.to_ndarray()
+
+    # --- shuffle_local / shuffle_global (index_methods.py:22-43)
+    cases = [(8, 1), (8, 5), (64, 1), (64, 7), (257, 1), (257, 13), (1000, 3), (4096, 1)]
+    out["shuffle/cases"] = np.asarray(cases)
+    for n_sd, n_cell in cases:
+        key = f"shuffle/{n_sd}_{n_cell}"
+        _, cell_start = random_cells(rng, n_sd, n_cell)
+        u01 = rng.uniform(0, 1, n_sd)
+        idx0 = rng.permutation(n_sd).astype(np.int64)
+        idx = Index.from_ndarray(idx0.copy())
+        backend.shuffle_local(
+            idx=idx.data, u01=Storage.from_ndarray(u01).data, cell_start=cell_start
+        )
+        out[key + "/cell_start"] = cell_start
+        out[key + "/u01"] = u01
+        out[key + "/idx0"] = idx0
+        out[key + "/local"] = idx.to_ndarray()
+        for length in (n_sd, n_sd - 3):
+            idx = Index.from_ndarray(idx0.copy())
+            backend.shuffle_global(idx=idx.data, length=length, u01=u01)
+            out[key + f"/global_{length}"] = idx.to_ndarray()
+
+    # --- counting sort (collisions_methods.py:587-631, 682-697)
+    cases = [(8, 2), (64, 7), (257, 13), (1000, 40)]
+    out["sort/cases"] = np.asarray(cases)
+    for n_sd, n_cell in cases:
+        key = f"sort/{n_sd}_{n_cell}"
+        cell_id = rng.integers(0, n_cell, size=n_sd).astype(np.int64)
+        cell_idx = rng.permutation(n_cell).astype(np.int64)
+        idx0 = rng.permutation(n_sd).astype(np.int64)
+        length = n_sd - (n_sd // 10)
+        idx = Index.from_ndarray(idx0.copy())
+        idx.length = length
+        cell_start = Storage.from_ndarray(np.zeros(n_cell + 1, dtype=np.int64))
+        caretaker = backend.make_cell_caretaker(
+            idx.shape, idx.dtype, n_cell + 1, scheme="counting_sort"
+        )
+        caretaker(
+            Storage.from_ndarray(cell_id), Index.from_ndarray(cell_idx), cell_start, idx
+        )
+        out[key + "/cell_id"] = cell_id
+        out[key + "/cell_idx"] = cell_idx
+        out[key + "/idx0"] = idx0
+        out[key + "/length"] = np.asarray(length)
+        out[key + "/new_idx"] = idx.to_ndarray()[:length]
+        out[key + "/cell_start"] = cell_start.to_ndarray()
+
+    # --- sort_by_key (index_methods.py:46-48), adaptive_sdm_end (collisions_methods.py:313-328)
+    for i, keys in enumerate(
+        ([5.0, 0.0, 5.0, 3.0], [0.0, 0.0, 0.0], [1.0, 0.5, 0.0, 0.0, 0.25, 1.0, 0.0])
+    ):
+        keys = np.asarray(keys)
+        cidx = Index.identity_index(len(keys))
+        cidx.sort_by_key(Storage.from_ndarray(keys))
+        out[f"sort_by_key/{i}/keys"] = keys
+        out[f"sort_by_key/{i}/out"] = cidx.to_ndarray()
+    for i, (dt_left, cs) in enumerate(
+        (
+            ([1.0, 0.0, 0.0], [0, 3, 5, 9]),
+            ([0.0, 0.0, 0.0], [0, 3, 5, 9]),
+            ([0.5, 0.0, 0.25, 0.0], [0, 2, 2, 7, 8]),
+        )
+    ):
+        end = backend.adaptive_sdm_end(
+            Storage.from_ndarray(np.asarray(dt_left)),
+            Storage.from_ndarray(np.asarray(cs, dtype=np.int64)),
+        )
+        out[f"adaptive_sdm_end/{i}/dt_left"] = np.asarray(dt_left)
+        out[f"adaptive_sdm_end/{i}/cell_start"] = np.asarray(cs, dtype=np.int64)
+        out[f"adaptive_sdm_end/{i}/end"] = np.asarray(end)
+
+    # --- remove_zero_n_or_flagged (collisions_methods.py:664-680)
+    for i, (n_sd, length, p_zero) in enumerate(
+        ((8, 8, 0.3), (64, 60, 0.2), (257, 257, 0.5), (257, 200, 0.9), (33, 33, 1.0))
+    ):
+        mult = rng.integers(1, 5, size=n_sd).astype(np.int64)
+        mult[rng.uniform(0, 1, n_sd) < p_zero] = 0
+        idx0 = rng.permutation(n_sd).astype(np.int64)
+        idx = Index.from_ndarray(idx0.copy())
+        idx.length = length
+        # pre-existing flagged slots beyond `length` (value == len(idx))
+        idx.data[length:] = n_sd
+        idx0 = idx.to_ndarray()
+        mult_s = IndexedStorage.from_ndarray(idx, mult)
+        idx.remove_zero_n_or_flagged(mult_s)
+        out[f"remove/{i}/mult"] = mult
+        out[f"remove/{i}/idx0"] = idx0
+        out[f"remove/{i}/length0"] = np.asarray(length)
+        out[f"remove/{i}/idx"] = idx.to_ndarray()
+        out[f"remove/{i}/length"] = np.asarray(len(idx))
+    out["remove/n"] = np.asarray(5)
+
+    # --- pair chain on sorted multi-cell state: find_pairs, sort_within_pair, pair ops, normalize,
+    #     scale_prob_for_adaptive_sdm_gamma, compute_gamma, collision_coalescence
+    cases = [(8, 1), (9, 2), (64, 5), (257, 13), (1000, 3)]
+    out["pairs/cases"] = np.asarray(cases)
+    for n_sd, n_cell in cases:
+        key = f"pairs/{n_sd}_{n_cell}"
+        # raw (unsorted) SD columns
+        cell_id = rng.integers(0, n_cell, size=n_sd).astype(np.int64)
+        mult = rng.integers(1, 40, size=n_sd).astype(np.int64)
+        mass = rng.uniform(1e-12, 1e-9, size=n_sd)
+        length = n_sd if n_sd % 2 else n_sd - 1  # exercise length < n_sd
+        idx0 = rng.permutation(n_sd).astype(np.int64)
+        idx = Index.from_ndarray(idx0.copy())
+        idx.length = length
+        cell_idx = Index.identity_index(n_cell)
+        cell_start = Storage.from_ndarray(np.zeros(n_cell + 1, dtype=np.int64))
+        cell_id_s = IndexedStorage.from_ndarray(idx, cell_id)
+        caretaker = backend.make_cell_caretaker(
+            idx.shape, idx.dtype, n_cell + 1, scheme="counting_sort"
+        )
+        caretaker(cell_id_s, cell_idx, cell_start, idx)
+        out[key + "/cell_id"] = cell_id
+        out[key + "/mult"] = mult
+        out[key + "/mass"] = mass
+        out[key + "/length"] = np.asarray(length)
+        out[key + "/idx_sorted"] = idx.to_ndarray()
+        out[key + "/cell_start"] = cell_start.to_ndarray()
+
+        flag = PairIndicator(n_sd)
+        flag.indicator[:] = False
+        flag.update(cell_start, cell_idx, cell_id_s)
+        out[key + "/flag"] = flag.indicator.to_ndarray()
+
+        mult_s = IndexedStorage.from_ndarray(idx, mult)
+        backend.sort_within_pair_by_attr(idx, flag, mult_s)
+        out[key + "/idx_pairsorted"] = idx.to_ndarray()
+
+        mass_s = IndexedStorage.from_ndarray(idx, mass)
+        for op in ("sum", "max", "min", "distance", "multiply"):
+            pw = PairwiseStorage.empty(n_sd // 2, dtype=float)
+            getattr(pw, op)(mass_s, flag)
+            out[key + f"/{op}_pair"] = pw.to_ndarray()
+        pw = PairwiseStorage.empty(n_sd // 2, dtype=float)
+        pw.max(mult_s, flag)
+        out[key + "/max_mult"] = pw.to_ndarray()
+
+        # prob = max(n) * K (Golovin-like), normalize
+        prob = PairwiseStorage.empty(n_sd // 2, dtype=float)
+        prob.max(mult_s, flag)
+        ksum = PairwiseStorage.empty(n_sd // 2, dtype=float)
+        ksum.sum(mass_s, flag)
+        ksum *= 3.0e8
+        prob *= ksum
+        norm_factor = Storage.empty(n_cell, dtype=float)
+        dt, dv = 10.0, 7.0
+        backend.normalize(
+            prob=prob,
+            cell_id=cell_id_s,
+            cell_idx=cell_idx,
+            cell_start=cell_start,
+            norm_factor=norm_factor,
+            timestep=dt,
+            dv=dv,
+        )
+        out[key + "/dt_dv"] = np.asarray([dt, dv])
+        out[key + "/norm_factor"] = norm_factor.to_ndarray()
+        out[key + "/prob_normalized"] = prob.to_ndarray()
+
+        # adaptive scaling
+        dt_left = Storage.from_ndarray(np.full(n_cell, dt))
+        n_substep = Storage.from_ndarray(np.zeros(n_cell, dtype=np.int64))
+        dt_min_stat = Storage.from_ndarray(np.full(n_cell, np.nan))
+        dt_min_stat[:] = dt
+        dt_range = (0.1, dt)
+        prob_ad = PairwiseStorage.from_ndarray(prob.to_ndarray())
+        backend.scale_prob_for_adaptive_sdm_gamma(
+            prob=prob_ad,
+            multiplicity=mult_s,
+            cell_id=cell_id_s,
+            dt_left=dt_left,
+            dt=dt,
+            dt_range=dt_range,
+            is_first_in_pair=flag,
+            stats_n_substep=n_substep,
+            stats_dt_min=dt_min_stat,
+        )
+        out[key + "/dt_range"] = np.asarray(dt_range)
+        out[key + "/prob_adaptive"] = prob_ad.to_ndarray()
+        out[key + "/dt_left"] = dt_left.to_ndarray()
+        out[key + "/n_substep"] = n_substep.to_ndarray()
+        out[key + "/stats_dt_min"] = dt_min_stat.to_ndarray()
+
+        # gamma (on the non-adaptive prob; amplified to get gamma > 1 and deficits)
+        rand = rng.uniform(0, 1, n_sd // 2)
+        prob_g = PairwiseStorage.from_ndarray(prob.to_ndarray() * 3.0)
+        out[key + "/prob_for_gamma"] = prob_g.to_ndarray()
+        cr = Storage.from_ndarray(np.zeros(n_cell, dtype=np.int64))
+        crd = Storage.from_ndarray(np.zeros(n_cell, dtype=np.int64))
+        backend.compute_gamma(
+            prob=prob_g,
+            rand=Storage.from_ndarray(rand),
+            multiplicity=mult_s,
+            cell_id=cell_id_s,
+            collision_rate_deficit=crd,
+            collision_rate=cr,
+            is_first_in_pair=flag,
+            out=prob_g,
+        )
+        out[key + "/rand"] = rand
+        out[key + "/gamma"] = prob_g.to_ndarray()
+        out[key + "/collision_rate"] = cr.to_ndarray()
+        out[key + "/collision_rate_deficit"] = crd.to_ndarray()
+
+        # coalescence update
+        attrs = IndexedStorage.from_ndarray(idx, mass.reshape(1, -1).copy())
+        healthy = Storage.from_ndarray(np.full((1,), 1))
+        coal = Storage.from_ndarray(np.zeros(n_cell, dtype=np.int64))
+        backend.collision_coalescence(
+            multiplicity=mult_s,
+            idx=idx,
+            attributes=attrs,
+            gamma=prob_g,
+            healthy=healthy,
+            cell_id=cell_id_s,
+            coalescence_rate=coal,
+            is_first_in_pair=flag,
+        )
+        out[key + "/mult_after"] = mult_s.to_ndarray(raw=True)
+        out[key + "/mass_after"] = attrs.to_ndarray(raw=True)[0]
+        out[key + "/healthy"] = healthy.to_ndarray()
+        out[key + "/coalescence_rate"] = coal.to_ndarray()
+
+    save("micro", **out)
+
+
+# ------------------------------------------------------------------------------------------
+# physics micro goldens: derived attributes, Gunn-Kinzer table, efficiencies, fragmentations
+# ------------------------------------------------------------------------------------------
+def gen_frag():
+    out = {}
+    rng = np.random.default_rng(777)
+    formulae = Formulae(
+        terminal_velocity="GunnKinzer1949", fragmentation_function="Straub2010Nf"
+    )
+    backend = CPU(formulae)
+    Index, IndexedStorage, PairIndicator, PairwiseStorage = _storages(backend)
+    Storage = backend.Storage
+    const = formulae.constants
+    out["const/rho_w"] = np.asarray(const.rho_w)
+    out["const/sgm_w"] = np.asarray(const.sgm_w)
+    out["const/PI_4_3"] = np.asarray(const.PI_4_3)
+    out["const/STRAUB_E_D1"] = np.asarray(const.STRAUB_E_D1)
+    out["const/STRAUB_MU2"] = np.asarray(const.STRAUB_MU2)
+    out["const/VEDDER_1987_A"] = np.asarray(const.VEDDER_1987_A)
+    out["const/VEDDER_1987_b"] = np.asarray(const.VEDDER_1987_b)
+    out["const/CM"] = np.asarray(const.CM)
+
+    class _P:  # minimal particulator-like holder for GunnKinzer1949
+        pass
+
+    from PySDM.dynamics.terminal_velocity import GunnKinzer1949
+
+    holder = _P()
+    holder.backend = backend
+    gk = GunnKinzer1949(holder)
+    out["gk/a"] = gk.a.to_ndarray()
+    out["gk/b"] = gk.b.to_ndarray()
+    out["gk/factor"] = np.asarray(gk.factor)
+    out["gk/maximum_radius"] = np.asarray(gk.maximum_radius)
+
+    n_sd = 512
+    radius = np.exp(rng.uniform(np.log(1e-6), np.log(3e-3), n_sd))
+    volume = const.PI_4_3 * radius**3
+    mass = const.rho_w * volume
+    idx = Index.identity_index(n_sd)
+    mass_s = IndexedStorage.from_ndarray(idx, mass)
+    vol_s = IndexedStorage.empty(idx, (n_sd,), float)
+    backend.volume_of_water_mass(vol_s, mass_s)
+    rad_s = IndexedStorage.empty(idx, (n_sd,), float)
+    rad_s.product(vol_s, 1 / const.PI_4_3)
+    rad_s **= 1 / 3
+    vel_s = IndexedStorage.empty(idx, (n_sd,), float)
+    gk(vel_s, rad_s)
+    out["derived/mass"] = mass
+    out["derived/volume"] = vol_s.to_ndarray(raw=True)
+    out["derived/radius"] = rad_s.to_ndarray(raw=True)
+    out["derived/velocity"] = vel_s.to_ndarray(raw=True)
+
+    # pairs (0,1), (2,3), ... all flagged
+    flag = PairIndicator(n_sd)
+    flag.indicator[:] = np.tile([True, False], n_sd // 2)
+    out["derived/flag"] = flag.indicator.to_ndarray()
+
+    class _Attr(dict):
+        pass
+
+    class _Part:
+        pass
+
+    part = _Part()
+    part.backend = backend
+    part.formulae = formulae
+    part.n_sd = n_sd
+    part.PairwiseStorage = PairwiseStorage
+    part.attributes = {
+        "volume": vol_s,
+        "radius": rad_s,
+        "relative fall velocity": vel_s,
+        "water mass": mass_s,
+    }
+
+    class _Builder:
+        particulator = part
+
+        @staticmethod
+        def request_attribute(_):
+            pass
+
+    # kernels
+    pw = PairwiseStorage.empty(n_sd // 2, dtype=float)
+    kern = Golovin(b=1.5e3)
+    kern.register(_Builder)
+    kern(pw, flag)
+    out["kernel/golovin"] = pw.to_ndarray()
+    kern = Geometric(collection_efficiency=1.0)
+    kern.register(_Builder)
+    kern(pw, flag)
+    out["kernel/geometric"] = pw.to_ndarray()
+
+    # efficiencies
+    for name, eff in (("berry1967", Berry1967()), ("straub2010", Straub2010Ec())):
+        eff.register(_Builder)
+        eff(pw, flag)
+        out[f"ec/{name}"] = pw.to_ndarray()
+
+    # fragmentations
+    u01 = rng.uniform(0, 1, n_sd // 2)
+    u01[:4] = [0.0, 1e-12, 1 - 1e-12, 0.999999]
+    u01_s = Storage.from_ndarray(u01)
+    out["frag/u01"] = u01
+    nf = PairwiseStorage.empty(n_sd // 2, dtype=float)
+    fm = PairwiseStorage.empty(n_sd // 2, dtype=float)
+    frag_cases = {
+        "always_n_4": AlwaysN(n=4),
+        "exp_100um": ExpFrag(scale=formulae.trivia.volume(radius=100 * si.um)),
+        "exp_100um_lim": ExpFrag(
+            scale=formulae.trivia.volume(radius=100 * si.um),
+            vmin=formulae.trivia.volume(radius=5 * si.um),
+            nfmax=10,
+        ),
+        "straub": Straub2010Nf(),
+        "straub_lim": Straub2010Nf(
+            vmin=formulae.trivia.volume(radius=30.531 * si.um) * 1e-3, nfmax=10
+        ),
+        "straub_ss": Straub2010Nf(vmin=(0.01 * si.mm) ** 3 * np.pi / 6, nfmax=10000),
+    }
+    for name, frag in frag_cases.items():
+        frag.register(_Builder)
+        frag(nf, fm, u01_s, flag)
+        out[f"frag/{name}/nf"] = nf.to_ndarray()
+        out[f"frag/{name}/mass"] = fm.to_ndarray()
+        out[f"frag/{name}/vmin"] = np.asarray(getattr(frag, "vmin", 0.0))
+        nfmax = getattr(frag, "nfmax", None)
+        out[f"frag/{name}/nfmax"] = np.asarray(-1.0 if nfmax is None else nfmax)
+    out["frag/exp_scale"] = np.asarray(formulae.trivia.volume(radius=100 * si.um))
+
+    save("physics", **out)
+
+
+# ------------------------------------------------------------------------------------------
+# trajectory goldens
+# ------------------------------------------------------------------------------------------
+def _snapshot(particulator, dyn, breakup):
+    attrs = particulator.attributes
+    idx = attrs._ParticleAttributes__idx
+    snap = {
+        "idx": idx.to_ndarray(),
+        "length": np.asarray(len(idx)),
+        "multiplicity": attrs["multiplicity"].to_ndarray(raw=True),
+        "attributes": attrs.get_extensive_attribute_storage().to_ndarray(raw=True),
+        "cell_start": attrs.cell_start.to_ndarray(),
+        "collision_rate": dyn.collision_rate.to_ndarray(),
+        "collision_rate_deficit": dyn.collision_rate_deficit.to_ndarray(),
+        "coalescence_rate": dyn.coalescence_rate.to_ndarray(),
+        "stats_n_substep": dyn.stats_n_substep.to_ndarray(),
+        "stats_dt_min": dyn.stats_dt_min.to_ndarray(),
+    }
+    if breakup:
+        snap["breakup_rate"] = dyn.breakup_rate.to_ndarray()
+        snap["breakup_rate_deficit"] = dyn.breakup_rate_deficit.to_ndarray()
+    return snap
+
+
+def run_traj(
+    *,
+    n_sd,
+    seed,
+    dt,
+    dv,
+    volume,
+    multiplicity,
+    make_dynamic,
+    record_steps,
+    formulae_kwargs=None,
+    grid=None,
+    cell_id=None,
+    breakup=False,
+):
+    formulae = Formulae(seed=seed, **(formulae_kwargs or {}))
+    env = Box(dv=dv, dt=dt)
+    if grid is not None:
+        env.mesh = Mesh(grid, size=tuple(float(g) for g in grid))
+        env.mesh.dv = dv
+    builder = Builder(n_sd=n_sd, backend=CPU(formulae), environment=env)
+    dyn = make_dynamic()
+    builder.add_dynamic(dyn)
+    attributes = {"volume": volume.copy(), "multiplicity": multiplicity.copy()}
+    if cell_id is not None:
+        attributes["cell id"] = cell_id.copy()
+    particulator = builder.build(attributes)
+    dyn = particulator.dynamics["Collision"]
+    out = {}
+    for step in record_steps:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            particulator.run(step - particulator.n_steps)
+        for k, v in _snapshot(particulator, dyn, breakup).items():
+            out[f"step{step}/{k}"] = v
+    return out
+
+
+def shima_init(n_sd, n_part=2**23, dv=1e6, radius=30.531e-6):
+    x0 = Formulae().trivia.volume(radius=radius)
+    spectrum = spectra.Exponential(norm_factor=n_part * dv, scale=x0)
+    volume, mult = ConstantMultiplicity(spectrum).sample(n_sd)
+    return volume, mult
+
+
+def gen_traj():
+    # ---- config 1/2 family: Shima 2009 Golovin box (Shima_et_al_2009/settings.py:14-33)
+    for n_sd in (2**8, 2**10, 2**12):
+        for seed in (44, 256):
+            for adaptive in (False, True):
+                volume, mult = shima_init(n_sd)
+                out = run_traj(
+                    n_sd=n_sd, seed=seed, dt=1.0, dv=1e6, volume=volume, multiplicity=mult,
+                    make_dynamic=lambda a=adaptive: Coalescence(
+                        collision_kernel=Golovin(b=1.5e3), adaptive=a
+                    ),
+                    record_steps=(1, 5, 50),
+                )
+                out["init/volume"] = volume
+                out["init/multiplicity"] = mult
+                out["cfg"] = np.asarray([n_sd, seed, int(adaptive), 1.0, 1e6, 1.5e3])
+                save(f"traj_golovin_n{n_sd}_s{seed}_a{int(adaptive)}", **out)
+
+    # ---- stress: tiny multiplicities (deaths -> compaction) and large dt (gamma>1, substeps)
+    for name, n_sd, dt, npart, adaptive, croupier in (
+        ("deaths", 2**10, 200.0, 2**3 / 1e6 * 2**10, False, None),
+        ("deaths_adaptive", 2**10, 200.0, 2**3 / 1e6 * 2**10, True, None),
+        ("substeps", 2**10, 600.0, 2**23, True, None),
+        ("multigamma", 2**10, 600.0, 2**23, False, None),
+        ("global", 2**10, 1.0, 2**23, True, "global"),
+        ("global_odd", 1001, 100.0, 2**23, False, "global"),
+        ("odd", 1001, 100.0, 2**23, True, None),
+        ("optrand", 2**10, 100.0, 2**23, True, "optrand"),
+    ):
+        volume, mult = shima_init(n_sd, n_part=npart)
+        dv = 1e6
+        if name.startswith("deaths"):
+            mult = (1 + (np.arange(n_sd) % 3)).astype(float)
+            dv = 6e-4
+        kwargs = {}
+        if croupier == "global":
+            kwargs["croupier"] = "global"
+        if croupier == "optrand":
+            kwargs["optimized_random"] = True
+        out = run_traj(
+            n_sd=n_sd, seed=44, dt=dt, dv=dv, volume=volume, multiplicity=mult,
+            make_dynamic=lambda a=adaptive, k=kwargs: Coalescence(
+                collision_kernel=Golovin(b=1.5e3), adaptive=a, **k
+            ),
+            record_steps=(1, 3, 10),
+        )
+        out["init/volume"] = volume
+        out["init/multiplicity"] = mult
+        out["cfg"] = np.asarray([n_sd, 44, int(adaptive), dt, dv, 1.5e3])
+        save(f"traj_golovin_{name}", **out)
+
+    # ---- Geometric kernel + Gunn-Kinzer (Berry_1967/settings.py:14-47), dv scaled with n_sd
+    for n_sd, adaptive in ((2**10, False), (2**10, True), (2**12, True)):
+        dv = 10.0 * n_sd / 2**13
+        x0 = Formulae().trivia.volume(radius=10e-6)
+        spectrum = spectra.Exponential(norm_factor=239e6 * dv, scale=x0)
+        volume, mult = ConstantMultiplicity(spectrum).sample(n_sd)
+        out = run_traj(
+            n_sd=n_sd, seed=44, dt=1.0, dv=dv, volume=volume, multiplicity=mult,
+            make_dynamic=lambda a=adaptive: Coalescence(
+                collision_kernel=Geometric(collection_efficiency=1), adaptive=a
+            ),
+            record_steps=(1, 10, 100),
+            formulae_kwargs={"terminal_velocity": "GunnKinzer1949"},
+        )
+        out["init/volume"] = volume
+        out["init/multiplicity"] = mult
+        out["cfg"] = np.asarray([n_sd, 44, int(adaptive), 1.0, dv, 1.0])
+        save(f"traj_geometric_n{n_sd}_a{int(adaptive)}", **out)
+
+    # ---- multi-cell (config 4 family): grid, random cell ids, Golovin and Geometric
+    rng = np.random.default_rng(2024)
+    for name, grid, n_sd, kern, adaptive, dt, optrand in (
+        ("golovin_4x4", (4, 4), 2**10, "golovin", True, 100.0, False),
+        ("golovin_4x4_na", (4, 4), 2**10, "golovin", False, 100.0, False),
+        ("golovin_8x8_sparse", (8, 8), 100, "golovin", True, 100.0, False),
+        ("geometric_4x4", (4, 4), 2**11, "geometric", True, 5.0, True),
+        ("geometric_3x5", (3, 5), 1500, "geometric", True, 30.0, False),
+    ):
+        n_cell = int(np.prod(grid))
+        cell_id = rng.integers(0, n_cell, size=n_sd).astype(np.int64)
+        if kern == "golovin":
+            volume, mult = shima_init(n_sd, n_part=2**23 / n_cell * 4)
+            dv = 1e6
+            make = lambda a=adaptive, o=optrand: Coalescence(
+                collision_kernel=Golovin(b=1.5e3), adaptive=a, optimized_random=o
+            )
+            fk = None
+        else:
+            dv = 10.0 * n_sd / 2**13 / n_cell * 16
+            x0 = Formulae().trivia.volume(radius=15e-6)
+            spectrum = spectra.Exponential(norm_factor=239e6 * dv * n_cell, scale=x0)
+            volume, mult = ConstantMultiplicity(spectrum).sample(n_sd)
+            make = lambda a=adaptive, o=optrand: Coalescence(
+                collision_kernel=Geometric(collection_efficiency=1),
+                adaptive=a,
+                optimized_random=o,
+            )
+            fk = {"terminal_velocity": "GunnKinzer1949"}
+        perm = rng.permutation(n_sd)
+        volume, mult = volume[perm], mult[perm]
+        out = run_traj(
+            n_sd=n_sd, seed=44, dt=dt, dv=dv, volume=volume, multiplicity=mult,
+            make_dynamic=make, record_steps=(1, 3, 10), formulae_kwargs=fk,
+            grid=grid, cell_id=cell_id,
+        )
+        out["init/volume"] = volume
+        out["init/multiplicity"] = mult
+        out["init/cell_id"] = cell_id
+        out["cfg"] = np.asarray([n_sd, 44, int(adaptive), dt, dv, n_cell, int(optrand)])
+        out["grid"] = np.asarray(grid)
+        save(f"traj_multicell_{name}", **out)
+
+
+def gen_breakup():
+    # ---- config 3 family: Geometric + Berry1967 Ec + ConstEb(1) + Exponential fragmentation
+    #      (deJong_Mackay_et_al_2023/settings_0D.py:21-52)
+    triv = Formulae().trivia
+    x0 = triv.volume(radius=30.531e-6)
+    for name, n_sd, seed, fragf, ecf, fname, hab, steps, dt in (
+        ("berry_exp", 2**10, 44, lambda: ExpFrag(scale=triv.volume(radius=100e-6)),
+         Berry1967, "Exponential", False, (1, 10, 60), 1.0),
+        ("berry_exp_dt10", 2**10, 256, lambda: ExpFrag(scale=triv.volume(radius=100e-6)),
+         Berry1967, "Exponential", False, (1, 5, 20), 10.0),
+        ("berry_exp_while", 2**9, 44, lambda: ExpFrag(scale=triv.volume(radius=100e-6)),
+         Berry1967, "Exponential", True, (1, 5, 20), 10.0),
+        ("const_alwaysn", 2**9, 44, lambda: AlwaysN(n=4),
+         lambda: ConstEc(Ec=0.3), "AlwaysN", False, (1, 5, 20), 10.0),
+        ("straub", 2**10, 44, lambda: Straub2010Nf(vmin=x0 * 1e-3, nfmax=10),
+         Straub2010Ec, "Straub2010Nf", False, (1, 10, 60), 5.0),
+    ):
+        volume, mult = shima_init(n_sd, n_part=100e6, dv=1.0)
+        out = run_traj(
+            n_sd=n_sd, seed=seed, dt=dt, dv=1.0, volume=volume, multiplicity=mult,
+            make_dynamic=lambda f=fragf, e=ecf: Collision(
+                collision_kernel=Geometric(),
+                coalescence_efficiency=e(),
+                breakup_efficiency=ConstEb(1.0),
+                fragmentation_function=f(),
+                adaptive=True,
+                warn_overflows=False,
+            ),
+            record_steps=steps,
+            formulae_kwargs={
+                "fragmentation_function": fname,
+                "handle_all_breakups": hab,
+                "terminal_velocity": "GunnKinzer1949",
+            },
+            breakup=True,
+        )
+        out["init/volume"] = volume
+        out["init/multiplicity"] = mult
+        out["cfg"] = np.asarray([n_sd, seed, 1, dt, 1.0, int(hab)])
+        save(f"traj_breakup_{name}", **out)
+
+    # ---- rain-spectrum stress (deJong_Mackay_et_al_2023/simulation_ss.py:13-52 flavour):
+    #      large drops so that Straub Ec < 1 and breakups actually happen
+    n_sd = 2**9
+    rng = np.random.default_rng(99)
+    radii = np.exp(rng.uniform(np.log(0.1e-3), np.log(2.5e-3), n_sd))
+    volume = triv.volume(radius=radii)
+    mult = np.full(n_sd, 1000.0)
+    for hab in (False, True):
+        out = run_traj(
+            n_sd=n_sd, seed=44, dt=10.0, dv=1e3, volume=volume, multiplicity=mult,
+            make_dynamic=lambda: Collision(
+                collision_kernel=Geometric(),
+                coalescence_efficiency=Straub2010Ec(),
+                breakup_efficiency=ConstEb(1.0),
+                fragmentation_function=Straub2010Nf(
+                    vmin=(0.01e-3) ** 3 * np.pi / 6, nfmax=10000
+                ),
+                adaptive=True,
+                warn_overflows=False,
+            ),
+            record_steps=(1, 5, 20),
+            formulae_kwargs={
+                "fragmentation_function": "Straub2010Nf",
+                "handle_all_breakups": hab,
+                "terminal_velocity": "GunnKinzer1949",
+            },
+            breakup=True,
+        )
+        out["init/volume"] = volume
+        out["init/multiplicity"] = mult
+        out["cfg"] = np.asarray([n_sd, 44, 1, 10.0, 1e3, int(hab)])
+        save(f"traj_breakup_straub_rain_hab{int(hab)}", **out)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["micro", "frag", "traj", "breakup"]
+    if "micro" in what:
+        gen_micro()
+    if "frag" in what:
+        gen_frag()
+    if "traj" in what:
+        gen_traj()
+    if "breakup" in what:
+        gen_breakup()
