@@ -1,0 +1,252 @@
+/*
+ * sdm_hip.h -- C ABI of libsdm_hip.so: the MI355X (gfx950) implementation of the SDM
+ * collision / coalescence / breakup hot path behind PySDM's backend-method interface.
+ *
+ * Every entry point is what a binding of the reference's backend for this path calls: one symbol
+ * per reference backend method (cited as reference file:line, relative to the reference root),
+ * plus the fused per-time-step entry `sdm_collision_step`.  Plain pointers and sizes only; all
+ * array pointers are DEVICE pointers owned by the caller (Storage.INT = int64, Storage.FLOAT =
+ * double, Storage.BOOL = uint8, PySDM/backends/impl_numba/storage.py:16-19).  The library keeps
+ * no persistent memory except the opaque sdm_ctx (scratch arena + stream).
+ *
+ * Return value: 0 = ok, negative = SDM_E_* (message via sdm_last_error()).  Functions whose
+ * reference counterpart returns a scalar write it through an out-pointer and synchronise the
+ * ctx stream; all other functions only enqueue work on the ctx stream.
+ */
+#ifndef SDM_HIP_H
+#define SDM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDM_OK 0
+#define SDM_E_ARG (-1)    /* bad argument (null pointer, negative size, unsupported option) */
+#define SDM_E_HIP (-2)    /* a HIP runtime call failed */
+#define SDM_E_NOMEM (-3)  /* scratch arena allocation failed */
+
+typedef struct sdm_ctx sdm_ctx;
+
+/* ---- context ------------------------------------------------------------------------- */
+int sdm_ctx_create(sdm_ctx **out, int device);
+int sdm_ctx_destroy(sdm_ctx *ctx);
+/* hipStream_t of the caller (e.g. torch's current stream); NULL = default stream */
+int sdm_ctx_set_stream(sdm_ctx *ctx, void *hip_stream);
+int sdm_ctx_synchronize(sdm_ctx *ctx);
+const char *sdm_last_error(void);
+int sdm_abi_version(void);
+
+/* ---- a-1 RNG: NumPy PCG64 stream, PySDM/backends/impl_numba/random.py:13-19 ------------
+ * out[i] = double number (offset + i) of the stream of PCG64 with the given state/inc
+ * (state_inc = {state_hi, state_lo, inc_hi, inc_lo} of numpy.random.PCG64(seed).state).      */
+int sdm_pcg64_uniform(sdm_ctx *ctx, double *out, int64_t n, const uint64_t state_inc[4],
+                      uint64_t offset);
+
+/* ---- a-2/a-3/a-19 index methods, PySDM/backends/impl_numba/methods/index_methods.py ----- */
+int sdm_identity_index(sdm_ctx *ctx, int64_t *idx, int64_t n);                   /* :14-20 */
+int sdm_shuffle_global(sdm_ctx *ctx, int64_t *idx, int64_t length, const double *u01); /* :22-29 */
+int sdm_shuffle_local(sdm_ctx *ctx, int64_t *idx, const double *u01, const int64_t *cell_start,
+                      int64_t n_cell);                                           /* :32-43 */
+int sdm_sort_by_key(sdm_ctx *ctx, int64_t *idx, const double *keys, int64_t n);  /* :46-48 */
+
+/* ---- a-18 / a-4, PySDM/backends/impl_numba/methods/collisions_methods.py --------------- */
+/* :664-680 ; idx_len = len(idx) = the "removed" sentinel; *new_length out (host), syncs */
+int sdm_remove_zero_n_or_flagged(sdm_ctx *ctx, const int64_t *multiplicity, int64_t *idx,
+                                 int64_t length, int64_t idx_len, int64_t *new_length);
+/* :587-631,682-697 ; writes new_idx[0:length) and cell_start[0:n_cell+1] (caller swaps buffers) */
+int sdm_counting_sort_by_cell_id(sdm_ctx *ctx, int64_t *new_idx, const int64_t *idx,
+                                 const int64_t *cell_id, const int64_t *cell_idx, int64_t length,
+                                 int64_t *cell_start, int64_t n_cell);
+/* :407-416 ; cell_origin is (n_dim, n_sd) row-major */
+int sdm_cell_id(sdm_ctx *ctx, int64_t *cell_id, const int64_t *cell_origin,
+                const int64_t *strides, int64_t n_dim, int64_t n_sd);
+
+/* ---- a-5..a-7 pair methods, PySDM/backends/impl_numba/methods/pair_methods.py ---------- */
+int sdm_find_pairs(sdm_ctx *ctx, const int64_t *cell_start, uint8_t *is_first_in_pair,
+                   const int64_t *cell_id, const int64_t *cell_idx, const int64_t *idx,
+                   int64_t length);                                              /* :34-55 */
+/* :126-140 ; attr_is_int: 1 = int64 column (multiplicity), 0 = double column */
+int sdm_sort_within_pair_by_attr(sdm_ctx *ctx, int64_t *idx, int64_t length,
+                                 const uint8_t *is_first_in_pair, const void *attr,
+                                 int attr_is_int);
+/* op: 0 sum :142-160, 1 max :57-75, 2 min :77-95, 3 distance :14-32, 4 multiply :162-180.
+ * Zero-fills out[0:n_out) first (semantic: prob == 0 means "no pair").                      */
+#define SDM_PAIR_SUM 0
+#define SDM_PAIR_MAX 1
+#define SDM_PAIR_MIN 2
+#define SDM_PAIR_DISTANCE 3
+#define SDM_PAIR_MULTIPLY 4
+int sdm_pair_op(sdm_ctx *ctx, int op, double *out, int64_t n_out, const void *in, int in_is_int,
+                const uint8_t *is_first_in_pair, const int64_t *idx, int64_t length);
+int sdm_sort_pair(sdm_ctx *ctx, double *out, int64_t n_out, const double *in,
+                  const uint8_t *is_first_in_pair, const int64_t *idx, int64_t length); /* :97-124 */
+
+/* ---- a-10..a-14 collisions methods, collisions_methods.py ------------------------------ */
+int sdm_normalize(sdm_ctx *ctx, double *prob, int64_t n_prob, const int64_t *cell_id,
+                  const int64_t *cell_idx, const int64_t *cell_start, double *norm_factor,
+                  int64_t n_cell, double timestep, double dv);                   /* :633-662 */
+int sdm_scale_prob_for_adaptive_sdm_gamma(sdm_ctx *ctx, double *prob, const int64_t *idx,
+                                          int64_t length, const int64_t *multiplicity,
+                                          const int64_t *cell_id, double *dt_left, int64_t n_cell,
+                                          double dt, double dt_min, double dt_max,
+                                          const uint8_t *is_first_in_pair,
+                                          int64_t *stats_n_substep,
+                                          double *stats_dt_min);                 /* :330-405 */
+int sdm_compute_gamma(sdm_ctx *ctx, const double *prob, const double *rand, const int64_t *idx,
+                      int64_t length, const int64_t *multiplicity, const int64_t *cell_id,
+                      int64_t *collision_rate_deficit, int64_t *collision_rate,
+                      const uint8_t *is_first_in_pair, double *out);             /* :522-585 */
+/* :313-328 ; *end out (host), syncs */
+int sdm_adaptive_sdm_end(sdm_ctx *ctx, const double *dt_left, int64_t n_cell,
+                         const int64_t *cell_start, int64_t *end);
+/* :418-453 (+ coalesce :44-59, flag_zero_multiplicity :38-41); attributes (n_attr, n_sd) */
+int sdm_collision_coalescence(sdm_ctx *ctx, int64_t *multiplicity, const int64_t *idx,
+                              int64_t length, double *attributes, int64_t n_attr, int64_t n_sd,
+                              const double *gamma, int64_t *healthy, const int64_t *cell_id,
+                              int64_t *coalescence_rate, const uint8_t *is_first_in_pair);
+/* :247-311 (+ :62-243); *n_overflow (device int64, may be NULL) counts "overflow" warnings */
+int sdm_collision_coalescence_breakup(
+    sdm_ctx *ctx, int64_t *multiplicity, const int64_t *idx, int64_t length, double *attributes,
+    int64_t n_attr, int64_t n_sd, const double *gamma, const double *rand, const double *Ec,
+    const double *Eb, const double *fragment_mass, int64_t *healthy, const int64_t *cell_id,
+    int64_t *coalescence_rate, int64_t *breakup_rate, int64_t *breakup_rate_deficit,
+    const uint8_t *is_first_in_pair, int64_t max_multiplicity, const double *particle_mass,
+    int handle_all_breakups, int64_t *n_overflow);
+/* :743-782 ; params[13] host array */
+int sdm_linear_collection_efficiency(sdm_ctx *ctx, const double params[13], double *output,
+                                     int64_t n_out, const double *radii,
+                                     const uint8_t *is_first_in_pair, const int64_t *idx,
+                                     int64_t length, double unit);
+
+/* ---- a-9 derived attributes ------------------------------------------------------------- */
+/* PySDM/backends/impl_numba/methods/terminal_velocity_methods.py:14-30 */
+int sdm_interpolation(sdm_ctx *ctx, double *output, const double *radius, int64_t n,
+                      double factor, const double *b, const double *c, int64_t table_len);
+/* PySDM/backends/impl_numba/methods/physics_methods.py:107-131 (liquid spheres) */
+int sdm_volume_of_water_mass(sdm_ctx *ctx, double *volume, const double *mass, int64_t n,
+                             double rho_w);
+int sdm_mass_of_water_volume(sdm_ctx *ctx, double *mass, const double *volume, int64_t n,
+                             double rho_w);
+
+/* ---- a-17 fragmentation, PySDM/backends/impl_numba/methods/fragmentation_methods.py ----- */
+/* :136-171 exp_fragmentation incl. limiters :76-95 ; nfmax < 0 == None */
+int sdm_exp_fragmentation(sdm_ctx *ctx, double *n_fragment, double scale, double *frag_volume,
+                          const double *x_plus_y, const double *rand, int64_t n, double vmin,
+                          double nfmax, double tol);
+/* :218-257,321-377 straub_fragmentation incl. limiters; consts = {CM, STRAUB_E_D1, STRAUB_MU2,
+ * VEDDER_1987_A, VEDDER_1987_b, PI} (host array)                                            */
+int sdm_straub_fragmentation(sdm_ctx *ctx, double *n_fragment, const double *CW,
+                             const double *gam, const double *ds, double *frag_volume,
+                             const double *v_max, const double *x_plus_y, const double *rand,
+                             int64_t n, double vmin, double nfmax, double *Nr1, double *Nr2,
+                             double *Nr3, double *Nr4, double *Nrt, double *d34,
+                             const double consts[6]);
+
+/* ---- f-1 moments, PySDM/backends/impl_numba/methods/moments_methods.py:14-99 ------------ */
+int sdm_moments(sdm_ctx *ctx, double *moment_0, double *moments, const int64_t *multiplicity,
+                const double *attr_data, const int64_t *cell_id, const int64_t *idx,
+                int64_t length, const double *ranks, int64_t n_ranks, int64_t n_cell,
+                double min_x, double max_x, const double *x_attr,
+                const double *weighting_attribute, double weighting_rank,
+                int skip_division_by_m0);
+
+/* ---- a-20 Storage element-wise ops, PySDM/backends/impl_numba/storage_impl.py ----------- */
+/* out[i] = a[i] (op) b[i]  or  a[i] (op) scalar when b == NULL.  out may alias a.            */
+#define SDM_EW_ADD 0
+#define SDM_EW_SUB 1
+#define SDM_EW_MUL 2
+#define SDM_EW_DIV 3
+#define SDM_EW_POW 4          /* sign(a) * |a| ** scalar  (storage_impl.py:75-78) */
+#define SDM_EW_DIV_IF_NOT_ZERO 5
+#define SDM_EW_FLOOR 6
+#define SDM_EW_EXP 7
+#define SDM_EW_ABS 8
+#define SDM_EW_FILL 9
+#define SDM_EW_ADD_MUL 10     /* out = a + scalar * b  (add_with_multiplier :19-21) */
+#define SDM_EW_MOD 11         /* Python-style % (row_modulo :36-41) */
+int sdm_elementwise_f64(sdm_ctx *ctx, int op, double *out, const double *a, const double *b,
+                        double scalar, int64_t n);
+int sdm_elementwise_i64(sdm_ctx *ctx, int op, int64_t *out, const int64_t *a, const int64_t *b,
+                        int64_t scalar, int64_t n);
+/* reductions (storage_impl.py:24-31): *result is a host pointer; syncs. kind: 0 min, 1 max */
+int sdm_reduce_f64(sdm_ctx *ctx, int kind, const double *a, int64_t n, double *result);
+
+/* ---- the fused per-time-step path (perf path) -------------------------------------------
+ * One call = one `Collision.__call__` (PySDM/dynamics/collisions/collision.py:174-234): all
+ * sub-steps of one time step: counting sort if unsorted, on-the-fly PCG64, shuffle, pairing,
+ * kernel/probability, (Ec/Eb/fragmentation,) adaptive dt, gamma, multiplicity/attribute update,
+ * counters, compaction of zero-multiplicity super-droplets.                                  */
+#define SDM_KERNEL_GOLOVIN 0    /* collision_kernels/golovin.py:14-16 ; kernel_param[0] = b */
+#define SDM_KERNEL_GEOMETRIC 1  /* collision_kernels/geometric.py:15-22 ; [0] = PI * E_coll */
+#define SDM_KERNEL_CONSTANT 2   /* collision_kernels/constantK.py ; [0] = a */
+#define SDM_EC_CONST 0          /* coalescence_efficiencies/constEc.py ; ec_param[0] = Ec */
+#define SDM_EC_BERRY1967 1      /* coalescence_efficiencies/berry1967.py */
+#define SDM_EC_STRAUB2010 2     /* coalescence_efficiencies/straub2010.py:27-50 */
+#define SDM_FRAG_ALWAYS_N 0     /* breakup_fragmentations/always_n.py ; frag_param[0] = n */
+#define SDM_FRAG_EXPONENTIAL 1  /* breakup_fragmentations/exponential.py ; [0] = scale */
+#define SDM_FRAG_STRAUB2010 2   /* breakup_fragmentations/straub2010.py */
+
+typedef struct sdm_step_cfg {
+  int64_t n_sd, n_cell, n_attr;
+  double dt, dv;
+  double dt_min, dt_max;      /* dt_coal_range after clamping (collision.py:115-116) */
+  int32_t adaptive;
+  int32_t substeps;           /* non-adaptive only */
+  int32_t croupier_local;     /* 1 = local (per-cell), 0 = global + re-sort */
+  int32_t optimized_random;   /* random_generator_optimizer.py:37-48 */
+  int32_t enable_breakup;
+  int32_t handle_all_breakups;
+  int32_t kernel, ec, frag;   /* SDM_KERNEL_*, SDM_EC_*, SDM_FRAG_* */
+  int32_t mass_attr;          /* row of `attributes` holding "signed water mass" */
+  double kernel_param[2];
+  double ec_param[2];
+  double eb_const;            /* breakup_efficiencies/constEb.py */
+  double frag_param[2];
+  double frag_vmin, frag_nfmax; /* nfmax < 0 == None */
+  double rho_w, sgm_w;
+  double straub_consts[6];    /* as sdm_straub_fragmentation */
+  double berry_params[13];
+  double berry_unit;
+  int64_t max_multiplicity;
+  uint64_t rng_state_inc[4];  /* PCG64 state/inc of seed (numpy.random.PCG64(seed).state) */
+  int64_t gk_table_len;       /* Gunn-Kinzer table length (0 if unused) */
+  double gk_factor;
+} sdm_step_cfg;
+
+typedef struct sdm_step_state {
+  int64_t *idx;               /* [n_sd] current permutation */
+  int64_t *tmp_idx;           /* [n_sd] counting-sort / shuffle double buffer */
+  int64_t *multiplicity;      /* [n_sd] */
+  double *attributes;         /* [n_attr, n_sd] extensive attributes */
+  int64_t *cell_id;           /* [n_sd] */
+  int64_t *cell_idx;          /* [n_cell] */
+  int64_t *cell_start;        /* [n_cell + 1] */
+  double *dt_left;            /* [n_cell] */
+  double *stats_dt_min;       /* [n_cell] */
+  int64_t *stats_n_substep;   /* [n_cell] */
+  int64_t *collision_rate, *collision_rate_deficit, *coalescence_rate;  /* [n_cell] */
+  int64_t *breakup_rate, *breakup_rate_deficit;                        /* [n_cell] or NULL */
+  const double *gk_a, *gk_b;  /* Gunn-Kinzer table (or NULL) */
+  /* device control block, int64[8]: {valid_n_sd, working_length, sorted, healthy,
+   * n_overflow, idx_swapped, reserved, reserved}; kept device-resident between calls */
+  int64_t *ctl;
+  uint64_t rng_offset;        /* doubles already drawn from the coll. stream (host-tracked) */
+  uint64_t rng_offset_breakup;/* doubles already drawn from the proc/frag streams */
+} sdm_step_state;
+
+typedef struct sdm_step_result {
+  int64_t n_substeps;         /* sub-steps executed in this call */
+  int64_t n_pairs;            /* candidate pairs processed (sum of working_length // 2) */
+  int64_t valid_n_sd;         /* live super-droplets after the call (-1 if not read back) */
+  int64_t idx_swapped;        /* 1 if state->idx / state->tmp_idx exchanged roles */
+  uint64_t rng_offset, rng_offset_breakup; /* updated stream positions */
+} sdm_step_result;
+
+int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *state,
+                       sdm_step_result *result, int read_back);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDM_HIP_H */

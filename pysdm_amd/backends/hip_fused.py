@@ -1,0 +1,137 @@
+"""Host side of the fused per-time-step route: packs the dynamic's configuration and the device
+state into the C structs of include/sdm_hip.h and calls `sdm_collision_step` once per time step.
+The control words (valid / working length, sorted, healthy) stay on the device between calls.
+"""
+import ctypes
+import warnings
+
+import torch
+
+from .. import _lib
+from .._lib import StepCfg, StepResult, StepState, c_ptr, check
+from .hip import _Context, pcg64_state_inc
+
+
+def _p(tensor):
+    return None if tensor is None else ctypes.c_void_p(tensor.data_ptr())
+
+
+class FusedStep:  # pylint: disable=too-many-instance-attributes
+    def __init__(self, backend, dynamic, parts):
+        self.backend = backend
+        self.dynamic = dynamic
+        self.particulator = part = dynamic.particulator
+        attrs = part.attributes
+        const = backend.formulae.constants
+        self.read_back = True
+        self.total_pairs = 0
+        self.total_substeps = 0
+
+        cfg = StepCfg()
+        cfg.n_sd, cfg.n_cell = part.n_sd, part.mesh.n_cell
+        storage = attrs.get_extensive_attribute_storage()
+        cfg.n_attr = storage.shape[0]
+        cfg.dt, cfg.dv = part.dt, part.mesh.dv
+        cfg.dt_min, cfg.dt_max = dynamic.dt_coal_range
+        cfg.adaptive = int(dynamic.adaptive)
+        cfg.substeps = int(dynamic.substeps)
+        cfg.croupier_local = int(dynamic.croupier == "local")
+        cfg.optimized_random = int(dynamic.optimized_random)
+        cfg.enable_breakup = int(dynamic.enable_breakup)
+        cfg.handle_all_breakups = int(backend.formulae.handle_all_breakups)
+        cfg.kernel = parts.get("kernel", 0)
+        cfg.ec = parts.get("ec", 0)
+        cfg.frag = parts.get("frag", 0)
+        keys = list(attrs.get_extensive_attribute_keys())
+        cfg.mass_attr = keys.index("signed water mass")
+        cfg.kernel_param = (ctypes.c_double * 2)(*parts.get("kernel_param", (0.0, 0.0)))
+        cfg.ec_param = (ctypes.c_double * 2)(*parts.get("ec_param", (0.0, 0.0)))
+        cfg.eb_const = parts.get("eb_const", 0.0)
+        cfg.frag_param = (ctypes.c_double * 2)(*parts.get("frag_param", (0.0, 0.0)))
+        cfg.frag_vmin = parts.get("frag_vmin", 0.0)
+        cfg.frag_nfmax = parts.get("frag_nfmax", -1.0)
+        cfg.rho_w, cfg.sgm_w = const.rho_w, const.sgm_w
+        cfg.straub_consts = backend.straub_consts()
+        cfg.berry_params = (ctypes.c_double * 13)(*parts.get("berry_params", (0.0,) * 13))
+        cfg.berry_unit = parts.get("berry_unit", 1.0)
+        cfg.max_multiplicity = int(dynamic.max_multiplicity)
+        cfg.rng_state_inc = (ctypes.c_uint64 * 4)(*pcg64_state_inc(backend.formulae.seed))
+        self.gk = None
+        if parts.get("needs_gk", False):
+            self.gk = attrs.get_attribute_object("relative fall velocity").approximation
+            cfg.gk_table_len = self.gk.a.data.numel()
+            cfg.gk_factor = float(self.gk.factor)
+        self.cfg = cfg
+
+        view = attrs._fused_view()  # pylint: disable=protected-access
+        self.idx = view["idx"]
+        self.tmp_idx = view["caretaker"].tmp_idx
+        self.ctl = torch.zeros(8, dtype=torch.int64, device=self.idx.data.device)
+        self._ctl_initialised = False
+        self.result = StepResult()
+
+    def _push_host_state(self):
+        view = self.particulator.attributes._fused_view()  # pylint: disable=protected-access
+        host = torch.tensor(
+            [view["valid_n_sd"], len(view["idx"]), int(view["sorted"]),
+             int(bool(view["healthy"])), 0, 0, 0, 0], dtype=torch.int64,
+        )
+        self.ctl.copy_(host)
+        self._ctl_initialised = True
+
+    def __call__(self):
+        dyn, attrs = self.dynamic, self.particulator.attributes
+        if not self._ctl_initialised:
+            self._push_host_state()
+        state = StepState()
+        state.idx = _p(self.idx.data)
+        state.tmp_idx = _p(self.tmp_idx.data)
+        state.multiplicity = _p(attrs["multiplicity"].data)
+        state.attributes = _p(attrs.get_extensive_attribute_storage().data)
+        state.cell_id = _p(attrs["cell id"].data)
+        state.cell_idx = _p(attrs.cell_idx.data)
+        state.cell_start = _p(attrs._fused_view()["cell_start"].data)  # pylint: disable=protected-access
+        state.dt_left = _p(dyn.dt_left.data)
+        state.stats_dt_min = _p(dyn.stats_dt_min.data)
+        state.stats_n_substep = _p(dyn.stats_n_substep.data)
+        state.collision_rate = _p(dyn.collision_rate.data)
+        state.collision_rate_deficit = _p(dyn.collision_rate_deficit.data)
+        state.coalescence_rate = _p(dyn.coalescence_rate.data)
+        if dyn.enable_breakup:
+            state.breakup_rate = _p(dyn.breakup_rate.data)
+            state.breakup_rate_deficit = _p(dyn.breakup_rate_deficit.data)
+        if self.gk is not None:
+            state.gk_a, state.gk_b = _p(self.gk.a.data), _p(self.gk.b.data)
+        state.ctl = _p(self.ctl)
+        state.rng_offset = dyn.rnd_opt_coll.rnd.offset
+        if dyn.enable_breakup:
+            state.rng_offset_breakup = dyn.rnd_opt_proc.rnd.offset
+        ctx = _Context.get()
+        check(ctx.lib.sdm_collision_step(ctx.handle, ctypes.byref(self.cfg), ctypes.byref(state),
+                                         ctypes.byref(self.result), int(self.read_back)))
+        res = self.result
+        if res.idx_swapped:
+            self.idx.data, self.tmp_idx.data = self.tmp_idx.data, self.idx.data
+        dyn.rnd_opt_coll.rnd.offset = res.rng_offset
+        if dyn.enable_breakup:
+            dyn.rnd_opt_proc.rnd.offset = res.rng_offset_breakup
+            dyn.rnd_opt_frag.rnd.offset = res.rng_offset_breakup
+        self.total_substeps += res.n_substeps
+        if res.n_pairs >= 0:
+            self.total_pairs += res.n_pairs
+        if self.read_back:
+            self._commit(ctx)
+        self.particulator.mark_collision_outputs_updated()
+
+    def _commit(self, _ctx):
+        words = self.ctl.cpu().numpy()
+        self.particulator.attributes._fused_commit(  # pylint: disable=protected-access
+            valid_n_sd=int(words[0]), sorted_flag=bool(words[2])
+        )
+        if words[4] > 0 and self.dynamic.warn_overflows:
+            warnings.warn("overflow")
+            self.ctl[4] = 0
+
+    def sync(self):
+        """bring the host-side bookkeeping up to date (needed after read_back=False steps)"""
+        self._commit(_Context.get())

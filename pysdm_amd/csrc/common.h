@@ -1,0 +1,156 @@
+// common.h -- shared host/device helpers of libsdm_hip (gfx950 only; wave = 64 lanes)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/sdm_hip.h"
+
+typedef unsigned __int128 u128;
+
+#define SDM_BLOCK 256
+#define SDM_WAVE 64
+
+struct ShufRec;  // shuffle.hip
+
+// ---- context ---------------------------------------------------------------------------
+struct sdm_ctx {
+  int device;
+  hipStream_t stream;
+  // scratch arena (grown on demand, never shrunk)
+  char *arena;
+  size_t arena_bytes;
+  // PCG64 jump table: tab[b] = {A^(2^b), C_(2^b)} for the increment `tab_inc`
+  u128 *pcg_tab;  // device, 64 x 2
+  u128 tab_inc;
+  bool tab_valid;
+  // pinned host mailbox for scalar read-backs
+  int64_t *mailbox;  // 16 x int64, hipHostMalloc
+  // device control words for fine-grained calls (int64[16])
+  int64_t *dscal;
+};
+
+void sdm_set_error(const char *fmt, ...);
+int sdm_reserve(sdm_ctx *ctx, size_t bytes);
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t e__ = (expr);                                                           \
+    if (e__ != hipSuccess) {                                                           \
+      sdm_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__,  \
+                    __LINE__);                                                         \
+      return SDM_E_HIP;                                                                \
+    }                                                                                  \
+  } while (0)
+
+#define ARG_TRY(cond)                                                          \
+  do {                                                                         \
+    if (!(cond)) {                                                             \
+      sdm_set_error("bad argument: %s (%s:%d)", #cond, __FILE__, __LINE__);    \
+      return SDM_E_ARG;                                                        \
+    }                                                                          \
+  } while (0)
+
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+static inline unsigned grid_for(int64_t n, int per_block = SDM_BLOCK) {
+  int64_t g = (n + per_block - 1) / per_block;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
+// carve helper for the scratch arena (256-B aligned pieces)
+struct Carver {
+  char *base;
+  size_t off;
+  explicit Carver(char *b) : base(b), off(0) {}
+  template <typename T>
+  T *take(size_t n) {
+    T *p = (T *)(base + off);
+    off += ((n * sizeof(T) + 255) / 256) * 256;
+    return p;
+  }
+};
+static inline size_t carve_size(size_t bytes) { return ((bytes + 255) / 256) * 256; }
+
+// ---- device helpers --------------------------------------------------------------------
+#ifdef __HIPCC__
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// largest c in [0, n_cell) with cell_start[c] <= i  (needs cell_start[0] <= i < cell_start[n_cell])
+__device__ __forceinline__ int64_t find_cell(const int64_t *__restrict__ cs, int64_t n_cell,
+                                             int64_t i) {
+  int64_t lo = 0, hi = n_cell;
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (cs[mid] <= i) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// ---- PCG64 (NumPy): XSL-RR 128/64 ----
+#define PCG_MULT_HI 0x2360ED051FC65DA4ULL
+#define PCG_MULT_LO 0x4385DF649FCCF645ULL
+
+__host__ __device__ __forceinline__ u128 pcg_mult() {
+  return (((u128)PCG_MULT_HI) << 64) | PCG_MULT_LO;
+}
+
+__host__ __device__ __forceinline__ double pcg_output(u128 state) {
+  const uint64_t hi = (uint64_t)(state >> 64), lo = (uint64_t)state;
+  const uint64_t x = hi ^ lo;
+  const unsigned r = (unsigned)(hi >> 58);
+  const uint64_t v = (x >> r) | (x << ((64 - r) & 63));
+  return (double)(v >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// state after `delta` further draws, using the per-increment jump table
+__device__ __forceinline__ u128 pcg_jump(u128 state, const u128 *__restrict__ tab,
+                                         uint64_t delta) {
+  int b = 0;
+  while (delta) {
+    if (delta & 1) state = state * tab[2 * b] + tab[2 * b + 1];
+    delta >>= 1;
+    ++b;
+  }
+  return state;
+}
+
+// wave-level reductions (all 64 lanes must participate)
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double t = __shfl_xor(v, o, 64);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+__device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor((long long)v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// atomic min on non-negative doubles through their (order-preserving) bit pattern
+__device__ __forceinline__ void atomic_min_pos_f64(double *addr, double v) {
+  atomicMin((unsigned long long *)addr, (unsigned long long)__double_as_longlong(v));
+}
+
+// Python-style round-half-even to int64 (round() in collisions_methods.py:124-125)
+__device__ __forceinline__ int64_t py_round(double x) { return (int64_t)rint(x); }
+
+#endif  // __HIPCC__

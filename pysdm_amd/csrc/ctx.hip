@@ -1,0 +1,296 @@
+// ctx.hip -- context, error reporting, PCG64 stream fill, Storage element-wise ops, reductions
+#include <stdarg.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void sdm_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char *sdm_last_error(void) { return g_err; }
+extern "C" int sdm_abi_version(void) { return 1; }
+
+extern "C" int sdm_ctx_create(sdm_ctx **out, int device) {
+  ARG_TRY(out != nullptr);
+  HIP_TRY(hipSetDevice(device));
+  sdm_ctx *ctx = new sdm_ctx();
+  memset(ctx, 0, sizeof(*ctx));
+  ctx->device = device;
+  ctx->stream = nullptr;
+  HIP_TRY(hipMalloc((void **)&ctx->pcg_tab, sizeof(u128) * 128));
+  HIP_TRY(hipHostMalloc((void **)&ctx->mailbox, sizeof(int64_t) * 16, hipHostMallocDefault));
+  HIP_TRY(hipMalloc((void **)&ctx->dscal, sizeof(int64_t) * 16));
+  HIP_TRY(hipMemset(ctx->dscal, 0, sizeof(int64_t) * 16));
+  *out = ctx;
+  return SDM_OK;
+}
+
+extern "C" int sdm_ctx_destroy(sdm_ctx *ctx) {
+  if (!ctx) return SDM_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->arena) (void)hipFree(ctx->arena);
+  if (ctx->pcg_tab) (void)hipFree(ctx->pcg_tab);
+  if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
+  if (ctx->dscal) (void)hipFree(ctx->dscal);
+  delete ctx;
+  return SDM_OK;
+}
+
+extern "C" int sdm_ctx_set_stream(sdm_ctx *ctx, void *hip_stream) {
+  ARG_TRY(ctx != nullptr);
+  ctx->stream = (hipStream_t)hip_stream;
+  return SDM_OK;
+}
+
+extern "C" int sdm_ctx_synchronize(sdm_ctx *ctx) {
+  ARG_TRY(ctx != nullptr);
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SDM_OK;
+}
+
+int sdm_reserve(sdm_ctx *ctx, size_t bytes) {
+  if (bytes <= ctx->arena_bytes) return SDM_OK;
+  // growing the arena must not race with work still using the old one
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->arena) HIP_TRY(hipFree(ctx->arena));
+  ctx->arena = nullptr;
+  ctx->arena_bytes = 0;
+  size_t want = bytes + bytes / 4 + (1 << 20);
+  hipError_t e = hipMalloc((void **)&ctx->arena, want);
+  if (e != hipSuccess) {
+    sdm_set_error("scratch arena: hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    return SDM_E_NOMEM;
+  }
+  ctx->arena_bytes = want;
+  return SDM_OK;
+}
+
+// ---- PCG64 -----------------------------------------------------------------------------
+__global__ void k_pcg_table(u128 *tab, u128 inc) {
+  u128 cur_mult = pcg_mult(), cur_plus = inc;
+  for (int b = 0; b < 64; ++b) {
+    tab[2 * b] = cur_mult;
+    tab[2 * b + 1] = cur_plus;
+    cur_plus = (cur_mult + 1) * cur_plus;
+    cur_mult *= cur_mult;
+  }
+}
+
+int sdm_pcg_prepare(sdm_ctx *ctx, const uint64_t state_inc[4]) {
+  const u128 inc = (((u128)state_inc[2]) << 64) | state_inc[3];
+  if (!ctx->tab_valid || ctx->tab_inc != inc) {
+    hipLaunchKernelGGL(k_pcg_table, dim3(1), dim3(1), 0, ctx->stream, ctx->pcg_tab, inc);
+    LAUNCH_CHECK();
+    ctx->tab_inc = inc;
+    ctx->tab_valid = true;
+  }
+  return SDM_OK;
+}
+
+// host-side jump-ahead (pcg_advance_lcg_128)
+u128 sdm_pcg_advance_host(u128 state, u128 inc, uint64_t delta) {
+  u128 acc_mult = 1, acc_plus = 0, cur_mult = pcg_mult(), cur_plus = inc;
+  while (delta > 0) {
+    if (delta & 1) {
+      acc_mult *= cur_mult;
+      acc_plus = acc_plus * cur_mult + cur_plus;
+    }
+    cur_plus = (cur_mult + 1) * cur_plus;
+    cur_mult *= cur_mult;
+    delta >>= 1;
+  }
+  return acc_mult * state + acc_plus;
+}
+
+#define PCG_ELEMS 4
+// out[i] = draw number (offset + i); `s_off` = generator state after `offset` draws
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_pcg_fill(double *__restrict__ out, int64_t n, u128 s_off, u128 inc,
+           const u128 *__restrict__ tab) {
+  __shared__ u128 s_blk;
+  const int64_t blk_first = (int64_t)blockIdx.x * (SDM_BLOCK * PCG_ELEMS);
+  if (threadIdx.x == 0) s_blk = pcg_jump(s_off, tab, (uint64_t)blk_first);
+  __syncthreads();
+  u128 state = pcg_jump(s_blk, tab, (uint64_t)threadIdx.x * PCG_ELEMS);
+  const int64_t first = blk_first + (int64_t)threadIdx.x * PCG_ELEMS;
+  const u128 mult = pcg_mult();
+  double v[PCG_ELEMS];
+#pragma unroll
+  for (int e = 0; e < PCG_ELEMS; ++e) {
+    state = state * mult + inc;
+    v[e] = pcg_output(state);
+  }
+  if (first + PCG_ELEMS <= n && (((uintptr_t)(out + first)) & 15) == 0) {
+    double2 *o = (double2 *)(out + first);
+    o[0] = make_double2(v[0], v[1]);
+    o[1] = make_double2(v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < PCG_ELEMS; ++e)
+      if (first + e < n) out[first + e] = v[e];
+  }
+}
+
+int sdm_pcg_fill_async(sdm_ctx *ctx, double *out, int64_t n, const uint64_t state_inc[4],
+                       uint64_t offset) {
+  if (n <= 0) return SDM_OK;
+  int rc = sdm_pcg_prepare(ctx, state_inc);
+  if (rc) return rc;
+  const u128 st = (((u128)state_inc[0]) << 64) | state_inc[1];
+  const u128 inc = (((u128)state_inc[2]) << 64) | state_inc[3];
+  const u128 s_off = sdm_pcg_advance_host(st, inc, offset);
+  hipLaunchKernelGGL(k_pcg_fill, dim3(grid_for(n, SDM_BLOCK * PCG_ELEMS)), dim3(SDM_BLOCK), 0,
+                     ctx->stream, out, n, s_off, inc, ctx->pcg_tab);
+  LAUNCH_CHECK();
+  return SDM_OK;
+}
+
+extern "C" int sdm_pcg64_uniform(sdm_ctx *ctx, double *out, int64_t n,
+                                 const uint64_t state_inc[4], uint64_t offset) {
+  ARG_TRY(ctx && state_inc && n >= 0 && (out || n == 0));
+  return sdm_pcg_fill_async(ctx, out, n, state_inc, offset);
+}
+
+// ---- element-wise ----------------------------------------------------------------------
+__device__ __forceinline__ double py_mod_f64(double a, double b) {
+  double r = fmod(a, b);
+  if (r != 0 && ((r < 0) != (b < 0))) r += b;
+  return r;
+}
+
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_ew_f64(int op, double *out, const double *a, const double *b, double s, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const double x = a ? a[i] : 0.0;
+  const double y = b ? b[i] : s;
+  double r;
+  switch (op) {
+    case SDM_EW_ADD: r = x + y; break;
+    case SDM_EW_SUB: r = x - y; break;
+    case SDM_EW_MUL: r = x * y; break;
+    case SDM_EW_DIV: r = x / y; break;
+    case SDM_EW_POW: {
+      const double sg = (x > 0) - (x < 0);
+      r = (x != x) ? x : sg * pow(fabs(x), s);
+      break;
+    }
+    case SDM_EW_DIV_IF_NOT_ZERO: r = (y != 0.0) ? x / y : x; break;
+    case SDM_EW_FLOOR: r = floor(x); break;
+    case SDM_EW_EXP: r = exp(x); break;
+    case SDM_EW_ABS: r = fabs(x); break;
+    case SDM_EW_FILL: r = y; break;
+    case SDM_EW_ADD_MUL: r = x + s * b[i]; break;
+    case SDM_EW_MOD: r = py_mod_f64(x, y); break;
+    default: r = x;
+  }
+  out[i] = r;
+}
+
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_ew_i64(int op, int64_t *out, const int64_t *a, const int64_t *b, int64_t s, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const int64_t x = a ? a[i] : 0;
+  const int64_t y = b ? b[i] : s;
+  int64_t r;
+  switch (op) {
+    case SDM_EW_ADD: r = x + y; break;
+    case SDM_EW_SUB: r = x - y; break;
+    case SDM_EW_MUL: r = x * y; break;
+    case SDM_EW_ABS: r = x < 0 ? -x : x; break;
+    case SDM_EW_FILL: r = y; break;
+    case SDM_EW_MOD: {
+      r = x % y;
+      if (r != 0 && ((r < 0) != (y < 0))) r += y;
+      break;
+    }
+    default: r = x;
+  }
+  out[i] = r;
+}
+
+extern "C" int sdm_elementwise_f64(sdm_ctx *ctx, int op, double *out, const double *a,
+                                   const double *b, double scalar, int64_t n) {
+  ARG_TRY(ctx && n >= 0 && (out || n == 0));
+  ARG_TRY(op >= 0 && op <= SDM_EW_MOD);
+  ARG_TRY(op != SDM_EW_ADD_MUL || b != nullptr);
+  if (n == 0) return SDM_OK;
+  hipLaunchKernelGGL(k_ew_f64, dim3(grid_for(n)), dim3(SDM_BLOCK), 0, ctx->stream, op, out, a,
+                     b, scalar, n);
+  LAUNCH_CHECK();
+  return SDM_OK;
+}
+
+extern "C" int sdm_elementwise_i64(sdm_ctx *ctx, int op, int64_t *out, const int64_t *a,
+                                   const int64_t *b, int64_t scalar, int64_t n) {
+  ARG_TRY(ctx && n >= 0 && (out || n == 0));
+  ARG_TRY(op == SDM_EW_ADD || op == SDM_EW_SUB || op == SDM_EW_MUL || op == SDM_EW_ABS ||
+          op == SDM_EW_FILL || op == SDM_EW_MOD);
+  if (n == 0) return SDM_OK;
+  hipLaunchKernelGGL(k_ew_i64, dim3(grid_for(n)), dim3(SDM_BLOCK), 0, ctx->stream, op, out, a,
+                     b, scalar, n);
+  LAUNCH_CHECK();
+  return SDM_OK;
+}
+
+// ---- min / max reduction (np.amin / np.amax: NaN propagates) ------------------------------
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_reduce_f64(int kind, const double *__restrict__ a, int64_t n, double *__restrict__ partial,
+             int *__restrict__ has_nan) {
+  __shared__ double sm[SDM_BLOCK / SDM_WAVE];
+  double v = kind == 0 ? INFINITY : -INFINITY;
+  bool nan = false;
+  for (int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * SDM_BLOCK) {
+    const double x = a[i];
+    nan |= (x != x);
+    if (kind == 0) v = x < v ? x : v; else v = x > v ? x : v;
+  }
+  if (__any(nan) && lane_id() == 0) atomicOr(has_nan, 1);
+  v = kind == 0 ? wave_min_f64(v) : wave_max_f64(v);
+  if (lane_id() == 0) sm[threadIdx.x / SDM_WAVE] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < SDM_BLOCK / SDM_WAVE; ++w)
+      v = kind == 0 ? (sm[w] < v ? sm[w] : v) : (sm[w] > v ? sm[w] : v);
+    partial[blockIdx.x] = v;
+  }
+}
+
+__global__ void k_reduce_final(int kind, const double *partial, int np, const int *has_nan,
+                               double *out) {
+  double v = kind == 0 ? INFINITY : -INFINITY;
+  for (int i = 0; i < np; ++i)
+    v = kind == 0 ? (partial[i] < v ? partial[i] : v) : (partial[i] > v ? partial[i] : v);
+  out[0] = *has_nan ? NAN : v;
+}
+
+extern "C" int sdm_reduce_f64(sdm_ctx *ctx, int kind, const double *a, int64_t n,
+                              double *result) {
+  ARG_TRY(ctx && a && n > 0 && result && (kind == 0 || kind == 1));
+  const int nb = (int)(grid_for(n) < 1024 ? grid_for(n) : 1024);
+  int rc = sdm_reserve(ctx, carve_size(sizeof(double) * 1024) + 512);
+  if (rc) return rc;
+  Carver cv(ctx->arena);
+  double *partial = cv.take<double>(1024);
+  int *has_nan = cv.take<int>(4);
+  double *out = (double *)(has_nan + 2);
+  HIP_TRY(hipMemsetAsync(has_nan, 0, sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(k_reduce_f64, dim3(nb), dim3(SDM_BLOCK), 0, ctx->stream, kind, a, n,
+                     partial, has_nan);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1), 0, ctx->stream, kind, partial, nb,
+                     has_nan, out);
+  LAUNCH_CHECK();
+  HIP_TRY(hipMemcpyAsync(ctx->mailbox, out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  memcpy(result, ctx->mailbox, sizeof(double));
+  return SDM_OK;
+}

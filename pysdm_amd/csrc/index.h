@@ -1,0 +1,23 @@
+// index.h -- async cores of the permutation-side kernels, shared with the fused step
+#pragma once
+#include "common.h"
+
+int sdm_pcg_prepare(sdm_ctx *ctx, const uint64_t state_inc[4]);
+u128 sdm_pcg_advance_host(u128 state, u128 inc, uint64_t delta);
+int sdm_pcg_fill_async(sdm_ctx *ctx, double *out, int64_t n, const uint64_t state_inc[4],
+                       uint64_t offset);
+
+size_t sdm_shuffle_scratch(int64_t n);
+int sdm_shuffle_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *idx0,
+                      const double *u01, const int64_t *cell_start, int64_t n_cell,
+                      const int64_t *p_length, int64_t length_bound, bool global);
+int sdm_sort_by_key_async(sdm_ctx *ctx, int64_t *idx, const double *keys, int64_t n);
+size_t sdm_compact_scratch(int64_t n);
+int sdm_compact_async(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity, int64_t *idx,
+                      const int64_t *p_length, int64_t length_bound, int64_t flag,
+                      const int64_t *p_enable, int64_t *ctl);
+size_t sdm_sort_scratch(int64_t length_bound, int64_t n_cell);
+int sdm_counting_sort_async(sdm_ctx *ctx, char *scratch, int64_t *new_idx, const int64_t *idx,
+                            const int64_t *cell_id, const int64_t *cell_idx,
+                            const int64_t *p_length, int64_t length_bound, int64_t *cell_start,
+                            int64_t n_cell);

@@ -1,0 +1,575 @@
+// index.hip -- permutation-side kernels: identity, the parallel-equivalent of the reference's
+// serial swap chains (shuffle_local / shuffle_global), cell sort, compaction.
+#include "common.h"
+#include "index.h"
+
+// ---------------------------------------------------------------------------------------
+// identity_index  (index_methods.py:14-20)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SDM_BLOCK) k_identity(int64_t *idx, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+  if (i < n) idx[i] = i;
+}
+
+extern "C" int sdm_identity_index(sdm_ctx *ctx, int64_t *idx, int64_t n) {
+  ARG_TRY(ctx && n >= 0 && (idx || n == 0));
+  if (n == 0) return SDM_OK;
+  hipLaunchKernelGGL(k_identity, dim3(grid_for(n)), dim3(SDM_BLOCK), 0, ctx->stream, idx, n);
+  LAUNCH_CHECK();
+  return SDM_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Shuffle.  The reference (index_methods.py:22-43) runs, per cell [lo, hi), the serial chain
+//     for i = hi-1 .. lo+1:  j_i = target(i);  swap(idx[i], idx[j_i])
+// (local: j_i = int(lo + u01[i]*(hi-lo)) anywhere in the cell; global: j_i = int(u01[i]*(i+1))).
+// All (i, j_i) are known up front, so the final content of position p is found by walking the
+// swap history backwards: the last event touching p is the one with the SMALLEST index among
+// {p itself (its "own" event)} U {i : j_i == p}; the content then came from the event's other
+// end, at the moment just before that event, i.e. after all events with a LARGER index; repeat
+// until a position has no earlier event, whose initial content is the answer.  Expected walk
+// length is ~2 events per position.  Build: per-position record {own target, #hits, first two
+// hitting events inline, rest in an overflow list}.  Bit-identical to the serial chain.
+// ---------------------------------------------------------------------------------------
+struct __align__(16) ShufRec {
+  int32_t j;    // target of this position's own event, -1 if none (first slot of its cell)
+  int32_t cnt;  // number of events i with j_i == this position
+  int32_t s0, s1;  // the first two of them in arrival order (any order; all get scanned)
+};
+
+template <bool GLOBAL>
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_shuffle_build(ShufRec *__restrict__ rec, int32_t *__restrict__ ovf_head,
+                int32_t *__restrict__ ovf_next, const double *__restrict__ u01,
+                const int64_t *__restrict__ cell_start, int64_t n_cell,
+                const int64_t *__restrict__ p_length, int64_t length_arg) {
+  const int64_t length = p_length ? *p_length : length_arg;
+  const int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+  if (i >= length) return;
+  int64_t j = -1;
+  if (GLOBAL) {
+    if (i >= 1) {
+      j = (int64_t)(u01[i] * (double)(i + 1));
+      j = j > i ? i : j;
+    }
+  } else {
+    const int64_t c = n_cell == 1 ? 0 : find_cell(cell_start, n_cell, i);
+    const int64_t lo = cell_start[c], hi = cell_start[c + 1];
+    if (i > lo) {
+      j = (int64_t)((double)lo + u01[i] * (double)(hi - lo));
+      // memory safety only: the reference would index past the cell with prob ~2^-43
+      j = j > hi - 1 ? hi - 1 : (j < lo ? lo : j);
+    }
+  }
+  rec[i].j = (int32_t)j;
+  if (j >= 0) {
+    const int c = atomicAdd(&rec[j].cnt, 1);
+    if (c == 0) rec[j].s0 = (int32_t)i;
+    else if (c == 1) rec[j].s1 = (int32_t)i;
+    else ovf_next[i] = atomicExch(&ovf_head[j], (int32_t)i);
+  }
+}
+
+template <bool GLOBAL>
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_shuffle_trace(int64_t *__restrict__ out, const int64_t *__restrict__ idx0,
+                const ShufRec *__restrict__ rec, const int32_t *__restrict__ ovf_head,
+                const int32_t *__restrict__ ovf_next, const int64_t *__restrict__ cell_start,
+                int64_t n_cell, const int64_t *__restrict__ p_length, int64_t length_arg) {
+  const int64_t length = p_length ? *p_length : length_arg;
+  const int64_t p = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+  if (p >= length) return;
+  int32_t e;  // only events with index > e are still "in the past" of the walk
+  if (GLOBAL) {
+    e = 0;
+  } else {
+    const int64_t c = n_cell == 1 ? 0 : find_cell(cell_start, n_cell, p);
+    e = (int32_t)cell_start[c];
+  }
+  int32_t q = (int32_t)p;
+  for (;;) {
+    const ShufRec r = rec[q];
+    int32_t best = INT32_MAX;
+    if (q > e && r.j >= 0) best = q;
+    if (r.cnt > 0 && r.s0 > e && r.s0 < best) best = r.s0;
+    if (r.cnt > 1 && r.s1 > e && r.s1 < best) best = r.s1;
+    if (r.cnt > 2)
+      for (int32_t t = ovf_head[q]; t >= 0; t = ovf_next[t])
+        if (t > e && t < best) best = t;
+    if (best == INT32_MAX) break;
+    // event `best` exchanged positions (best, j_best); q is one end, continue at the other
+    q = (best == q) ? r.j : best;
+    e = best;
+  }
+  out[p] = idx0[q];
+}
+
+static size_t shuffle_scratch_bytes(int64_t n) {
+  return carve_size(sizeof(ShufRec) * n) + 2 * carve_size(sizeof(int32_t) * n) +
+         carve_size(sizeof(int64_t) * n);
+}
+
+// out-of-place core: out[0:length) = shuffled idx0[0:length); arena must be reserved by caller
+int sdm_shuffle_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *idx0,
+                      const double *u01, const int64_t *cell_start, int64_t n_cell,
+                      const int64_t *p_length, int64_t length_bound, bool global) {
+  if (length_bound <= 0) return SDM_OK;
+  Carver cv(scratch);
+  ShufRec *rec = cv.take<ShufRec>(length_bound);
+  int32_t *ovf_head = cv.take<int32_t>(length_bound);
+  int32_t *ovf_next = cv.take<int32_t>(length_bound);
+  HIP_TRY(hipMemsetAsync(rec, 0, sizeof(ShufRec) * length_bound, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ovf_head, 0xFF, sizeof(int32_t) * length_bound, ctx->stream));
+  const dim3 grid(grid_for(length_bound)), block(SDM_BLOCK);
+  if (global) {
+    hipLaunchKernelGGL(k_shuffle_build<true>, grid, block, 0, ctx->stream, rec, ovf_head,
+                       ovf_next, u01, cell_start, n_cell, p_length, length_bound);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_shuffle_trace<true>, grid, block, 0, ctx->stream, out, idx0, rec,
+                       ovf_head, ovf_next, cell_start, n_cell, p_length, length_bound);
+  } else {
+    hipLaunchKernelGGL(k_shuffle_build<false>, grid, block, 0, ctx->stream, rec, ovf_head,
+                       ovf_next, u01, cell_start, n_cell, p_length, length_bound);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_shuffle_trace<false>, grid, block, 0, ctx->stream, out, idx0, rec,
+                       ovf_head, ovf_next, cell_start, n_cell, p_length, length_bound);
+  }
+  LAUNCH_CHECK();
+  return SDM_OK;
+}
+
+size_t sdm_shuffle_scratch(int64_t n) { return shuffle_scratch_bytes(n) - carve_size(sizeof(int64_t) * n); }
+
+extern "C" int sdm_shuffle_global(sdm_ctx *ctx, int64_t *idx, int64_t length,
+                                  const double *u01) {
+  ARG_TRY(ctx && length >= 0 && length < INT32_MAX && (length == 0 || (idx && u01)));
+  if (length < 2) return SDM_OK;
+  int rc = sdm_reserve(ctx, shuffle_scratch_bytes(length));
+  if (rc) return rc;
+  int64_t *out = (int64_t *)(ctx->arena + sdm_shuffle_scratch(length));
+  rc = sdm_shuffle_async(ctx, ctx->arena, out, idx, u01, nullptr, 1, nullptr, length, true);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(idx, out, sizeof(int64_t) * length, hipMemcpyDeviceToDevice,
+                         ctx->stream));
+  return SDM_OK;
+}
+
+// shuffle_local needs the working length = cell_start[n_cell], which lives on the device: the
+// kernels read it from there; the launch is sized by `length_bound` (<= len(idx)).
+extern "C" int sdm_shuffle_local(sdm_ctx *ctx, int64_t *idx, const double *u01,
+                                 const int64_t *cell_start, int64_t n_cell) {
+  ARG_TRY(ctx && idx && u01 && cell_start && n_cell >= 1);
+  // one small read-back keeps this fine-grained entry simple (the fused path avoids it)
+  HIP_TRY(hipMemcpyAsync(ctx->mailbox, cell_start + n_cell, sizeof(int64_t),
+                         hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const int64_t length = ctx->mailbox[0];
+  ARG_TRY(length >= 0 && length < INT32_MAX);
+  if (length < 2) return SDM_OK;
+  int rc = sdm_reserve(ctx, shuffle_scratch_bytes(length));
+  if (rc) return rc;
+  int64_t *out = (int64_t *)(ctx->arena + sdm_shuffle_scratch(length));
+  rc = sdm_shuffle_async(ctx, ctx->arena, out, idx, u01, cell_start, n_cell, nullptr, length,
+                         false);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(idx, out, sizeof(int64_t) * length, hipMemcpyDeviceToDevice,
+                         ctx->stream));
+  return SDM_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// sort_by_key (index_methods.py:46-48): idx[:] = argsort(keys, kind="stable")[::-1]
+// n = number of cells; O(n^2 / threads) rank counting, keys staged through LDS tiles.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_sort_by_key(int64_t *__restrict__ idx, const double *__restrict__ keys, int64_t n) {
+  __shared__ double tile[SDM_BLOCK];
+  const int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+  const double ki = i < n ? keys[i] : 0.0;
+  int64_t rank = 0;
+  for (int64_t base = 0; base < n; base += SDM_BLOCK) {
+    const int64_t jj = base + threadIdx.x;
+    tile[threadIdx.x] = jj < n ? keys[jj] : 0.0;
+    __syncthreads();
+    const int m = (int)((n - base) < SDM_BLOCK ? (n - base) : SDM_BLOCK);
+    if (i < n)
+      for (int t = 0; t < m; ++t) {
+        const double kj = tile[t];
+        rank += (kj < ki) || (kj == ki && (base + t) < i);
+      }
+    __syncthreads();
+  }
+  if (i < n) idx[n - 1 - rank] = i;
+}
+
+int sdm_sort_by_key_async(sdm_ctx *ctx, int64_t *idx, const double *keys, int64_t n) {
+  if (n <= 0) return SDM_OK;
+  hipLaunchKernelGGL(k_sort_by_key, dim3(grid_for(n)), dim3(SDM_BLOCK), 0, ctx->stream, idx,
+                     keys, n);
+  LAUNCH_CHECK();
+  return SDM_OK;
+}
+
+extern "C" int sdm_sort_by_key(sdm_ctx *ctx, int64_t *idx, const double *keys, int64_t n) {
+  ARG_TRY(ctx && n >= 0 && (n == 0 || (idx && keys)));
+  return sdm_sort_by_key_async(ctx, idx, keys, n);
+}
+
+// ---------------------------------------------------------------------------------------
+// remove_zero_n_or_flagged (collisions_methods.py:664-680).  The serial loop fills each dead
+// slot of the surviving prefix [0, new_len) with the last live element still in the tail, taken
+// from the end backwards: the r-th dead prefix slot (ascending) receives the r-th live tail
+// element (descending); every tail slot ends up holding the sentinel.  Done here with prefix
+// counts; wavefront ballot + popcount give the in-wave ranks.
+// ctl words: [0] length in, [1] new length out, [2] number of prefix holes, [3] total dead
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sd_dead(const int64_t *__restrict__ multiplicity,
+                                        const int64_t *__restrict__ idx, int64_t i,
+                                        int64_t flag) {
+  const int64_t v = idx[i];
+  return v == flag || multiplicity[v] == 0;
+}
+
+// per-block dead counts
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_compact_count(const int64_t *__restrict__ multiplicity, const int64_t *__restrict__ idx,
+                const int64_t *__restrict__ p_length, int64_t flag,
+                const int64_t *__restrict__ p_enable, int32_t *__restrict__ block_dead) {
+  if (p_enable && *p_enable != 0) return;  // healthy: nothing to do
+  const int64_t length = *p_length;
+  const int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+  __shared__ int sm[SDM_BLOCK / SDM_WAVE];
+  const bool dead = i < length && sd_dead(multiplicity, idx, i, flag);
+  const int c = __popcll(__ballot(dead));
+  if (lane_id() == 0) sm[threadIdx.x / SDM_WAVE] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_dead[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// exclusive scan of block counts (single block), total -> ctl
+__global__ void __launch_bounds__(1024)
+k_compact_scan(int32_t *__restrict__ block_dead, int nb, int64_t *__restrict__ ctl,
+               const int64_t *__restrict__ p_length, const int64_t *__restrict__ p_enable) {
+  if (p_enable && *p_enable != 0) {
+    if (threadIdx.x == 0) { ctl[1] = *p_length; ctl[2] = 0; ctl[3] = 0; }
+    return;
+  }
+  __shared__ int sm[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    const int b = base + threadIdx.x;
+    const int v = b < nb ? block_dead[b] : 0;
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int t = threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
+      __syncthreads();
+      sm[threadIdx.x] += t;
+      __syncthreads();
+    }
+    const int incl = sm[threadIdx.x];
+    if (b < nb) block_dead[b] = carry + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int64_t length = *p_length;
+    ctl[3] = carry;
+    ctl[1] = length - carry;
+    ctl[2] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_compact_lists(const int64_t *__restrict__ multiplicity, const int64_t *__restrict__ idx,
+                const int64_t *__restrict__ p_length, int64_t flag,
+                const int32_t *__restrict__ block_off, int64_t *__restrict__ ctl,
+                int32_t *__restrict__ holes, int64_t *__restrict__ fillers) {
+  const int64_t total_dead = ctl[3];
+  if (total_dead == 0) return;
+  const int64_t length = *p_length, new_len = ctl[1];
+  const int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+  __shared__ int sm[SDM_BLOCK / SDM_WAVE];
+  const bool in = i < length;
+  const bool dead = in && sd_dead(multiplicity, idx, i, flag);
+  const unsigned long long m = __ballot(dead);
+  const int lane = lane_id(), w = threadIdx.x / SDM_WAVE;
+  if (lane == 0) sm[w] = __popcll(m);
+  __syncthreads();
+  int before = block_off[blockIdx.x];
+  for (int k = 0; k < w; ++k) before += sm[k];
+  const int64_t dp = before + __popcll(m & ((1ull << lane) - 1));  // dead in [0, i)
+  if (!in) return;
+  if (i == new_len) ctl[2] = dp;  // holes in the surviving prefix
+  if (i < new_len) {
+    if (dead) holes[dp] = (int32_t)i;
+  } else if (!dead) {
+    const int64_t r = (length - 1 - i) - (total_dead - dp);  // live elements after i
+    fillers[r] = idx[i];
+  }
+}
+
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_compact_apply(int64_t *__restrict__ idx, const int64_t *__restrict__ p_length, int64_t flag,
+                const int64_t *__restrict__ ctl, const int32_t *__restrict__ holes,
+                const int64_t *__restrict__ fillers) {
+  if (ctl[3] == 0) return;
+  const int64_t length = *p_length, new_len = ctl[1], n_holes = ctl[2];
+  const int64_t t = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+  // threads [0, length - new_len): one tail slot each, and (if t < n_holes) one hole each
+  if (t < length - new_len) {
+    idx[new_len + t] = flag;
+    if (t < n_holes) idx[holes[t]] = fillers[t];
+  }
+}
+
+size_t sdm_compact_scratch(int64_t n) {
+  return carve_size(sizeof(int32_t) * (grid_for(n) + 1)) + carve_size(sizeof(int32_t) * n) +
+         carve_size(sizeof(int64_t) * n);
+}
+
+// p_length: device scalar with the current length; p_enable: optional device "healthy" word
+// (compaction runs only if *p_enable == 0); ctl[1] receives the new length.
+int sdm_compact_async(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity, int64_t *idx,
+                      const int64_t *p_length, int64_t length_bound, int64_t flag,
+                      const int64_t *p_enable, int64_t *ctl) {
+  if (length_bound <= 0) return SDM_OK;
+  Carver cv(scratch);
+  const int nb = (int)grid_for(length_bound);
+  int32_t *block_dead = cv.take<int32_t>(nb + 1);
+  int32_t *holes = cv.take<int32_t>(length_bound);
+  int64_t *fillers = cv.take<int64_t>(length_bound);
+  const dim3 grid(nb), block(SDM_BLOCK);
+  hipLaunchKernelGGL(k_compact_count, grid, block, 0, ctx->stream, multiplicity, idx, p_length,
+                     flag, p_enable, block_dead);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, ctx->stream, block_dead, nb, ctl,
+                     p_length, p_enable);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_compact_lists, grid, block, 0, ctx->stream, multiplicity, idx, p_length,
+                     flag, block_dead, ctl, holes, fillers);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_compact_apply, grid, block, 0, ctx->stream, idx, p_length, flag, ctl,
+                     holes, fillers);
+  LAUNCH_CHECK();
+  return SDM_OK;
+}
+
+extern "C" int sdm_remove_zero_n_or_flagged(sdm_ctx *ctx, const int64_t *multiplicity,
+                                            int64_t *idx, int64_t length, int64_t idx_len,
+                                            int64_t *new_length) {
+  ARG_TRY(ctx && new_length && length >= 0 && length <= idx_len && idx_len < INT32_MAX);
+  if (length == 0) { *new_length = 0; return SDM_OK; }
+  ARG_TRY(multiplicity && idx);
+  int rc = sdm_reserve(ctx, sdm_compact_scratch(length));
+  if (rc) return rc;
+  int64_t *ctl = ctx->dscal;
+  HIP_TRY(hipMemcpyAsync(ctl, &length, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  rc = sdm_compact_async(ctx, ctx->arena, multiplicity, idx, ctl, length, idx_len, nullptr, ctl);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->mailbox, ctl + 1, sizeof(int64_t), hipMemcpyDeviceToHost,
+                         ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *new_length = ctx->mailbox[0];
+  return SDM_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// counting sort by cell (collisions_methods.py:682-697): stable sort of idx[0:length) by
+// key = cell_idx[cell_id[idx[i]]]; cell_start = exclusive prefix of the key histogram.
+// One wavefront per tile: per-tile histograms -> column scan -> in-order scatter where equal
+// keys inside a 64-chunk are ranked with ballot-built peer masks.
+// ---------------------------------------------------------------------------------------
+#define SORT_TILE 1024
+
+__device__ __forceinline__ int64_t sort_key(const int64_t *__restrict__ idx,
+                                            const int64_t *__restrict__ cell_id,
+                                            const int64_t *__restrict__ cell_idx, int64_t i) {
+  return cell_idx[cell_id[idx[i]]];
+}
+
+__global__ void __launch_bounds__(SDM_WAVE)
+k_sort_hist(int32_t *__restrict__ H, const int64_t *__restrict__ idx,
+            const int64_t *__restrict__ cell_id, const int64_t *__restrict__ cell_idx,
+            const int64_t *__restrict__ p_length, int64_t n_cell, int64_t tile) {
+  const int64_t length = *p_length;
+  const int64_t first = (int64_t)blockIdx.x * tile;
+  int32_t *row = H + (int64_t)blockIdx.x * n_cell;
+  for (int64_t i = first + threadIdx.x; i < first + tile && i < length; i += SDM_WAVE)
+    atomicAdd(&row[sort_key(idx, cell_id, cell_idx, i)], 1);
+}
+
+// per key: exclusive scan down the tiles; totals -> count[c]
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_sort_colscan(int32_t *__restrict__ H, int64_t *__restrict__ count, int64_t n_cell, int nb) {
+  const int64_t c = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+  if (c >= n_cell) return;
+  int32_t run = 0;
+  for (int b = 0; b < nb; ++b) {
+    const int32_t t = H[(int64_t)b * n_cell + c];
+    H[(int64_t)b * n_cell + c] = run;
+    run += t;
+  }
+  count[c] = run;
+}
+
+// cell_start[0..n_cell] = exclusive scan of count (single block, chunked)
+__global__ void __launch_bounds__(1024)
+k_sort_cellstart(const int64_t *__restrict__ count, int64_t *__restrict__ cell_start,
+                 int64_t n_cell) {
+  __shared__ int64_t sm[1024];
+  __shared__ int64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n_cell; base += 1024) {
+    const int64_t c = base + threadIdx.x;
+    const int64_t v = c < n_cell ? count[c] : 0;
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int64_t t = threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
+      __syncthreads();
+      sm[threadIdx.x] += t;
+      __syncthreads();
+    }
+    const int64_t incl = sm[threadIdx.x];
+    if (c < n_cell) cell_start[c] = carry + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cell_start[n_cell] = carry;
+}
+
+__global__ void __launch_bounds__(SDM_WAVE)
+k_sort_scatter(int64_t *__restrict__ new_idx, int32_t *__restrict__ H,
+               const int64_t *__restrict__ idx, const int64_t *__restrict__ cell_id,
+               const int64_t *__restrict__ cell_idx, const int64_t *__restrict__ cell_start,
+               const int64_t *__restrict__ p_length, int64_t n_cell, int64_t tile, int key_bits) {
+  const int64_t length = *p_length;
+  const int64_t first = (int64_t)blockIdx.x * tile;
+  int32_t *row = H + (int64_t)blockIdx.x * n_cell;
+  const int lane = threadIdx.x;
+  for (int64_t base = first; base < first + tile && base < length; base += SDM_WAVE) {
+    const int64_t i = base + lane;
+    const bool in = i < first + tile && i < length;
+    const int64_t v = in ? idx[i] : 0;
+    const int64_t key = in ? cell_idx[cell_id[v]] : -1;
+    // peers = lanes holding the same key
+    unsigned long long peers = __ballot(in);
+    for (int b = 0; b < key_bits; ++b) {
+      const bool bit = (key >> b) & 1;
+      const unsigned long long m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    if (in) {
+      const int rank = __popcll(peers & ((1ull << lane) - 1));
+      const int leader = 63 - __clzll(peers);
+      int32_t basepos = 0;
+      if (lane == leader) basepos = atomicAdd(&row[key], __popcll(peers));
+      basepos = __shfl(basepos, leader, 64);
+      new_idx[cell_start[key] + basepos + rank] = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_sort_single_cell(int64_t *__restrict__ new_idx, const int64_t *__restrict__ idx,
+                   const int64_t *__restrict__ p_length, int64_t *__restrict__ cell_start) {
+  const int64_t length = *p_length;
+  const int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+  if (i < length) new_idx[i] = idx[i];
+  if (i == 0) { cell_start[0] = 0; cell_start[1] = length; }
+}
+
+static void sort_geometry(int64_t length_bound, int64_t n_cell, int64_t *tile, int *nb) {
+  // keep the tile-histogram matrix below 256 MiB
+  int64_t t = SORT_TILE;
+  const int64_t max_rows = (int64_t)(64 << 20) / (n_cell > 0 ? n_cell : 1);
+  while ((length_bound + t - 1) / t > (max_rows > 1 ? max_rows : 1)) t *= 2;
+  *tile = t;
+  *nb = (int)((length_bound + t - 1) / t);
+  if (*nb < 1) *nb = 1;
+}
+
+size_t sdm_sort_scratch(int64_t length_bound, int64_t n_cell) {
+  if (n_cell <= 1) return 256;
+  int64_t tile;
+  int nb;
+  sort_geometry(length_bound, n_cell, &tile, &nb);
+  return carve_size(sizeof(int32_t) * (size_t)nb * n_cell) + carve_size(sizeof(int64_t) * n_cell);
+}
+
+int sdm_counting_sort_async(sdm_ctx *ctx, char *scratch, int64_t *new_idx, const int64_t *idx,
+                            const int64_t *cell_id, const int64_t *cell_idx,
+                            const int64_t *p_length, int64_t length_bound, int64_t *cell_start,
+                            int64_t n_cell) {
+  if (n_cell == 1) {
+    hipLaunchKernelGGL(k_sort_single_cell, dim3(grid_for(length_bound)), dim3(SDM_BLOCK), 0,
+                       ctx->stream, new_idx, idx, p_length, cell_start);
+    LAUNCH_CHECK();
+    return SDM_OK;
+  }
+  int64_t tile;
+  int nb;
+  sort_geometry(length_bound, n_cell, &tile, &nb);
+  Carver cv(scratch);
+  int32_t *H = cv.take<int32_t>((size_t)nb * n_cell);
+  int64_t *count = cv.take<int64_t>(n_cell);
+  int key_bits = 1;
+  while ((1ll << key_bits) < n_cell) ++key_bits;
+  HIP_TRY(hipMemsetAsync(H, 0, sizeof(int32_t) * (size_t)nb * n_cell, ctx->stream));
+  hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(SDM_WAVE), 0, ctx->stream, H, idx, cell_id,
+                     cell_idx, p_length, n_cell, tile);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_sort_colscan, dim3(grid_for(n_cell)), dim3(SDM_BLOCK), 0, ctx->stream, H,
+                     count, n_cell, nb);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_sort_cellstart, dim3(1), dim3(1024), 0, ctx->stream, count, cell_start,
+                     n_cell);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(SDM_WAVE), 0, ctx->stream, new_idx, H, idx,
+                     cell_id, cell_idx, cell_start, p_length, n_cell, tile, key_bits);
+  LAUNCH_CHECK();
+  return SDM_OK;
+}
+
+extern "C" int sdm_counting_sort_by_cell_id(sdm_ctx *ctx, int64_t *new_idx, const int64_t *idx,
+                                            const int64_t *cell_id, const int64_t *cell_idx,
+                                            int64_t length, int64_t *cell_start,
+                                            int64_t n_cell) {
+  ARG_TRY(ctx && cell_start && n_cell >= 1 && length >= 0);
+  ARG_TRY(length == 0 || (new_idx && idx && cell_id && cell_idx));
+  int rc = sdm_reserve(ctx, sdm_sort_scratch(length, n_cell));
+  if (rc) return rc;
+  int64_t *p_length = ctx->dscal + 8;
+  HIP_TRY(hipMemcpyAsync(p_length, &length, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  return sdm_counting_sort_async(ctx, ctx->arena, new_idx, idx, cell_id, cell_idx, p_length,
+                                 length > 0 ? length : 1, cell_start, n_cell);
+}
+
+// ---------------------------------------------------------------------------------------
+// cell_id = strides . cell_origin  (collisions_methods.py:407-416)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_cell_id(int64_t *__restrict__ cell_id, const int64_t *__restrict__ cell_origin,
+          const int64_t *__restrict__ strides, int64_t n_dim, int64_t n_sd) {
+  const int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+  if (i >= n_sd) return;
+  int64_t s = 0;
+  for (int64_t d = 0; d < n_dim; ++d) s += strides[d] * cell_origin[d * n_sd + i];
+  cell_id[i] = s;
+}
+
+extern "C" int sdm_cell_id(sdm_ctx *ctx, int64_t *cell_id, const int64_t *cell_origin,
+                           const int64_t *strides, int64_t n_dim, int64_t n_sd) {
+  ARG_TRY(ctx && n_sd >= 0 && n_dim >= 1 && (n_sd == 0 || (cell_id && cell_origin && strides)));
+  if (n_sd == 0) return SDM_OK;
+  hipLaunchKernelGGL(k_cell_id, dim3(grid_for(n_sd)), dim3(SDM_BLOCK), 0, ctx->stream, cell_id,
+                     cell_origin, strides, n_dim, n_sd);
+  LAUNCH_CHECK();
+  return SDM_OK;
+}

@@ -1,0 +1,624 @@
+"""The SDM collision / coalescence / breakup dynamic and its pluggable parts.
+
+Host-side mirror of PySDM/dynamics/collisions/collision.py:41-349 (`Collision`, `Coalescence`,
+`Breakup`), .../collision_kernels/{golovin.py:14-16, geometric.py:15-22, constantK.py},
+.../coalescence_efficiencies/{constEc.py, berry1967.py, _parameterized.py:17-25,
+straub2010.py:27-50}, .../breakup_efficiencies/constEb.py,
+.../breakup_fragmentations/{always_n.py, exponential.py:23-37, straub2010.py:42-101,
+impl/volume_based.py:10-17} and PySDM/dynamics/impl/random_generator_optimizer*.py.
+
+Two execution routes, both on the backend's device code:
+  * the method-by-method route: the chain of backend calls the reference makes;
+  * the fused route (`backend.collision_step`, one C call per time step) taken when the backend
+    offers it and every plugged part has a device-side descriptor (`fused_descriptor`).
+"""
+import math
+import warnings
+from collections import namedtuple
+
+import numpy as np
+
+from ..attributes import Multiplicity
+from ..physics import constants as const
+from ..physics.constants import si
+
+DEFAULTS = namedtuple("_", ("dt_coal_range", "adaptive", "substeps", "max_multiplicity"))(
+    dt_coal_range=(0.1 * si.second, 100.0 * si.second),
+    adaptive=True,
+    substeps=1,
+    max_multiplicity=Multiplicity.MAX_VALUE // int(2e5),
+)
+
+
+# ---- random-number reuse helpers ------------------------------------------------------------
+class RandomGeneratorOptimizer:  # pylint: disable=too-many-instance-attributes
+    """one generator feeding `pairs_rand` (n_sd [+ shift]) then `rand` (n_sd // 2) per draw;
+    with `optimized_random` one draw per time step and a window sliding by one per sub-step"""
+
+    PAIRS = True
+
+    def __init__(self, optimized_random, dt_min, seed):
+        self.particulator = None
+        self.optimized_random = optimized_random
+        self.dt_min = dt_min
+        self.seed = seed
+        self.substep = 0
+        self.pairs_rand = None
+        self.rand = None
+        self.rnd = None
+
+    def register(self, builder):
+        self.particulator = builder.particulator
+        n_sd = self.particulator.n_sd
+        shift = math.ceil(self.particulator.dt / self.dt_min) if self.optimized_random else 0
+        if self.PAIRS:
+            self.pairs_rand = self.particulator.Storage.empty(n_sd + shift, dtype=float)
+        self.rand = self.particulator.Storage.empty(n_sd // 2, dtype=float)
+        self.rnd = self.particulator.Random(n_sd + shift, self.seed)
+
+    def reset(self):
+        self.substep = 0
+
+    def get_random_arrays(self):
+        if not self.optimized_random or self.substep == 0:
+            if self.PAIRS:
+                self.pairs_rand.urand(self.rnd)
+            self.rand.urand(self.rnd)
+        shift = self.substep if self.optimized_random else 0
+        self.substep += 1
+        if not self.PAIRS:
+            return self.rand
+        return self.pairs_rand[shift : self.particulator.n_sd + shift], self.rand
+
+
+class RandomGeneratorOptimizerNoPair(RandomGeneratorOptimizer):
+    PAIRS = False
+
+
+# ---- collision kernels ----------------------------------------------------------------------
+class Golovin:
+    def __init__(self, b):
+        self.b = b
+        self.particulator = None
+
+    def register(self, builder):
+        self.particulator = builder.particulator
+        builder.request_attribute("volume")
+
+    def __call__(self, output, is_first_in_pair):
+        output.sum(self.particulator.attributes["volume"], is_first_in_pair)
+        output *= self.b
+
+    def fused_descriptor(self):
+        return {"kernel": 0, "kernel_param": (float(self.b), 0.0)}
+
+
+class ConstantK:
+    def __init__(self, a):
+        self.a = a
+        self.particulator = None
+
+    def register(self, builder):
+        self.particulator = builder.particulator
+
+    def __call__(self, output, is_first_in_pair):
+        output.fill(self.a)
+
+    def fused_descriptor(self):
+        return None  # fill() also covers pair-less slots: keep the method-by-method route
+
+
+class Geometric:
+    def __init__(self, collection_efficiency=1.0, x="volume"):
+        self.collection_efficiency = collection_efficiency
+        self.x = x
+        self.particulator = None
+        self.pair_tmp = None
+
+    def register(self, builder):
+        self.particulator = builder.particulator
+        builder.request_attribute("radius")
+        builder.request_attribute("relative fall velocity")
+        self.pair_tmp = self.particulator.PairwiseStorage.empty(
+            self.particulator.n_sd // 2, dtype=float
+        )
+
+    def __call__(self, output, is_first_in_pair):
+        output.sum(self.particulator.attributes["radius"], is_first_in_pair)
+        output **= 2
+        output *= const.PI * self.collection_efficiency
+        self.pair_tmp.distance(
+            self.particulator.attributes["relative fall velocity"], is_first_in_pair
+        )
+        output *= self.pair_tmp
+
+    def fused_descriptor(self):
+        return {"kernel": 1, "kernel_param": (const.PI * self.collection_efficiency, 0.0),
+                "needs_gk": True}
+
+
+# ---- efficiencies ---------------------------------------------------------------------------
+class ConstEc:
+    def __init__(self, Ec=1.0):
+        self.Ec = Ec
+        self.particulator = None
+
+    def register(self, builder):
+        self.particulator = builder.particulator
+
+    def __call__(self, output, is_first_in_pair):
+        output.fill(self.Ec)
+
+    def fused_descriptor(self):
+        return {"ec": 0, "ec_param": (float(self.Ec), 0.0)}
+
+
+class ConstEb:
+    def __init__(self, Eb=1.0):
+        self.Eb = Eb
+        self.particulator = None
+
+    def register(self, builder):
+        self.particulator = builder.particulator
+
+    def __call__(self, output, is_first_in_pair):
+        output.fill(self.Eb)
+
+    def fused_descriptor(self):
+        return {"eb_const": float(self.Eb)}
+
+
+class Parameterized:
+    def __init__(self, params):
+        self.particulator = None
+        self.params = params
+
+    def register(self, builder):
+        self.particulator = builder.particulator
+        builder.request_attribute("radius")
+
+    def __call__(self, output, is_first_in_pair):
+        self.particulator.backend.linear_collection_efficiency(
+            params=self.params,
+            output=output,
+            radii=self.particulator.attributes["radius"],
+            is_first_in_pair=is_first_in_pair,
+            unit=si.um,
+        )
+        output **= 2
+
+    def fused_descriptor(self):
+        return {"ec": 1, "berry_params": tuple(float(p) for p in self.params),
+                "berry_unit": si.um}
+
+
+class Berry1967(Parameterized):  # pylint: disable=too-few-public-methods
+    def __init__(self):
+        super().__init__((1, 1, -27, 1.65, -58, 1.9, 15, 1.13, 16.7, 1, 0.004, 4, 8))
+
+
+class Straub2010Ec:
+    def __init__(self):
+        self.particulator = None
+        self.arrays = {}
+        self.const = None
+
+    def register(self, builder):
+        self.particulator = builder.particulator
+        self.const = self.particulator.formulae.constants
+        builder.request_attribute("volume")
+        builder.request_attribute("relative fall velocity")
+        for key in ("Sc", "tmp", "tmp2", "We"):
+            self.arrays[key] = self.particulator.PairwiseStorage.empty(
+                self.particulator.n_sd // 2, dtype=float
+            )
+
+    def __call__(self, output, is_first_in_pair):
+        arr, attrs = self.arrays, self.particulator.attributes
+        arr["tmp"].sum(attrs["volume"], is_first_in_pair)
+        arr["Sc"].fill(arr["tmp"])
+        arr["Sc"] *= 6 / self.const.PI
+        arr["tmp"] *= 2
+        arr["tmp2"].distance(attrs["relative fall velocity"], is_first_in_pair)
+        arr["tmp2"] **= 2
+        arr["We"].multiply(attrs["volume"], is_first_in_pair)
+        arr["We"].divide_if_not_zero(arr["tmp"])
+        arr["We"] *= arr["tmp2"]
+        arr["We"] *= self.const.rho_w
+        arr["Sc"] **= 2 / 3
+        arr["Sc"] *= self.const.PI * self.const.sgm_w
+        arr["We"].divide_if_not_zero(arr["Sc"])
+        arr["We"] *= -1.15
+        arr["We"].exp()
+        output.fill(arr["We"])
+
+    def fused_descriptor(self):
+        return {"ec": 2, "needs_gk": True}
+
+
+# ---- fragmentation functions ----------------------------------------------------------------
+class AlwaysN:
+    def __init__(self, n):
+        self.particulator = None
+        self.N = n
+
+    def register(self, builder):
+        self.particulator = builder.particulator
+
+    def __call__(self, nf, frag_mass, u01, is_first_in_pair):
+        nf.fill(self.N)
+        frag_mass.sum(self.particulator.attributes["water mass"], is_first_in_pair)
+        frag_mass /= self.N
+
+    def fused_descriptor(self):
+        return {"frag": 0, "frag_param": (float(self.N), 0.0)}
+
+
+class VolumeBasedFragmentationFunction:
+    def __init__(self):
+        self.particulator = None
+
+    def register(self, builder):
+        self.particulator = builder.particulator
+        builder.request_attribute("volume")
+
+    def __call__(self, nf, frag_mass, u01, is_first_in_pair):
+        # volumes are written into the mass array, then converted in place
+        self.compute_fragment_number_and_volumes(nf, frag_mass, u01, is_first_in_pair)
+        self.particulator.backend.mass_of_water_volume(frag_mass, frag_mass)
+
+    def compute_fragment_number_and_volumes(self, nf, frag_volume, u01, is_first_in_pair):
+        raise NotImplementedError()
+
+
+class Exponential(VolumeBasedFragmentationFunction):
+    def __init__(self, scale, vmin=0.0, nfmax=None):
+        super().__init__()
+        self.scale = scale
+        self.vmin = vmin
+        self.nfmax = nfmax
+        self.sum_of_volumes = None
+
+    def register(self, builder):
+        super().register(builder)
+        self.sum_of_volumes = self.particulator.PairwiseStorage.empty(
+            self.particulator.n_sd // 2, dtype=float
+        )
+
+    def compute_fragment_number_and_volumes(self, nf, frag_volume, u01, is_first_in_pair):
+        self.sum_of_volumes.sum(self.particulator.attributes["volume"], is_first_in_pair)
+        self.particulator.backend.exp_fragmentation(
+            n_fragment=nf,
+            scale=self.scale,
+            frag_volume=frag_volume,
+            x_plus_y=self.sum_of_volumes,
+            rand=u01,
+            vmin=self.vmin,
+            nfmax=self.nfmax,
+        )
+
+    def fused_descriptor(self):
+        return {"frag": 1, "frag_param": (float(self.scale), 0.0), "frag_vmin": float(self.vmin),
+                "frag_nfmax": -1.0 if self.nfmax is None else float(self.nfmax)}
+
+
+class Straub2010Nf(VolumeBasedFragmentationFunction):
+    # pylint: disable=too-many-instance-attributes
+    def __init__(self, vmin=0.0, nfmax=None):
+        super().__init__()
+        self.vmin = vmin
+        self.nfmax = nfmax
+        self.arrays = {}
+        self.straub_tmp = {}
+        self.max_size = None
+        self.sum_of_volumes = None
+        self.const = None
+
+    def register(self, builder):
+        super().register(builder)
+        pairwise = self.particulator.PairwiseStorage
+        n_pairs = self.particulator.n_sd // 2
+        self.max_size = pairwise.empty(n_pairs, dtype=float)
+        self.sum_of_volumes = pairwise.empty(n_pairs, dtype=float)
+        self.const = self.particulator.formulae.constants
+        builder.request_attribute("radius")
+        builder.request_attribute("relative fall velocity")
+        for key in ("Sc", "tmp", "tmp2", "CKE", "We", "gam", "CW", "ds"):
+            self.arrays[key] = pairwise.empty(n_pairs, dtype=float)
+        for key in ("Nr1", "Nr2", "Nr3", "Nr4", "Nrt", "d34"):
+            self.straub_tmp[key] = pairwise.empty(n_pairs, dtype=float)
+
+    def sc_factor(self):
+        return self.const.PI * self.const.sgm_w * (6 / self.const.PI) ** (2 / 3)
+
+    def compute_fragment_number_and_volumes(self, nf, frag_volume, u01, is_first_in_pair):
+        arr, attrs = self.arrays, self.particulator.attributes
+        self.max_size.max(attrs["volume"], is_first_in_pair)
+        self.sum_of_volumes.sum(attrs["volume"], is_first_in_pair)
+        arr["ds"].min(attrs["radius"], is_first_in_pair)
+        arr["ds"] *= 2
+        # dimensionless numbers; CW = CKE * We
+        arr["tmp"].sum(attrs["volume"], is_first_in_pair)
+        arr["Sc"].fill(arr["tmp"])
+        arr["Sc"] **= 2 / 3
+        arr["Sc"] *= self.sc_factor()
+        arr["tmp2"].distance(attrs["relative fall velocity"], is_first_in_pair)
+        arr["tmp2"] **= 2
+        arr["CKE"].multiply(attrs["volume"], is_first_in_pair)
+        arr["CKE"].divide_if_not_zero(arr["tmp"])
+        arr["CKE"] *= arr["tmp2"]
+        arr["CKE"] *= self.const.rho_w / 2
+        arr["We"].fill(arr["CKE"])
+        arr["We"].divide_if_not_zero(arr["Sc"])
+        arr["CW"].fill(arr["We"])
+        arr["CW"] *= arr["CKE"]
+        arr["CW"] /= si.uJ
+        arr["gam"].max(attrs["radius"], is_first_in_pair)
+        arr["tmp"].min(attrs["radius"], is_first_in_pair)
+        arr["gam"].divide_if_not_zero(arr["tmp"])
+        for key in ("Nr1", "Nr2", "Nr3", "Nr4", "Nrt"):
+            self.straub_tmp[key].fill(0)
+        self.particulator.backend.straub_fragmentation(
+            n_fragment=nf, CW=arr["CW"], gam=arr["gam"], ds=arr["ds"], frag_volume=frag_volume,
+            v_max=self.max_size, x_plus_y=self.sum_of_volumes, rand=u01, vmin=self.vmin,
+            nfmax=self.nfmax, **self.straub_tmp,
+        )
+
+    def fused_descriptor(self):
+        return {"frag": 2, "frag_param": (0.0, self.sc_factor()), "frag_vmin": float(self.vmin),
+                "frag_nfmax": -1.0 if self.nfmax is None else float(self.nfmax),
+                "needs_gk": True}
+
+
+# ---- the dynamic ----------------------------------------------------------------------------
+class Collision:  # pylint: disable=too-many-instance-attributes
+    DYNAMIC_KEY = "Collision"
+
+    def __init__(self, *, collision_kernel, coalescence_efficiency, breakup_efficiency,
+                 fragmentation_function, croupier=None, optimized_random=False,
+                 substeps: int = DEFAULTS.substeps, adaptive: bool = DEFAULTS.adaptive,
+                 dt_coal_range=DEFAULTS.dt_coal_range, enable_breakup: bool = True,
+                 warn_overflows: bool = True, fused=None):
+        assert substeps == 1 or adaptive is False
+        assert dt_coal_range[0] > 0
+        self.particulator = None
+        self.enable = True
+        self.enable_breakup = enable_breakup
+        self.warn_overflows = warn_overflows
+        self.max_multiplicity = DEFAULTS.max_multiplicity
+        self.collision_kernel = collision_kernel
+        self.compute_coalescence_efficiency = coalescence_efficiency
+        self.compute_breakup_efficiency = breakup_efficiency
+        self.compute_number_of_fragments = fragmentation_function
+        self.rnd_opt_frag = self.rnd_opt_coll = self.rnd_opt_proc = None
+        self.croupier = croupier
+        self.optimized_random = optimized_random
+        self.__substeps = substeps
+        self.adaptive = adaptive
+        self.dt_coal_range = tuple(dt_coal_range)
+        self.fused = fused  # None: use the fused route when available; False: never
+        self._fused_state = None
+        for name in ("stats_n_substep", "stats_dt_min", "kernel_temp", "n_fragment",
+                     "fragment_mass", "Ec_temp", "Eb_temp", "norm_factor_temp", "gamma",
+                     "is_first_in_pair", "dt_left", "collision_rate", "collision_rate_deficit",
+                     "coalescence_rate", "breakup_rate", "breakup_rate_deficit"):
+            setattr(self, name, None)
+
+    @property
+    def substeps(self):
+        return self.__substeps
+
+    def register(self, builder):
+        part = self.particulator = builder.particulator
+        rnd_args = {"optimized_random": self.optimized_random, "dt_min": self.dt_coal_range[0],
+                    "seed": builder.formulae.seed}
+        self.rnd_opt_coll = RandomGeneratorOptimizer(**rnd_args)
+        if self.enable_breakup:
+            self.rnd_opt_proc = RandomGeneratorOptimizerNoPair(**rnd_args)
+            self.rnd_opt_frag = RandomGeneratorOptimizerNoPair(**rnd_args)
+        if part.n_sd < 2:
+            raise ValueError("No one to collide with!")
+        if self.dt_coal_range[1] > part.dt:
+            self.dt_coal_range = (self.dt_coal_range[0], part.dt)
+        assert self.dt_coal_range[0] <= self.dt_coal_range[1]
+
+        n_pairs, n_cell = part.n_sd // 2, part.mesh.n_cell
+
+        def pairwise():
+            return part.PairwiseStorage.empty(n_pairs, dtype=float)
+
+        def counter():
+            return part.Storage.from_ndarray(np.zeros(n_cell, dtype=int))
+
+        self.kernel_temp = pairwise()
+        self.norm_factor_temp = part.Storage.empty(n_cell, dtype=float)
+        self.gamma = pairwise()
+        self.is_first_in_pair = part.PairIndicator(part.n_sd)
+        self.dt_left = part.Storage.empty(n_cell, dtype=float)
+        self.stats_n_substep = part.Storage.empty(n_cell, dtype=int)
+        self.stats_n_substep[:] = 0 if self.adaptive else self.__substeps
+        self.stats_dt_min = part.Storage.empty(n_cell, dtype=float)
+        self.stats_dt_min[:] = np.nan
+        self.rnd_opt_coll.register(builder)
+        self.collision_kernel.register(builder)
+        if self.croupier is None:
+            self.croupier = part.backend.default_croupier
+        self.collision_rate = counter()
+        self.collision_rate_deficit = counter()
+        self.coalescence_rate = counter()
+        if self.enable_breakup:
+            self.n_fragment = pairwise()
+            self.fragment_mass = pairwise()
+            self.Ec_temp = pairwise()
+            self.Eb_temp = pairwise()
+            self.rnd_opt_proc.register(builder)
+            self.rnd_opt_frag.register(builder)
+            self.compute_coalescence_efficiency.register(builder)
+            self.compute_breakup_efficiency.register(builder)
+            self.compute_number_of_fragments.register(builder)
+            self.breakup_rate = counter()
+            self.breakup_rate_deficit = counter()
+
+    # -- fused route --------------------------------------------------------------------------
+    def fused_config(self):
+        """device-side description of this dynamic, or None if some part has none"""
+        parts = [self.collision_kernel]
+        if self.enable_breakup:
+            parts += [self.compute_coalescence_efficiency, self.compute_breakup_efficiency,
+                      self.compute_number_of_fragments]
+        cfg = {}
+        for part in parts:
+            desc = part.fused_descriptor() if hasattr(part, "fused_descriptor") else None
+            if desc is None:
+                return None
+            cfg["needs_gk"] = cfg.get("needs_gk", False) or desc.pop("needs_gk", False)
+            cfg.update(desc)
+        return cfg
+
+    def _use_fused(self):
+        if self.fused is False or not hasattr(self.particulator.backend, "collision_step"):
+            return False
+        if self._fused_state is None:
+            cfg = self.fused_config()
+            self._fused_state = (
+                False if cfg is None else self.particulator.backend.make_collision_step(self, cfg)
+            )
+        return self._fused_state is not False
+
+    def __call__(self):
+        if not self.enable:
+            return
+        if self._use_fused():
+            self.particulator.backend.collision_step(self._fused_state)
+            return
+        attributes = self.particulator.attributes
+        if not self.adaptive:
+            for _ in range(self.__substeps):
+                self.step()
+        else:
+            self.dt_left[:] = self.particulator.dt
+            while attributes.get_working_length() != 0:
+                attributes.cell_idx.sort_by_key(self.dt_left)
+                self.step()
+                attributes.cut_working_length(self.particulator.adaptive_sdm_end(self.dt_left))
+            attributes.reset_working_length()
+            attributes.reset_cell_idx()
+        self.rnd_opt_coll.reset()
+        if self.enable_breakup:
+            self.rnd_opt_proc.reset()
+            self.rnd_opt_frag.reset()
+
+    def step(self):
+        pairs_rand, rand = self.rnd_opt_coll.get_random_arrays()
+        self.toss_candidate_pairs_and_sort_within_pair_by_multiplicity(
+            self.is_first_in_pair, pairs_rand
+        )
+        prob = self.gamma
+        self.compute_probabilities_of_collision(self.is_first_in_pair, out=prob)
+        proc_rand = None
+        if self.enable_breakup:
+            proc_rand = self.rnd_opt_proc.get_random_arrays()
+            rand_frag = self.rnd_opt_frag.get_random_arrays()
+            self.compute_coalescence_efficiency(self.Ec_temp, self.is_first_in_pair)
+            self.compute_breakup_efficiency(self.Eb_temp, self.is_first_in_pair)
+            self.compute_number_of_fragments(
+                self.n_fragment, self.fragment_mass, rand_frag, self.is_first_in_pair
+            )
+        self.compute_gamma(prob=prob, rand=rand, is_first_in_pair=self.is_first_in_pair,
+                           out=self.gamma)
+        self.particulator.collision_coalescence_breakup(
+            enable_breakup=self.enable_breakup,
+            gamma=self.gamma,
+            rand=proc_rand,
+            Ec=self.Ec_temp,
+            Eb=self.Eb_temp,
+            fragment_mass=self.fragment_mass,
+            coalescence_rate=self.coalescence_rate,
+            breakup_rate=self.breakup_rate,
+            breakup_rate_deficit=self.breakup_rate_deficit,
+            is_first_in_pair=self.is_first_in_pair,
+            warn_overflows=self.warn_overflows,
+            max_multiplicity=self.max_multiplicity,
+        )
+
+    def toss_candidate_pairs_and_sort_within_pair_by_multiplicity(self, is_first_in_pair, u01):
+        attributes = self.particulator.attributes
+        attributes.permutation(u01, self.croupier == "local")
+        is_first_in_pair.update(attributes.cell_start, attributes.cell_idx, attributes["cell id"])
+        self.particulator.sort_within_pair_by_attr(is_first_in_pair, attr_name="multiplicity")
+
+    def compute_probabilities_of_collision(self, is_first_in_pair, out):
+        """eq. (20) of Shima et al. 2009"""
+        self.collision_kernel(self.kernel_temp, is_first_in_pair)
+        out.max(self.particulator.attributes["multiplicity"], is_first_in_pair)
+        out *= self.kernel_temp
+        self.particulator.normalize(out, self.norm_factor_temp)
+
+    def compute_gamma(self, prob, rand, is_first_in_pair, out):
+        attributes = self.particulator.attributes
+        if self.adaptive:
+            self.particulator.backend.scale_prob_for_adaptive_sdm_gamma(
+                prob=prob,
+                multiplicity=attributes["multiplicity"],
+                cell_id=attributes["cell id"],
+                dt_left=self.dt_left,
+                dt=self.particulator.dt,
+                dt_range=self.dt_coal_range,
+                is_first_in_pair=is_first_in_pair,
+                stats_n_substep=self.stats_n_substep,
+                stats_dt_min=self.stats_dt_min,
+            )
+            if self.stats_dt_min.amin() == self.dt_coal_range[0]:
+                warnings.warn("adaptive time-step reached dt_min")
+        else:
+            prob /= self.__substeps
+        self.particulator.backend.compute_gamma(
+            prob=prob,
+            rand=rand,
+            multiplicity=attributes["multiplicity"],
+            cell_id=attributes["cell id"],
+            collision_rate_deficit=self.collision_rate_deficit,
+            collision_rate=self.collision_rate,
+            is_first_in_pair=is_first_in_pair,
+            out=out,
+        )
+
+
+class Coalescence(Collision):
+    def __init__(self, *, collision_kernel, coalescence_efficiency=None, croupier=None,
+                 optimized_random=False, substeps: int = DEFAULTS.substeps,
+                 adaptive: bool = DEFAULTS.adaptive, dt_coal_range=DEFAULTS.dt_coal_range,
+                 fused=None):
+        super().__init__(
+            collision_kernel=collision_kernel,
+            coalescence_efficiency=coalescence_efficiency or ConstEc(Ec=1),
+            breakup_efficiency=ConstEb(Eb=0),
+            fragmentation_function=AlwaysN(n=1),
+            croupier=croupier,
+            optimized_random=optimized_random,
+            substeps=substeps,
+            adaptive=adaptive,
+            dt_coal_range=dt_coal_range,
+            enable_breakup=False,
+            fused=fused,
+        )
+
+
+class Breakup(Collision):
+    def __init__(self, *, collision_kernel, fragmentation_function, croupier=None,
+                 optimized_random=False, substeps: int = DEFAULTS.substeps,
+                 adaptive: bool = DEFAULTS.adaptive, dt_coal_range=DEFAULTS.dt_coal_range,
+                 warn_overflows=True, fused=None):
+        super().__init__(
+            collision_kernel=collision_kernel,
+            coalescence_efficiency=ConstEc(Ec=0.0),
+            breakup_efficiency=ConstEb(Eb=1.0),
+            fragmentation_function=fragmentation_function,
+            croupier=croupier,
+            optimized_random=optimized_random,
+            substeps=substeps,
+            adaptive=adaptive,
+            dt_coal_range=dt_coal_range,
+            warn_overflows=warn_overflows,
+            fused=fused,
+        )

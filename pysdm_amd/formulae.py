@@ -1,0 +1,78 @@
+"""`Formulae`: the options + constants object a backend is constructed with.
+
+Collision-path subset of PySDM/formulae.py:27-67 (same keyword names: `seed`, `constants`,
+`terminal_velocity`, `fragmentation_function`, `handle_all_breakups`,
+`particle_shape_and_density`); everything unrelated to the path is absent.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+
+from .physics import constants as _const
+
+
+class _Trivia:  # PySDM/physics/trivia.py:19-28
+    @staticmethod
+    def volume(radius):
+        return _const.PI_4_3 * np.power(radius, 3)
+
+    @staticmethod
+    def radius(volume):
+        return np.power(volume / _const.PI_4_3, _const.ONE_THIRD)
+
+
+class _LiquidSpheres:  # PySDM/physics/particle_shape_and_density/liquid_spheres.py:9-23
+    __name__ = "LiquidSpheres"
+
+    @staticmethod
+    def supports_mixed_phase(_=None):
+        return False
+
+    @staticmethod
+    def mass_to_volume(mass):
+        return mass / _const.rho_w
+
+    @staticmethod
+    def volume_to_mass(volume):
+        return _const.rho_w * volume
+
+
+class Formulae:  # pylint: disable=too-few-public-methods,too-many-arguments
+    def __init__(
+        self,
+        *,
+        constants=None,
+        seed=None,
+        fastmath=True,
+        fragmentation_function="AlwaysN",
+        particle_shape_and_density="LiquidSpheres",
+        terminal_velocity="GunnKinzer1949",
+        handle_all_breakups=False,
+    ):
+        if particle_shape_and_density != "LiquidSpheres":
+            raise NotImplementedError(particle_shape_and_density)
+        if terminal_velocity != "GunnKinzer1949":
+            raise NotImplementedError(terminal_velocity)
+        values = {
+            k: getattr(_const, k)
+            for k in dir(_const)
+            if not k.startswith("_") and isinstance(getattr(_const, k), (int, float))
+        }
+        values.update(constants or {})
+        self.constants = SimpleNamespace(**values)
+        self.seed = seed or _const.default_random_seed
+        self.fastmath = fastmath
+        self.fragmentation_function = fragmentation_function
+        self.handle_all_breakups = handle_all_breakups
+        self.trivia = _Trivia()
+        self.particle_shape_and_density = _LiquidSpheres()
+        self.terminal_velocity = terminal_velocity
+
+    @property
+    def terminal_velocity_class(self):
+        from .dynamics.terminal_velocity import GunnKinzer1949  # pylint: disable=import-outside-toplevel
+
+        return GunnKinzer1949
+
+    def __str__(self):
+        return f"Formulae(seed={self.seed}, fragmentation_function={self.fragmentation_function})"

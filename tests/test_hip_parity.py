@@ -1,0 +1,58 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the goldens recorded from the
+reference and against the oracle on the same seeded inputs.  Integer state bit-exact; floating
+point bit-exact on the coalescence-only paths, 1e-12 relative where device transcendentals
+(OCML pow/log/exp...) feed attributes (breakup)."""
+import numpy as np
+import pytest
+
+from . import micro_cases as mc
+from .trajectory import golden_files, run_and_compare, setup_from_golden, snapshot
+
+pytestmark = pytest.mark.gpu
+
+EXACT_ON_GPU = {"volume", "golovin", "frag_always_n_4"}
+
+
+@pytest.fixture(scope="module", name="kit")
+def kit_fixture(hip_backend_class):
+    return mc.Kit(hip_backend_class, fragmentation_function="Straub2010Nf")
+
+
+@pytest.mark.parametrize("check", [mc.check_pcg64, mc.check_shuffle,
+                                   mc.check_shuffle_known_answers, mc.check_counting_sort,
+                                   mc.check_sort_by_key_and_adaptive_end, mc.check_remove_zero,
+                                   mc.check_pair_chain])
+def test_method_goldens(check, kit):
+    check(kit)
+
+
+def test_physics_goldens(kit):
+    mc.check_physics(kit, exact=EXACT_ON_GPU, rtol=1e-13)
+
+
+COALESCENCE = (golden_files("traj_golovin_*.npz") + golden_files("traj_geometric_*.npz")
+               + golden_files("traj_multicell_*.npz"))
+
+
+@pytest.mark.parametrize("fused", [False, None], ids=["methods", "fused"])
+@pytest.mark.parametrize("name", COALESCENCE)
+def test_coalescence_trajectories_bit_exact(name, fused, hip_backend_class):
+    run_and_compare(name, hip_backend_class, fused=fused)
+
+
+@pytest.mark.parametrize("fused", [False, None], ids=["methods", "fused"])
+@pytest.mark.parametrize("name", golden_files("traj_breakup_*.npz"))
+def test_breakup_trajectories(name, fused, hip_backend_class):
+    run_and_compare(name, hip_backend_class, fused=fused, float_rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["traj_golovin_n4096_s44_a1", "traj_multicell_geometric_4x4"])
+def test_fused_equals_oracle_beyond_goldens(name, hip_backend_class, oracle_backend_class):
+    """same seeded inputs, more steps than the goldens hold"""
+    snaps = []
+    for backend_class in (hip_backend_class, oracle_backend_class):
+        particulator, dynamic, _, _ = setup_from_golden(name, backend_class)
+        particulator.run(120)
+        snaps.append(snapshot(particulator, dynamic))
+    for key, value in snaps[0].items():
+        np.testing.assert_array_equal(value, snaps[1][key], err_msg=key)
