@@ -154,7 +154,7 @@ class StorageBase:
         return raw_element
 
     def __setitem__(self, key, value):
-        self._assign_raw(self.data, key, value.data if hasattr(value, "data") else value)
+        self._assign_raw(self.data, key, value.data if isinstance(value, StorageBase) else value)
         return self
 
     # ---- in-place arithmetic (storage.py:63-109) -----------------------------------------------
@@ -178,14 +178,14 @@ class StorageBase:
         return self
 
     def __imul__(self, other):
-        if hasattr(other, "data"):
+        if isinstance(other, StorageBase):
             self._ew(EW_MUL, self.data, other.data)
         else:
             self._ew(EW_MUL, self.data, None, other)
         return self
 
     def __itruediv__(self, other):
-        if hasattr(other, "data"):
+        if isinstance(other, StorageBase):
             self._ew(EW_DIV, self.data, other.data)
         else:
             self._ew(EW_DIV, self.data, None, other)
@@ -226,7 +226,7 @@ class StorageBase:
         return self
 
     def product(self, multiplicand, multiplier):
-        if hasattr(multiplier, "data"):
+        if isinstance(multiplier, StorageBase):
             self._ew(EW_MUL, multiplicand.data, multiplier.data)
         else:
             self._ew(EW_MUL, multiplicand.data, None, multiplier)

@@ -569,12 +569,15 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
     }
     u01 = S.pairs_rand + (cfg->optimized_random ? n_sub : 0);
     // (d) permutation (particle_attributes.py:98-105)
-    rc = sdm_shuffle_async(ctx, S.shuffle, alt, cur, u01, st->cell_start, C, st->ctl + CTL_WORK,
-                           N, !cfg->croupier_local);
+    // shuffle_local visits every cell of cell_start, also those beyond a cut working length
+    // (index_methods.py:35); shuffle_global covers the working length (index.py:43-45)
+    const int64_t *p_shuffle_len = cfg->croupier_local ? st->cell_start + C : st->ctl + CTL_WORK;
+    rc = sdm_shuffle_async(ctx, S.shuffle, alt, cur, u01, st->cell_start, C, p_shuffle_len, N,
+                           !cfg->croupier_local);
     if (rc) return rc;
     // positions beyond the working length keep their content: the shuffle core writes only
     // [0, work) of `alt`, so carry the rest over
-    hipLaunchKernelGGL(k_copy_tail, dim3(grid_for(N)), blk, 0, s, alt, cur, st->ctl + CTL_WORK, N);
+    hipLaunchKernelGGL(k_copy_tail, dim3(grid_for(N)), blk, 0, s, alt, cur, p_shuffle_len, N);
     LAUNCH_CHECK();
     { int64_t *t = cur; cur = alt; alt = t; }
     ++swaps;

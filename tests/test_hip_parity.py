@@ -54,5 +54,9 @@ def test_fused_equals_oracle_beyond_goldens(name, hip_backend_class, oracle_back
         particulator, dynamic, _, _ = setup_from_golden(name, backend_class)
         particulator.run(120)
         snaps.append(snapshot(particulator, dynamic))
+    length = int(snaps[0]["length"])
     for key, value in snaps[0].items():
-        np.testing.assert_array_equal(value, snaps[1][key], err_msg=key)
+        ref = snaps[1][key]
+        if key == "idx":  # beyond `length`: dead storage (see trajectory.compare)
+            value, ref = value[:length], ref[:length]
+        np.testing.assert_array_equal(value, ref, err_msg=key)
