@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the SDM collision hot path on MI355X.
+
+A "step" is one `Collision.__call__` (one time step of the Shima-2009 box: PCG64 draws, pair
+permutation, Golovin probabilities, gamma, multiplicity/attribute update, compaction) over the
+whole super-droplet population, state resident in HBM.  Metric (BASELINE.json): candidate
+super-droplet pairs per second; with --gpus N every rank runs an independent realisation of the
+box (the 0-D box has a single cell: "replicas only", no data-path collective) and rank 0 reports
+the aggregate.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+
+One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel of the step against the
+HBM peak with the algorithmic bytes of SURVEY.md section 8(d) (136 B per candidate pair for the
+coalescence-only box), timed live with HIP events on the library's stream; `cpu_baseline` times
+the oracle (serial C restatement of the reference algorithm) on the host for a bounded sample.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_PAIR = 136   # 24 u01 + 32 idx + 32 multiplicity + 16 cell id + 32*A, A=1
+
+
+def shima_box(n_sd, backend_class, seed, adaptive=False, dt=1.0, fused=None):
+    """Shima et al. 2009 0-D coalescence box (examples/PySDM_examples/Shima_et_al_2009/
+    settings.py:14-33): Golovin b=1500/s, n_part=2^23 /m^3, dv=1e6 m^3, X0=vol(30.531 um)"""
+    from pysdm_amd import Builder, Formulae
+    from pysdm_amd.dynamics.collisions import Coalescence, Golovin
+    from pysdm_amd.environments import Box
+    from pysdm_amd.initialisation import ConstantMultiplicity, Exponential
+
+    formulae = Formulae(seed=seed)
+    dv = 1e6
+    spectrum = Exponential(norm_factor=2**23 * dv, scale=formulae.trivia.volume(radius=30.531e-6))
+    volume, multiplicity = ConstantMultiplicity(spectrum).sample(n_sd)
+    builder = Builder(n_sd=n_sd, backend=backend_class(formulae), environment=Box(dt=dt, dv=dv))
+    dynamic = Coalescence(collision_kernel=Golovin(b=1.5e3), adaptive=adaptive, fused=fused)
+    builder.add_dynamic(dynamic)
+    particulator = builder.build({"volume": volume, "multiplicity": multiplicity})
+    return particulator, dynamic
+
+
+def cpu_baseline(n_sd, seconds_budget=15.0):
+    """the oracle (kind "port": serial C restatement of the reference's Numba-backend algorithm,
+    driven method by method like the reference) on one host core, same box, bounded sample"""
+    from oracle.backend import OracleBackend
+
+    particulator, _ = shima_box(n_sd, OracleBackend, seed=44)
+    particulator.run(1)  # warm-up (first-touch, lazy attribute allocation)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        particulator.run(1)
+        steps += 1
+        elapsed = time.perf_counter() - t0
+        if elapsed > seconds_budget or steps >= 200:
+            break
+    pairs = steps * (n_sd // 2)
+    return {
+        "value": pairs / elapsed,
+        "unit": "candidate SD-pairs/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{steps} time steps of the same n_sd={n_sd} Shima-2009 Golovin box "
+                  f"({elapsed:.1f} s of CPU work, oracle/sdm_oracle.c via oracle/backend.py)",
+    }
+
+
+def phase_timing(lib, handle):
+    from pysdm_amd._lib import check
+
+    n = 12
+    ms = (ctypes.c_double * n)()
+    count = (ctypes.c_int64 * n)()
+    check(lib.sdm_ctx_read_timing(handle, ms, count))
+    lib.sdm_phase_name.restype = ctypes.c_char_p
+    return {lib.sdm_phase_name(i).decode(): (ms[i], count[i]) for i in range(n) if count[i] > 0}
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--steps", type=int, default=200)
+    parser.add_argument("--warmup", type=int, default=20)
+    parser.add_argument("--n-sd", type=int, default=2**20)
+    parser.add_argument("--adaptive", type=int, default=0)
+    parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--roofline-steps", type=int, default=50)
+    args = parser.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from pysdm_amd.backends import HIP
+    from pysdm_amd.backends.hip import _Context
+
+    n_sd = args.n_sd
+    # every rank: an independent realisation (seed 44 + rank) of the same box
+    particulator, dynamic = shima_box(n_sd, HIP, seed=44 + rank, adaptive=bool(args.adaptive))
+    particulator.run(1)  # builds the fused step, allocates scratch
+    fused = dynamic._fused_state  # pylint: disable=protected-access
+    assert fused not in (None, False), "the fused HIP route must be the one benchmarked"
+    fused.read_back = bool(args.adaptive)  # non-adaptive: no host read-back inside the timed loop
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    particulator.run(args.warmup)
+    fused.total_pairs = 0
+    barrier()
+    t0 = time.perf_counter()
+    particulator.run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    fused.sync()
+    if args.adaptive:
+        pairs = fused.total_pairs
+    else:  # one sub-step per time step over the whole (still complete) population
+        assert particulator.attributes.super_droplet_count == n_sd, "droplets were removed"
+        pairs = args.steps * (n_sd // 2)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    p = torch.tensor([float(pairs)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(p, op=dist.ReduceOp.SUM)
+    elapsed_max, pairs_total = float(t.item()), float(p.item())
+
+    roofline = None
+    baseline = None
+    if rank == 0:
+        # ---- per-kernel durations, HIP events on the library's own stream (separate pass)
+        ctx = _Context.get()
+        from pysdm_amd._lib import check
+
+        check(ctx.lib.sdm_ctx_set_timing(ctx.handle, 1))
+        fused.read_back = True  # events are resolved per call
+        particulator.run(args.roofline_steps)
+        phases = phase_timing(ctx.lib, ctx.handle)
+        check(ctx.lib.sdm_ctx_set_timing(ctx.handle, 0))
+        per_launch = {k: v[0] / v[1] for k, v in phases.items()}
+        per_step = {k: v[0] / args.roofline_steps for k, v in phases.items()}
+        dominant = max(per_step, key=per_step.get)
+        dom_ms = per_launch[dominant]
+        launch_pairs = n_sd // 2
+        achieved = BYTES_PER_PAIR * launch_pairs / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(traffic_file):
+            with open(traffic_file, encoding="utf-8") as f:
+                traffic = json.load(f).get(dominant)
+        roofline = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": dominant, "kernel_ms": dom_ms,
+            "algorithmic_bytes_per_launch": BYTES_PER_PAIR * launch_pairs,
+            "phase_ms_per_step": {k: round(v, 5) for k, v in sorted(per_step.items())},
+        }
+        if not args.no_cpu_baseline:
+            baseline = cpu_baseline(n_sd)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        value = pairs_total / elapsed_max
+        print(json.dumps({
+            "metric": "candidate SD-pairs/s (Shima-2009 0-D box, n_sd=2^20 per GPU)",
+            "value": value,
+            "unit": "candidate SD-pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "Shima 2009 0D box, Golovin kernel b=1500/s, n_sd=2^20 per GPU, "
+                            "dt=1 s, " + ("adaptive" if args.adaptive else "non-adaptive")
+                            + " (BASELINE.json configs[1]); replicas only for N>1",
+                "n_sd": n_sd,
+                "seed": 44,
+                "route": "fused sdm_collision_step",
+            },
+            "shima_box_3600_steps_s": elapsed_max / args.steps * 3600,
+            "roofline": roofline,
+            "cpu_baseline": baseline,
+        }))
+
+
+if __name__ == "__main__":
+    main()

@@ -36,6 +36,26 @@ int sdm_ctx_set_stream(sdm_ctx *ctx, void *hip_stream);
 int sdm_ctx_synchronize(sdm_ctx *ctx);
 const char *sdm_last_error(void);
 int sdm_abi_version(void);
+/* per-phase timing with HIP events recorded on the ctx stream around the kernels of the fused
+ * step (measurement only; cf. the reference's per-dynamic WallTimer, PySDM/impl/wall_timer.py).
+ * sdm_ctx_read_timing synchronises, adds the elapsed times of all recorded regions to ms[phase] /
+ * count[phase] (arrays of SDM_N_PHASES) and clears the recording.                            */
+#define SDM_PHASE_SORT 0
+#define SDM_PHASE_RNG 1
+#define SDM_PHASE_SHUFFLE_CLEAR 2
+#define SDM_PHASE_SHUFFLE_BUILD 3
+#define SDM_PHASE_SHUFFLE_TRACE 4
+#define SDM_PHASE_TAIL_COPY 5
+#define SDM_PHASE_CELLS_PRE 6
+#define SDM_PHASE_PAIR_PROB 7
+#define SDM_PHASE_CELLS_ADAPTIVE 8
+#define SDM_PHASE_PAIR_UPDATE 9
+#define SDM_PHASE_SANITIZE 10
+#define SDM_PHASE_ADAPTIVE_END 11
+#define SDM_N_PHASES 12
+int sdm_ctx_set_timing(sdm_ctx *ctx, int enable);
+int sdm_ctx_read_timing(sdm_ctx *ctx, double *ms, int64_t *count);
+const char *sdm_phase_name(int phase);
 
 /* ---- a-1 RNG: NumPy PCG64 stream, PySDM/backends/impl_numba/random.py:13-19 ------------
  * out[i] = double number (offset + i) of the stream of PCG64 with the given state/inc

@@ -10,6 +10,7 @@
 typedef unsigned __int128 u128;
 
 #define SDM_BLOCK 256
+#define SDM_MAX_EVENTS 8192
 #define SDM_WAVE 64
 
 struct ShufRec;  // shuffle.hip
@@ -29,6 +30,21 @@ struct sdm_ctx {
   int64_t *mailbox;  // 16 x int64, hipHostMalloc
   // device control words for fine-grained calls (int64[16])
   int64_t *dscal;
+  // optional per-phase timing with HIP events on the ctx stream (bench / profiling only)
+  bool timing;
+  hipEvent_t *ev;      // pool of SDM_MAX_EVENTS events
+  int *ev_phase;       // phase id of each (begin, end) pair
+  int n_ev;            // events used (2 per timed region)
+  double phase_ms[SDM_N_PHASES];
+  int64_t phase_count[SDM_N_PHASES];
+};
+
+void sdm_phase_begin(sdm_ctx *ctx, int phase);
+void sdm_phase_end(sdm_ctx *ctx);
+struct PhaseScope {
+  sdm_ctx *c;
+  PhaseScope(sdm_ctx *ctx, int phase) : c(ctx) { if (c->timing) sdm_phase_begin(c, phase); }
+  ~PhaseScope() { if (c->timing) sdm_phase_end(c); }
 };
 
 void sdm_set_error(const char *fmt, ...);

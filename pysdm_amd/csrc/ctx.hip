@@ -38,8 +38,66 @@ extern "C" int sdm_ctx_destroy(sdm_ctx *ctx) {
   if (ctx->pcg_tab) (void)hipFree(ctx->pcg_tab);
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   if (ctx->dscal) (void)hipFree(ctx->dscal);
+  if (ctx->ev) {
+    for (int i = 0; i < SDM_MAX_EVENTS; ++i) (void)hipEventDestroy(ctx->ev[i]);
+    delete[] ctx->ev;
+    delete[] ctx->ev_phase;
+  }
   delete ctx;
   return SDM_OK;
+}
+
+void sdm_phase_begin(sdm_ctx *ctx, int phase) {
+  if (ctx->n_ev + 2 > SDM_MAX_EVENTS) { ctx->ev_phase[SDM_MAX_EVENTS / 2 - 1] = -1; return; }
+  ctx->ev_phase[ctx->n_ev / 2] = phase;
+  (void)hipEventRecord(ctx->ev[ctx->n_ev], ctx->stream);
+  ctx->n_ev += 1;
+}
+
+void sdm_phase_end(sdm_ctx *ctx) {
+  if (!(ctx->n_ev & 1)) return;  // begin was dropped (pool full)
+  (void)hipEventRecord(ctx->ev[ctx->n_ev], ctx->stream);
+  ctx->n_ev += 1;
+}
+
+extern "C" int sdm_ctx_set_timing(sdm_ctx *ctx, int enable) {
+  ARG_TRY(ctx != nullptr);
+  if (enable && !ctx->ev) {
+    ctx->ev = new hipEvent_t[SDM_MAX_EVENTS];
+    ctx->ev_phase = new int[SDM_MAX_EVENTS / 2];
+    for (int i = 0; i < SDM_MAX_EVENTS; ++i) HIP_TRY(hipEventCreate(&ctx->ev[i]));
+  }
+  ctx->timing = enable != 0;
+  return SDM_OK;
+}
+
+extern "C" int sdm_ctx_read_timing(sdm_ctx *ctx, double *ms, int64_t *count) {
+  ARG_TRY(ctx && ms && count);
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i + 1 < ctx->n_ev; i += 2) {
+    const int phase = ctx->ev_phase[i / 2];
+    if (phase < 0 || phase >= SDM_N_PHASES) continue;
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, ctx->ev[i], ctx->ev[i + 1]));
+    ctx->phase_ms[phase] += t;
+    ctx->phase_count[phase] += 1;
+  }
+  ctx->n_ev = 0;
+  for (int p = 0; p < SDM_N_PHASES; ++p) {
+    ms[p] = ctx->phase_ms[p];
+    count[p] = ctx->phase_count[p];
+    ctx->phase_ms[p] = 0;
+    ctx->phase_count[p] = 0;
+  }
+  return SDM_OK;
+}
+
+extern "C" const char *sdm_phase_name(int phase) {
+  static const char *names[SDM_N_PHASES] = {
+      "counting_sort", "pcg64_fill", "shuffle_clear", "shuffle_build", "shuffle_trace",
+      "tail_copy", "cells_pre", "pair_prob", "cells_adaptive", "pair_update", "sanitize",
+      "adaptive_end"};
+  return (phase >= 0 && phase < SDM_N_PHASES) ? names[phase] : "?";
 }
 
 extern "C" int sdm_ctx_set_stream(sdm_ctx *ctx, void *hip_stream) {

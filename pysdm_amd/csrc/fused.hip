@@ -551,11 +551,15 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
     // (b) cell_start getter: counting sort if unsorted (particle_attributes.py:51-55)
     sdm_step_state cur_state = *st;
     cur_state.idx = cur;
-    rc = cond_sort(ctx, cfg, &cur_state, S);
-    if (rc) return rc;
+    {
+      PhaseScope ph(ctx, SDM_PHASE_SORT);
+      rc = cond_sort(ctx, cfg, &cur_state, S);
+      if (rc) return rc;
+    }
     // (c) random numbers (random_generator_optimizer.py:37-48)
     const double *u01;
     if (!cfg->optimized_random || n_sub == 0) {
+      PhaseScope ph(ctx, SDM_PHASE_RNG);
       rc = sdm_pcg_fill_async(ctx, S.pairs_rand, N + shift, cfg->rng_state_inc, off);
       if (rc) return rc;
       rc = sdm_pcg_fill_async(ctx, S.rand, P, cfg->rng_state_inc, off + (uint64_t)(N + shift));
@@ -577,8 +581,11 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
     if (rc) return rc;
     // positions beyond the working length keep their content: the shuffle core writes only
     // [0, work) of `alt`, so carry the rest over
-    hipLaunchKernelGGL(k_copy_tail, dim3(grid_for(N)), blk, 0, s, alt, cur, p_shuffle_len, N);
-    LAUNCH_CHECK();
+    {
+      PhaseScope ph(ctx, SDM_PHASE_TAIL_COPY);
+      hipLaunchKernelGGL(k_copy_tail, dim3(grid_for(N)), blk, 0, s, alt, cur, p_shuffle_len, N);
+      LAUNCH_CHECK();
+    }
     { int64_t *t = cur; cur = alt; alt = t; }
     ++swaps;
     if (!cfg->croupier_local) {
@@ -590,25 +597,38 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
     }
     A.idx = cur;
     // (e) probabilities
-    hipLaunchKernelGGL(k_cells_pre, dim3(grid_for(C)), blk, 0, s, *cfg, A);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_pair_prob, dim3(grid_for(P)), blk, 0, s, *cfg, A);
-    LAUNCH_CHECK();
+    {
+      PhaseScope ph(ctx, SDM_PHASE_CELLS_PRE);
+      hipLaunchKernelGGL(k_cells_pre, dim3(grid_for(C)), blk, 0, s, *cfg, A);
+      LAUNCH_CHECK();
+    }
+    {
+      PhaseScope ph(ctx, SDM_PHASE_PAIR_PROB);
+      hipLaunchKernelGGL(k_pair_prob, dim3(grid_for(P)), blk, 0, s, *cfg, A);
+      LAUNCH_CHECK();
+    }
     if (cfg->adaptive) {
+      PhaseScope ph(ctx, SDM_PHASE_CELLS_ADAPTIVE);
       hipLaunchKernelGGL(k_cells_adaptive, dim3(grid_for(C)), blk, 0, s, *cfg, A);
       LAUNCH_CHECK();
     }
     // (f) gamma + update
-    hipLaunchKernelGGL(k_pair_update, dim3(grid_for(P)), blk, 0, s, *cfg, A);
-    LAUNCH_CHECK();
+    {
+      PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
+      hipLaunchKernelGGL(k_pair_update, dim3(grid_for(P)), blk, 0, s, *cfg, A);
+      LAUNCH_CHECK();
+    }
     // (g) sanitize (particle_attributes.py:67-73)
-    hipLaunchKernelGGL(k_pre_sanitize, dim3(1), dim3(1), 0, s, st->ctl);
-    LAUNCH_CHECK();
-    rc = sdm_compact_async(ctx, S.compact, st->multiplicity, cur, st->ctl + CTL_WORK, N, N,
-                           st->ctl + CTL_HEALTHY, S.cctl);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_post_sanitize, dim3(1), dim3(1), 0, s, st->ctl, S.cctl);
-    LAUNCH_CHECK();
+    {
+      PhaseScope ph(ctx, SDM_PHASE_SANITIZE);
+      hipLaunchKernelGGL(k_pre_sanitize, dim3(1), dim3(1), 0, s, st->ctl);
+      LAUNCH_CHECK();
+      rc = sdm_compact_async(ctx, S.compact, st->multiplicity, cur, st->ctl + CTL_WORK, N, N,
+                             st->ctl + CTL_HEALTHY, S.cctl);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_post_sanitize, dim3(1), dim3(1), 0, s, st->ctl, S.cctl);
+      LAUNCH_CHECK();
+    }
     ++n_sub;
     if (!cfg->adaptive && work_host >= 0) n_pairs += work_host / 2;
     if (cfg->adaptive) {

@@ -118,23 +118,32 @@ int sdm_shuffle_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *
   ShufRec *rec = cv.take<ShufRec>(length_bound);
   int32_t *ovf_head = cv.take<int32_t>(length_bound);
   int32_t *ovf_next = cv.take<int32_t>(length_bound);
-  HIP_TRY(hipMemsetAsync(rec, 0, sizeof(ShufRec) * length_bound, ctx->stream));
-  HIP_TRY(hipMemsetAsync(ovf_head, 0xFF, sizeof(int32_t) * length_bound, ctx->stream));
-  const dim3 grid(grid_for(length_bound)), block(SDM_BLOCK);
-  if (global) {
-    hipLaunchKernelGGL(k_shuffle_build<true>, grid, block, 0, ctx->stream, rec, ovf_head,
-                       ovf_next, u01, cell_start, n_cell, p_length, length_bound);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_shuffle_trace<true>, grid, block, 0, ctx->stream, out, idx0, rec,
-                       ovf_head, ovf_next, cell_start, n_cell, p_length, length_bound);
-  } else {
-    hipLaunchKernelGGL(k_shuffle_build<false>, grid, block, 0, ctx->stream, rec, ovf_head,
-                       ovf_next, u01, cell_start, n_cell, p_length, length_bound);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_shuffle_trace<false>, grid, block, 0, ctx->stream, out, idx0, rec,
-                       ovf_head, ovf_next, cell_start, n_cell, p_length, length_bound);
+  {
+    PhaseScope ph(ctx, SDM_PHASE_SHUFFLE_CLEAR);
+    HIP_TRY(hipMemsetAsync(rec, 0, sizeof(ShufRec) * length_bound, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ovf_head, 0xFF, sizeof(int32_t) * length_bound, ctx->stream));
   }
-  LAUNCH_CHECK();
+  const dim3 grid(grid_for(length_bound)), block(SDM_BLOCK);
+  {
+    PhaseScope ph(ctx, SDM_PHASE_SHUFFLE_BUILD);
+    if (global)
+      hipLaunchKernelGGL(k_shuffle_build<true>, grid, block, 0, ctx->stream, rec, ovf_head,
+                         ovf_next, u01, cell_start, n_cell, p_length, length_bound);
+    else
+      hipLaunchKernelGGL(k_shuffle_build<false>, grid, block, 0, ctx->stream, rec, ovf_head,
+                         ovf_next, u01, cell_start, n_cell, p_length, length_bound);
+    LAUNCH_CHECK();
+  }
+  {
+    PhaseScope ph(ctx, SDM_PHASE_SHUFFLE_TRACE);
+    if (global)
+      hipLaunchKernelGGL(k_shuffle_trace<true>, grid, block, 0, ctx->stream, out, idx0, rec,
+                         ovf_head, ovf_next, cell_start, n_cell, p_length, length_bound);
+    else
+      hipLaunchKernelGGL(k_shuffle_trace<false>, grid, block, 0, ctx->stream, out, idx0, rec,
+                         ovf_head, ovf_next, cell_start, n_cell, p_length, length_bound);
+    LAUNCH_CHECK();
+  }
   return SDM_OK;
 }
 
