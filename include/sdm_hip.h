@@ -263,8 +263,12 @@ typedef struct sdm_step_result {
   uint64_t rng_offset, rng_offset_breakup; /* updated stream positions */
 } sdm_step_result;
 
+/* flags: bit 0 = read the control block back (fills result->valid_n_sd; synchronises);
+ *        bit 1 = state->ctl was freshly written by the host (first call / after host-side edits) */
+#define SDM_STEP_READ_BACK 1
+#define SDM_STEP_FRESH_CTL 2
 int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *state,
-                       sdm_step_result *result, int read_back);
+                       sdm_step_result *result, int flags);
 
 #ifdef __cplusplus
 }

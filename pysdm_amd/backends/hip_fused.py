@@ -81,8 +81,10 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
 
     def __call__(self):
         dyn, attrs = self.dynamic, self.particulator.attributes
+        flags = int(self.read_back)
         if not self._ctl_initialised:
             self._push_host_state()
+            flags |= 2
         state = StepState()
         state.idx = _p(self.idx.data)
         state.tmp_idx = _p(self.tmp_idx.data)
@@ -108,7 +110,7 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
             state.rng_offset_breakup = dyn.rnd_opt_proc.rnd.offset
         ctx = _Context.get()
         check(ctx.lib.sdm_collision_step(ctx.handle, ctypes.byref(self.cfg), ctypes.byref(state),
-                                         ctypes.byref(self.result), int(self.read_back)))
+                                         ctypes.byref(self.result), flags))
         res = self.result
         if res.idx_swapped:
             self.idx.data, self.tmp_idx.data = self.tmp_idx.data, self.idx.data

@@ -37,14 +37,17 @@ struct FusedArgs {
   const double *gk_a, *gk_b;
   int64_t *ctl;
   // scratch
-  const double *rand;     // [P] collision stream
-  const double *rand_b;   // [P] proc_rand == rand_frag (same seed, same stream position)
+  // PCG64 streams, evaluated in the kernels (no u01 arrays): `s_rand` = state of the collision
+  // generator at the first draw of `rand` (after pairs_rand), `s_rand_b` = state of the
+  // proc_rand / rand_frag generators (same seed, same position: identical values)
+  u128 s_rand, s_rand_b, rng_inc;
+  const u128 *rng_tab;
   double *prob;           // [P]
   uint8_t *pair_off;      // [P] 0: pair starts at 2d, 1: at 2d+1, 2: no pair
   int32_t *pair_cid;      // [P] raw cell id of the pair (n_cell > 1)
   double *Ec;             // [P]
   double *fragment_mass;  // [P]
-  double *dt_todo, *cell_min, *norm_factor;  // [C]
+  double *dt_todo, *cell_min;  // [C]
 };
 
 // wave-aggregated int64 counter add: one atomic per wave when all contributing lanes share cid
@@ -63,253 +66,226 @@ __device__ __forceinline__ void counter_add(int64_t *__restrict__ counter, int64
   }
 }
 
-// ---- norm factors (collisions_methods.py:643-650) + per-cell adaptive init -----------------
+// one draw per thread: element (block_first + tid) of the stream starting at `s_base`
+__device__ __forceinline__ double stream_draw(u128 s_base, u128 inc, const u128 *__restrict__ tab,
+                                              u128 *lds_slot) {
+  if (threadIdx.x == 0) *lds_slot = pcg_jump(s_base, tab, (uint64_t)blockIdx.x * SDM_BLOCK);
+  __syncthreads();
+  u128 state = pcg_jump(*lds_slot, tab, (uint64_t)threadIdx.x);
+  state = state * pcg_mult() + inc;
+  return pcg_output(state);
+}
+
+// collisions_methods.py:643-650 (left-to-right evaluation)
+__device__ __forceinline__ double norm_factor_of(const sdm_step_cfg &cfg,
+                                                 const int64_t *__restrict__ cell_start,
+                                                 int64_t c) {
+  const int64_t sd_num = cell_start[c + 1] - cell_start[c];
+  return sd_num < 2 ? 0.0
+                    : cfg.dt / cfg.dv * (double)sd_num * (double)(sd_num - 1) / 2 /
+                          (double)(sd_num / 2);
+}
+
+// ---- per-cell adaptive init (collisions_methods.py:355-356) -----------------------------------
 __global__ void __launch_bounds__(SDM_BLOCK) k_cells_pre(sdm_step_cfg cfg, FusedArgs A) {
   const int64_t c = TID();
   if (c >= cfg.n_cell) return;
-  const int64_t sd_num = A.cell_start[c + 1] - A.cell_start[c];
-  A.norm_factor[c] = sd_num < 2 ? 0.0
-                                : cfg.dt / cfg.dv * (double)sd_num * (double)(sd_num - 1) / 2 /
-                                      (double)(sd_num / 2);
-  if (cfg.adaptive) {
-    const double l = A.dt_left[c];
-    A.dt_todo[c] = l < cfg.dt_max ? l : cfg.dt_max;
-    A.cell_min[c] = INFINITY;
-  }
+  const double l = A.dt_left[c];
+  A.dt_todo[c] = l < cfg.dt_max ? l : cfg.dt_max;
+  A.cell_min[c] = INFINITY;
 }
 
-// ---- pairing + probability -------------------------------------------------------------------
-__global__ void __launch_bounds__(SDM_BLOCK) k_pair_prob(sdm_step_cfg cfg, FusedArgs A) {
-  const int64_t W = A.ctl[CTL_WORK];
-  const int64_t d = TID();
-  const int64_t n_slots = cfg.n_sd / 2;
-  bool have = false;
-  int64_t i = 0, j = 0, k = 0, cid_j = 0;
-  double prob = 0.0, dt_optimal = INFINITY;
-  if (d < n_slots) {
-    // find_pairs (pair_methods.py:34-55) for positions 2d and 2d+1
-    if (cfg.n_cell == 1) {
-      if (2 * d + 1 < W) { have = true; i = 2 * d; }
-    } else {
+struct PairInfo {
+  bool have;
+  uint8_t off;
+  int64_t j, k, nj, nk, cid_j;
+  double prob, ec, fm, dt_optimal;
+};
+
+// pairing (find_pairs + sort_within_pair), kernel, probability, [Ec, fragment mass], [optimal dt]
+// for pair slot d; `u_b` = the slot's draw of the breakup streams
+__device__ __forceinline__ PairInfo pair_prob_body(const sdm_step_cfg &cfg, const FusedArgs &A,
+                                                   int64_t d, int64_t W, double u_b) {
+  PairInfo R;
+  R.have = false; R.off = 2; R.j = R.k = R.nj = R.nk = R.cid_j = 0;
+  R.prob = 0.0; R.ec = 0.0; R.fm = 0.0; R.dt_optimal = INFINITY;
+  int64_t i = 0;
+  // find_pairs (pair_methods.py:34-55) for positions 2d and 2d+1
+  if (cfg.n_cell == 1) {
+    if (2 * d + 1 < W) { R.have = true; i = 2 * d; }
+  } else {
 #pragma unroll
-      for (int o = 0; o < 2 && !have; ++o) {
-        const int64_t p = 2 * d + o;
-        if (p < W - 1) {
-          const int64_t ca = A.cell_id[A.idx[p]], cb = A.cell_id[A.idx[p + 1]];
-          const int64_t dd = p - A.cell_start[A.cell_idx[ca]];
-          if (ca == cb && (dd & 1) == 0) { have = true; i = p; }
-        }
-      }
-    }
-    uint8_t off = 2;
-    if (have) {
-      off = (uint8_t)(i - 2 * d);
-      j = A.idx[i];
-      k = A.idx[i + 1];
-      int64_t nj = A.multiplicity[j], nk = A.multiplicity[k];
-      // sort_within_pair_by_attr (pair_methods.py:126-140)
-      if (nj < nk) {
-        const int64_t t = j; j = k; k = t;
-        const int64_t tn = nj; nj = nk; nk = tn;
-        A.idx[i] = j;
-        A.idx[i + 1] = k;
-      }
-      cid_j = cfg.n_cell == 1 ? 0 : A.cell_id[j];
-      const double *mass = A.attributes + (int64_t)cfg.mass_attr * cfg.n_sd;
-      const double vj = volume_of_mass(mass[j], cfg.rho_w), vk = volume_of_mass(mass[k], cfg.rho_w);
-      double rj = 0, rk = 0, uj = 0, uk = 0;
-      const bool need_r = cfg.kernel == SDM_KERNEL_GEOMETRIC ||
-                          (cfg.enable_breakup && (cfg.ec != SDM_EC_CONST ||
-                                                  cfg.frag == SDM_FRAG_STRAUB2010));
-      if (need_r) {
-        const double inv = 1 / (3.14159265358979323846 * 4 / 3);
-        rj = radius_of_volume(vj, inv);
-        rk = radius_of_volume(vk, inv);
-        if (A.gk_a) {
-          uj = gk_interpolate(rj, cfg.gk_factor, A.gk_a, A.gk_b, cfg.gk_table_len);
-          uk = gk_interpolate(rk, cfg.gk_factor, A.gk_a, A.gk_b, cfg.gk_table_len);
-        }
-      }
-      double K;
-      switch (cfg.kernel) {
-        case SDM_KERNEL_GOLOVIN: K = (vj + vk) * cfg.kernel_param[0]; break;
-        case SDM_KERNEL_GEOMETRIC: {
-          const double s = rj + rk;
-          K = (s * s) * cfg.kernel_param[0];
-          K *= fabs(uj - uk);
-          break;
-        }
-        default: K = cfg.kernel_param[0];
-      }
-      // collision.py:249-254: prob = max(n) ; *= K ; normalize (cell of RAW SD #d: quirk)
-      prob = (double)nj;
-      prob *= K;
-      prob *= cfg.n_cell == 1 ? A.norm_factor[0] : A.norm_factor[A.cell_idx[A.cell_id[d]]];
-      if (cfg.enable_breakup) {
-        double ec;
-        switch (cfg.ec) {
-          case SDM_EC_CONST: ec = cfg.ec_param[0]; break;
-          case SDM_EC_BERRY1967: {
-            const double e = linear_collection_efficiency(cfg.berry_params, rj, rk, cfg.berry_unit);
-            ec = e * e;
-            break;
-          }
-          default: {  // coalescence_efficiencies/straub2010.py:27-50
-            double tmp = vj + vk;
-            double Sc = tmp * (6 / 3.14159265358979323846);
-            tmp *= 2;
-            double tmp2 = fabs(uj - uk);
-            tmp2 = tmp2 * tmp2;
-            double We = vj * vk;
-            if (tmp != 0.0) We /= tmp;
-            We *= tmp2;
-            We *= cfg.rho_w;
-            Sc = signed_pow(Sc, 2.0 / 3.0);
-            Sc *= 3.14159265358979323846 * cfg.sgm_w;
-            if (Sc != 0.0) We /= Sc;
-            We *= -1.15;
-            ec = exp(We);
-          }
-        }
-        A.Ec[d] = ec;
-        const double u = A.rand_b[d];
-        double fm;
-        switch (cfg.frag) {
-          case SDM_FRAG_ALWAYS_N: fm = (mass[j] + mass[k]) / cfg.frag_param[0]; break;
-          case SDM_FRAG_EXPONENTIAL: {
-            const double a = 1 - u;
-            double fv = -cfg.frag_param[0] * log(a > 1e-5 ? a : 1e-5), nf;
-            fragmentation_limiters(nf, fv, cfg.frag_vmin, cfg.frag_nfmax, vj + vk);
-            fm = cfg.rho_w * fv;
-            break;
-          }
-          default: {  // breakup_fragmentations/straub2010.py:42-101
-            const double v_max = vj > vk ? vj : vk;
-            const double x_plus_y = vj + vk;
-            const double ds = (rj < rk ? rj : rk) * 2;
-            double tmp = vj + vk;
-            double Sc = signed_pow(tmp, 2.0 / 3.0);
-            Sc *= cfg.frag_param[1];  // PI * sgm_w * (6/PI)**(2/3), one host-side constant
-            double tmp2 = fabs(uj - uk);
-            tmp2 = tmp2 * tmp2;
-            double CKE = vj * vk;
-            if (tmp != 0.0) CKE /= tmp;
-            CKE *= tmp2;
-            CKE *= cfg.rho_w / 2;
-            double We = CKE;
-            if (Sc != 0.0) We /= Sc;
-            double CW = We;
-            CW *= CKE;
-            CW /= 1e-6;  // si.uJ
-            double gam = rj > rk ? rj : rk;
-            const double rmin = rj < rk ? rj : rk;
-            if (rmin != 0.0) gam /= rmin;
-            StraubTmp T = {0, 0, 0, 0, 0, 0};
-            double fv = straub_fragment_volume(CW, gam, ds, v_max, u, cfg.straub_consts, T), nf;
-            fragmentation_limiters(nf, fv, cfg.frag_vmin, cfg.frag_nfmax, x_plus_y);
-            fm = cfg.rho_w * fv;
-          }
-        }
-        A.fragment_mass[d] = fm;
-      }
-      if (cfg.adaptive && prob != 0) {
-        // collisions_methods.py:359-368
-        const int64_t prop = nj / nk;
-        dt_optimal = cfg.dt * (double)prop / prob;
-        dt_optimal = dt_optimal > cfg.dt_min ? dt_optimal : cfg.dt_min;
-      }
-    }
-    A.prob[d] = prob;
-    A.pair_off[d] = off;
-    if (cfg.n_cell > 1) A.pair_cid[d] = (int32_t)cid_j;
-  }
-  if (cfg.adaptive) {
-    const bool active = have && prob != 0;
-    const unsigned long long am = __ballot(active);
-    if (am != 0) {
-      const int first = __ffsll((long long)am) - 1;
-      const int64_t cid0 = __shfl((long long)cid_j, first, 64);
-      if (__all(!active || cid_j == cid0)) {
-        const double m = wave_min_f64(active ? dt_optimal : INFINITY);
-        if (lane_id() == first) atomic_min_pos_f64(&A.cell_min[cid0], m);
-      } else if (active) {
-        atomic_min_pos_f64(&A.cell_min[cid_j], dt_optimal);
+    for (int o = 0; o < 2 && !R.have; ++o) {
+      const int64_t p = 2 * d + o;
+      if (p < W - 1) {
+        const int64_t ca = A.cell_id[A.idx[p]], cb = A.cell_id[A.idx[p + 1]];
+        const int64_t dd = p - A.cell_start[A.cell_idx[ca]];
+        if (ca == cb && (dd & 1) == 0) { R.have = true; i = p; }
       }
     }
   }
+  if (!R.have) return R;
+  R.off = (uint8_t)(i - 2 * d);
+  int64_t j = A.idx[i], k = A.idx[i + 1];
+  int64_t nj = A.multiplicity[j], nk = A.multiplicity[k];
+  // sort_within_pair_by_attr (pair_methods.py:126-140)
+  if (nj < nk) {
+    const int64_t t = j; j = k; k = t;
+    const int64_t tn = nj; nj = nk; nk = tn;
+    A.idx[i] = j;
+    A.idx[i + 1] = k;
+  }
+  R.j = j; R.k = k; R.nj = nj; R.nk = nk;
+  R.cid_j = cfg.n_cell == 1 ? 0 : A.cell_id[j];
+  const double *mass = A.attributes + (int64_t)cfg.mass_attr * cfg.n_sd;
+  const double vj = volume_of_mass(mass[j], cfg.rho_w), vk = volume_of_mass(mass[k], cfg.rho_w);
+  double rj = 0, rk = 0, uj = 0, uk = 0;
+  const bool need_r = cfg.kernel == SDM_KERNEL_GEOMETRIC ||
+                      (cfg.enable_breakup && (cfg.ec != SDM_EC_CONST ||
+                                              cfg.frag == SDM_FRAG_STRAUB2010));
+  if (need_r) {
+    const double inv = 1 / (3.14159265358979323846 * 4 / 3);
+    rj = radius_of_volume(vj, inv);
+    rk = radius_of_volume(vk, inv);
+    if (A.gk_a) {
+      uj = gk_interpolate(rj, cfg.gk_factor, A.gk_a, A.gk_b, cfg.gk_table_len);
+      uk = gk_interpolate(rk, cfg.gk_factor, A.gk_a, A.gk_b, cfg.gk_table_len);
+    }
+  }
+  double K;
+  switch (cfg.kernel) {
+    case SDM_KERNEL_GOLOVIN: K = (vj + vk) * cfg.kernel_param[0]; break;
+    case SDM_KERNEL_GEOMETRIC: {
+      const double s = rj + rk;
+      K = (s * s) * cfg.kernel_param[0];
+      K *= fabs(uj - uk);
+      break;
+    }
+    default: K = cfg.kernel_param[0];
+  }
+  // collision.py:249-254: prob = max(n) ; *= K ; normalize (cell of RAW SD #d: reference quirk)
+  double prob = (double)nj;
+  prob *= K;
+  prob *= norm_factor_of(cfg, A.cell_start, cfg.n_cell == 1 ? 0 : A.cell_idx[A.cell_id[d]]);
+  R.prob = prob;
+  if (cfg.enable_breakup) {
+    switch (cfg.ec) {
+      case SDM_EC_CONST: R.ec = cfg.ec_param[0]; break;
+      case SDM_EC_BERRY1967: {
+        const double e = linear_collection_efficiency(cfg.berry_params, rj, rk, cfg.berry_unit);
+        R.ec = e * e;
+        break;
+      }
+      default: {  // coalescence_efficiencies/straub2010.py:27-50
+        double tmp = vj + vk;
+        double Sc = tmp * (6 / 3.14159265358979323846);
+        tmp *= 2;
+        double tmp2 = fabs(uj - uk);
+        tmp2 = tmp2 * tmp2;
+        double We = vj * vk;
+        if (tmp != 0.0) We /= tmp;
+        We *= tmp2;
+        We *= cfg.rho_w;
+        Sc = signed_pow(Sc, 2.0 / 3.0);
+        Sc *= 3.14159265358979323846 * cfg.sgm_w;
+        if (Sc != 0.0) We /= Sc;
+        We *= -1.15;
+        R.ec = exp(We);
+      }
+    }
+    switch (cfg.frag) {
+      case SDM_FRAG_ALWAYS_N: R.fm = (mass[j] + mass[k]) / cfg.frag_param[0]; break;
+      case SDM_FRAG_EXPONENTIAL: {
+        const double a = 1 - u_b;
+        double fv = -cfg.frag_param[0] * log(a > 1e-5 ? a : 1e-5), nf;
+        fragmentation_limiters(nf, fv, cfg.frag_vmin, cfg.frag_nfmax, vj + vk);
+        R.fm = cfg.rho_w * fv;
+        break;
+      }
+      default: {  // breakup_fragmentations/straub2010.py:42-101
+        const double v_max = vj > vk ? vj : vk;
+        const double x_plus_y = vj + vk;
+        const double ds = (rj < rk ? rj : rk) * 2;
+        double tmp = vj + vk;
+        double Sc = signed_pow(tmp, 2.0 / 3.0);
+        Sc *= cfg.frag_param[1];  // PI * sgm_w * (6/PI)**(2/3), one host-side constant
+        double tmp2 = fabs(uj - uk);
+        tmp2 = tmp2 * tmp2;
+        double CKE = vj * vk;
+        if (tmp != 0.0) CKE /= tmp;
+        CKE *= tmp2;
+        CKE *= cfg.rho_w / 2;
+        double We = CKE;
+        if (Sc != 0.0) We /= Sc;
+        double CW = We;
+        CW *= CKE;
+        CW /= 1e-6;  // si.uJ
+        double gam = rj > rk ? rj : rk;
+        const double rmin = rj < rk ? rj : rk;
+        if (rmin != 0.0) gam /= rmin;
+        StraubTmp T = {0, 0, 0, 0, 0, 0};
+        double fv = straub_fragment_volume(CW, gam, ds, v_max, u_b, cfg.straub_consts, T), nf;
+        fragmentation_limiters(nf, fv, cfg.frag_vmin, cfg.frag_nfmax, x_plus_y);
+        R.fm = cfg.rho_w * fv;
+      }
+    }
+  }
+  if (cfg.adaptive && prob != 0) {
+    // collisions_methods.py:359-368
+    const int64_t prop = nj / nk;
+    double t = cfg.dt * (double)prop / prob;
+    R.dt_optimal = t > cfg.dt_min ? t : cfg.dt_min;
+  }
+  return R;
 }
 
-// ---- per-cell adaptive bookkeeping (collisions_methods.py:357-374) ---------------------------
-__global__ void __launch_bounds__(SDM_BLOCK) k_cells_adaptive(sdm_step_cfg cfg, FusedArgs A) {
-  const int64_t c = TID();
-  if (c >= cfg.n_cell) return;
-  if (A.ctl[CTL_WORK] == 0) return;
-  const double m = A.cell_min[c];
-  double t = A.dt_todo[c];
-  if (m < t) t = m;
-  A.dt_todo[c] = t;
-  const double s = A.stats_dt_min[c];
-  A.stats_dt_min[c] = m < s ? m : s;  // Python min(s, m): NaN-sticky
-  A.dt_left[c] -= t;
-  if (t > 0) A.stats_n_substep[c] += 1;
-}
-
-// ---- gamma + update ----------------------------------------------------------------------------
-__global__ void __launch_bounds__(SDM_BLOCK) k_pair_update(sdm_step_cfg cfg, FusedArgs A) {
-  const int64_t W = A.ctl[CTL_WORK];
-  const int64_t d = TID();
+// compute_gamma + collision_coalescence[_breakup] for slot d (all lanes of the wave must call).
+// p = the (already dt-scaled) probability; u = the slot's `rand`; j/k valid if `known`.
+__device__ __forceinline__ void pair_update_body(const sdm_step_cfg &cfg, const FusedArgs &A,
+                                                 int64_t d, bool in_range, double p, double u,
+                                                 double u_b, bool known, int64_t off,
+                                                 int64_t j, int64_t k, double ec, double fm) {
   bool collide = false;
-  int64_t j = 0, k = 0, cid = 0, nk = 0, gi = 0, gc = 0;
+  int64_t cid = 0, nk = 0, gi = 0, gc = 0;
   double g = 0;
-  if (d < W / 2) {
-    double p = A.prob[d];
-    if (p != 0) {
-      if (cfg.adaptive) {
-        cid = cfg.n_cell > 1 ? A.pair_cid[d] : 0;
-        p *= A.dt_todo[cid] / cfg.dt;  // collisions_methods.py:369-372
-      } else {
-        p /= (double)cfg.substeps;  // collision.py:279
-      }
-    }
-    g = ceil(p - A.rand[d]);  // collisions_methods.py:560
-    // pair_indices' skip (gamma == 0) also covers "no pair": off == 2 implies prob == 0,
-    // hence gamma = ceil(-rand) = -0.0
-    if (g != 0) {
-      const int64_t off = A.pair_off[d];
-      if (off < 2) {
-        collide = true;
+  if (in_range) {
+    g = ceil(p - u);  // collisions_methods.py:560
+    // pair_indices' skip (gamma == 0) also covers "no pair": then prob == 0, gamma = -0.0
+    if (g != 0 && off < 2) {
+      collide = true;
+      if (!known) {
         j = A.idx[2 * d + off];
         k = A.idx[2 * d + 1 + off];
-        nk = A.multiplicity[k];
-        const int64_t prop = A.multiplicity[j] / nk;
-        gi = (int64_t)g;
-        gc = gi < prop ? gi : prop;
-        cid = cfg.n_cell == 1 ? 0 : A.cell_id[j];
-        g = (double)gc;
       }
+      nk = A.multiplicity[k];
+      const int64_t prop = A.multiplicity[j] / nk;
+      gi = (int64_t)g;
+      gc = gi < prop ? gi : prop;
+      cid = cfg.n_cell == 1 ? 0 : A.cell_id[j];
+      g = (double)gc;
     }
   }
   counter_add(A.collision_rate, cid, gc * nk, collide);
   counter_add(A.collision_rate_deficit, cid, (gi - gc) * nk, collide);
   collide = collide && g != 0;
   bool coal = collide;
-  bool ovf = false;
   if (cfg.enable_breakup && collide) {
-    const double r = A.rand_b[d], ec = A.Ec[d], eb = cfg.eb_const;
-    if (r - (ec + (1 - ec) * eb) > 0) {
+    const double eb = cfg.eb_const;
+    if (u_b - (ec + (1 - ec) * eb) > 0) {
       collide = false;  // bounce
       coal = false;
-    } else if (!(r - ec < 0)) {
+    } else if (!(u_b - ec < 0)) {
       coal = false;
+      bool ovf = false;
       const double *mass = A.attributes + (int64_t)cfg.mass_attr * cfg.n_sd;
       // break_up / break_up_while (collisions_methods.py:135-243); counters through atomics
       double gamma_deficit = g;
       if (!cfg.handle_all_breakups) {
         double take_from_j, new_mult_k;
         int64_t gamma_j_k;
-        compute_transfer_multiplicities(g, A.multiplicity[j], nk, mass[j], mass[k],
-                                        A.fragment_mass[d], cfg.max_multiplicity, take_from_j,
-                                        new_mult_k, gamma_j_k, ovf);
+        compute_transfer_multiplicities(g, A.multiplicity[j], nk, mass[j], mass[k], fm,
+                                        cfg.max_multiplicity, take_from_j, new_mult_k,
+                                        gamma_j_k, ovf);
         gamma_deficit = g - (double)gamma_j_k;
         if (gamma_j_k) atomicAdd((unsigned long long *)&A.breakup_rate[cid],
                                  (unsigned long long)(gamma_j_k * nk));
@@ -319,7 +295,6 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_update(sdm_step_cfg cfg, Fus
         apply_breakup_transfer(j, k, take_from_j, new_mult_k, A.multiplicity, A.attributes,
                                cfg.n_attr, cfg.n_sd);
       } else {
-        const double fm = A.fragment_mass[d];
         while (gamma_deficit > 0) {
           double take_from_j, new_mult_k, gamma_j_k;
           const int64_t mj = A.multiplicity[j], mk = A.multiplicity[k];
@@ -359,11 +334,95 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_update(sdm_step_cfg cfg, Fus
   if (collide && (A.multiplicity[k] == 0 || A.multiplicity[j] == 0)) A.ctl[CTL_HEALTHY] = 0;
 }
 
+// ---- non-adaptive: everything about a pair in one kernel -------------------------------------
+__global__ void __launch_bounds__(SDM_BLOCK) k_pair_all(sdm_step_cfg cfg, FusedArgs A) {
+  __shared__ u128 lds[2];
+  const int64_t W = A.ctl[CTL_WORK];
+  const int64_t d = TID();
+  const double u = stream_draw(A.s_rand, A.rng_inc, A.rng_tab, &lds[0]);
+  const double u_b =
+      cfg.enable_breakup ? stream_draw(A.s_rand_b, A.rng_inc, A.rng_tab, &lds[1]) : 0.0;
+  const bool in_slots = d < cfg.n_sd / 2;
+  PairInfo R;
+  R.have = false; R.off = 2; R.prob = 0; R.j = R.k = 0; R.ec = R.fm = 0;
+  if (in_slots) R = pair_prob_body(cfg, A, d, W, u_b);
+  double p = R.prob;
+  if (p != 0) p /= (double)cfg.substeps;  // collision.py:279
+  pair_update_body(cfg, A, d, in_slots && d < W / 2, p, u, u_b, true, R.off, R.j, R.k, R.ec,
+                   R.fm);
+}
+
+// ---- adaptive: probabilities first (per-cell min of the optimal dt is a global dependency) ---
+__global__ void __launch_bounds__(SDM_BLOCK) k_pair_prob(sdm_step_cfg cfg, FusedArgs A) {
+  __shared__ u128 lds[1];
+  const int64_t W = A.ctl[CTL_WORK];
+  const int64_t d = TID();
+  const double u_b =
+      cfg.enable_breakup ? stream_draw(A.s_rand_b, A.rng_inc, A.rng_tab, &lds[0]) : 0.0;
+  PairInfo R;
+  R.have = false; R.prob = 0; R.cid_j = 0; R.dt_optimal = INFINITY; R.off = 2; R.ec = R.fm = 0;
+  if (d < cfg.n_sd / 2) {
+    R = pair_prob_body(cfg, A, d, W, u_b);
+    A.prob[d] = R.prob;
+    A.pair_off[d] = R.off;
+    if (cfg.n_cell > 1) A.pair_cid[d] = (int32_t)R.cid_j;
+    if (cfg.enable_breakup) { A.Ec[d] = R.ec; A.fragment_mass[d] = R.fm; }
+  }
+  const bool active = R.have && R.prob != 0;
+  const unsigned long long am = __ballot(active);
+  if (am != 0) {
+    const int first = __ffsll((long long)am) - 1;
+    const int64_t cid0 = __shfl((long long)R.cid_j, first, 64);
+    if (__all(!active || R.cid_j == cid0)) {
+      const double m = wave_min_f64(active ? R.dt_optimal : INFINITY);
+      if (lane_id() == first) atomic_min_pos_f64(&A.cell_min[cid0], m);
+    } else if (active) {
+      atomic_min_pos_f64(&A.cell_min[R.cid_j], R.dt_optimal);
+    }
+  }
+}
+
+// ---- per-cell adaptive bookkeeping (collisions_methods.py:357-374) ---------------------------
+__global__ void __launch_bounds__(SDM_BLOCK) k_cells_adaptive(sdm_step_cfg cfg, FusedArgs A) {
+  const int64_t c = TID();
+  if (c >= cfg.n_cell) return;
+  if (A.ctl[CTL_WORK] == 0) return;
+  const double m = A.cell_min[c];
+  double t = A.dt_todo[c];
+  if (m < t) t = m;
+  A.dt_todo[c] = t;
+  const double s = A.stats_dt_min[c];
+  A.stats_dt_min[c] = m < s ? m : s;  // Python min(s, m): NaN-sticky
+  A.dt_left[c] -= t;
+  if (t > 0) A.stats_n_substep[c] += 1;
+}
+
+__global__ void __launch_bounds__(SDM_BLOCK) k_pair_update(sdm_step_cfg cfg, FusedArgs A) {
+  __shared__ u128 lds[2];
+  const int64_t W = A.ctl[CTL_WORK];
+  const int64_t d = TID();
+  const double u = stream_draw(A.s_rand, A.rng_inc, A.rng_tab, &lds[0]);
+  const double u_b =
+      cfg.enable_breakup ? stream_draw(A.s_rand_b, A.rng_inc, A.rng_tab, &lds[1]) : 0.0;
+  const bool in_range = d < W / 2;
+  double p = 0, ec = 0, fm = 0;
+  int64_t off = 2;
+  if (in_range) {
+    p = A.prob[d];
+    off = A.pair_off[d];
+    if (p != 0) {
+      const int64_t cid = cfg.n_cell > 1 ? A.pair_cid[d] : 0;
+      p *= A.dt_todo[cid] / cfg.dt;  // collisions_methods.py:369-372
+    }
+    if (cfg.enable_breakup) { ec = A.Ec[d]; fm = A.fragment_mass[d]; }
+  }
+  pair_update_body(cfg, A, d, in_range, p, u, u_b, false, off, 0, 0, ec, fm);
+}
+
 // ---- control-word kernels -------------------------------------------------------------------
-// conditional counting sort support: the sort cores read the length from ctl[CTL_WORK]; whether
-// to run is decided on the device by ctl[CTL_SORTED].
+// conditional counting sort (multi-cell): the sort cores read the length from gate_len (0
+// disables them); whether to run is decided on the device by ctl[CTL_SORTED].
 __global__ void k_sort_gate(int64_t *ctl, int64_t *gate_len) {
-  // gate_len[0] = length to sort (0 disables every kernel of the sort core)
   gate_len[0] = ctl[CTL_SORTED] ? 0 : ctl[CTL_WORK];
 }
 
@@ -381,29 +440,21 @@ k_sort_commit(int64_t *__restrict__ idx, const int64_t *__restrict__ sorted_buf,
 __global__ void k_sort_done(int64_t *ctl) { ctl[CTL_SORTED] = 1; }
 __global__ void k_mark_unsorted(int64_t *ctl) { ctl[CTL_SORTED] = 0; }
 
-__global__ void k_post_sanitize(int64_t *ctl, const int64_t *cctl) {
-  if (ctl[CTL_HEALTHY] == 0) {
-    ctl[CTL_VALID] = cctl[1];
-    ctl[CTL_WORK] = cctl[1];
-    ctl[CTL_SORTED] = 0;
-    ctl[CTL_HEALTHY] = 1;
-  }
+// single cell: the sort is the identity, only cell_start = {0, length} has to be right
+__global__ void k_single_cell_init(int64_t *ctl, int64_t *cell_start) {
+  cell_start[0] = 0;
+  cell_start[1] = ctl[CTL_WORK];
+  ctl[CTL_SORTED] = 1;
 }
 
-__global__ void k_pre_sanitize(int64_t *ctl) {
-  // particle_attributes.py:69: idx.length = valid_n_sd before removal
-  if (ctl[CTL_HEALTHY] == 0) ctl[CTL_WORK] = ctl[CTL_VALID];
+// collision.py:185-187 for one cell: working length = whole cell while dt_left > 0
+__global__ void k_set_work_single(int64_t *ctl, const double *dt_left,
+                                  const int64_t *cell_start) {
+  ctl[CTL_WORK] = dt_left[0] != 0 ? cell_start[1] : 0;
 }
 
 __global__ void k_set_work(int64_t *ctl, const int64_t *end) { ctl[CTL_WORK] = end[0]; }
 __global__ void k_reset_work(int64_t *ctl) { ctl[CTL_WORK] = ctl[CTL_VALID]; }
-
-__global__ void __launch_bounds__(SDM_BLOCK)
-k_copy_tail(int64_t *__restrict__ dst, const int64_t *__restrict__ src,
-            const int64_t *__restrict__ p_from, int64_t n) {
-  const int64_t i = TID();
-  if (i >= *p_from && i < n) dst[i] = src[i];
-}
 
 __global__ void __launch_bounds__(SDM_BLOCK) k_fill_f64(double *p, double v, int64_t n) {
   const int64_t i = TID();
@@ -412,8 +463,7 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_fill_f64(double *p, double v, int
 
 // ---------------------------------------------------------------------------------------------
 struct FusedScratch {
-  double *pairs_rand, *rand, *rand_b, *prob, *Ec, *fragment_mass, *dt_todo, *cell_min,
-      *norm_factor;
+  double *prob, *Ec, *fragment_mass, *dt_todo, *cell_min;
   uint8_t *pair_off;
   int32_t *pair_cid;
   int64_t *sorted_buf, *cs_tmp, *gate_len, *cctl, *end2;
@@ -421,22 +471,19 @@ struct FusedScratch {
   size_t total;
 };
 
-static FusedScratch layout(char *base, const sdm_step_cfg *cfg, int64_t shift) {
+static FusedScratch layout(char *base, const sdm_step_cfg *cfg) {
   FusedScratch S;
   Carver cv(base);
   const int64_t N = cfg->n_sd, P = N / 2 > 0 ? N / 2 : 1, C = cfg->n_cell;
-  S.pairs_rand = cv.take<double>(N + shift);
-  S.rand = cv.take<double>(P);
-  S.rand_b = cv.take<double>(P);
-  S.prob = cv.take<double>(P);
-  S.Ec = cv.take<double>(P);
-  S.fragment_mass = cv.take<double>(P);
+  const bool split = cfg->adaptive != 0;  // prob etc. cross a kernel boundary only then
+  S.prob = cv.take<double>(split ? P : 1);
+  S.Ec = cv.take<double>(split && cfg->enable_breakup ? P : 1);
+  S.fragment_mass = cv.take<double>(split && cfg->enable_breakup ? P : 1);
   S.dt_todo = cv.take<double>(C);
   S.cell_min = cv.take<double>(C);
-  S.norm_factor = cv.take<double>(C);
-  S.pair_off = cv.take<uint8_t>(P);
-  S.pair_cid = cv.take<int32_t>(P);
-  S.sorted_buf = cv.take<int64_t>(N);
+  S.pair_off = cv.take<uint8_t>(split ? P : 1);
+  S.pair_cid = cv.take<int32_t>(split ? P : 1);
+  S.sorted_buf = cv.take<int64_t>(C > 1 ? N : 1);
   S.cs_tmp = cv.take<int64_t>(C + 1);
   S.gate_len = cv.take<int64_t>(4);
   S.cctl = cv.take<int64_t>(8);
@@ -451,15 +498,17 @@ static FusedScratch layout(char *base, const sdm_step_cfg *cfg, int64_t shift) {
   return S;
 }
 
-static int cond_sort(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st,
+static int cond_sort(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st, int64_t *idx,
                      const FusedScratch &S) {
+  if (cfg->n_cell == 1) return SDM_OK;  // identity; cell_start kept right by the compaction
+  PhaseScope ph(ctx, SDM_PHASE_SORT);
   hipLaunchKernelGGL(k_sort_gate, dim3(1), dim3(1), 0, ctx->stream, st->ctl, S.gate_len);
   LAUNCH_CHECK();
-  int rc = sdm_counting_sort_async(ctx, S.sort, S.sorted_buf, st->idx, st->cell_id, st->cell_idx,
+  int rc = sdm_counting_sort_async(ctx, S.sort, S.sorted_buf, idx, st->cell_id, st->cell_idx,
                                    S.gate_len, cfg->n_sd, S.cs_tmp, cfg->n_cell);
   if (rc) return rc;
   const int64_t n = cfg->n_sd > cfg->n_cell + 1 ? cfg->n_sd : cfg->n_cell + 1;
-  hipLaunchKernelGGL(k_sort_commit, dim3(grid_for(n)), dim3(SDM_BLOCK), 0, ctx->stream, st->idx,
+  hipLaunchKernelGGL(k_sort_commit, dim3(grid_for(n)), dim3(SDM_BLOCK), 0, ctx->stream, idx,
                      S.sorted_buf, st->cell_start, S.cs_tmp, cfg->n_cell, st->ctl, S.gate_len);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_sort_done, dim3(1), dim3(1), 0, ctx->stream, st->ctl);
@@ -467,8 +516,10 @@ static int cond_sort(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st,
   return SDM_OK;
 }
 
+// flags: bit 0 = read the control block back at the end; bit 1 = the control block was freshly
+// pushed by the host (single-cell bookkeeping has to be initialised)
 extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st,
-                                  sdm_step_result *res, int read_back) {
+                                  sdm_step_result *res, int flags) {
   ARG_TRY(ctx && cfg && st && res);
   ARG_TRY(cfg->n_sd >= 2 && cfg->n_sd < INT32_MAX && cfg->n_cell >= 1 && cfg->n_attr >= 1);
   ARG_TRY(st->idx && st->tmp_idx && st->multiplicity && st->attributes && st->cell_id &&
@@ -480,6 +531,7 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   ARG_TRY(cfg->adaptive || cfg->substeps >= 1);
   ARG_TRY(cfg->mass_attr >= 0 && cfg->mass_attr < cfg->n_attr);
   ARG_TRY(cfg->dt_min > 0);
+  const bool read_back = (flags & 1) != 0;
 
   const int64_t N = cfg->n_sd, P = N / 2, C = cfg->n_cell;
   // random_generator_optimizer.py:21-25
@@ -489,10 +541,14 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
     shift = (int64_t)q;
     if ((double)shift < q) shift += 1;
   }
-  FusedScratch S = layout(nullptr, cfg, shift);
+  FusedScratch S = layout(nullptr, cfg);
   int rc = sdm_reserve(ctx, S.total);
   if (rc) return rc;
-  S = layout(ctx->arena, cfg, shift);
+  S = layout(ctx->arena, cfg);
+  rc = sdm_pcg_prepare(ctx, cfg->rng_state_inc);
+  if (rc) return rc;
+  const u128 rng_state = (((u128)cfg->rng_state_inc[0]) << 64) | cfg->rng_state_inc[1];
+  const u128 rng_inc = (((u128)cfg->rng_state_inc[2]) << 64) | cfg->rng_state_inc[3];
 
   FusedArgs A;
   memset(&A, 0, sizeof(A));
@@ -512,8 +568,8 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   A.gk_a = st->gk_a;
   A.gk_b = st->gk_b;
   A.ctl = st->ctl;
-  A.rand = S.rand;
-  A.rand_b = S.rand_b;
+  A.rng_inc = rng_inc;
+  A.rng_tab = ctx->pcg_tab;
   A.prob = S.prob;
   A.pair_off = S.pair_off;
   A.pair_cid = S.pair_cid;
@@ -521,14 +577,18 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   A.fragment_mass = S.fragment_mass;
   A.dt_todo = S.dt_todo;
   A.cell_min = S.cell_min;
-  A.norm_factor = S.norm_factor;
 
   uint64_t off = st->rng_offset, off_b = st->rng_offset_breakup;
+  uint64_t draw_off = off, draw_off_b = off_b;  // stream positions of the current draw
   int64_t n_sub = 0, n_pairs = 0, swaps = 0;
   int64_t *cur = st->idx, *alt = st->tmp_idx;
   hipStream_t s = ctx->stream;
-  const dim3 blk(SDM_BLOCK);
+  const dim3 blk(SDM_BLOCK), one(1);
 
+  if (C == 1 && (flags & 2)) {
+    hipLaunchKernelGGL(k_single_cell_init, one, one, 0, s, st->ctl, st->cell_start);
+    LAUNCH_CHECK();
+  }
   if (cfg->adaptive) {  // collision.py:180: dt_left[:] = dt
     hipLaunchKernelGGL(k_fill_f64, dim3(grid_for(C)), blk, 0, s, st->dt_left, cfg->dt, C);
     LAUNCH_CHECK();
@@ -549,98 +609,89 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
       if (rc) return rc;
     }
     // (b) cell_start getter: counting sort if unsorted (particle_attributes.py:51-55)
-    sdm_step_state cur_state = *st;
-    cur_state.idx = cur;
-    {
-      PhaseScope ph(ctx, SDM_PHASE_SORT);
-      rc = cond_sort(ctx, cfg, &cur_state, S);
-      if (rc) return rc;
-    }
-    // (c) random numbers (random_generator_optimizer.py:37-48)
-    const double *u01;
-    if (!cfg->optimized_random || n_sub == 0) {
-      PhaseScope ph(ctx, SDM_PHASE_RNG);
-      rc = sdm_pcg_fill_async(ctx, S.pairs_rand, N + shift, cfg->rng_state_inc, off);
-      if (rc) return rc;
-      rc = sdm_pcg_fill_async(ctx, S.rand, P, cfg->rng_state_inc, off + (uint64_t)(N + shift));
-      if (rc) return rc;
-      off += (uint64_t)(N + shift + P);
-      if (cfg->enable_breakup) {
-        rc = sdm_pcg_fill_async(ctx, S.rand_b, P, cfg->rng_state_inc, off_b);
-        if (rc) return rc;
-        off_b += (uint64_t)P;
-      }
-    }
-    u01 = S.pairs_rand + (cfg->optimized_random ? n_sub : 0);
-    // (d) permutation (particle_attributes.py:98-105)
-    // shuffle_local visits every cell of cell_start, also those beyond a cut working length
-    // (index_methods.py:35); shuffle_global covers the working length (index.py:43-45)
-    const int64_t *p_shuffle_len = cfg->croupier_local ? st->cell_start + C : st->ctl + CTL_WORK;
-    rc = sdm_shuffle_async(ctx, S.shuffle, alt, cur, u01, st->cell_start, C, p_shuffle_len, N,
-                           !cfg->croupier_local);
+    rc = cond_sort(ctx, cfg, st, cur, S);
     if (rc) return rc;
-    // positions beyond the working length keep their content: the shuffle core writes only
-    // [0, work) of `alt`, so carry the rest over
-    {
-      PhaseScope ph(ctx, SDM_PHASE_TAIL_COPY);
-      hipLaunchKernelGGL(k_copy_tail, dim3(grid_for(N)), blk, 0, s, alt, cur, p_shuffle_len, N);
-      LAUNCH_CHECK();
+    // (c) random numbers (random_generator_optimizer.py:37-48): a draw = pairs_rand (N + shift)
+    // then rand (P) from the collision generator, P from each breakup generator
+    if (!cfg->optimized_random || n_sub == 0) {
+      draw_off = off;
+      draw_off_b = off_b;
+      off += (uint64_t)(N + shift + P);
+      if (cfg->enable_breakup) off_b += (uint64_t)P;
     }
+    A.s_rand = sdm_pcg_advance_host(rng_state, rng_inc, draw_off + (uint64_t)(N + shift));
+    A.s_rand_b = sdm_pcg_advance_host(rng_state, rng_inc, draw_off_b);
+    // (d) permutation (particle_attributes.py:98-105).  shuffle_local visits every cell of
+    // cell_start, also those beyond a cut working length (index_methods.py:35); shuffle_global
+    // covers the working length (index.py:43-45).  u01[i] = draw (window shift + i).
+    const int64_t *p_shuffle_len = cfg->croupier_local ? st->cell_start + C : st->ctl + CTL_WORK;
+    rc = sdm_shuffle_async(ctx, S.shuffle, alt, cur, nullptr, st->cell_start, C, p_shuffle_len, N,
+                           !cfg->croupier_local, N, cfg->rng_state_inc,
+                           draw_off + (uint64_t)(cfg->optimized_random ? n_sub : 0));
+    if (rc) return rc;
     { int64_t *t = cur; cur = alt; alt = t; }
     ++swaps;
-    if (!cfg->croupier_local) {
-      hipLaunchKernelGGL(k_mark_unsorted, dim3(1), dim3(1), 0, s, st->ctl);
+    if (!cfg->croupier_local && C > 1) {
+      hipLaunchKernelGGL(k_mark_unsorted, one, one, 0, s, st->ctl);
       LAUNCH_CHECK();
-      cur_state.idx = cur;
-      rc = cond_sort(ctx, cfg, &cur_state, S);
+      rc = cond_sort(ctx, cfg, st, cur, S);
       if (rc) return rc;
     }
     A.idx = cur;
-    // (e) probabilities
-    {
-      PhaseScope ph(ctx, SDM_PHASE_CELLS_PRE);
-      hipLaunchKernelGGL(k_cells_pre, dim3(grid_for(C)), blk, 0, s, *cfg, A);
-      LAUNCH_CHECK();
-    }
-    {
-      PhaseScope ph(ctx, SDM_PHASE_PAIR_PROB);
-      hipLaunchKernelGGL(k_pair_prob, dim3(grid_for(P)), blk, 0, s, *cfg, A);
-      LAUNCH_CHECK();
-    }
-    if (cfg->adaptive) {
-      PhaseScope ph(ctx, SDM_PHASE_CELLS_ADAPTIVE);
-      hipLaunchKernelGGL(k_cells_adaptive, dim3(grid_for(C)), blk, 0, s, *cfg, A);
-      LAUNCH_CHECK();
-    }
-    // (f) gamma + update
-    {
+    // (e)+(f) probabilities, gamma, update
+    if (!cfg->adaptive) {
       PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
-      hipLaunchKernelGGL(k_pair_update, dim3(grid_for(P)), blk, 0, s, *cfg, A);
+      hipLaunchKernelGGL(k_pair_all, dim3(grid_for(P)), blk, 0, s, *cfg, A);
       LAUNCH_CHECK();
+    } else {
+      {
+        PhaseScope ph(ctx, SDM_PHASE_CELLS_PRE);
+        hipLaunchKernelGGL(k_cells_pre, dim3(grid_for(C)), blk, 0, s, *cfg, A);
+        LAUNCH_CHECK();
+      }
+      {
+        PhaseScope ph(ctx, SDM_PHASE_PAIR_PROB);
+        hipLaunchKernelGGL(k_pair_prob, dim3(grid_for(P)), blk, 0, s, *cfg, A);
+        LAUNCH_CHECK();
+      }
+      {
+        PhaseScope ph(ctx, SDM_PHASE_CELLS_ADAPTIVE);
+        hipLaunchKernelGGL(k_cells_adaptive, dim3(grid_for(C)), blk, 0, s, *cfg, A);
+        LAUNCH_CHECK();
+      }
+      {
+        PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
+        hipLaunchKernelGGL(k_pair_update, dim3(grid_for(P)), blk, 0, s, *cfg, A);
+        LAUNCH_CHECK();
+      }
     }
-    // (g) sanitize (particle_attributes.py:67-73)
+    // (g) sanitize (particle_attributes.py:67-73), decided on the device by the healthy word
     {
       PhaseScope ph(ctx, SDM_PHASE_SANITIZE);
-      hipLaunchKernelGGL(k_pre_sanitize, dim3(1), dim3(1), 0, s, st->ctl);
-      LAUNCH_CHECK();
-      rc = sdm_compact_async(ctx, S.compact, st->multiplicity, cur, st->ctl + CTL_WORK, N, N,
-                             st->ctl + CTL_HEALTHY, S.cctl);
+      rc = sdm_compact_async(ctx, S.compact, st->multiplicity, cur, nullptr, N, N, st->ctl, S.cctl,
+                             C == 1 ? st->cell_start : nullptr);
       if (rc) return rc;
-      hipLaunchKernelGGL(k_post_sanitize, dim3(1), dim3(1), 0, s, st->ctl, S.cctl);
-      LAUNCH_CHECK();
     }
     ++n_sub;
     if (!cfg->adaptive && work_host >= 0) n_pairs += work_host / 2;
     if (cfg->adaptive) {
       // (h) collision.py:185-187 cut_working_length(adaptive_sdm_end(dt_left))
-      cur_state.idx = cur;
-      rc = cond_sort(ctx, cfg, &cur_state, S);
-      if (rc) return rc;
       n_pairs += work_host / 2;
-      rc = sdm_adaptive_end_async(ctx, st->dt_left, C, st->cell_start, S.end2, S.end2 + 1);
-      if (rc) return rc;
-      hipLaunchKernelGGL(k_set_work, dim3(1), dim3(1), 0, s, st->ctl, S.end2 + 1);
-      LAUNCH_CHECK();
+      if (C > 1) {
+        rc = cond_sort(ctx, cfg, st, cur, S);
+        if (rc) return rc;
+      }
+      PhaseScope ph(ctx, SDM_PHASE_ADAPTIVE_END);
+      if (C == 1) {
+        hipLaunchKernelGGL(k_set_work_single, one, one, 0, s, st->ctl, st->dt_left,
+                           st->cell_start);
+        LAUNCH_CHECK();
+      } else {
+        rc = sdm_adaptive_end_async(ctx, st->dt_left, C, st->cell_start, S.end2, S.end2 + 1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_set_work, one, one, 0, s, st->ctl, S.end2 + 1);
+        LAUNCH_CHECK();
+      }
       HIP_TRY(hipMemcpyAsync(ctx->mailbox + 3, st->ctl + CTL_WORK, sizeof(int64_t),
                              hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
@@ -649,16 +700,14 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   }
   if (cfg->adaptive) {
     // collision.py:189-190 reset_working_length(); reset_cell_idx() (identity + sort)
-    hipLaunchKernelGGL(k_reset_work, dim3(1), dim3(1), 0, s, st->ctl);
+    hipLaunchKernelGGL(k_reset_work, one, one, 0, s, st->ctl);
     LAUNCH_CHECK();
     if (C > 1) {
       rc = sdm_identity_index(ctx, st->cell_idx, C);
       if (rc) return rc;
-      hipLaunchKernelGGL(k_mark_unsorted, dim3(1), dim3(1), 0, s, st->ctl);
+      hipLaunchKernelGGL(k_mark_unsorted, one, one, 0, s, st->ctl);
       LAUNCH_CHECK();
-      sdm_step_state cur_state = *st;
-      cur_state.idx = cur;
-      rc = cond_sort(ctx, cfg, &cur_state, S);
+      rc = cond_sort(ctx, cfg, st, cur, S);
       if (rc) return rc;
     }
   }

@@ -10,12 +10,13 @@ int sdm_pcg_fill_async(sdm_ctx *ctx, double *out, int64_t n, const uint64_t stat
 size_t sdm_shuffle_scratch(int64_t n);
 int sdm_shuffle_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *idx0,
                       const double *u01, const int64_t *cell_start, int64_t n_cell,
-                      const int64_t *p_length, int64_t length_bound, bool global);
+                      const int64_t *p_length, int64_t length_bound, bool global,
+                      int64_t n_total, const uint64_t *rng_state_inc, uint64_t rng_offset);
 int sdm_sort_by_key_async(sdm_ctx *ctx, int64_t *idx, const double *keys, int64_t n);
 size_t sdm_compact_scratch(int64_t n);
 int sdm_compact_async(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity, int64_t *idx,
                       const int64_t *p_length, int64_t length_bound, int64_t flag,
-                      const int64_t *p_enable, int64_t *ctl);
+                      int64_t *fctl, int64_t *ctl, int64_t *cell_start_single);
 size_t sdm_sort_scratch(int64_t length_bound, int64_t n_cell);
 int sdm_counting_sort_async(sdm_ctx *ctx, char *scratch, int64_t *new_idx, const int64_t *idx,
                             const int64_t *cell_id, const int64_t *cell_idx,

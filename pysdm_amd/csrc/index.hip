@@ -37,48 +37,95 @@ struct __align__(16) ShufRec {
   int32_t s0, s1;  // the first two of them in arrival order (any order; all get scanned)
 };
 
-template <bool GLOBAL>
+#define SHUF_ELEMS 4  // positions per thread in the build kernel
+
+// RNG = true: u01[i] is draw number (offset + i) of the PCG64 stream, generated in place
+// (`s_off` = generator state after `offset` draws); RNG = false: u01 read from memory.
+template <bool GLOBAL, bool RNG>
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_shuffle_build(ShufRec *__restrict__ rec, int32_t *__restrict__ ovf_head,
                 int32_t *__restrict__ ovf_next, const double *__restrict__ u01,
                 const int64_t *__restrict__ cell_start, int64_t n_cell,
-                const int64_t *__restrict__ p_length, int64_t length_arg) {
+                const int64_t *__restrict__ p_length, int64_t length_arg, u128 s_off, u128 inc,
+                const u128 *__restrict__ tab) {
   const int64_t length = p_length ? *p_length : length_arg;
-  const int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
-  if (i >= length) return;
-  int64_t j = -1;
-  if (GLOBAL) {
-    if (i >= 1) {
-      j = (int64_t)(u01[i] * (double)(i + 1));
-      j = j > i ? i : j;
+  const int64_t blk_first = (int64_t)blockIdx.x * (SDM_BLOCK * SHUF_ELEMS);
+  if (blk_first >= length) return;
+  const int64_t first = blk_first + (int64_t)threadIdx.x * SHUF_ELEMS;
+  double u[SHUF_ELEMS];
+  if (RNG) {
+    __shared__ u128 s_blk;
+    if (threadIdx.x == 0) s_blk = pcg_jump(s_off, tab, (uint64_t)blk_first);
+    __syncthreads();
+    u128 state = pcg_jump(s_blk, tab, (uint64_t)threadIdx.x * SHUF_ELEMS);
+    const u128 mult = pcg_mult();
+#pragma unroll
+    for (int e = 0; e < SHUF_ELEMS; ++e) {
+      state = state * mult + inc;
+      u[e] = pcg_output(state);
     }
   } else {
-    const int64_t c = n_cell == 1 ? 0 : find_cell(cell_start, n_cell, i);
-    const int64_t lo = cell_start[c], hi = cell_start[c + 1];
-    if (i > lo) {
-      j = (int64_t)((double)lo + u01[i] * (double)(hi - lo));
-      // memory safety only: the reference would index past the cell with prob ~2^-43
-      j = j > hi - 1 ? hi - 1 : (j < lo ? lo : j);
+#pragma unroll
+    for (int e = 0; e < SHUF_ELEMS; ++e) u[e] = first + e < length ? u01[first + e] : 0.0;
+  }
+  int64_t j[SHUF_ELEMS];
+  int64_t lo = 0, hi = 0;
+  bool have_cell = false;
+#pragma unroll
+  for (int e = 0; e < SHUF_ELEMS; ++e) {
+    const int64_t i = first + e;
+    j[e] = -1;
+    if (i >= length) continue;
+    if (GLOBAL) {
+      if (i >= 1) {
+        const int64_t t = (int64_t)(u[e] * (double)(i + 1));
+        j[e] = t > i ? i : t;
+      }
+    } else {
+      if (!have_cell || i >= hi) {
+        const int64_t c = n_cell == 1 ? 0 : find_cell(cell_start, n_cell, i);
+        lo = cell_start[c];
+        hi = cell_start[c + 1];
+        have_cell = true;
+      }
+      if (i > lo) {
+        const int64_t t = (int64_t)((double)lo + u[e] * (double)(hi - lo));
+        // memory safety only: the reference would index past the cell with prob ~2^-43
+        j[e] = t > hi - 1 ? hi - 1 : (t < lo ? lo : t);
+      }
     }
   }
-  rec[i].j = (int32_t)j;
-  if (j >= 0) {
-    const int c = atomicAdd(&rec[j].cnt, 1);
-    if (c == 0) rec[j].s0 = (int32_t)i;
-    else if (c == 1) rec[j].s1 = (int32_t)i;
-    else ovf_next[i] = atomicExch(&ovf_head[j], (int32_t)i);
+  // own-event targets: 4 consecutive records, stored as one row of int32 j fields
+  int slot[SHUF_ELEMS];
+#pragma unroll
+  for (int e = 0; e < SHUF_ELEMS; ++e) {
+    if (first + e < length) rec[first + e].j = (int32_t)j[e];
+    slot[e] = j[e] >= 0 ? atomicAdd(&rec[j[e]].cnt, 1) : -1;  // independent: all in flight
+  }
+#pragma unroll
+  for (int e = 0; e < SHUF_ELEMS; ++e) {
+    if (slot[e] < 0) continue;
+    const int32_t i = (int32_t)(first + e);
+    if (slot[e] == 0) rec[j[e]].s0 = i;
+    else if (slot[e] == 1) rec[j[e]].s1 = i;
+    else ovf_next[i] = atomicExch(&ovf_head[j[e]], i);
   }
 }
 
+// positions [length, n_total) keep their content (copied through)
 template <bool GLOBAL>
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_shuffle_trace(int64_t *__restrict__ out, const int64_t *__restrict__ idx0,
                 const ShufRec *__restrict__ rec, const int32_t *__restrict__ ovf_head,
                 const int32_t *__restrict__ ovf_next, const int64_t *__restrict__ cell_start,
-                int64_t n_cell, const int64_t *__restrict__ p_length, int64_t length_arg) {
+                int64_t n_cell, const int64_t *__restrict__ p_length, int64_t length_arg,
+                int64_t n_total) {
   const int64_t length = p_length ? *p_length : length_arg;
   const int64_t p = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
-  if (p >= length) return;
+  if (p >= length) {
+    if (p < n_total) out[p] = idx0[p];
+    return;
+  }
   int32_t e;  // only events with index > e are still "in the past" of the walk
   if (GLOBAL) {
     e = 0;
@@ -93,9 +140,14 @@ k_shuffle_trace(int64_t *__restrict__ out, const int64_t *__restrict__ idx0,
     if (q > e && r.j >= 0) best = q;
     if (r.cnt > 0 && r.s0 > e && r.s0 < best) best = r.s0;
     if (r.cnt > 1 && r.s1 > e && r.s1 < best) best = r.s1;
-    if (r.cnt > 2)
-      for (int32_t t = ovf_head[q]; t >= 0; t = ovf_next[t])
+    if (r.cnt > 2) {
+      // overflow list: exactly cnt-2 nodes (the list head needs no initialisation)
+      int32_t t = ovf_head[q];
+      for (int c = 2; c < r.cnt; ++c) {
         if (t > e && t < best) best = t;
+        t = ovf_next[t];
+      }
+    }
     if (best == INT32_MAX) break;
     // event `best` exchanged positions (best, j_best); q is one end, continue at the other
     q = (best == q) ? r.j : best;
@@ -109,39 +161,52 @@ static size_t shuffle_scratch_bytes(int64_t n) {
          carve_size(sizeof(int64_t) * n);
 }
 
-// out-of-place core: out[0:length) = shuffled idx0[0:length); arena must be reserved by caller
+// out-of-place core: out[0:length) = shuffled idx0[0:length), out[length:n_total) = idx0[...].
+// u01 == nullptr: draws generated in the kernel from (rng_state_inc, rng_offset).
 int sdm_shuffle_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *idx0,
                       const double *u01, const int64_t *cell_start, int64_t n_cell,
-                      const int64_t *p_length, int64_t length_bound, bool global) {
+                      const int64_t *p_length, int64_t length_bound, bool global,
+                      int64_t n_total, const uint64_t *rng_state_inc, uint64_t rng_offset) {
   if (length_bound <= 0) return SDM_OK;
   Carver cv(scratch);
   ShufRec *rec = cv.take<ShufRec>(length_bound);
   int32_t *ovf_head = cv.take<int32_t>(length_bound);
   int32_t *ovf_next = cv.take<int32_t>(length_bound);
+  u128 s_off = 0, inc = 0;
+  if (!u01) {
+    int rc = sdm_pcg_prepare(ctx, rng_state_inc);
+    if (rc) return rc;
+    const u128 st = (((u128)rng_state_inc[0]) << 64) | rng_state_inc[1];
+    inc = (((u128)rng_state_inc[2]) << 64) | rng_state_inc[3];
+    s_off = sdm_pcg_advance_host(st, inc, rng_offset);
+  }
   {
     PhaseScope ph(ctx, SDM_PHASE_SHUFFLE_CLEAR);
     HIP_TRY(hipMemsetAsync(rec, 0, sizeof(ShufRec) * length_bound, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ovf_head, 0xFF, sizeof(int32_t) * length_bound, ctx->stream));
   }
-  const dim3 grid(grid_for(length_bound)), block(SDM_BLOCK);
+  const dim3 block(SDM_BLOCK);
   {
     PhaseScope ph(ctx, SDM_PHASE_SHUFFLE_BUILD);
-    if (global)
-      hipLaunchKernelGGL(k_shuffle_build<true>, grid, block, 0, ctx->stream, rec, ovf_head,
-                         ovf_next, u01, cell_start, n_cell, p_length, length_bound);
-    else
-      hipLaunchKernelGGL(k_shuffle_build<false>, grid, block, 0, ctx->stream, rec, ovf_head,
-                         ovf_next, u01, cell_start, n_cell, p_length, length_bound);
+    const dim3 grid(grid_for(length_bound, SDM_BLOCK * SHUF_ELEMS));
+#define LAUNCH_BUILD(G, R)                                                                    \
+  hipLaunchKernelGGL((k_shuffle_build<G, R>), grid, block, 0, ctx->stream, rec, ovf_head,     \
+                     ovf_next, u01, cell_start, n_cell, p_length, length_bound, s_off, inc,   \
+                     ctx->pcg_tab)
+    if (global) { if (u01) LAUNCH_BUILD(true, false); else LAUNCH_BUILD(true, true); }
+    else { if (u01) LAUNCH_BUILD(false, false); else LAUNCH_BUILD(false, true); }
+#undef LAUNCH_BUILD
     LAUNCH_CHECK();
   }
   {
     PhaseScope ph(ctx, SDM_PHASE_SHUFFLE_TRACE);
+    const int64_t span = n_total > length_bound ? n_total : length_bound;
+    const dim3 grid(grid_for(span));
     if (global)
       hipLaunchKernelGGL(k_shuffle_trace<true>, grid, block, 0, ctx->stream, out, idx0, rec,
-                         ovf_head, ovf_next, cell_start, n_cell, p_length, length_bound);
+                         ovf_head, ovf_next, cell_start, n_cell, p_length, length_bound, n_total);
     else
       hipLaunchKernelGGL(k_shuffle_trace<false>, grid, block, 0, ctx->stream, out, idx0, rec,
-                         ovf_head, ovf_next, cell_start, n_cell, p_length, length_bound);
+                         ovf_head, ovf_next, cell_start, n_cell, p_length, length_bound, n_total);
     LAUNCH_CHECK();
   }
   return SDM_OK;
@@ -156,7 +221,8 @@ extern "C" int sdm_shuffle_global(sdm_ctx *ctx, int64_t *idx, int64_t length,
   int rc = sdm_reserve(ctx, shuffle_scratch_bytes(length));
   if (rc) return rc;
   int64_t *out = (int64_t *)(ctx->arena + sdm_shuffle_scratch(length));
-  rc = sdm_shuffle_async(ctx, ctx->arena, out, idx, u01, nullptr, 1, nullptr, length, true);
+  rc = sdm_shuffle_async(ctx, ctx->arena, out, idx, u01, nullptr, 1, nullptr, length, true, 0,
+                         nullptr, 0);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(idx, out, sizeof(int64_t) * length, hipMemcpyDeviceToDevice,
                          ctx->stream));
@@ -179,7 +245,7 @@ extern "C" int sdm_shuffle_local(sdm_ctx *ctx, int64_t *idx, const double *u01,
   if (rc) return rc;
   int64_t *out = (int64_t *)(ctx->arena + sdm_shuffle_scratch(length));
   rc = sdm_shuffle_async(ctx, ctx->arena, out, idx, u01, cell_start, n_cell, nullptr, length,
-                         false);
+                         false, 0, nullptr, 0);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(idx, out, sizeof(int64_t) * length, hipMemcpyDeviceToDevice,
                          ctx->stream));
@@ -239,40 +305,59 @@ __device__ __forceinline__ bool sd_dead(const int64_t *__restrict__ multiplicity
   return v == flag || multiplicity[v] == 0;
 }
 
-// per-block dead counts
+// Fused-step hooks: `fctl` (may be NULL) is the fused control block {valid, work, sorted,
+// healthy, ...}; with it the compaction runs only if fctl[3] == 0 (unhealthy), over
+// [0, fctl[0]) (particle_attributes.py:69), and its last block finally commits
+// valid = work = new length, sorted = 0, healthy = 1 (single-cell: cell_start = {0, new length},
+// sorted stays 1, since the sort of one cell is the identity).
+#define FCTL_VALID 0
+#define FCTL_WORK 1
+#define FCTL_SORTED 2
+#define FCTL_HEALTHY 3
+
+__device__ __forceinline__ bool last_block_done(unsigned int *ticket) {
+  __shared__ bool is_last;
+  __threadfence();  // this block's writes first
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = atomicAdd(ticket, 1u);
+    is_last = (t == gridDim.x - 1);
+    if (is_last) *ticket = 0;  // re-arm for the next launch
+  }
+  __syncthreads();
+  if (is_last) __threadfence();  // acquire: drop stale L1 lines before reading others' results
+  return is_last;
+}
+
+// per-block dead counts; the last block to finish scans them (exclusive) and publishes totals
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_compact_count(const int64_t *__restrict__ multiplicity, const int64_t *__restrict__ idx,
                 const int64_t *__restrict__ p_length, int64_t flag,
-                const int64_t *__restrict__ p_enable, int32_t *__restrict__ block_dead) {
-  if (p_enable && *p_enable != 0) return;  // healthy: nothing to do
-  const int64_t length = *p_length;
+                const int64_t *__restrict__ fctl, int32_t *__restrict__ block_dead, int nb,
+                int64_t *__restrict__ ctl, unsigned int *__restrict__ ticket) {
+  if (fctl && fctl[FCTL_HEALTHY] != 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctl[1] = fctl[FCTL_WORK]; ctl[2] = 0; ctl[3] = 0; }
+    return;
+  }
+  const int64_t length = fctl ? fctl[FCTL_VALID] : *p_length;
   const int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
-  __shared__ int sm[SDM_BLOCK / SDM_WAVE];
+  __shared__ int sm[SDM_BLOCK];
   const bool dead = i < length && sd_dead(multiplicity, idx, i, flag);
   const int c = __popcll(__ballot(dead));
   if (lane_id() == 0) sm[threadIdx.x / SDM_WAVE] = c;
   __syncthreads();
   if (threadIdx.x == 0) block_dead[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
-}
-
-// exclusive scan of block counts (single block), total -> ctl
-__global__ void __launch_bounds__(1024)
-k_compact_scan(int32_t *__restrict__ block_dead, int nb, int64_t *__restrict__ ctl,
-               const int64_t *__restrict__ p_length, const int64_t *__restrict__ p_enable) {
-  if (p_enable && *p_enable != 0) {
-    if (threadIdx.x == 0) { ctl[1] = *p_length; ctl[2] = 0; ctl[3] = 0; }
-    return;
-  }
-  __shared__ int sm[1024];
+  if (!last_block_done(ticket)) return;
+  // exclusive scan of block_dead[0:nb) by this (last) block, SDM_BLOCK entries per round
   __shared__ int carry;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
-  for (int base = 0; base < nb; base += 1024) {
+  for (int base = 0; base < nb; base += SDM_BLOCK) {
     const int b = base + threadIdx.x;
-    const int v = b < nb ? block_dead[b] : 0;
+    const int v = b < nb ? ((volatile int32_t *)block_dead)[b] : 0;
     sm[threadIdx.x] = v;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
+    for (int o = 1; o < SDM_BLOCK; o <<= 1) {
       const int t = threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
       __syncthreads();
       sm[threadIdx.x] += t;
@@ -281,11 +366,10 @@ k_compact_scan(int32_t *__restrict__ block_dead, int nb, int64_t *__restrict__ c
     const int incl = sm[threadIdx.x];
     if (b < nb) block_dead[b] = carry + incl - v;
     __syncthreads();
-    if (threadIdx.x == 1023) carry += incl;
+    if (threadIdx.x == SDM_BLOCK - 1) carry += incl;
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const int64_t length = *p_length;
     ctl[3] = carry;
     ctl[1] = length - carry;
     ctl[2] = 0;
@@ -295,11 +379,12 @@ k_compact_scan(int32_t *__restrict__ block_dead, int nb, int64_t *__restrict__ c
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_compact_lists(const int64_t *__restrict__ multiplicity, const int64_t *__restrict__ idx,
                 const int64_t *__restrict__ p_length, int64_t flag,
-                const int32_t *__restrict__ block_off, int64_t *__restrict__ ctl,
-                int32_t *__restrict__ holes, int64_t *__restrict__ fillers) {
+                const int64_t *__restrict__ fctl, const int32_t *__restrict__ block_off,
+                int64_t *__restrict__ ctl, int32_t *__restrict__ holes,
+                int64_t *__restrict__ fillers) {
   const int64_t total_dead = ctl[3];
   if (total_dead == 0) return;
-  const int64_t length = *p_length, new_len = ctl[1];
+  const int64_t length = fctl ? fctl[FCTL_VALID] : *p_length, new_len = ctl[1];
   const int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
   __shared__ int sm[SDM_BLOCK / SDM_WAVE];
   const bool in = i < length;
@@ -323,15 +408,32 @@ k_compact_lists(const int64_t *__restrict__ multiplicity, const int64_t *__restr
 
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_compact_apply(int64_t *__restrict__ idx, const int64_t *__restrict__ p_length, int64_t flag,
-                const int64_t *__restrict__ ctl, const int32_t *__restrict__ holes,
-                const int64_t *__restrict__ fillers) {
-  if (ctl[3] == 0) return;
-  const int64_t length = *p_length, new_len = ctl[1], n_holes = ctl[2];
-  const int64_t t = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
-  // threads [0, length - new_len): one tail slot each, and (if t < n_holes) one hole each
-  if (t < length - new_len) {
-    idx[new_len + t] = flag;
-    if (t < n_holes) idx[holes[t]] = fillers[t];
+                int64_t *__restrict__ fctl, const int64_t *__restrict__ ctl,
+                const int32_t *__restrict__ holes, const int64_t *__restrict__ fillers,
+                int64_t *__restrict__ cell_start_single, unsigned int *__restrict__ ticket) {
+  if (fctl && fctl[FCTL_HEALTHY] != 0) return;
+  const int64_t new_len = ctl[1];
+  if (ctl[3] != 0) {
+    const int64_t length = fctl ? fctl[FCTL_VALID] : *p_length, n_holes = ctl[2];
+    const int64_t t = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+    // threads [0, length - new_len): one tail slot each, and (if t < n_holes) one hole each
+    if (t < length - new_len) {
+      idx[new_len + t] = flag;
+      if (t < n_holes) idx[holes[t]] = fillers[t];
+    }
+  }
+  if (!fctl) return;
+  if (!last_block_done(ticket)) return;
+  if (threadIdx.x == 0) {
+    fctl[FCTL_VALID] = new_len;
+    fctl[FCTL_WORK] = new_len;
+    fctl[FCTL_HEALTHY] = 1;
+    if (cell_start_single) {
+      cell_start_single[0] = 0;
+      cell_start_single[1] = new_len;
+    } else {
+      fctl[FCTL_SORTED] = 0;
+    }
   }
 }
 
@@ -340,29 +442,28 @@ size_t sdm_compact_scratch(int64_t n) {
          carve_size(sizeof(int64_t) * n);
 }
 
-// p_length: device scalar with the current length; p_enable: optional device "healthy" word
-// (compaction runs only if *p_enable == 0); ctl[1] receives the new length.
+// Without fctl: compacts idx[0:*p_length); ctl[1] receives the new length.  With fctl (fused
+// step): see the comment above FCTL_*; cell_start_single != NULL marks the single-cell case.
+// `ticket`: two zero-initialised device words.
 int sdm_compact_async(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity, int64_t *idx,
                       const int64_t *p_length, int64_t length_bound, int64_t flag,
-                      const int64_t *p_enable, int64_t *ctl) {
+                      int64_t *fctl, int64_t *ctl, int64_t *cell_start_single) {
   if (length_bound <= 0) return SDM_OK;
   Carver cv(scratch);
   const int nb = (int)grid_for(length_bound);
   int32_t *block_dead = cv.take<int32_t>(nb + 1);
   int32_t *holes = cv.take<int32_t>(length_bound);
   int64_t *fillers = cv.take<int64_t>(length_bound);
+  unsigned int *ticket = (unsigned int *)(ctx->dscal + 14);
   const dim3 grid(nb), block(SDM_BLOCK);
   hipLaunchKernelGGL(k_compact_count, grid, block, 0, ctx->stream, multiplicity, idx, p_length,
-                     flag, p_enable, block_dead);
-  LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, ctx->stream, block_dead, nb, ctl,
-                     p_length, p_enable);
+                     flag, fctl, block_dead, nb, ctl, ticket);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_compact_lists, grid, block, 0, ctx->stream, multiplicity, idx, p_length,
-                     flag, block_dead, ctl, holes, fillers);
+                     flag, fctl, block_dead, ctl, holes, fillers);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_compact_apply, grid, block, 0, ctx->stream, idx, p_length, flag, ctl,
-                     holes, fillers);
+  hipLaunchKernelGGL(k_compact_apply, grid, block, 0, ctx->stream, idx, p_length, flag, fctl,
+                     ctl, holes, fillers, cell_start_single, ticket + 1);
   LAUNCH_CHECK();
   return SDM_OK;
 }
@@ -377,7 +478,8 @@ extern "C" int sdm_remove_zero_n_or_flagged(sdm_ctx *ctx, const int64_t *multipl
   if (rc) return rc;
   int64_t *ctl = ctx->dscal;
   HIP_TRY(hipMemcpyAsync(ctl, &length, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-  rc = sdm_compact_async(ctx, ctx->arena, multiplicity, idx, ctl, length, idx_len, nullptr, ctl);
+  rc = sdm_compact_async(ctx, ctx->arena, multiplicity, idx, ctl, length, idx_len, nullptr, ctl,
+                         nullptr);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(ctx->mailbox, ctl + 1, sizeof(int64_t), hipMemcpyDeviceToHost,
                          ctx->stream));
