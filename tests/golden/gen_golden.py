@@ -715,8 +715,35 @@ def gen_breakup():
         save(f"traj_breakup_straub_rain_hab{int(hab)}", **out)
 
 
+def gen_shards():
+    """sub-domain runs for the cell-sharding tests: a multi-cell case split into 2 contiguous
+    blocks of cells; each block is run by the reference on its own (same seed), cell ids renumbered
+    to the local range"""
+    gold = np.load(os.path.join(OUT, "traj_multicell_golovin_4x4.npz"))
+    n_sd, seed, adaptive, dt, dv, n_cell = (gold["cfg"][i] for i in range(6))
+    n_cell, world = int(n_cell), 2
+    for rank in range(world):
+        base, extra = divmod(n_cell, world)
+        first = rank * base + min(rank, extra)
+        last = first + base + (1 if rank < extra else 0)
+        cell_id = gold["init/cell_id"]
+        mine = np.flatnonzero((cell_id >= first) & (cell_id < last))
+        out = run_traj(
+            n_sd=len(mine), seed=int(seed), dt=float(dt), dv=float(dv),
+            volume=gold["init/volume"][mine], multiplicity=gold["init/multiplicity"][mine],
+            make_dynamic=lambda: Coalescence(collision_kernel=Golovin(b=1.5e3),
+                                             adaptive=bool(adaptive)),
+            record_steps=(1, 3, 10), grid=(last - first,), cell_id=cell_id[mine] - first,
+        )
+        out["cfg"] = np.asarray([len(mine), seed, adaptive, dt, dv, last - first])
+        out["global_indices"] = mine
+        save(f"shard_golovin_4x4_r{rank}of{world}", **out)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["micro", "frag", "traj", "breakup"]
+    what = sys.argv[1:] or ["micro", "frag", "traj", "breakup", "shards"]
+    if "shards" in what:
+        gen_shards()
     if "micro" in what:
         gen_micro()
     if "frag" in what:
