@@ -41,7 +41,7 @@ class StepState(ctypes.Structure):  # == sdm_step_state
         ("stats_dt_min", c_ptr), ("stats_n_substep", c_ptr), ("collision_rate", c_ptr),
         ("collision_rate_deficit", c_ptr), ("coalescence_rate", c_ptr), ("breakup_rate", c_ptr),
         ("breakup_rate_deficit", c_ptr), ("gk_a", c_ptr), ("gk_b", c_ptr), ("ctl", c_ptr),
-        ("rng_offset", c_u64), ("rng_offset_breakup", c_u64),
+        ("nm", c_ptr), ("rng_offset", c_u64), ("rng_offset_breakup", c_u64),
     ]
 
 

@@ -67,7 +67,10 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
         self.idx = view["idx"]
         self.tmp_idx = view["caretaker"].tmp_idx
         self.ctl = torch.zeros(8, dtype=torch.int64, device=self.idx.data.device)
+        # {multiplicity, mass} mirror, 16 B per super-droplet (see sdm_step_state.nm)
+        self.nm = torch.empty(2 * part.n_sd, dtype=torch.int64, device=self.idx.data.device)
         self._ctl_initialised = False
+        self._stamps = None
         self.result = StepResult()
 
     def _push_host_state(self):
@@ -82,6 +85,10 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
     def __call__(self):
         dyn, attrs = self.dynamic, self.particulator.attributes
         flags = int(self.read_back)
+        # anything else that touched multiplicities / attributes since the last fused call
+        # (method-by-method calls, uploads) invalidates the device-side bookkeeping
+        if self._stamps != self._timestamps():
+            self._ctl_initialised = False
         if not self._ctl_initialised:
             self._push_host_state()
             flags |= 2
@@ -105,6 +112,7 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
         if self.gk is not None:
             state.gk_a, state.gk_b = _p(self.gk.a.data), _p(self.gk.b.data)
         state.ctl = _p(self.ctl)
+        state.nm = _p(self.nm)
         state.rng_offset = dyn.rnd_opt_coll.rnd.offset
         if dyn.enable_breakup:
             state.rng_offset_breakup = dyn.rnd_opt_proc.rnd.offset
@@ -124,6 +132,12 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
         if self.read_back:
             self._commit(ctx)
         self.particulator.mark_collision_outputs_updated()
+        self._stamps = self._timestamps()
+
+    def _timestamps(self):
+        attrs = self.particulator.attributes
+        names = ["multiplicity", "cell id"] + list(attrs.get_extensive_attribute_keys())
+        return tuple(attrs.get_attribute_object(name).timestamp for name in names)
 
     def _commit(self, _ctx):
         words = self.ctl.cpu().numpy()

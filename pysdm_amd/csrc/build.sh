@@ -6,12 +6,23 @@ OUT=../libsdm_hip.so
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
 objs=()
+pids=()
 for f in ctx index collisions fused; do
-  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ physics.h -nt $f.o ] || [ index.h -nt $f.o ] || [ ../../include/sdm_hip.h -nt $f.o ]; then
+  stale=0
+  [ -f $f.o ] || stale=1
+  for dep in $f.hip common.h physics.h index.h shuffle_device.h ../../include/sdm_hip.h; do
+    [ $stale = 1 ] || { [ $dep -nt $f.o ] && stale=1; } || true
+  done
+  if [ $stale = 1 ]; then
+    rm -f $f.o
     $HIPCC $FLAGS -c $f.hip -o $f.o &
+    pids+=($!)
   fi
   objs+=($f.o)
 done
-wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT "${objs[@]}"
+for pid in "${pids[@]:-}"; do
+  [ -z "$pid" ] || wait "$pid"
+done
+rm -f $OUT
+$HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined -o $OUT "${objs[@]}"
 echo "built $(realpath $OUT)"

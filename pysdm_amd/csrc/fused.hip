@@ -21,6 +21,8 @@ int sdm_adaptive_end_async(sdm_ctx *ctx, const double *dt_left, int64_t n_cell,
 
 #define TID() ((int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x)
 
+struct __align__(16) NM { int64_t n; double m; };
+
 struct FusedArgs {
   // state
   int64_t *idx;
@@ -48,6 +50,14 @@ struct FusedArgs {
   double *Ec;             // [P]
   double *fragment_mass;  // [P]
   double *dt_todo, *cell_min;  // [C]
+  // single-cell fast path: the pair kernels do the shuffle's backward walk themselves (two
+  // positions per thread) and write the permuted, pair-sorted idx once; NULL otherwise
+  const PackRec *rec;
+  const int32_t *ovf_head, *ovf_next;
+  const int64_t *idx_prev;  // previous permutation (source of the dead tail)
+  // {multiplicity, mass} of each super-droplet side by side (one random line per gather instead
+  // of two); a mirror of the SoA columns kept current by the update code, NULL = not in use
+  NM *nm;
 };
 
 // wave-aggregated int64 counter add: one atomic per wave when all contributing lanes share cid
@@ -104,15 +114,29 @@ struct PairInfo {
 
 // pairing (find_pairs + sort_within_pair), kernel, probability, [Ec, fragment mass], [optimal dt]
 // for pair slot d; `u_b` = the slot's draw of the breakup streams
+template <int KERNEL, bool BREAKUP>
 __device__ __forceinline__ PairInfo pair_prob_body(const sdm_step_cfg &cfg, const FusedArgs &A,
                                                    int64_t d, int64_t W, double u_b) {
   PairInfo R;
   R.have = false; R.off = 2; R.j = R.k = R.nj = R.nk = R.cid_j = 0;
   R.prob = 0.0; R.ec = 0.0; R.fm = 0.0; R.dt_optimal = INFINITY;
   int64_t i = 0;
+  int64_t tj = 0, tk = 0;
   // find_pairs (pair_methods.py:34-55) for positions 2d and 2d+1
   if (cfg.n_cell == 1) {
     if (2 * d + 1 < W) { R.have = true; i = 2 * d; }
+    if (A.rec) {  // permutation resolved here (shuffle_local of the single cell [0, W))
+      if (R.have) {
+        walk_packed2(A.rec, A.ovf_head, A.ovf_next, (int32_t)(2 * d), (int32_t)(2 * d + 1), 0, tj,
+                     tk);
+      } else {
+        for (int o = 0; o < 2; ++o) {  // unpaired last position / dead tail
+          const int64_t p = 2 * d + o;
+          if (p < W) A.idx[p] = walk_packed(A.rec, A.ovf_head, A.ovf_next, (int32_t)p, 0);
+          else if (p < cfg.n_sd) A.idx[p] = A.idx_prev[p];
+        }
+      }
+    }
   } else {
 #pragma unroll
     for (int o = 0; o < 2 && !R.have; ++o) {
@@ -126,23 +150,35 @@ __device__ __forceinline__ PairInfo pair_prob_body(const sdm_step_cfg &cfg, cons
   }
   if (!R.have) return R;
   R.off = (uint8_t)(i - 2 * d);
-  int64_t j = A.idx[i], k = A.idx[i + 1];
-  int64_t nj = A.multiplicity[j], nk = A.multiplicity[k];
+  const bool traced = A.rec != nullptr;
+  int64_t j = traced ? tj : A.idx[i], k = traced ? tk : A.idx[i + 1];
+  const double *mass = A.attributes + (int64_t)cfg.mass_attr * cfg.n_sd;
+  int64_t nj, nk;
+  double mj, mk;
+  if (A.nm) {
+    const NM a = A.nm[j], b = A.nm[k];
+    nj = a.n; mj = a.m; nk = b.n; mk = b.m;
+  } else {
+    nj = A.multiplicity[j]; nk = A.multiplicity[k];
+    mj = mass[j]; mk = mass[k];
+  }
   // sort_within_pair_by_attr (pair_methods.py:126-140)
-  if (nj < nk) {
+  const bool swap = nj < nk;
+  if (swap) {
     const int64_t t = j; j = k; k = t;
     const int64_t tn = nj; nj = nk; nk = tn;
+    const double tm = mj; mj = mk; mk = tm;
+  }
+  if (swap || traced) {
     A.idx[i] = j;
     A.idx[i + 1] = k;
   }
   R.j = j; R.k = k; R.nj = nj; R.nk = nk;
   R.cid_j = cfg.n_cell == 1 ? 0 : A.cell_id[j];
-  const double *mass = A.attributes + (int64_t)cfg.mass_attr * cfg.n_sd;
-  const double vj = volume_of_mass(mass[j], cfg.rho_w), vk = volume_of_mass(mass[k], cfg.rho_w);
+  const double vj = volume_of_mass(mj, cfg.rho_w), vk = volume_of_mass(mk, cfg.rho_w);
   double rj = 0, rk = 0, uj = 0, uk = 0;
-  const bool need_r = cfg.kernel == SDM_KERNEL_GEOMETRIC ||
-                      (cfg.enable_breakup && (cfg.ec != SDM_EC_CONST ||
-                                              cfg.frag == SDM_FRAG_STRAUB2010));
+  const bool need_r = KERNEL == SDM_KERNEL_GEOMETRIC ||
+                      (BREAKUP && (cfg.ec != SDM_EC_CONST || cfg.frag == SDM_FRAG_STRAUB2010));
   if (need_r) {
     const double inv = 1 / (3.14159265358979323846 * 4 / 3);
     rj = radius_of_volume(vj, inv);
@@ -153,22 +189,21 @@ __device__ __forceinline__ PairInfo pair_prob_body(const sdm_step_cfg &cfg, cons
     }
   }
   double K;
-  switch (cfg.kernel) {
-    case SDM_KERNEL_GOLOVIN: K = (vj + vk) * cfg.kernel_param[0]; break;
-    case SDM_KERNEL_GEOMETRIC: {
-      const double s = rj + rk;
-      K = (s * s) * cfg.kernel_param[0];
-      K *= fabs(uj - uk);
-      break;
-    }
-    default: K = cfg.kernel_param[0];
+  if (KERNEL == SDM_KERNEL_GOLOVIN) {
+    K = (vj + vk) * cfg.kernel_param[0];
+  } else if (KERNEL == SDM_KERNEL_GEOMETRIC) {
+    const double s = rj + rk;
+    K = (s * s) * cfg.kernel_param[0];
+    K *= fabs(uj - uk);
+  } else {
+    K = cfg.kernel_param[0];
   }
   // collision.py:249-254: prob = max(n) ; *= K ; normalize (cell of RAW SD #d: reference quirk)
   double prob = (double)nj;
   prob *= K;
   prob *= norm_factor_of(cfg, A.cell_start, cfg.n_cell == 1 ? 0 : A.cell_idx[A.cell_id[d]]);
   R.prob = prob;
-  if (cfg.enable_breakup) {
+  if (BREAKUP) {
     switch (cfg.ec) {
       case SDM_EC_CONST: R.ec = cfg.ec_param[0]; break;
       case SDM_EC_BERRY1967: {
@@ -194,7 +229,7 @@ __device__ __forceinline__ PairInfo pair_prob_body(const sdm_step_cfg &cfg, cons
       }
     }
     switch (cfg.frag) {
-      case SDM_FRAG_ALWAYS_N: R.fm = (mass[j] + mass[k]) / cfg.frag_param[0]; break;
+      case SDM_FRAG_ALWAYS_N: R.fm = (mj + mk) / cfg.frag_param[0]; break;
       case SDM_FRAG_EXPONENTIAL: {
         const double a = 1 - u_b;
         double fv = -cfg.frag_param[0] * log(a > 1e-5 ? a : 1e-5), nf;
@@ -241,6 +276,7 @@ __device__ __forceinline__ PairInfo pair_prob_body(const sdm_step_cfg &cfg, cons
 
 // compute_gamma + collision_coalescence[_breakup] for slot d (all lanes of the wave must call).
 // p = the (already dt-scaled) probability; u = the slot's `rand`; j/k valid if `known`.
+template <bool BREAKUP>
 __device__ __forceinline__ void pair_update_body(const sdm_step_cfg &cfg, const FusedArgs &A,
                                                  int64_t d, bool in_range, double p, double u,
                                                  double u_b, bool known, int64_t off,
@@ -269,7 +305,7 @@ __device__ __forceinline__ void pair_update_body(const sdm_step_cfg &cfg, const 
   counter_add(A.collision_rate_deficit, cid, (gi - gc) * nk, collide);
   collide = collide && g != 0;
   bool coal = collide;
-  if (cfg.enable_breakup && collide) {
+  if (BREAKUP && collide) {
     const double eb = cfg.eb_const;
     if (u_b - (ec + (1 - ec) * eb) > 0) {
       collide = false;  // bounce
@@ -331,42 +367,51 @@ __device__ __forceinline__ void pair_update_body(const sdm_step_cfg &cfg, const 
   }
   counter_add(A.coalescence_rate, cid, (int64_t)(g * (double)nk), coal);
   if (coal) coalesce_pair(j, k, g, A.multiplicity, A.attributes, cfg.n_attr, cfg.n_sd);
-  if (collide && (A.multiplicity[k] == 0 || A.multiplicity[j] == 0)) A.ctl[CTL_HEALTHY] = 0;
+  if (collide) {
+    const int64_t n_j = A.multiplicity[j], n_k = A.multiplicity[k];
+    if (n_k == 0 || n_j == 0) A.ctl[CTL_HEALTHY] = 0;
+    if (A.nm) {
+      const double *mass = A.attributes + (int64_t)cfg.mass_attr * cfg.n_sd;
+      NM a, b;
+      a.n = n_j; a.m = mass[j];
+      b.n = n_k; b.m = mass[k];
+      A.nm[j] = a;
+      A.nm[k] = b;
+    }
+  }
 }
 
 // ---- non-adaptive: everything about a pair in one kernel -------------------------------------
+template <int KERNEL, bool BREAKUP>
 __global__ void __launch_bounds__(SDM_BLOCK) k_pair_all(sdm_step_cfg cfg, FusedArgs A) {
   __shared__ u128 lds[2];
   const int64_t W = A.ctl[CTL_WORK];
   const int64_t d = TID();
   const double u = stream_draw(A.s_rand, A.rng_inc, A.rng_tab, &lds[0]);
-  const double u_b =
-      cfg.enable_breakup ? stream_draw(A.s_rand_b, A.rng_inc, A.rng_tab, &lds[1]) : 0.0;
-  const bool in_slots = d < cfg.n_sd / 2;
+  const double u_b = BREAKUP ? stream_draw(A.s_rand_b, A.rng_inc, A.rng_tab, &lds[1]) : 0.0;
   PairInfo R;
   R.have = false; R.off = 2; R.prob = 0; R.j = R.k = 0; R.ec = R.fm = 0;
-  if (in_slots) R = pair_prob_body(cfg, A, d, W, u_b);
+  if (d < (cfg.n_sd + 1) / 2) R = pair_prob_body<KERNEL, BREAKUP>(cfg, A, d, W, u_b);
   double p = R.prob;
   if (p != 0) p /= (double)cfg.substeps;  // collision.py:279
-  pair_update_body(cfg, A, d, in_slots && d < W / 2, p, u, u_b, true, R.off, R.j, R.k, R.ec,
-                   R.fm);
+  pair_update_body<BREAKUP>(cfg, A, d, d < W / 2, p, u, u_b, true, R.off, R.j, R.k, R.ec, R.fm);
 }
 
 // ---- adaptive: probabilities first (per-cell min of the optimal dt is a global dependency) ---
+template <int KERNEL, bool BREAKUP>
 __global__ void __launch_bounds__(SDM_BLOCK) k_pair_prob(sdm_step_cfg cfg, FusedArgs A) {
   __shared__ u128 lds[1];
   const int64_t W = A.ctl[CTL_WORK];
   const int64_t d = TID();
-  const double u_b =
-      cfg.enable_breakup ? stream_draw(A.s_rand_b, A.rng_inc, A.rng_tab, &lds[0]) : 0.0;
+  const double u_b = BREAKUP ? stream_draw(A.s_rand_b, A.rng_inc, A.rng_tab, &lds[0]) : 0.0;
   PairInfo R;
   R.have = false; R.prob = 0; R.cid_j = 0; R.dt_optimal = INFINITY; R.off = 2; R.ec = R.fm = 0;
+  if (d < (cfg.n_sd + 1) / 2) R = pair_prob_body<KERNEL, BREAKUP>(cfg, A, d, W, u_b);
   if (d < cfg.n_sd / 2) {
-    R = pair_prob_body(cfg, A, d, W, u_b);
     A.prob[d] = R.prob;
     A.pair_off[d] = R.off;
     if (cfg.n_cell > 1) A.pair_cid[d] = (int32_t)R.cid_j;
-    if (cfg.enable_breakup) { A.Ec[d] = R.ec; A.fragment_mass[d] = R.fm; }
+    if (BREAKUP) { A.Ec[d] = R.ec; A.fragment_mass[d] = R.fm; }
   }
   const bool active = R.have && R.prob != 0;
   const unsigned long long am = __ballot(active);
@@ -397,13 +442,13 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_cells_adaptive(sdm_step_cfg cfg, 
   if (t > 0) A.stats_n_substep[c] += 1;
 }
 
+template <bool BREAKUP>
 __global__ void __launch_bounds__(SDM_BLOCK) k_pair_update(sdm_step_cfg cfg, FusedArgs A) {
   __shared__ u128 lds[2];
   const int64_t W = A.ctl[CTL_WORK];
   const int64_t d = TID();
   const double u = stream_draw(A.s_rand, A.rng_inc, A.rng_tab, &lds[0]);
-  const double u_b =
-      cfg.enable_breakup ? stream_draw(A.s_rand_b, A.rng_inc, A.rng_tab, &lds[1]) : 0.0;
+  const double u_b = BREAKUP ? stream_draw(A.s_rand_b, A.rng_inc, A.rng_tab, &lds[1]) : 0.0;
   const bool in_range = d < W / 2;
   double p = 0, ec = 0, fm = 0;
   int64_t off = 2;
@@ -414,9 +459,9 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_update(sdm_step_cfg cfg, Fus
       const int64_t cid = cfg.n_cell > 1 ? A.pair_cid[d] : 0;
       p *= A.dt_todo[cid] / cfg.dt;  // collisions_methods.py:369-372
     }
-    if (cfg.enable_breakup) { ec = A.Ec[d]; fm = A.fragment_mass[d]; }
+    if (BREAKUP) { ec = A.Ec[d]; fm = A.fragment_mass[d]; }
   }
-  pair_update_body(cfg, A, d, in_range, p, u, u_b, false, off, 0, 0, ec, fm);
+  pair_update_body<BREAKUP>(cfg, A, d, in_range, p, u, u_b, false, off, 0, 0, ec, fm);
 }
 
 // ---- control-word kernels -------------------------------------------------------------------
@@ -439,6 +484,17 @@ k_sort_commit(int64_t *__restrict__ idx, const int64_t *__restrict__ sorted_buf,
 
 __global__ void k_sort_done(int64_t *ctl) { ctl[CTL_SORTED] = 1; }
 __global__ void k_mark_unsorted(int64_t *ctl) { ctl[CTL_SORTED] = 0; }
+
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_nm_init(NM *__restrict__ nm, const int64_t *__restrict__ multiplicity,
+          const double *__restrict__ mass, int64_t n) {
+  const int64_t i = TID();
+  if (i >= n) return;
+  NM v;
+  v.n = multiplicity[i];
+  v.m = mass[i];
+  nm[i] = v;
+}
 
 // single cell: the sort is the identity, only cell_start = {0, length} has to be right
 __global__ void k_single_cell_init(int64_t *ctl, int64_t *cell_start) {
@@ -516,6 +572,26 @@ static int cond_sort(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st, 
   return SDM_OK;
 }
 
+// kernel specialisations: collision kernel kind x breakup on/off (keeps the coalescence-only
+// kernels free of the breakup code's registers)
+#define DISPATCH_PAIR(KERN, GRID)                                                              \
+  do {                                                                                         \
+    const bool brk__ = cfg->enable_breakup != 0;                                               \
+    switch (cfg->kernel) {                                                                     \
+      case SDM_KERNEL_GOLOVIN:                                                                 \
+        if (brk__) hipLaunchKernelGGL((KERN<SDM_KERNEL_GOLOVIN, true>), GRID, blk, 0, s, *cfg, A); \
+        else hipLaunchKernelGGL((KERN<SDM_KERNEL_GOLOVIN, false>), GRID, blk, 0, s, *cfg, A);  \
+        break;                                                                                 \
+      case SDM_KERNEL_GEOMETRIC:                                                               \
+        if (brk__) hipLaunchKernelGGL((KERN<SDM_KERNEL_GEOMETRIC, true>), GRID, blk, 0, s, *cfg, A); \
+        else hipLaunchKernelGGL((KERN<SDM_KERNEL_GEOMETRIC, false>), GRID, blk, 0, s, *cfg, A); \
+        break;                                                                                 \
+      default:                                                                                 \
+        if (brk__) hipLaunchKernelGGL((KERN<SDM_KERNEL_CONSTANT, true>), GRID, blk, 0, s, *cfg, A); \
+        else hipLaunchKernelGGL((KERN<SDM_KERNEL_CONSTANT, false>), GRID, blk, 0, s, *cfg, A); \
+    }                                                                                          \
+  } while (0)
+
 // flags: bit 0 = read the control block back at the end; bit 1 = the control block was freshly
 // pushed by the host (single-cell bookkeeping has to be initialised)
 extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st,
@@ -585,6 +661,12 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   hipStream_t s = ctx->stream;
   const dim3 blk(SDM_BLOCK), one(1);
 
+  A.nm = (NM *)st->nm;
+  if (st->nm && (flags & 2)) {
+    hipLaunchKernelGGL(k_nm_init, dim3(grid_for(N)), blk, 0, s, (NM *)st->nm, st->multiplicity,
+                       st->attributes + (int64_t)cfg->mass_attr * N, N);
+    LAUNCH_CHECK();
+  }
   if (C == 1 && (flags & 2)) {
     hipLaunchKernelGGL(k_single_cell_init, one, one, 0, s, st->ctl, st->cell_start);
     LAUNCH_CHECK();
@@ -625,10 +707,23 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
     // cell_start, also those beyond a cut working length (index_methods.py:35); shuffle_global
     // covers the working length (index.py:43-45).  u01[i] = draw (window shift + i).
     const int64_t *p_shuffle_len = cfg->croupier_local ? st->cell_start + C : st->ctl + CTL_WORK;
-    rc = sdm_shuffle_async(ctx, S.shuffle, alt, cur, nullptr, st->cell_start, C, p_shuffle_len, N,
-                           !cfg->croupier_local, N, cfg->rng_state_inc,
-                           draw_off + (uint64_t)(cfg->optimized_random ? n_sub : 0));
-    if (rc) return rc;
+    const uint64_t u01_off = draw_off + (uint64_t)(cfg->optimized_random ? n_sub : 0);
+    const bool split = C == 1 && cfg->croupier_local && sdm_shuffle_can_split(N, false);
+    if (split) {
+      // single cell: event records only; the pair kernels walk them (2 positions per thread)
+      ShuffleViews views;
+      rc = sdm_shuffle_build_async(ctx, S.shuffle, cur, st->cell_start, C, p_shuffle_len, N,
+                                   cfg->rng_state_inc, u01_off, &views);
+      if (rc) return rc;
+      A.rec = views.rec;
+      A.ovf_head = views.ovf_head;
+      A.ovf_next = views.ovf_next;
+      A.idx_prev = cur;
+    } else {
+      rc = sdm_shuffle_async(ctx, S.shuffle, alt, cur, nullptr, st->cell_start, C, p_shuffle_len,
+                             N, !cfg->croupier_local, N, cfg->rng_state_inc, u01_off);
+      if (rc) return rc;
+    }
     { int64_t *t = cur; cur = alt; alt = t; }
     ++swaps;
     if (!cfg->croupier_local && C > 1) {
@@ -641,7 +736,7 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
     // (e)+(f) probabilities, gamma, update
     if (!cfg->adaptive) {
       PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
-      hipLaunchKernelGGL(k_pair_all, dim3(grid_for(P)), blk, 0, s, *cfg, A);
+      DISPATCH_PAIR(k_pair_all, dim3(grid_for((N + 1) / 2)));
       LAUNCH_CHECK();
     } else {
       {
@@ -651,7 +746,7 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
       }
       {
         PhaseScope ph(ctx, SDM_PHASE_PAIR_PROB);
-        hipLaunchKernelGGL(k_pair_prob, dim3(grid_for(P)), blk, 0, s, *cfg, A);
+        DISPATCH_PAIR(k_pair_prob, dim3(grid_for((N + 1) / 2)));
         LAUNCH_CHECK();
       }
       {
@@ -661,7 +756,10 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
       }
       {
         PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
-        hipLaunchKernelGGL(k_pair_update, dim3(grid_for(P)), blk, 0, s, *cfg, A);
+        if (cfg->enable_breakup)
+          hipLaunchKernelGGL(k_pair_update<true>, dim3(grid_for(P)), blk, 0, s, *cfg, A);
+        else
+          hipLaunchKernelGGL(k_pair_update<false>, dim3(grid_for(P)), blk, 0, s, *cfg, A);
         LAUNCH_CHECK();
       }
     }

@@ -1,6 +1,7 @@
 // index.h -- async cores of the permutation-side kernels, shared with the fused step
 #pragma once
 #include "common.h"
+#include "shuffle_device.h"
 
 int sdm_pcg_prepare(sdm_ctx *ctx, const uint64_t state_inc[4]);
 u128 sdm_pcg_advance_host(u128 state, u128 inc, uint64_t delta);
@@ -22,3 +23,8 @@ int sdm_counting_sort_async(sdm_ctx *ctx, char *scratch, int64_t *new_idx, const
                             const int64_t *cell_id, const int64_t *cell_idx,
                             const int64_t *p_length, int64_t length_bound, int64_t *cell_start,
                             int64_t n_cell);
+bool sdm_shuffle_can_split(int64_t n, bool global);
+int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
+                            const int64_t *cell_start, int64_t n_cell, const int64_t *p_length,
+                            int64_t length_bound, const uint64_t *rng_state_inc,
+                            uint64_t rng_offset, ShuffleViews *views);

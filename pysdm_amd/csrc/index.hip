@@ -2,6 +2,7 @@
 // serial swap chains (shuffle_local / shuffle_global), cell sort, compaction.
 #include "common.h"
 #include "index.h"
+#include "shuffle_device.h"
 
 // ---------------------------------------------------------------------------------------
 // identity_index  (index_methods.py:14-20)
@@ -161,6 +162,12 @@ static size_t shuffle_scratch_bytes(int64_t n) {
          carve_size(sizeof(int64_t) * n);
 }
 
+static bool binned_ok(int64_t n, bool global);
+static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *idx0,
+                                const double *u01, const int64_t *cell_start, int64_t n_cell,
+                                const int64_t *p_length, int64_t length_bound, int64_t n_total,
+                                u128 s_off, u128 inc, ShuffleViews *views);
+
 // out-of-place core: out[0:length) = shuffled idx0[0:length), out[length:n_total) = idx0[...].
 // u01 == nullptr: draws generated in the kernel from (rng_state_inc, rng_offset).
 int sdm_shuffle_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *idx0,
@@ -180,6 +187,9 @@ int sdm_shuffle_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *
     inc = (((u128)rng_state_inc[2]) << 64) | rng_state_inc[3];
     s_off = sdm_pcg_advance_host(st, inc, rng_offset);
   }
+  if (binned_ok(length_bound, global))
+    return shuffle_binned_async(ctx, scratch, out, idx0, u01, cell_start, n_cell, p_length,
+                                length_bound, n_total, s_off, inc, nullptr);
   {
     PhaseScope ph(ctx, SDM_PHASE_SHUFFLE_CLEAR);
     HIP_TRY(hipMemsetAsync(rec, 0, sizeof(ShufRec) * length_bound, ctx->stream));
@@ -212,13 +222,335 @@ int sdm_shuffle_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *
   return SDM_OK;
 }
 
-size_t sdm_shuffle_scratch(int64_t n) { return shuffle_scratch_bytes(n) - carve_size(sizeof(int64_t) * n); }
+// ---------------------------------------------------------------------------------------
+// Binned build (local croupier): the same event records without a single global atomic.
+// Positions are cut into tiles of BIN_POS; an event (i, j_i) is routed to the tile of its target
+// j_i (count -> column scan -> scatter, all ranking done with LDS atomics), then one workgroup per
+// tile assembles the records of its BIN_POS positions in LDS and writes them out whole:
+//   PackRec {own target j (-1 none), first hit s0 (-1 none), second hit s1 (-1 none),
+//            initial content of the position (int32) | bit 31 = "more hits in the overflow list"}
+// so the backward walk needs no separate gather of the initial content.  u01 comes either from
+// memory or from the PCG64 stream evaluated in place (16 consecutive draws per thread).
+// ---------------------------------------------------------------------------------------
+#define BIN_POS 2048
+#define BIN_THREADS 256
+#define BIN_PER_THREAD 8
+#define BIN_SHIFT 11
+
+// PackRec and the backward walk live in shuffle_device.h (shared with the fused pair kernels)
+
+// own-event targets of BIN_PER_THREAD consecutive positions from `first` (local croupier)
+template <bool RNG>
+__device__ __forceinline__ void targets16(int64_t first, int64_t length,
+                                          const double *__restrict__ u01,
+                                          const int64_t *__restrict__ cell_start, int64_t n_cell,
+                                          u128 s_tile, u128 inc, const u128 *__restrict__ tab,
+                                          int32_t (&j)[BIN_PER_THREAD]) {
+  u128 state = 0;
+  if (RNG) state = pcg_jump(s_tile, tab, (uint64_t)threadIdx.x * BIN_PER_THREAD);
+  const u128 mult = pcg_mult();
+  int64_t lo = 0, hi = 0;
+  bool have_cell = false;
+#pragma unroll
+  for (int e = 0; e < BIN_PER_THREAD; ++e) {
+    const int64_t i = first + e;
+    double u = 0.0;
+    if (RNG) {
+      state = state * mult + inc;
+      u = pcg_output(state);
+    } else if (i < length) {
+      u = u01[i];
+    }
+    j[e] = -1;
+    if (i >= length) continue;
+    if (!have_cell || i >= hi) {
+      const int64_t c = n_cell == 1 ? 0 : find_cell(cell_start, n_cell, i);
+      lo = cell_start[c];
+      hi = cell_start[c + 1];
+      have_cell = true;
+    }
+    if (i > lo) {
+      const int64_t t = (int64_t)((double)lo + u * (double)(hi - lo));
+      // memory safety only: the reference would index past the cell with prob ~2^-43
+      j[e] = (int32_t)(t > hi - 1 ? hi - 1 : (t < lo ? lo : t));
+    }
+  }
+}
+
+__device__ __forceinline__ u128 tile_state(u128 s_off, const u128 *__restrict__ tab,
+                                           u128 *lds_slot) {
+  if (threadIdx.x == 0) *lds_slot = pcg_jump(s_off, tab, (uint64_t)blockIdx.x * BIN_POS);
+  __syncthreads();
+  return *lds_slot;
+}
+
+// K1: per event tile, histogram of target tiles -> cnt[tile][bin]
+template <bool RNG>
+__global__ void __launch_bounds__(BIN_THREADS)
+k_bin_count(int32_t *__restrict__ cnt, int n_bins, const double *__restrict__ u01,
+            const int64_t *__restrict__ cell_start, int64_t n_cell,
+            const int64_t *__restrict__ p_length, int64_t length_arg, u128 s_off, u128 inc,
+            const u128 *__restrict__ tab) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int32_t *hist = (int32_t *)smem;
+  __shared__ u128 s_slot;
+  const int64_t length = p_length ? *p_length : length_arg;
+  for (int b = threadIdx.x; b < n_bins; b += BIN_THREADS) hist[b] = 0;
+  const u128 s_tile = RNG ? tile_state(s_off, tab, &s_slot) : 0;
+  __syncthreads();
+  const int64_t first = (int64_t)blockIdx.x * BIN_POS + (int64_t)threadIdx.x * BIN_PER_THREAD;
+  int32_t j[BIN_PER_THREAD];
+  targets16<RNG>(first, length, u01, cell_start, n_cell, s_tile, inc, tab, j);
+#pragma unroll
+  for (int e = 0; e < BIN_PER_THREAD; ++e)
+    if (j[e] >= 0) atomicAdd(&hist[j[e] >> BIN_SHIFT], 1);
+  __syncthreads();
+  for (int b = threadIdx.x; b < n_bins; b += BIN_THREADS)
+    cnt[(int64_t)blockIdx.x * n_bins + b] = hist[b];
+}
+
+// K2: one workgroup per bin: exclusive scan down the tiles (column of cnt), total -> total[bin]
+__global__ void __launch_bounds__(BIN_THREADS)
+k_bin_colscan(int32_t *__restrict__ cnt, int32_t *__restrict__ total, int n_bins) {
+  __shared__ int sm[BIN_THREADS];
+  __shared__ int carry;
+  const int bin = blockIdx.x;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n_bins; base += BIN_THREADS) {  // n_tiles == n_bins
+    const int t = base + threadIdx.x;
+    const int v = t < n_bins ? cnt[(int64_t)t * n_bins + bin] : 0;
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < BIN_THREADS; o <<= 1) {
+      const int a = threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
+      __syncthreads();
+      sm[threadIdx.x] += a;
+      __syncthreads();
+    }
+    const int incl = sm[threadIdx.x];
+    if (t < n_bins) cnt[(int64_t)t * n_bins + bin] = carry + incl - v;
+    __syncthreads();
+    if (threadIdx.x == BIN_THREADS - 1) carry += incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) total[bin] = carry;
+}
+
+// exclusive scan of total[0:n_bins) into LDS (every workgroup of K3 / K4 does its own)
+__device__ __forceinline__ void bin_starts(const int32_t *__restrict__ total, int n_bins,
+                                           int32_t *start /* LDS, n_bins + 1 */) {
+  __shared__ int sm[BIN_THREADS];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n_bins; base += BIN_THREADS) {
+    const int b = base + threadIdx.x;
+    const int v = b < n_bins ? total[b] : 0;
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < BIN_THREADS; o <<= 1) {
+      const int a = threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
+      __syncthreads();
+      sm[threadIdx.x] += a;
+      __syncthreads();
+    }
+    const int incl = sm[threadIdx.x];
+    if (b < n_bins) start[b] = carry + incl - v;
+    __syncthreads();
+    if (threadIdx.x == BIN_THREADS - 1) carry += incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) start[n_bins] = carry;
+  __syncthreads();
+}
+
+// K3: route every event to its target tile's segment
+template <bool RNG>
+__global__ void __launch_bounds__(BIN_THREADS)
+k_bin_scatter(int2 *__restrict__ events, const int32_t *__restrict__ pre,
+              const int32_t *__restrict__ total, int n_bins, const double *__restrict__ u01,
+              const int64_t *__restrict__ cell_start, int64_t n_cell,
+              const int64_t *__restrict__ p_length, int64_t length_arg, u128 s_off, u128 inc,
+              const u128 *__restrict__ tab) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int32_t *cursor = (int32_t *)smem;  // n_bins + 1
+  __shared__ u128 s_slot;
+  const int64_t length = p_length ? *p_length : length_arg;
+  bin_starts(total, n_bins, cursor);
+  for (int b = threadIdx.x; b < n_bins; b += BIN_THREADS)
+    cursor[b] += pre[(int64_t)blockIdx.x * n_bins + b];
+  const u128 s_tile = RNG ? tile_state(s_off, tab, &s_slot) : 0;
+  __syncthreads();
+  const int64_t first = (int64_t)blockIdx.x * BIN_POS + (int64_t)threadIdx.x * BIN_PER_THREAD;
+  int32_t j[BIN_PER_THREAD];
+  targets16<RNG>(first, length, u01, cell_start, n_cell, s_tile, inc, tab, j);
+#pragma unroll
+  for (int e = 0; e < BIN_PER_THREAD; ++e)
+    if (j[e] >= 0) {
+      const int slot = atomicAdd(&cursor[j[e] >> BIN_SHIFT], 1);
+      events[slot] = make_int2((int)(first + e), j[e]);
+    }
+}
+
+// K4: one workgroup per tile of positions: assemble and write its records
+template <bool RNG>
+__global__ void __launch_bounds__(BIN_THREADS)
+k_bin_build(PackRec *__restrict__ rec, int32_t *__restrict__ ovf_head,
+            int32_t *__restrict__ ovf_next, const int2 *__restrict__ events,
+            const int32_t *__restrict__ total, int n_bins, const int64_t *__restrict__ idx0,
+            const double *__restrict__ u01, const int64_t *__restrict__ cell_start,
+            int64_t n_cell, const int64_t *__restrict__ p_length, int64_t length_arg, u128 s_off,
+            u128 inc, const u128 *__restrict__ tab) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int32_t *start = (int32_t *)smem;                // n_bins + 1
+  int32_t *s0 = start + ((n_bins + 1 + 3) & ~3);   // BIN_POS each below
+  int32_t *s1 = s0 + BIN_POS, *head = s1 + BIN_POS, *jown = head + BIN_POS;
+  __shared__ u128 s_slot;
+  const int64_t length = p_length ? *p_length : length_arg;
+  const int64_t base = (int64_t)blockIdx.x * BIN_POS;
+  if (base >= length) return;
+  bin_starts(total, n_bins, start);
+  for (int q = threadIdx.x; q < BIN_POS; q += BIN_THREADS) { s0[q] = -1; s1[q] = -1; head[q] = -1; }
+  const u128 s_tile = RNG ? tile_state(s_off, tab, &s_slot) : 0;
+  __syncthreads();
+  // hits on this tile's positions: first two inline (claimed by compare-and-swap), rest listed
+  const int ev_first = start[blockIdx.x], ev_last = start[blockIdx.x + 1];
+  for (int t = ev_first + threadIdx.x; t < ev_last; t += BIN_THREADS) {
+    const int2 ev = events[t];
+    const int q = ev.y - (int)base;
+    if (atomicCAS(&s0[q], -1, ev.x) != -1)
+      if (atomicCAS(&s1[q], -1, ev.x) != -1)
+        ovf_next[ev.x] = atomicExch(&head[q], ev.x);  // -1 terminated, built entirely here
+  }
+  // own events: consecutive positions per thread (sequential PCG64 steps), staged through LDS
+  // so that the record stores and the idx0 loads below are coalesced
+  int32_t j[BIN_PER_THREAD];
+  targets16<RNG>(base + (int64_t)threadIdx.x * BIN_PER_THREAD, length, u01, cell_start, n_cell,
+                 s_tile, inc, tab, j);
+#pragma unroll
+  for (int e = 0; e < BIN_PER_THREAD; ++e) jown[threadIdx.x * BIN_PER_THREAD + e] = j[e];
+  __syncthreads();
+  for (int q = threadIdx.x; q < BIN_POS; q += BIN_THREADS) {
+    const int64_t p = base + q;
+    if (p >= length) break;
+    const int32_t h = head[q];
+    PackRec r;
+    r.j = jown[q];
+    r.s0 = s0[q];
+    r.s1 = s1[q];
+    r.val = (int32_t)idx0[p] | (h >= 0 ? (int32_t)0x80000000 : 0);
+    rec[p] = r;
+    if (h >= 0) ovf_head[p] = h;
+  }
+}
+
+// backward walk over packed records; positions [length, n_total) are copied through
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_trace_packed(int64_t *__restrict__ out, const int64_t *__restrict__ idx0,
+               const PackRec *__restrict__ rec, const int32_t *__restrict__ ovf_head,
+               const int32_t *__restrict__ ovf_next, const int64_t *__restrict__ cell_start,
+               int64_t n_cell, const int64_t *__restrict__ p_length, int64_t length_arg,
+               int64_t n_total) {
+  const int64_t length = p_length ? *p_length : length_arg;
+  const int64_t p = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+  if (p >= length) {
+    if (p < n_total) out[p] = idx0[p];
+    return;
+  }
+  const int64_t c = n_cell == 1 ? 0 : find_cell(cell_start, n_cell, p);
+  out[p] = walk_packed(rec, ovf_head, ovf_next, (int32_t)p, (int32_t)cell_start[c]);
+}
+
+static int bin_count(int64_t n) { return (int)((n + BIN_POS - 1) / BIN_POS); }
+
+static size_t binned_scratch_bytes(int64_t n) {
+  const size_t nb = (size_t)bin_count(n);
+  return carve_size(sizeof(PackRec) * n) + 2 * carve_size(sizeof(int32_t) * n) +
+         carve_size(sizeof(int2) * n) + carve_size(sizeof(int32_t) * nb * nb) +
+         carve_size(sizeof(int32_t) * (nb + 1));
+}
+
+// usable while the count matrix stays small and LDS holds the per-bin arrays
+static bool binned_ok(int64_t n, bool global) { return !global && n >= 2 && bin_count(n) <= 4096; }
+
+static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *idx0,
+                                const double *u01, const int64_t *cell_start, int64_t n_cell,
+                                const int64_t *p_length, int64_t length_bound, int64_t n_total,
+                                u128 s_off, u128 inc, ShuffleViews *views) {
+  Carver cv(scratch);
+  const int nb = bin_count(length_bound);
+  PackRec *rec = cv.take<PackRec>(length_bound);
+  int32_t *ovf_head = cv.take<int32_t>(length_bound);
+  int32_t *ovf_next = cv.take<int32_t>(length_bound);
+  int2 *events = cv.take<int2>(length_bound);
+  int32_t *cnt = cv.take<int32_t>((size_t)nb * nb);
+  int32_t *total = cv.take<int32_t>(nb + 1);
+  const dim3 block(BIN_THREADS), grid(nb);
+  const size_t lds_hist = sizeof(int32_t) * (size_t)(nb + 1);
+  const size_t lds_build = sizeof(int32_t) * (size_t)(((nb + 1 + 3) & ~3) + 4 * BIN_POS);
+  {
+    PhaseScope ph(ctx, SDM_PHASE_SHUFFLE_BUILD);
+#define BIN_LAUNCH(R)                                                                          \
+  do {                                                                                         \
+    hipLaunchKernelGGL((k_bin_count<R>), grid, block, lds_hist, ctx->stream, cnt, nb, u01,     \
+                       cell_start, n_cell, p_length, length_bound, s_off, inc, ctx->pcg_tab);  \
+    hipLaunchKernelGGL(k_bin_colscan, grid, block, 0, ctx->stream, cnt, total, nb);            \
+    hipLaunchKernelGGL((k_bin_scatter<R>), grid, block, lds_hist, ctx->stream, events, cnt,    \
+                       total, nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc, \
+                       ctx->pcg_tab);                                                          \
+    hipLaunchKernelGGL((k_bin_build<R>), grid, block, lds_build, ctx->stream, rec, ovf_head,   \
+                       ovf_next, events, total, nb, idx0, u01, cell_start, n_cell, p_length,   \
+                       length_bound, s_off, inc, ctx->pcg_tab);                                \
+  } while (0)
+    if (u01) BIN_LAUNCH(false); else BIN_LAUNCH(true);
+#undef BIN_LAUNCH
+    LAUNCH_CHECK();
+  }
+  if (views) {  // build only: the caller's kernels do the walk
+    views->rec = rec;
+    views->ovf_head = ovf_head;
+    views->ovf_next = ovf_next;
+    return SDM_OK;
+  }
+  {
+    PhaseScope ph(ctx, SDM_PHASE_SHUFFLE_TRACE);
+    const int64_t span = n_total > length_bound ? n_total : length_bound;
+    hipLaunchKernelGGL(k_trace_packed, dim3(grid_for(span)), dim3(SDM_BLOCK), 0, ctx->stream, out,
+                       idx0, rec, ovf_head, ovf_next, cell_start, n_cell, p_length, length_bound,
+                       n_total);
+    LAUNCH_CHECK();
+  }
+  return SDM_OK;
+}
+
+// records only (binned build, local croupier, in-kernel PCG64): the walk is left to the caller
+bool sdm_shuffle_can_split(int64_t n, bool global) { return binned_ok(n, global); }
+
+int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
+                            const int64_t *cell_start, int64_t n_cell, const int64_t *p_length,
+                            int64_t length_bound, const uint64_t *rng_state_inc,
+                            uint64_t rng_offset, ShuffleViews *views) {
+  int rc = sdm_pcg_prepare(ctx, rng_state_inc);
+  if (rc) return rc;
+  const u128 st = (((u128)rng_state_inc[0]) << 64) | rng_state_inc[1];
+  const u128 inc = (((u128)rng_state_inc[2]) << 64) | rng_state_inc[3];
+  const u128 s_off = sdm_pcg_advance_host(st, inc, rng_offset);
+  return shuffle_binned_async(ctx, scratch, nullptr, idx0, nullptr, cell_start, n_cell, p_length,
+                              length_bound, 0, s_off, inc, views);
+}
+
+size_t sdm_shuffle_scratch(int64_t n) {
+  const size_t a = shuffle_scratch_bytes(n) - carve_size(sizeof(int64_t) * n);
+  const size_t b = binned_scratch_bytes(n);
+  return a > b ? a : b;
+}
 
 extern "C" int sdm_shuffle_global(sdm_ctx *ctx, int64_t *idx, int64_t length,
                                   const double *u01) {
   ARG_TRY(ctx && length >= 0 && length < INT32_MAX && (length == 0 || (idx && u01)));
   if (length < 2) return SDM_OK;
-  int rc = sdm_reserve(ctx, shuffle_scratch_bytes(length));
+  int rc = sdm_reserve(ctx, sdm_shuffle_scratch(length) + carve_size(sizeof(int64_t) * length));
   if (rc) return rc;
   int64_t *out = (int64_t *)(ctx->arena + sdm_shuffle_scratch(length));
   rc = sdm_shuffle_async(ctx, ctx->arena, out, idx, u01, nullptr, 1, nullptr, length, true, 0,
@@ -241,7 +573,7 @@ extern "C" int sdm_shuffle_local(sdm_ctx *ctx, int64_t *idx, const double *u01,
   const int64_t length = ctx->mailbox[0];
   ARG_TRY(length >= 0 && length < INT32_MAX);
   if (length < 2) return SDM_OK;
-  int rc = sdm_reserve(ctx, shuffle_scratch_bytes(length));
+  int rc = sdm_reserve(ctx, sdm_shuffle_scratch(length) + carve_size(sizeof(int64_t) * length));
   if (rc) return rc;
   int64_t *out = (int64_t *)(ctx->arena + sdm_shuffle_scratch(length));
   rc = sdm_shuffle_async(ctx, ctx->arena, out, idx, u01, cell_start, n_cell, nullptr, length,
