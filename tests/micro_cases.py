@@ -277,3 +277,39 @@ def check_physics(kit, exact, rtol):  # pylint: disable=too-many-locals
         frag(nf, fm, u01, flag)
         cmp("frag_" + name, nf.to_ndarray(), g[f"frag/{name}/nf"])
         cmp("frag_" + name, fm.to_ndarray(), g[f"frag/{name}/mass"])
+
+
+def check_moments(kit):
+    """moments (PySDM/backends/impl_numba/methods/moments_methods.py:14-99) against the analytic
+    sums in float64 (order of the atomic adds is free: 1e-12), multi-cell, with a range filter"""
+    rng = np.random.default_rng(3)
+    n_sd, n_cell = 1000, 7
+    idx = kit.Index.from_ndarray(rng.permutation(n_sd).astype(np.int64))
+    idx.length = kit.Storage.INT(900)
+    mult = rng.integers(1, 1000, n_sd).astype(np.int64)
+    vol = rng.uniform(1e-15, 1e-12, n_sd)
+    cell = rng.integers(0, n_cell, n_sd).astype(np.int64)
+    ranks = np.array([1.0, 2.0, 1 / 3])
+    m0 = kit.Storage.empty(n_cell, dtype=float)
+    mom = kit.Storage.empty((len(ranks), n_cell), dtype=float)
+    lo, hi = 2e-13, 9e-13
+    args = {
+        "moment_0": m0, "moments": mom,
+        "multiplicity": kit.IndexedStorage.from_ndarray(idx, mult),
+        "attr_data": kit.IndexedStorage.from_ndarray(idx, vol),
+        "cell_id": kit.IndexedStorage.from_ndarray(idx, cell), "idx": idx, "length": 900,
+        "ranks": kit.Storage.from_ndarray(ranks), "min_x": lo, "max_x": hi,
+        "x_attr": kit.IndexedStorage.from_ndarray(idx, vol),
+        "weighting_attribute": kit.IndexedStorage.from_ndarray(idx, vol), "weighting_rank": 0,
+    }
+    live = idx.to_ndarray()[:900]
+    sel = live[(vol[live] >= lo) & (vol[live] < hi)]
+    for skip in (True, False):
+        kit.backend.moments(**args, skip_division_by_m0=skip)
+        exp0 = np.bincount(cell[sel], weights=mult[sel].astype(float), minlength=n_cell)
+        np.testing.assert_allclose(m0.to_ndarray(), exp0, rtol=1e-12)
+        for k, rank in enumerate(ranks):
+            expk = np.bincount(cell[sel], weights=mult[sel] * vol[sel] ** rank, minlength=n_cell)
+            if not skip:
+                expk = np.where(exp0 != 0, expk / np.where(exp0 != 0, exp0, 1), 0)
+            np.testing.assert_allclose(mom.to_ndarray()[k], expk, rtol=1e-12)
