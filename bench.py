@@ -32,47 +32,58 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_PAIR = 136   # 24 u01 + 32 idx + 32 multiplicity + 16 cell id + 32*A, A=1
 
 
-def shima_box(n_sd, backend_class, seed, adaptive=False, dt=1.0, fused=None):
-    """Shima et al. 2009 0-D coalescence box (examples/PySDM_examples/Shima_et_al_2009/
-    settings.py:14-33): Golovin b=1500/s, n_part=2^23 /m^3, dv=1e6 m^3, X0=vol(30.531 um)"""
-    from pysdm_amd import Builder, Formulae
-    from pysdm_amd.dynamics.collisions import Coalescence, Golovin
-    from pysdm_amd.environments import Box
-    from pysdm_amd.initialisation import ConstantMultiplicity, Exponential
-
-    formulae = Formulae(seed=seed)
-    dv = 1e6
-    spectrum = Exponential(norm_factor=2**23 * dv, scale=formulae.trivia.volume(radius=30.531e-6))
-    volume, multiplicity = ConstantMultiplicity(spectrum).sample(n_sd)
-    builder = Builder(n_sd=n_sd, backend=backend_class(formulae), environment=Box(dt=dt, dv=dv))
-    dynamic = Coalescence(collision_kernel=Golovin(b=1.5e3), adaptive=adaptive, fused=fused)
-    builder.add_dynamic(dynamic)
-    particulator = builder.build({"volume": volume, "multiplicity": multiplicity})
-    return particulator, dynamic
+WORKLOADS = {
+    "shima": "Shima 2009 0D box, Golovin kernel b=1500/s, n_sd=2^20 per GPU, dt=1 s "
+             "(BASELINE.json configs[1]); replicas only for N>1",
+    "berry_breakup": "Berry 1967 0D box, geometric kernel + Berry1967 Ec + exponential "
+                     "fragmentation, n_sd=2^20 per GPU (configs[2]); replicas only for N>1",
+    "straub": "Straub 2010 Ec + fragmentation, geometric kernel, n_sd=2^22 per GPU (configs[4]); "
+              "replicas only for N>1",
+    "kinematic2d": "32x32 cells, 2^22 super-droplets, geometric kernel, adaptive, "
+                   "optimized_random, dt=5 s (configs[3]); cells sharded over the ranks",
+}
 
 
-def cpu_baseline(n_sd, seconds_budget=15.0):
+def build_workload(name, backend_class, rank, world, n_sd=None, adaptive=None):
+    from pysdm_amd import sharding
+    from pysdm_amd.examples import CONFIGS, make_box
+
+    if name == "kinematic2d":
+        n_cell = int(np.prod(CONFIGS[name]["grid"]))
+        block = sharding.cell_block(n_cell, rank, world) if world > 1 else None
+        return make_box(backend_class, name, n_sd=n_sd, adaptive=adaptive, cell_block=block)
+    # 0-D boxes: every rank an independent realisation (seed 44 + rank)
+    return make_box(backend_class, name, n_sd=n_sd, adaptive=adaptive, seed=44 + rank)
+
+
+def cpu_baseline(workload, n_sd, adaptive, seconds_budget=15.0):
     """the oracle (kind "port": serial C restatement of the reference's Numba-backend algorithm,
     driven method by method like the reference) on one host core, same box, bounded sample"""
     from oracle.backend import OracleBackend
 
-    particulator, _ = shima_box(n_sd, OracleBackend, seed=44)
+    particulator, dynamic = build_workload(workload, OracleBackend, 0, 1, n_sd, adaptive)
     particulator.run(1)  # warm-up (first-touch, lazy attribute allocation)
     steps, t0 = 0, time.perf_counter()
+    substeps0 = int(dynamic.stats_n_substep.to_ndarray().sum())
     while True:
         particulator.run(1)
         steps += 1
         elapsed = time.perf_counter() - t0
         if elapsed > seconds_budget or steps >= 200:
             break
-    pairs = steps * (n_sd // 2)
+    if dynamic.adaptive:  # candidate pairs = sum over sub-steps (all cells still full-length)
+        n_cell = particulator.mesh.n_cell
+        substeps = int(dynamic.stats_n_substep.to_ndarray().sum()) - substeps0
+        pairs = substeps * (particulator.n_sd // n_cell // 2)
+    else:
+        pairs = steps * (n_sd // 2)
     return {
         "value": pairs / elapsed,
         "unit": "candidate SD-pairs/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"{steps} time steps of the same n_sd={n_sd} Shima-2009 Golovin box "
-                  f"({elapsed:.1f} s of CPU work, oracle/sdm_oracle.c via oracle/backend.py)",
+        "sample": f"{steps} time steps of the same workload ({workload}, n_sd={particulator.n_sd}; "
+                  f"{elapsed:.1f} s of CPU work, oracle/sdm_oracle.c via oracle/backend.py)",
     }
 
 
@@ -92,8 +103,9 @@ def main():
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--steps", type=int, default=200)
     parser.add_argument("--warmup", type=int, default=20)
-    parser.add_argument("--n-sd", type=int, default=2**20)
-    parser.add_argument("--adaptive", type=int, default=0)
+    parser.add_argument("--workload", default="shima", choices=sorted(WORKLOADS))
+    parser.add_argument("--n-sd", type=int, default=None)
+    parser.add_argument("--adaptive", type=int, default=None)
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--roofline-steps", type=int, default=50)
     args = parser.parse_args()
@@ -112,13 +124,14 @@ def main():
     from pysdm_amd.backends import HIP
     from pysdm_amd.backends.hip import _Context
 
-    n_sd = args.n_sd
-    # every rank: an independent realisation (seed 44 + rank) of the same box
-    particulator, dynamic = shima_box(n_sd, HIP, seed=44 + rank, adaptive=bool(args.adaptive))
+    adaptive = None if args.adaptive is None else bool(args.adaptive)
+    particulator, dynamic = build_workload(args.workload, HIP, rank, world, args.n_sd, adaptive)
+    n_sd = particulator.n_sd
     particulator.run(1)  # builds the fused step, allocates scratch
     fused = dynamic._fused_state  # pylint: disable=protected-access
     assert fused not in (None, False), "the fused HIP route must be the one benchmarked"
-    fused.read_back = bool(args.adaptive)  # non-adaptive: no host read-back inside the timed loop
+    # non-adaptive: no host read-back inside the timed loop
+    fused.read_back = bool(dynamic.adaptive)
 
     def barrier():
         torch.cuda.synchronize()
@@ -134,7 +147,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     fused.sync()
-    if args.adaptive:
+    if dynamic.adaptive:
         pairs = fused.total_pairs
     else:  # one sub-step per time step over the whole (still complete) population
         assert particulator.attributes.super_droplet_count == n_sd, "droplets were removed"
@@ -164,7 +177,8 @@ def main():
         dominant = max(per_step, key=per_step.get)
         dom_ms = per_launch[dominant]
         launch_pairs = n_sd // 2
-        achieved = BYTES_PER_PAIR * launch_pairs / (dom_ms * 1e-3) / 1e9
+        bytes_per_pair = BYTES_PER_PAIR + (16 if dynamic.enable_breakup else 0)
+        achieved = bytes_per_pair * launch_pairs / (dom_ms * 1e-3) / 1e9
         traffic = None
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(traffic_file):
@@ -174,11 +188,11 @@ def main():
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel": dominant, "kernel_ms": dom_ms,
-            "algorithmic_bytes_per_launch": BYTES_PER_PAIR * launch_pairs,
+            "algorithmic_bytes_per_launch": bytes_per_pair * launch_pairs,
             "phase_ms_per_step": {k: round(v, 5) for k, v in sorted(per_step.items())},
         }
         if not args.no_cpu_baseline:
-            baseline = cpu_baseline(n_sd)
+            baseline = cpu_baseline(args.workload, args.n_sd, adaptive)
 
     if world > 1:
         dist.barrier()
@@ -186,7 +200,7 @@ def main():
     if rank == 0:
         value = pairs_total / elapsed_max
         print(json.dumps({
-            "metric": "candidate SD-pairs/s (Shima-2009 0-D box, n_sd=2^20 per GPU)",
+            "metric": "candidate SD-pairs/s per GPU x GPUs (" + args.workload + ")",
             "value": value,
             "unit": "candidate SD-pairs/s",
             "n_gpus": world,
@@ -194,14 +208,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.workload == "kinematic2d" else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "Shima 2009 0D box, Golovin kernel b=1500/s, n_sd=2^20 per GPU, "
-                            "dt=1 s, " + ("adaptive" if args.adaptive else "non-adaptive")
-                            + " (BASELINE.json configs[1]); replicas only for N>1",
+                "workload": WORKLOADS[args.workload] + "; "
+                            + ("adaptive" if dynamic.adaptive else "non-adaptive"),
                 "n_sd": n_sd,
                 "seed": 44,
                 "route": "fused sdm_collision_step",

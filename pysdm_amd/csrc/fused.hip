@@ -766,8 +766,8 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
     // (g) sanitize (particle_attributes.py:67-73), decided on the device by the healthy word
     {
       PhaseScope ph(ctx, SDM_PHASE_SANITIZE);
-      rc = sdm_compact_async(ctx, S.compact, st->multiplicity, cur, nullptr, N, N, st->ctl, S.cctl,
-                             C == 1 ? st->cell_start : nullptr);
+      rc = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl, S.cctl,
+                                   C == 1 ? st->cell_start : nullptr);
       if (rc) return rc;
     }
     ++n_sub;

@@ -28,3 +28,6 @@ int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
                             const int64_t *cell_start, int64_t n_cell, const int64_t *p_length,
                             int64_t length_bound, const uint64_t *rng_state_inc,
                             uint64_t rng_offset, ShuffleViews *views);
+int sdm_compact_fused_async(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity,
+                            int64_t *idx, int64_t length_bound, int64_t flag, int64_t *fctl,
+                            int64_t *ctl, int64_t *cell_start_single);

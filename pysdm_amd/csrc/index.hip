@@ -232,27 +232,30 @@ int sdm_shuffle_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *
 // so the backward walk needs no separate gather of the initial content.  u01 comes either from
 // memory or from the PCG64 stream evaluated in place (16 consecutive draws per thread).
 // ---------------------------------------------------------------------------------------
-#define BIN_POS 2048
-#define BIN_THREADS 256
-#define BIN_PER_THREAD 8
+#define BIN_POS 2048     // positions per bin (K4 workgroup)
 #define BIN_SHIFT 11
+#define BIN_THREADS 256
+#define EV_TILE 4096     // events per K1 / K3 workgroup
+#define EV_PER_THREAD 16 // K3: 256 threads
+#define K1_THREADS 1024  // K1: sequential PCG64 steps per thread kept short
+#define K1_PER_THREAD 4
 
 // PackRec and the backward walk live in shuffle_device.h (shared with the fused pair kernels)
 
 // own-event targets of BIN_PER_THREAD consecutive positions from `first` (local croupier)
-template <bool RNG>
-__device__ __forceinline__ void targets16(int64_t first, int64_t length,
+template <bool RNG, int PER>
+__device__ __forceinline__ void targets_run(int64_t first, int64_t length,
                                           const double *__restrict__ u01,
                                           const int64_t *__restrict__ cell_start, int64_t n_cell,
                                           u128 s_tile, u128 inc, const u128 *__restrict__ tab,
-                                          int32_t (&j)[BIN_PER_THREAD]) {
+                                          int32_t (&j)[PER]) {
   u128 state = 0;
-  if (RNG) state = pcg_jump(s_tile, tab, (uint64_t)threadIdx.x * BIN_PER_THREAD);
+  if (RNG) state = pcg_jump(s_tile, tab, (uint64_t)threadIdx.x * PER);
   const u128 mult = pcg_mult();
   int64_t lo = 0, hi = 0;
   bool have_cell = false;
 #pragma unroll
-  for (int e = 0; e < BIN_PER_THREAD; ++e) {
+  for (int e = 0; e < PER; ++e) {
     const int64_t i = first + e;
     double u = 0.0;
     if (RNG) {
@@ -277,144 +280,183 @@ __device__ __forceinline__ void targets16(int64_t first, int64_t length,
   }
 }
 
-__device__ __forceinline__ u128 tile_state(u128 s_off, const u128 *__restrict__ tab,
-                                           u128 *lds_slot) {
-  if (threadIdx.x == 0) *lds_slot = pcg_jump(s_off, tab, (uint64_t)blockIdx.x * BIN_POS);
+// block-wide exclusive scan of one value per thread (BIN_THREADS threads); returns the exclusive
+// prefix, *total receives the block sum
+__device__ __forceinline__ int block_excl_scan(int v, int *total) {
+  __shared__ int wsum[BIN_THREADS / SDM_WAVE];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  __syncthreads();  // protects wsum against the previous call
+  if (lane == 63) wsum[w] = incl;
   __syncthreads();
-  return *lds_slot;
+  int base = 0, sum = 0;
+#pragma unroll
+  for (int k = 0; k < BIN_THREADS / SDM_WAVE; ++k) {
+    if (k < w) base += wsum[k];
+    sum += wsum[k];
+  }
+  *total = sum;
+  return base + incl - v;
 }
 
-// K1: per event tile, histogram of target tiles -> cnt[tile][bin]
+// K1: per event tile (EV_TILE positions): own-event targets -> jarr, histogram of their target
+// bins -> cnt[tile][bin]
 template <bool RNG>
-__global__ void __launch_bounds__(BIN_THREADS)
-k_bin_count(int32_t *__restrict__ cnt, int n_bins, const double *__restrict__ u01,
-            const int64_t *__restrict__ cell_start, int64_t n_cell,
-            const int64_t *__restrict__ p_length, int64_t length_arg, u128 s_off, u128 inc,
-            const u128 *__restrict__ tab) {
+__global__ void __launch_bounds__(K1_THREADS)
+k_bin_count(int32_t *__restrict__ cnt, int32_t *__restrict__ jarr, int n_bins,
+            const double *__restrict__ u01, const int64_t *__restrict__ cell_start,
+            int64_t n_cell, const int64_t *__restrict__ p_length, int64_t length_arg, u128 s_off,
+            u128 inc, const u128 *__restrict__ tab) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int32_t *hist = (int32_t *)smem;
   __shared__ u128 s_slot;
   const int64_t length = p_length ? *p_length : length_arg;
-  for (int b = threadIdx.x; b < n_bins; b += BIN_THREADS) hist[b] = 0;
-  const u128 s_tile = RNG ? tile_state(s_off, tab, &s_slot) : 0;
+  for (int b = threadIdx.x; b < n_bins; b += K1_THREADS) hist[b] = 0;
+  if (RNG) {
+    if (threadIdx.x == 0) s_slot = pcg_jump(s_off, tab, (uint64_t)blockIdx.x * EV_TILE);
+  }
   __syncthreads();
-  const int64_t first = (int64_t)blockIdx.x * BIN_POS + (int64_t)threadIdx.x * BIN_PER_THREAD;
-  int32_t j[BIN_PER_THREAD];
-  targets16<RNG>(first, length, u01, cell_start, n_cell, s_tile, inc, tab, j);
+  const u128 s_tile = RNG ? s_slot : 0;
+  const int64_t first = (int64_t)blockIdx.x * EV_TILE + (int64_t)threadIdx.x * K1_PER_THREAD;
+  int32_t j[K1_PER_THREAD];
+  targets_run<RNG, K1_PER_THREAD>(first, length, u01, cell_start, n_cell, s_tile, inc, tab, j);
 #pragma unroll
-  for (int e = 0; e < BIN_PER_THREAD; ++e)
+  for (int e = 0; e < K1_PER_THREAD; ++e) {
     if (j[e] >= 0) atomicAdd(&hist[j[e] >> BIN_SHIFT], 1);
+    if (first + e < length) jarr[first + e] = j[e];
+  }
   __syncthreads();
-  for (int b = threadIdx.x; b < n_bins; b += BIN_THREADS)
+  for (int b = threadIdx.x; b < n_bins; b += K1_THREADS)
     cnt[(int64_t)blockIdx.x * n_bins + b] = hist[b];
 }
 
-// K2: one workgroup per bin: exclusive scan down the tiles (column of cnt), total -> total[bin]
+// K2: one workgroup per bin: exclusive scan down the event tiles (column of cnt) -> pre,
+// column total -> total[bin]
 __global__ void __launch_bounds__(BIN_THREADS)
-k_bin_colscan(int32_t *__restrict__ cnt, int32_t *__restrict__ total, int n_bins) {
-  __shared__ int sm[BIN_THREADS];
-  __shared__ int carry;
+k_bin_colscan(int32_t *__restrict__ cnt, int32_t *__restrict__ total, int n_bins, int n_tiles) {
   const int bin = blockIdx.x;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < n_bins; base += BIN_THREADS) {  // n_tiles == n_bins
-    const int t = base + threadIdx.x;
-    const int v = t < n_bins ? cnt[(int64_t)t * n_bins + bin] : 0;
-    sm[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 1; o < BIN_THREADS; o <<= 1) {
-      const int a = threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
-      __syncthreads();
-      sm[threadIdx.x] += a;
-      __syncthreads();
-    }
-    const int incl = sm[threadIdx.x];
-    if (t < n_bins) cnt[(int64_t)t * n_bins + bin] = carry + incl - v;
-    __syncthreads();
-    if (threadIdx.x == BIN_THREADS - 1) carry += incl;
-    __syncthreads();
+  const int per = (n_tiles + BIN_THREADS - 1) / BIN_THREADS;
+  const int t0 = threadIdx.x * per;
+  int sum = 0;
+  for (int k = 0; k < per; ++k) {
+    const int t = t0 + k;
+    if (t < n_tiles) sum += cnt[(int64_t)t * n_bins + bin];
   }
-  if (threadIdx.x == 0) total[bin] = carry;
+  int all;
+  int run = block_excl_scan(sum, &all);
+  for (int k = 0; k < per; ++k) {
+    const int t = t0 + k;
+    if (t < n_tiles) {
+      const int v = cnt[(int64_t)t * n_bins + bin];
+      cnt[(int64_t)t * n_bins + bin] = run;
+      run += v;
+    }
+  }
+  if (threadIdx.x == 0) total[bin] = all;
 }
 
 // exclusive scan of total[0:n_bins) into LDS (every workgroup of K3 / K4 does its own)
 __device__ __forceinline__ void bin_starts(const int32_t *__restrict__ total, int n_bins,
                                            int32_t *start /* LDS, n_bins + 1 */) {
-  __shared__ int sm[BIN_THREADS];
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < n_bins; base += BIN_THREADS) {
-    const int b = base + threadIdx.x;
-    const int v = b < n_bins ? total[b] : 0;
-    sm[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 1; o < BIN_THREADS; o <<= 1) {
-      const int a = threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
-      __syncthreads();
-      sm[threadIdx.x] += a;
-      __syncthreads();
+  const int per = (n_bins + BIN_THREADS - 1) / BIN_THREADS;
+  const int b0 = threadIdx.x * per;
+  int sum = 0;
+  for (int k = 0; k < per; ++k)
+    if (b0 + k < n_bins) sum += total[b0 + k];
+  int all;
+  int run = block_excl_scan(sum, &all);
+  for (int k = 0; k < per; ++k)
+    if (b0 + k < n_bins) {
+      start[b0 + k] = run;
+      run += total[b0 + k];
     }
-    const int incl = sm[threadIdx.x];
-    if (b < n_bins) start[b] = carry + incl - v;
-    __syncthreads();
-    if (threadIdx.x == BIN_THREADS - 1) carry += incl;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) start[n_bins] = carry;
+  if (threadIdx.x == 0) start[n_bins] = all;
   __syncthreads();
 }
 
-// K3: route every event to its target tile's segment
-template <bool RNG>
+// K3: route every event to its target bin's segment.  The tile's events are first ordered by
+// bin in LDS so that each (tile, bin) run leaves as consecutive lanes -> consecutive addresses.
 __global__ void __launch_bounds__(BIN_THREADS)
 k_bin_scatter(int2 *__restrict__ events, const int32_t *__restrict__ pre,
-              const int32_t *__restrict__ total, int n_bins, const double *__restrict__ u01,
-              const int64_t *__restrict__ cell_start, int64_t n_cell,
-              const int64_t *__restrict__ p_length, int64_t length_arg, u128 s_off, u128 inc,
-              const u128 *__restrict__ tab) {
+              const int32_t *__restrict__ total, const int32_t *__restrict__ jarr, int n_bins,
+              const int64_t *__restrict__ p_length, int64_t length_arg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int32_t *cursor = (int32_t *)smem;  // n_bins + 1
-  __shared__ u128 s_slot;
+  int32_t *gbase = (int32_t *)smem;          // n_bins + 1 : global slot of this tile's run
+  int32_t *lstart = gbase + n_bins + 1;      // n_bins + 1 : local slot of the run
+  int32_t *lcount = lstart + n_bins + 1;     // n_bins
+  int2 *ev_buf = (int2 *)(lcount + ((n_bins + 1) & ~1));  // EV_TILE
+  int32_t *gdst = (int32_t *)(ev_buf + EV_TILE);            // EV_TILE
   const int64_t length = p_length ? *p_length : length_arg;
-  bin_starts(total, n_bins, cursor);
-  for (int b = threadIdx.x; b < n_bins; b += BIN_THREADS)
-    cursor[b] += pre[(int64_t)blockIdx.x * n_bins + b];
-  const u128 s_tile = RNG ? tile_state(s_off, tab, &s_slot) : 0;
+  const int64_t tile_first = (int64_t)blockIdx.x * EV_TILE;
+  if (tile_first >= length) return;
+  bin_starts(total, n_bins, gbase);
+  for (int b = threadIdx.x; b < n_bins; b += BIN_THREADS) {
+    gbase[b] += pre[(int64_t)blockIdx.x * n_bins + b];
+    lcount[b] = 0;
+  }
   __syncthreads();
-  const int64_t first = (int64_t)blockIdx.x * BIN_POS + (int64_t)threadIdx.x * BIN_PER_THREAD;
-  int32_t j[BIN_PER_THREAD];
-  targets16<RNG>(first, length, u01, cell_start, n_cell, s_tile, inc, tab, j);
+  int32_t j[EV_PER_THREAD];
 #pragma unroll
-  for (int e = 0; e < BIN_PER_THREAD; ++e)
+  for (int e = 0; e < EV_PER_THREAD; ++e) {
+    const int64_t i = tile_first + e * BIN_THREADS + threadIdx.x;
+    j[e] = i < length ? jarr[i] : -1;
+    if (j[e] >= 0) atomicAdd(&lcount[j[e] >> BIN_SHIFT], 1);
+  }
+  __syncthreads();
+  {  // lstart = exclusive scan of lcount; lcount reset to serve as the placement cursor
+    const int per = (n_bins + BIN_THREADS - 1) / BIN_THREADS;
+    const int b0 = threadIdx.x * per;
+    int sum = 0;
+    for (int k = 0; k < per; ++k)
+      if (b0 + k < n_bins) sum += lcount[b0 + k];
+    int all;
+    int run = block_excl_scan(sum, &all);
+    for (int k = 0; k < per; ++k)
+      if (b0 + k < n_bins) {
+        lstart[b0 + k] = run;
+        run += lcount[b0 + k];
+        lcount[b0 + k] = 0;
+      }
+    if (threadIdx.x == 0) lstart[n_bins] = all;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < EV_PER_THREAD; ++e)
     if (j[e] >= 0) {
-      const int slot = atomicAdd(&cursor[j[e] >> BIN_SHIFT], 1);
-      events[slot] = make_int2((int)(first + e), j[e]);
+      const int b = j[e] >> BIN_SHIFT;
+      const int r = atomicAdd(&lcount[b], 1);
+      const int ls = lstart[b] + r;
+      ev_buf[ls] = make_int2((int)(tile_first + e * BIN_THREADS + threadIdx.x), j[e]);
+      gdst[ls] = gbase[b] + r;
     }
+  __syncthreads();
+  const int n_ev = lstart[n_bins];
+  for (int t = threadIdx.x; t < n_ev; t += BIN_THREADS) events[gdst[t]] = ev_buf[t];
 }
 
-// K4: one workgroup per tile of positions: assemble and write its records
-template <bool RNG>
+// K4: one workgroup per bin (BIN_POS positions): assemble and write its records
 __global__ void __launch_bounds__(BIN_THREADS)
 k_bin_build(PackRec *__restrict__ rec, int32_t *__restrict__ ovf_head,
             int32_t *__restrict__ ovf_next, const int2 *__restrict__ events,
-            const int32_t *__restrict__ total, int n_bins, const int64_t *__restrict__ idx0,
-            const double *__restrict__ u01, const int64_t *__restrict__ cell_start,
-            int64_t n_cell, const int64_t *__restrict__ p_length, int64_t length_arg, u128 s_off,
-            u128 inc, const u128 *__restrict__ tab) {
+            const int32_t *__restrict__ total, const int32_t *__restrict__ jarr, int n_bins,
+            const int64_t *__restrict__ idx0, const int64_t *__restrict__ p_length,
+            int64_t length_arg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int32_t *start = (int32_t *)smem;                // n_bins + 1
   int32_t *s0 = start + ((n_bins + 1 + 3) & ~3);   // BIN_POS each below
-  int32_t *s1 = s0 + BIN_POS, *head = s1 + BIN_POS, *jown = head + BIN_POS;
-  __shared__ u128 s_slot;
+  int32_t *s1 = s0 + BIN_POS, *head = s1 + BIN_POS;
   const int64_t length = p_length ? *p_length : length_arg;
   const int64_t base = (int64_t)blockIdx.x * BIN_POS;
   if (base >= length) return;
   bin_starts(total, n_bins, start);
   for (int q = threadIdx.x; q < BIN_POS; q += BIN_THREADS) { s0[q] = -1; s1[q] = -1; head[q] = -1; }
-  const u128 s_tile = RNG ? tile_state(s_off, tab, &s_slot) : 0;
   __syncthreads();
-  // hits on this tile's positions: first two inline (claimed by compare-and-swap), rest listed
+  // hits on this bin's positions: first two inline (claimed by compare-and-swap), rest listed
   const int ev_first = start[blockIdx.x], ev_last = start[blockIdx.x + 1];
   for (int t = ev_first + threadIdx.x; t < ev_last; t += BIN_THREADS) {
     const int2 ev = events[t];
@@ -423,20 +465,13 @@ k_bin_build(PackRec *__restrict__ rec, int32_t *__restrict__ ovf_head,
       if (atomicCAS(&s1[q], -1, ev.x) != -1)
         ovf_next[ev.x] = atomicExch(&head[q], ev.x);  // -1 terminated, built entirely here
   }
-  // own events: consecutive positions per thread (sequential PCG64 steps), staged through LDS
-  // so that the record stores and the idx0 loads below are coalesced
-  int32_t j[BIN_PER_THREAD];
-  targets16<RNG>(base + (int64_t)threadIdx.x * BIN_PER_THREAD, length, u01, cell_start, n_cell,
-                 s_tile, inc, tab, j);
-#pragma unroll
-  for (int e = 0; e < BIN_PER_THREAD; ++e) jown[threadIdx.x * BIN_PER_THREAD + e] = j[e];
   __syncthreads();
   for (int q = threadIdx.x; q < BIN_POS; q += BIN_THREADS) {
     const int64_t p = base + q;
     if (p >= length) break;
     const int32_t h = head[q];
     PackRec r;
-    r.j = jown[q];
+    r.j = jarr[p];
     r.s0 = s0[q];
     r.s1 = s1[q];
     r.val = (int32_t)idx0[p] | (h >= 0 ? (int32_t)0x80000000 : 0);
@@ -463,48 +498,54 @@ k_trace_packed(int64_t *__restrict__ out, const int64_t *__restrict__ idx0,
 }
 
 static int bin_count(int64_t n) { return (int)((n + BIN_POS - 1) / BIN_POS); }
+static int ev_tile_count(int64_t n) { return (int)((n + EV_TILE - 1) / EV_TILE); }
 
 static size_t binned_scratch_bytes(int64_t n) {
-  const size_t nb = (size_t)bin_count(n);
-  return carve_size(sizeof(PackRec) * n) + 2 * carve_size(sizeof(int32_t) * n) +
-         carve_size(sizeof(int2) * n) + carve_size(sizeof(int32_t) * nb * nb) +
+  const size_t nb = (size_t)bin_count(n), nt = (size_t)ev_tile_count(n);
+  return carve_size(sizeof(PackRec) * n) + 3 * carve_size(sizeof(int32_t) * n) +
+         carve_size(sizeof(int2) * n) + carve_size(sizeof(int32_t) * nb * nt) +
          carve_size(sizeof(int32_t) * (nb + 1));
 }
 
-// usable while the count matrix stays small and LDS holds the per-bin arrays
-static bool binned_ok(int64_t n, bool global) { return !global && n >= 2 && bin_count(n) <= 4096; }
+// usable while the count matrix stays small and LDS holds the per-bin arrays of K3
+static bool binned_ok(int64_t n, bool global) { return !global && n >= 2 && bin_count(n) <= 2048; }
 
 static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *idx0,
                                 const double *u01, const int64_t *cell_start, int64_t n_cell,
                                 const int64_t *p_length, int64_t length_bound, int64_t n_total,
                                 u128 s_off, u128 inc, ShuffleViews *views) {
   Carver cv(scratch);
-  const int nb = bin_count(length_bound);
+  const int nb = bin_count(length_bound), nt = ev_tile_count(length_bound);
   PackRec *rec = cv.take<PackRec>(length_bound);
   int32_t *ovf_head = cv.take<int32_t>(length_bound);
   int32_t *ovf_next = cv.take<int32_t>(length_bound);
+  int32_t *jarr = cv.take<int32_t>(length_bound);
   int2 *events = cv.take<int2>(length_bound);
-  int32_t *cnt = cv.take<int32_t>((size_t)nb * nb);
+  int32_t *cnt = cv.take<int32_t>((size_t)nb * nt);
   int32_t *total = cv.take<int32_t>(nb + 1);
-  const dim3 block(BIN_THREADS), grid(nb);
+  const dim3 block(BIN_THREADS);
   const size_t lds_hist = sizeof(int32_t) * (size_t)(nb + 1);
-  const size_t lds_build = sizeof(int32_t) * (size_t)(((nb + 1 + 3) & ~3) + 4 * BIN_POS);
+  const size_t lds_scatter = sizeof(int32_t) * (size_t)(2 * (nb + 1) + ((nb + 1) & ~1)) +
+                             (sizeof(int2) + sizeof(int32_t)) * EV_TILE;
+  const size_t lds_build = sizeof(int32_t) * (size_t)(((nb + 1 + 3) & ~3) + 3 * BIN_POS);
+  if (lds_scatter > 65536)  // gfx950 has 160 KiB of LDS per CU; > 64 KiB dynamic needs opting in
+    HIP_TRY(hipFuncSetAttribute((const void *)k_bin_scatter,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scatter));
   {
     PhaseScope ph(ctx, SDM_PHASE_SHUFFLE_BUILD);
-#define BIN_LAUNCH(R)                                                                          \
-  do {                                                                                         \
-    hipLaunchKernelGGL((k_bin_count<R>), grid, block, lds_hist, ctx->stream, cnt, nb, u01,     \
-                       cell_start, n_cell, p_length, length_bound, s_off, inc, ctx->pcg_tab);  \
-    hipLaunchKernelGGL(k_bin_colscan, grid, block, 0, ctx->stream, cnt, total, nb);            \
-    hipLaunchKernelGGL((k_bin_scatter<R>), grid, block, lds_hist, ctx->stream, events, cnt,    \
-                       total, nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc, \
-                       ctx->pcg_tab);                                                          \
-    hipLaunchKernelGGL((k_bin_build<R>), grid, block, lds_build, ctx->stream, rec, ovf_head,   \
-                       ovf_next, events, total, nb, idx0, u01, cell_start, n_cell, p_length,   \
-                       length_bound, s_off, inc, ctx->pcg_tab);                                \
-  } while (0)
-    if (u01) BIN_LAUNCH(false); else BIN_LAUNCH(true);
-#undef BIN_LAUNCH
+    if (u01)
+      hipLaunchKernelGGL((k_bin_count<false>), dim3(nt), dim3(K1_THREADS), lds_hist, ctx->stream, cnt, jarr,
+                         nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc,
+                         ctx->pcg_tab);
+    else
+      hipLaunchKernelGGL((k_bin_count<true>), dim3(nt), dim3(K1_THREADS), lds_hist, ctx->stream, cnt, jarr,
+                         nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc,
+                         ctx->pcg_tab);
+    hipLaunchKernelGGL(k_bin_colscan, dim3(nb), block, 0, ctx->stream, cnt, total, nb, nt);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(nt), block, lds_scatter, ctx->stream, events, cnt,
+                       total, jarr, nb, p_length, length_bound);
+    hipLaunchKernelGGL(k_bin_build, dim3(nb), block, lds_build, ctx->stream, rec, ovf_head,
+                       ovf_next, events, total, jarr, nb, idx0, p_length, length_bound);
     LAUNCH_CHECK();
   }
   if (views) {  // build only: the caller's kernels do the walk
@@ -767,6 +808,150 @@ k_compact_apply(int64_t *__restrict__ idx, const int64_t *__restrict__ p_length,
       fctl[FCTL_SORTED] = 0;
     }
   }
+}
+
+// ---- single-launch variant for the fused step: exits at once while healthy; otherwise the
+// same four phases separated by a software grid barrier.  The grid is COMPACT_GRID workgroups
+// (<= one per CU: always co-resident); every spin is bounded (bar[2] is set on time-out).
+#define COMPACT_GRID 256
+
+__device__ __forceinline__ bool grid_barrier(unsigned int *bar, unsigned int target) {
+  __shared__ bool ok;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();  // release this workgroup's writes
+    atomicAdd(&bar[0], 1u);
+    unsigned int spins = 0;
+    ok = true;
+    while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 24)) { ok = false; bar[2] = 1; break; }
+    }
+    __threadfence();  // acquire: drop stale L1 lines before reading the others' results
+  }
+  __syncthreads();
+  return ok;
+}
+
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restrict__ idx,
+                     int64_t flag, int64_t *__restrict__ fctl, int32_t *__restrict__ block_dead,
+                     int nb, int64_t *__restrict__ ctl, int32_t *__restrict__ holes,
+                     int64_t *__restrict__ fillers, int64_t *__restrict__ cell_start_single,
+                     unsigned int *__restrict__ bar) {
+  if (fctl[FCTL_HEALTHY] != 0) return;
+  const int64_t length = fctl[FCTL_VALID];
+  __shared__ int sm[SDM_BLOCK];
+  __shared__ int carry;
+  const int lane = lane_id(), w = threadIdx.x / SDM_WAVE;
+  // phase A: dead count of every tile of SDM_BLOCK positions
+  for (int tile = blockIdx.x; tile < nb; tile += COMPACT_GRID) {
+    const int64_t i = (int64_t)tile * SDM_BLOCK + threadIdx.x;
+    const bool dead = i < length && sd_dead(multiplicity, idx, i, flag);
+    const int c = __popcll(__ballot(dead));
+    __syncthreads();
+    if (lane == 0) sm[w] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_dead[tile] = sm[0] + sm[1] + sm[2] + sm[3];
+  }
+  if (!grid_barrier(bar, 1 * COMPACT_GRID)) return;
+  // phase B: workgroup 0 scans the tile counts (exclusive) and publishes the totals
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += SDM_BLOCK) {
+      const int b = base + threadIdx.x;
+      const int v = b < nb ? ((volatile int32_t *)block_dead)[b] : 0;
+      sm[threadIdx.x] = v;
+      __syncthreads();
+      for (int o = 1; o < SDM_BLOCK; o <<= 1) {
+        const int t = threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
+        __syncthreads();
+        sm[threadIdx.x] += t;
+        __syncthreads();
+      }
+      const int incl = sm[threadIdx.x];
+      if (b < nb) block_dead[b] = carry + incl - v;
+      __syncthreads();
+      if (threadIdx.x == SDM_BLOCK - 1) carry += incl;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      ctl[3] = carry;
+      ctl[1] = length - carry;
+      ctl[2] = 0;
+    }
+  }
+  if (!grid_barrier(bar, 2 * COMPACT_GRID)) return;
+  const int64_t total_dead = ((volatile int64_t *)ctl)[3], new_len = ((volatile int64_t *)ctl)[1];
+  // phase C: holes of the surviving prefix, live elements of the tail (from the end backwards)
+  if (total_dead != 0)
+    for (int tile = blockIdx.x; tile < nb; tile += COMPACT_GRID) {
+      const int64_t i = (int64_t)tile * SDM_BLOCK + threadIdx.x;
+      const bool in = i < length;
+      const bool dead = in && sd_dead(multiplicity, idx, i, flag);
+      const unsigned long long m = __ballot(dead);
+      __syncthreads();
+      if (lane == 0) sm[w] = __popcll(m);
+      __syncthreads();
+      int before = ((volatile int32_t *)block_dead)[tile];
+      for (int k = 0; k < w; ++k) before += sm[k];
+      const int64_t dp = before + __popcll(m & ((1ull << lane) - 1));
+      if (in) {
+        if (i == new_len) ctl[2] = dp;
+        if (i < new_len) {
+          if (dead) holes[dp] = (int32_t)i;
+        } else if (!dead) {
+          fillers[(length - 1 - i) - (total_dead - dp)] = idx[i];
+        }
+      }
+    }
+  if (!grid_barrier(bar, 3 * COMPACT_GRID)) return;
+  // phase D: apply
+  if (total_dead != 0) {
+    const int64_t n_holes = ((volatile int64_t *)ctl)[2];
+    for (int64_t t = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x; t < length - new_len;
+         t += (int64_t)COMPACT_GRID * SDM_BLOCK) {
+      idx[new_len + t] = flag;
+      if (t < n_holes) idx[((volatile int32_t *)holes)[t]] = ((volatile int64_t *)fillers)[t];
+    }
+  }
+  if (!grid_barrier(bar, 4 * COMPACT_GRID)) return;
+  // every workgroup is past the last barrier once it arrives here: the last one re-arms the
+  // barrier words and commits the control words
+  __shared__ bool last;
+  if (threadIdx.x == 0) last = atomicAdd(&bar[1], 1u) == COMPACT_GRID - 1;
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    bar[0] = 0;
+    bar[1] = 0;
+    fctl[FCTL_VALID] = new_len;
+    fctl[FCTL_WORK] = new_len;
+    fctl[FCTL_HEALTHY] = 1;
+    if (cell_start_single) {
+      cell_start_single[0] = 0;
+      cell_start_single[1] = new_len;
+    } else {
+      fctl[FCTL_SORTED] = 0;
+    }
+  }
+}
+
+// `bar`: 4 zero-initialised device words owned by the caller (persist across launches)
+int sdm_compact_fused_async(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity,
+                            int64_t *idx, int64_t length_bound, int64_t flag, int64_t *fctl,
+                            int64_t *ctl, int64_t *cell_start_single) {
+  Carver cv(scratch);
+  const int nb = (int)grid_for(length_bound);
+  int32_t *block_dead = cv.take<int32_t>(nb + 1);
+  int32_t *holes = cv.take<int32_t>(length_bound);
+  int64_t *fillers = cv.take<int64_t>(length_bound);
+  unsigned int *bar = (unsigned int *)(ctx->dscal + 12);
+  hipLaunchKernelGGL(k_compact_persistent, dim3(COMPACT_GRID), dim3(SDM_BLOCK), 0, ctx->stream,
+                     multiplicity, idx, flag, fctl, block_dead, nb, ctl, holes, fillers,
+                     cell_start_single, bar);
+  LAUNCH_CHECK();
+  return SDM_OK;
 }
 
 size_t sdm_compact_scratch(int64_t n) {

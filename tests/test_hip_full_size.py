@@ -7,46 +7,15 @@ import warnings
 import numpy as np
 import pytest
 
-from pysdm_amd import Builder, Formulae
-from pysdm_amd.dynamics.collisions import (
-    Berry1967,
-    Coalescence,
-    Collision,
-    ConstEb,
-    Exponential,
-    Geometric,
-    Golovin,
-    Straub2010Ec,
-    Straub2010Nf,
-)
-from pysdm_amd.environments import Box, Mesh
-from pysdm_amd.initialisation import ConstantMultiplicity
-from pysdm_amd.initialisation import Exponential as ExponentialSpectrum
+from pysdm_amd.examples import CONFIGS, make_box
 
 from .trajectory import snapshot
 
 pytestmark = pytest.mark.gpu
-TRIVIA = Formulae().trivia
 
 
-def box(backend_class, *, n_sd, dynamic, n_part, dv, radius, dt=1.0, seed=44, formulae_kwargs=None,
-        grid=None):
-    formulae = Formulae(seed=seed, **(formulae_kwargs or {}))
-    spectrum = ExponentialSpectrum(norm_factor=n_part * dv, scale=TRIVIA.volume(radius=radius))
-    volume, multiplicity = ConstantMultiplicity(spectrum).sample(n_sd)
-    env = Box(dt=dt, dv=dv)
-    attributes = {"volume": volume, "multiplicity": multiplicity}
-    if grid is not None:
-        n_cell = int(np.prod(grid))
-        env.mesh = Mesh(grid, size=tuple(float(g) for g in grid))
-        env.mesh.dv = dv / n_cell
-        rng = np.random.default_rng(7)
-        attributes["cell id"] = rng.integers(0, n_cell, size=n_sd).astype(np.int64)
-        order = rng.permutation(n_sd)
-        attributes["volume"], attributes["multiplicity"] = volume[order], multiplicity[order]
-    builder = Builder(n_sd=n_sd, backend=backend_class(formulae), environment=env)
-    builder.add_dynamic(dynamic)
-    return builder.build(attributes), dynamic
+def box(backend_class, name, adaptive, fused):
+    return make_box(backend_class, name, adaptive=adaptive, fused=fused)
 
 
 def run(particulator, steps):
@@ -76,50 +45,15 @@ def invariants(snap, n_sd, total_mass0, rtol):
     np.testing.assert_allclose(np.sum(n[live].astype(float) * m[live]), total_mass0, rtol=rtol)
 
 
-CONFIGS = {
-    # BASELINE.json configs[1]: Shima 2009 box, Golovin, n_sd = 2^20
-    "shima_2p20": dict(n_sd=2**20, n_part=2**23, dv=1e6, radius=30.531e-6,
-                       make=lambda adaptive, fused: Coalescence(
-                           collision_kernel=Golovin(b=1.5e3), adaptive=adaptive, fused=fused)),
-    # configs[2]: Berry 1967 box, geometric kernel + breakup, n_sd = 2^20
-    "berry_breakup_2p20": dict(
-        n_sd=2**20, n_part=239e6, dv=10.0 * 2**20 / 2**13, radius=10e-6,
-        formulae_kwargs={"fragmentation_function": "Exponential"},
-        make=lambda adaptive, fused: Collision(
-            collision_kernel=Geometric(), coalescence_efficiency=Berry1967(),
-            breakup_efficiency=ConstEb(1.0),
-            fragmentation_function=Exponential(scale=TRIVIA.volume(radius=100e-6)),
-            adaptive=adaptive, warn_overflows=False, fused=fused)),
-    # configs[4]: Straub 2010 breakup + geometric kernel, n_sd = 2^22
-    "straub_2p22": dict(
-        n_sd=2**22, n_part=100e6, dv=1.0 * 2**22 / 2**10, radius=30.531e-6,
-        formulae_kwargs={"fragmentation_function": "Straub2010Nf"},
-        make=lambda adaptive, fused: Collision(
-            collision_kernel=Geometric(), coalescence_efficiency=Straub2010Ec(),
-            breakup_efficiency=ConstEb(1.0),
-            fragmentation_function=Straub2010Nf(
-                vmin=TRIVIA.volume(radius=30.531e-6) * 1e-3, nfmax=10),
-            adaptive=adaptive, warn_overflows=False, fused=fused)),
-    # configs[3]: 32 x 32 cells, 2^22 super-droplets (4096 per cell), geometric kernel, adaptive
-    "kinematic_32x32_2p22": dict(
-        n_sd=2**22, n_part=239e6, dv=2197.0 * 1024, radius=15e-6, dt=5.0, grid=(32, 32),
-        make=lambda adaptive, fused: Coalescence(
-            collision_kernel=Geometric(collection_efficiency=1), adaptive=adaptive,
-            optimized_random=True, fused=fused)),
-}
-
-
 @pytest.mark.parametrize("name,adaptive,steps", [
-    ("shima_2p20", False, 3), ("shima_2p20", True, 2), ("berry_breakup_2p20", True, 2),
-    ("straub_2p22", True, 1), ("kinematic_32x32_2p22", True, 1),
+    ("shima", False, 3), ("shima", True, 2), ("berry_breakup", True, 2),
+    ("straub", True, 1), ("kinematic2d", True, 1),
 ])
 def test_full_size_fused_equals_oracle(name, adaptive, steps, hip_backend_class,
                                        oracle_backend_class):
-    cfg = dict(CONFIGS[name])
-    make = cfg.pop("make")
     snaps = []
     for backend_class in (hip_backend_class, oracle_backend_class):
-        particulator, dynamic = box(backend_class, dynamic=make(adaptive, None), **cfg)
+        particulator, dynamic = box(backend_class, name, adaptive, None)
         # (taken for both backends: reading cell_start sorts by cell, which must happen at the
         # same point of both histories -- before the first sort_by_key of an adaptive step)
         first = snapshot(particulator, dynamic)
@@ -129,17 +63,14 @@ def test_full_size_fused_equals_oracle(name, adaptive, steps, hip_backend_class,
         snaps.append(snapshot(particulator, dynamic))
     breakup = "breakup" in name or "straub" in name
     assert_same(snaps[0], snaps[1], float_rtol=1e-12 if breakup else 0.0)
-    invariants(snaps[0], cfg["n_sd"], mass0, rtol=1e-9 if breakup else 1e-12)
+    invariants(snaps[0], CONFIGS[name]["n_sd"], mass0, rtol=1e-9 if breakup else 1e-12)
 
 
-@pytest.mark.parametrize("name,adaptive,steps", [("shima_2p20", True, 20),
-                                                 ("kinematic_32x32_2p22", True, 2)])
+@pytest.mark.parametrize("name,adaptive,steps", [("shima", True, 20), ("kinematic2d", True, 2)])
 def test_full_size_routes_agree(name, adaptive, steps, hip_backend_class):
-    cfg = dict(CONFIGS[name])
-    make = cfg.pop("make")
     snaps = []
     for fused in (None, False):
-        particulator, dynamic = box(hip_backend_class, dynamic=make(adaptive, fused), **cfg)
+        particulator, dynamic = box(hip_backend_class, name, adaptive, fused)
         run(particulator, steps)
         snaps.append(snapshot(particulator, dynamic))
     assert_same(snaps[0], snaps[1])
