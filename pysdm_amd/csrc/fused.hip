@@ -47,9 +47,9 @@ struct FusedArgs {
   double *prob;           // [P]
   uint8_t *pair_off;      // [P] 0: pair starts at 2d, 1: at 2d+1, 2: no pair
   int32_t *pair_cid;      // [P] raw cell id of the pair (n_cell > 1)
-  double *Ec;             // [P]
-  double *fragment_mass;  // [P]
   double *dt_todo, *cell_min;  // [C]
+  double *block_min;           // single cell: per-workgroup partial minima of the optimal dt
+  int n_block_min;
   // single-cell fast path: the pair kernels do the shuffle's backward walk themselves (two
   // positions per thread) and write the permuted, pair-sorted idx once; NULL otherwise
   const PackRec *rec;
@@ -105,11 +105,90 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_cells_pre(sdm_step_cfg cfg, Fused
   A.cell_min[c] = INFINITY;
 }
 
+// Ec (coalescence efficiency) and fragment mass of one pair from the members' masses -- only
+// evaluated for pairs that actually collide (they are pure functions of the pair's state before
+// the update, so evaluating them lazily gives the values the reference computes for all pairs)
+__device__ __forceinline__ void breakup_params(const sdm_step_cfg &cfg, const FusedArgs &A,
+                                               double mj, double mk, double u_b, double &ec,
+                                               double &fm) {
+  const double vj = volume_of_mass(mj, cfg.rho_w), vk = volume_of_mass(mk, cfg.rho_w);
+  double rj = 0, rk = 0, uj = 0, uk = 0;
+  if (cfg.ec != SDM_EC_CONST || cfg.frag == SDM_FRAG_STRAUB2010) {
+    const double inv = 1 / (3.14159265358979323846 * 4 / 3);
+    rj = radius_of_volume(vj, inv);
+    rk = radius_of_volume(vk, inv);
+    if (A.gk_a) {
+      uj = gk_interpolate(rj, cfg.gk_factor, A.gk_a, A.gk_b, cfg.gk_table_len);
+      uk = gk_interpolate(rk, cfg.gk_factor, A.gk_a, A.gk_b, cfg.gk_table_len);
+    }
+  }
+    switch (cfg.ec) {
+      case SDM_EC_CONST: ec = cfg.ec_param[0]; break;
+      case SDM_EC_BERRY1967: {
+        const double e = linear_collection_efficiency(cfg.berry_params, rj, rk, cfg.berry_unit);
+        ec = e * e;
+        break;
+      }
+      default: {  // coalescence_efficiencies/straub2010.py:27-50
+        double tmp = vj + vk;
+        double Sc = tmp * (6 / 3.14159265358979323846);
+        tmp *= 2;
+        double tmp2 = fabs(uj - uk);
+        tmp2 = tmp2 * tmp2;
+        double We = vj * vk;
+        if (tmp != 0.0) We /= tmp;
+        We *= tmp2;
+        We *= cfg.rho_w;
+        Sc = signed_pow(Sc, 2.0 / 3.0);
+        Sc *= 3.14159265358979323846 * cfg.sgm_w;
+        if (Sc != 0.0) We /= Sc;
+        We *= -1.15;
+        ec = exp(We);
+      }
+    }
+    switch (cfg.frag) {
+      case SDM_FRAG_ALWAYS_N: fm = (mj + mk) / cfg.frag_param[0]; break;
+      case SDM_FRAG_EXPONENTIAL: {
+        const double a = 1 - u_b;
+        double fv = -cfg.frag_param[0] * log(a > 1e-5 ? a : 1e-5), nf;
+        fragmentation_limiters(nf, fv, cfg.frag_vmin, cfg.frag_nfmax, vj + vk);
+        fm = cfg.rho_w * fv;
+        break;
+      }
+      default: {  // breakup_fragmentations/straub2010.py:42-101
+        const double v_max = vj > vk ? vj : vk;
+        const double x_plus_y = vj + vk;
+        const double ds = (rj < rk ? rj : rk) * 2;
+        double tmp = vj + vk;
+        double Sc = signed_pow(tmp, 2.0 / 3.0);
+        Sc *= cfg.frag_param[1];  // PI * sgm_w * (6/PI)**(2/3), one host-side constant
+        double tmp2 = fabs(uj - uk);
+        tmp2 = tmp2 * tmp2;
+        double CKE = vj * vk;
+        if (tmp != 0.0) CKE /= tmp;
+        CKE *= tmp2;
+        CKE *= cfg.rho_w / 2;
+        double We = CKE;
+        if (Sc != 0.0) We /= Sc;
+        double CW = We;
+        CW *= CKE;
+        CW /= 1e-6;  // si.uJ
+        double gam = rj > rk ? rj : rk;
+        const double rmin = rj < rk ? rj : rk;
+        if (rmin != 0.0) gam /= rmin;
+        StraubTmp T = {0, 0, 0, 0, 0, 0};
+        double fv = straub_fragment_volume(CW, gam, ds, v_max, u_b, cfg.straub_consts, T), nf;
+        fragmentation_limiters(nf, fv, cfg.frag_vmin, cfg.frag_nfmax, x_plus_y);
+        fm = cfg.rho_w * fv;
+      }
+    }
+}
+
 struct PairInfo {
   bool have;
   uint8_t off;
   int64_t j, k, nj, nk, cid_j;
-  double prob, ec, fm, dt_optimal;
+  double prob, dt_optimal;
 };
 
 // pairing (find_pairs + sort_within_pair), kernel, probability, [Ec, fragment mass], [optimal dt]
@@ -119,7 +198,7 @@ __device__ __forceinline__ PairInfo pair_prob_body(const sdm_step_cfg &cfg, cons
                                                    int64_t d, int64_t W, double u_b) {
   PairInfo R;
   R.have = false; R.off = 2; R.j = R.k = R.nj = R.nk = R.cid_j = 0;
-  R.prob = 0.0; R.ec = 0.0; R.fm = 0.0; R.dt_optimal = INFINITY;
+  R.prob = 0.0; R.dt_optimal = INFINITY;
   int64_t i = 0;
   int64_t tj = 0, tk = 0;
   // find_pairs (pair_methods.py:34-55) for positions 2d and 2d+1
@@ -177,8 +256,7 @@ __device__ __forceinline__ PairInfo pair_prob_body(const sdm_step_cfg &cfg, cons
   R.cid_j = cfg.n_cell == 1 ? 0 : A.cell_id[j];
   const double vj = volume_of_mass(mj, cfg.rho_w), vk = volume_of_mass(mk, cfg.rho_w);
   double rj = 0, rk = 0, uj = 0, uk = 0;
-  const bool need_r = KERNEL == SDM_KERNEL_GEOMETRIC ||
-                      (BREAKUP && (cfg.ec != SDM_EC_CONST || cfg.frag == SDM_FRAG_STRAUB2010));
+  const bool need_r = KERNEL == SDM_KERNEL_GEOMETRIC;
   if (need_r) {
     const double inv = 1 / (3.14159265358979323846 * 4 / 3);
     rj = radius_of_volume(vj, inv);
@@ -203,68 +281,6 @@ __device__ __forceinline__ PairInfo pair_prob_body(const sdm_step_cfg &cfg, cons
   prob *= K;
   prob *= norm_factor_of(cfg, A.cell_start, cfg.n_cell == 1 ? 0 : A.cell_idx[A.cell_id[d]]);
   R.prob = prob;
-  if (BREAKUP) {
-    switch (cfg.ec) {
-      case SDM_EC_CONST: R.ec = cfg.ec_param[0]; break;
-      case SDM_EC_BERRY1967: {
-        const double e = linear_collection_efficiency(cfg.berry_params, rj, rk, cfg.berry_unit);
-        R.ec = e * e;
-        break;
-      }
-      default: {  // coalescence_efficiencies/straub2010.py:27-50
-        double tmp = vj + vk;
-        double Sc = tmp * (6 / 3.14159265358979323846);
-        tmp *= 2;
-        double tmp2 = fabs(uj - uk);
-        tmp2 = tmp2 * tmp2;
-        double We = vj * vk;
-        if (tmp != 0.0) We /= tmp;
-        We *= tmp2;
-        We *= cfg.rho_w;
-        Sc = signed_pow(Sc, 2.0 / 3.0);
-        Sc *= 3.14159265358979323846 * cfg.sgm_w;
-        if (Sc != 0.0) We /= Sc;
-        We *= -1.15;
-        R.ec = exp(We);
-      }
-    }
-    switch (cfg.frag) {
-      case SDM_FRAG_ALWAYS_N: R.fm = (mj + mk) / cfg.frag_param[0]; break;
-      case SDM_FRAG_EXPONENTIAL: {
-        const double a = 1 - u_b;
-        double fv = -cfg.frag_param[0] * log(a > 1e-5 ? a : 1e-5), nf;
-        fragmentation_limiters(nf, fv, cfg.frag_vmin, cfg.frag_nfmax, vj + vk);
-        R.fm = cfg.rho_w * fv;
-        break;
-      }
-      default: {  // breakup_fragmentations/straub2010.py:42-101
-        const double v_max = vj > vk ? vj : vk;
-        const double x_plus_y = vj + vk;
-        const double ds = (rj < rk ? rj : rk) * 2;
-        double tmp = vj + vk;
-        double Sc = signed_pow(tmp, 2.0 / 3.0);
-        Sc *= cfg.frag_param[1];  // PI * sgm_w * (6/PI)**(2/3), one host-side constant
-        double tmp2 = fabs(uj - uk);
-        tmp2 = tmp2 * tmp2;
-        double CKE = vj * vk;
-        if (tmp != 0.0) CKE /= tmp;
-        CKE *= tmp2;
-        CKE *= cfg.rho_w / 2;
-        double We = CKE;
-        if (Sc != 0.0) We /= Sc;
-        double CW = We;
-        CW *= CKE;
-        CW /= 1e-6;  // si.uJ
-        double gam = rj > rk ? rj : rk;
-        const double rmin = rj < rk ? rj : rk;
-        if (rmin != 0.0) gam /= rmin;
-        StraubTmp T = {0, 0, 0, 0, 0, 0};
-        double fv = straub_fragment_volume(CW, gam, ds, v_max, u_b, cfg.straub_consts, T), nf;
-        fragmentation_limiters(nf, fv, cfg.frag_vmin, cfg.frag_nfmax, x_plus_y);
-        R.fm = cfg.rho_w * fv;
-      }
-    }
-  }
   if (cfg.adaptive && prob != 0) {
     // collisions_methods.py:359-368
     const int64_t prop = nj / nk;
@@ -280,7 +296,7 @@ template <bool BREAKUP>
 __device__ __forceinline__ void pair_update_body(const sdm_step_cfg &cfg, const FusedArgs &A,
                                                  int64_t d, bool in_range, double p, double u,
                                                  double u_b, bool known, int64_t off,
-                                                 int64_t j, int64_t k, double ec, double fm) {
+                                                 int64_t j, int64_t k) {
   bool collide = false;
   int64_t cid = 0, nk = 0, gi = 0, gc = 0;
   double g = 0;
@@ -307,6 +323,11 @@ __device__ __forceinline__ void pair_update_body(const sdm_step_cfg &cfg, const 
   bool coal = collide;
   if (BREAKUP && collide) {
     const double eb = cfg.eb_const;
+    double ec, fm;
+    {
+      const double *mass0 = A.attributes + (int64_t)cfg.mass_attr * cfg.n_sd;
+      breakup_params(cfg, A, mass0[j], mass0[k], u_b, ec, fm);
+    }
     if (u_b - (ec + (1 - ec) * eb) > 0) {
       collide = false;  // bounce
       coal = false;
@@ -390,30 +411,41 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_all(sdm_step_cfg cfg, FusedA
   const double u = stream_draw(A.s_rand, A.rng_inc, A.rng_tab, &lds[0]);
   const double u_b = BREAKUP ? stream_draw(A.s_rand_b, A.rng_inc, A.rng_tab, &lds[1]) : 0.0;
   PairInfo R;
-  R.have = false; R.off = 2; R.prob = 0; R.j = R.k = 0; R.ec = R.fm = 0;
+  R.have = false; R.off = 2; R.prob = 0; R.j = R.k = 0;
   if (d < (cfg.n_sd + 1) / 2) R = pair_prob_body<KERNEL, BREAKUP>(cfg, A, d, W, u_b);
   double p = R.prob;
   if (p != 0) p /= (double)cfg.substeps;  // collision.py:279
-  pair_update_body<BREAKUP>(cfg, A, d, d < W / 2, p, u, u_b, true, R.off, R.j, R.k, R.ec, R.fm);
+  pair_update_body<BREAKUP>(cfg, A, d, d < W / 2, p, u, u_b, true, R.off, R.j, R.k);
 }
 
 // ---- adaptive: probabilities first (per-cell min of the optimal dt is a global dependency) ---
 template <int KERNEL, bool BREAKUP>
 __global__ void __launch_bounds__(SDM_BLOCK) k_pair_prob(sdm_step_cfg cfg, FusedArgs A) {
-  __shared__ u128 lds[1];
   const int64_t W = A.ctl[CTL_WORK];
   const int64_t d = TID();
-  const double u_b = BREAKUP ? stream_draw(A.s_rand_b, A.rng_inc, A.rng_tab, &lds[0]) : 0.0;
+  const double u_b = 0.0;  // breakup parameters are evaluated in k_pair_update
   PairInfo R;
-  R.have = false; R.prob = 0; R.cid_j = 0; R.dt_optimal = INFINITY; R.off = 2; R.ec = R.fm = 0;
+  R.have = false; R.prob = 0; R.cid_j = 0; R.dt_optimal = INFINITY; R.off = 2;
   if (d < (cfg.n_sd + 1) / 2) R = pair_prob_body<KERNEL, BREAKUP>(cfg, A, d, W, u_b);
   if (d < cfg.n_sd / 2) {
     A.prob[d] = R.prob;
     A.pair_off[d] = R.off;
     if (cfg.n_cell > 1) A.pair_cid[d] = (int32_t)R.cid_j;
-    if (BREAKUP) { A.Ec[d] = R.ec; A.fragment_mass[d] = R.fm; }
   }
   const bool active = R.have && R.prob != 0;
+  if (cfg.n_cell == 1) {
+    // one cell: no atomics on a single word; workgroup minimum -> block_min[blockIdx]
+    __shared__ double wmin[SDM_BLOCK / SDM_WAVE];
+    const double m = wave_min_f64(active ? R.dt_optimal : INFINITY);
+    if (lane_id() == 0) wmin[threadIdx.x / SDM_WAVE] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double b = wmin[0];
+      for (int w = 1; w < SDM_BLOCK / SDM_WAVE; ++w) b = wmin[w] < b ? wmin[w] : b;
+      A.block_min[blockIdx.x] = b;
+    }
+    return;
+  }
   const unsigned long long am = __ballot(active);
   if (am != 0) {
     const int first = __ffsll((long long)am) - 1;
@@ -429,10 +461,26 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_prob(sdm_step_cfg cfg, Fused
 
 // ---- per-cell adaptive bookkeeping (collisions_methods.py:357-374) ---------------------------
 __global__ void __launch_bounds__(SDM_BLOCK) k_cells_adaptive(sdm_step_cfg cfg, FusedArgs A) {
+  if (cfg.n_cell == 1) {  // fold the per-workgroup partial minima (one workgroup launched)
+    __shared__ double wmin[SDM_BLOCK / SDM_WAVE];
+    double m = INFINITY;
+    for (int b = threadIdx.x; b < A.n_block_min; b += SDM_BLOCK) {
+      const double v = A.block_min[b];
+      m = v < m ? v : m;
+    }
+    m = wave_min_f64(m);
+    if (lane_id() == 0) wmin[threadIdx.x / SDM_WAVE] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < SDM_BLOCK / SDM_WAVE; ++w) m = wmin[w] < m ? wmin[w] : m;
+      A.cell_min[0] = m;
+    }
+    __syncthreads();
+  }
   const int64_t c = TID();
   if (c >= cfg.n_cell) return;
   if (A.ctl[CTL_WORK] == 0) return;
-  const double m = A.cell_min[c];
+  const double m = ((volatile double *)A.cell_min)[c];
   double t = A.dt_todo[c];
   if (m < t) t = m;
   A.dt_todo[c] = t;
@@ -450,7 +498,7 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_update(sdm_step_cfg cfg, Fus
   const double u = stream_draw(A.s_rand, A.rng_inc, A.rng_tab, &lds[0]);
   const double u_b = BREAKUP ? stream_draw(A.s_rand_b, A.rng_inc, A.rng_tab, &lds[1]) : 0.0;
   const bool in_range = d < W / 2;
-  double p = 0, ec = 0, fm = 0;
+  double p = 0;
   int64_t off = 2;
   if (in_range) {
     p = A.prob[d];
@@ -459,9 +507,8 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_update(sdm_step_cfg cfg, Fus
       const int64_t cid = cfg.n_cell > 1 ? A.pair_cid[d] : 0;
       p *= A.dt_todo[cid] / cfg.dt;  // collisions_methods.py:369-372
     }
-    if (BREAKUP) { ec = A.Ec[d]; fm = A.fragment_mass[d]; }
   }
-  pair_update_body<BREAKUP>(cfg, A, d, in_range, p, u, u_b, false, off, 0, 0, ec, fm);
+  pair_update_body<BREAKUP>(cfg, A, d, in_range, p, u, u_b, false, off, 0, 0);
 }
 
 // ---- control-word kernels -------------------------------------------------------------------
@@ -519,7 +566,7 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_fill_f64(double *p, double v, int
 
 // ---------------------------------------------------------------------------------------------
 struct FusedScratch {
-  double *prob, *Ec, *fragment_mass, *dt_todo, *cell_min;
+  double *prob, *dt_todo, *cell_min, *block_min;
   uint8_t *pair_off;
   int32_t *pair_cid;
   int64_t *sorted_buf, *cs_tmp, *gate_len, *cctl, *end2;
@@ -533,10 +580,9 @@ static FusedScratch layout(char *base, const sdm_step_cfg *cfg) {
   const int64_t N = cfg->n_sd, P = N / 2 > 0 ? N / 2 : 1, C = cfg->n_cell;
   const bool split = cfg->adaptive != 0;  // prob etc. cross a kernel boundary only then
   S.prob = cv.take<double>(split ? P : 1);
-  S.Ec = cv.take<double>(split && cfg->enable_breakup ? P : 1);
-  S.fragment_mass = cv.take<double>(split && cfg->enable_breakup ? P : 1);
   S.dt_todo = cv.take<double>(C);
   S.cell_min = cv.take<double>(C);
+  S.block_min = cv.take<double>(grid_for((cfg->n_sd + 1) / 2) + 1);
   S.pair_off = cv.take<uint8_t>(split ? P : 1);
   S.pair_cid = cv.take<int32_t>(split ? P : 1);
   S.sorted_buf = cv.take<int64_t>(C > 1 ? N : 1);
@@ -554,9 +600,13 @@ static FusedScratch layout(char *base, const sdm_step_cfg *cfg) {
   return S;
 }
 
+// `known`: what the host knows about ctl[CTL_SORTED] (1 sorted, 0 unsorted, -1 unknown);
+// afterwards the device state is sorted in any case
 static int cond_sort(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st, int64_t *idx,
-                     const FusedScratch &S) {
+                     const FusedScratch &S, int *known) {
   if (cfg->n_cell == 1) return SDM_OK;  // identity; cell_start kept right by the compaction
+  if (*known == 1) return SDM_OK;
+  *known = 1;
   PhaseScope ph(ctx, SDM_PHASE_SORT);
   hipLaunchKernelGGL(k_sort_gate, dim3(1), dim3(1), 0, ctx->stream, st->ctl, S.gate_len);
   LAUNCH_CHECK();
@@ -649,10 +699,10 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   A.prob = S.prob;
   A.pair_off = S.pair_off;
   A.pair_cid = S.pair_cid;
-  A.Ec = S.Ec;
-  A.fragment_mass = S.fragment_mass;
   A.dt_todo = S.dt_todo;
   A.cell_min = S.cell_min;
+  A.block_min = S.block_min;
+  A.n_block_min = (int)grid_for((N + 1) / 2);
 
   uint64_t off = st->rng_offset, off_b = st->rng_offset_breakup;
   uint64_t draw_off = off, draw_off_b = off_b;  // stream positions of the current draw
@@ -676,11 +726,14 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
     LAUNCH_CHECK();
   }
   int64_t work_host = -1;
+  int sorted_host = -1;  // host's knowledge of ctl[CTL_SORTED]
   if (cfg->adaptive || read_back) {
-    HIP_TRY(hipMemcpyAsync(ctx->mailbox + 3, st->ctl + CTL_WORK, sizeof(int64_t),
-                           hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ctx->mailbox + 8, st->ctl, sizeof(int64_t) * 4, hipMemcpyDeviceToHost,
+                           s));
     HIP_TRY(hipStreamSynchronize(s));
-    work_host = ctx->mailbox[3];
+    work_host = ctx->mailbox[8 + CTL_WORK];
+    sorted_host = (int)ctx->mailbox[8 + CTL_SORTED];
+    if (C == 1 && (flags & 2)) sorted_host = 1;
   }
   for (;;) {
     if (!cfg->adaptive && n_sub >= cfg->substeps) break;
@@ -691,7 +744,7 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
       if (rc) return rc;
     }
     // (b) cell_start getter: counting sort if unsorted (particle_attributes.py:51-55)
-    rc = cond_sort(ctx, cfg, st, cur, S);
+    rc = cond_sort(ctx, cfg, st, cur, S, &sorted_host);
     if (rc) return rc;
     // (c) random numbers (random_generator_optimizer.py:37-48): a draw = pairs_rand (N + shift)
     // then rand (P) from the collision generator, P from each breakup generator
@@ -729,7 +782,8 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
     if (!cfg->croupier_local && C > 1) {
       hipLaunchKernelGGL(k_mark_unsorted, one, one, 0, s, st->ctl);
       LAUNCH_CHECK();
-      rc = cond_sort(ctx, cfg, st, cur, S);
+      sorted_host = 0;
+      rc = cond_sort(ctx, cfg, st, cur, S, &sorted_host);
       if (rc) return rc;
     }
     A.idx = cur;
@@ -769,31 +823,40 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
       rc = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl, S.cctl,
                                    C == 1 ? st->cell_start : nullptr);
       if (rc) return rc;
+      if (C > 1) sorted_host = -1;  // a compaction (decided on the device) un-sorts
     }
     ++n_sub;
     if (!cfg->adaptive && work_host >= 0) n_pairs += work_host / 2;
     if (cfg->adaptive) {
       // (h) collision.py:185-187 cut_working_length(adaptive_sdm_end(dt_left))
       n_pairs += work_host / 2;
-      if (C > 1) {
-        rc = cond_sort(ctx, cfg, st, cur, S);
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        {
+          PhaseScope ph(ctx, SDM_PHASE_ADAPTIVE_END);
+          if (C == 1) {
+            hipLaunchKernelGGL(k_set_work_single, one, one, 0, s, st->ctl, st->dt_left,
+                               st->cell_start);
+            LAUNCH_CHECK();
+          } else {
+            rc = sdm_adaptive_end_async(ctx, st->dt_left, C, st->cell_start, S.end2, S.end2 + 1);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_set_work, one, one, 0, s, st->ctl, S.end2 + 1);
+            LAUNCH_CHECK();
+          }
+          HIP_TRY(hipMemcpyAsync(ctx->mailbox + 8, st->ctl, sizeof(int64_t) * 4,
+                                 hipMemcpyDeviceToHost, s));
+          HIP_TRY(hipStreamSynchronize(s));
+        }
+        work_host = ctx->mailbox[8 + CTL_WORK];
+        if (C == 1 || ctx->mailbox[8 + CTL_SORTED] != 0) { sorted_host = C == 1 ? sorted_host : 1; break; }
+        // a compaction happened in this sub-step: sort by cell first (particle_attributes.py
+        // cell_start getter), then the end of the working range is taken from the new cell_start
+        sorted_host = 0;
+        hipLaunchKernelGGL(k_reset_work, one, one, 0, s, st->ctl);  // sanitize left work = valid
+        LAUNCH_CHECK();
+        rc = cond_sort(ctx, cfg, st, cur, S, &sorted_host);
         if (rc) return rc;
       }
-      PhaseScope ph(ctx, SDM_PHASE_ADAPTIVE_END);
-      if (C == 1) {
-        hipLaunchKernelGGL(k_set_work_single, one, one, 0, s, st->ctl, st->dt_left,
-                           st->cell_start);
-        LAUNCH_CHECK();
-      } else {
-        rc = sdm_adaptive_end_async(ctx, st->dt_left, C, st->cell_start, S.end2, S.end2 + 1);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_set_work, one, one, 0, s, st->ctl, S.end2 + 1);
-        LAUNCH_CHECK();
-      }
-      HIP_TRY(hipMemcpyAsync(ctx->mailbox + 3, st->ctl + CTL_WORK, sizeof(int64_t),
-                             hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      work_host = ctx->mailbox[3];
     }
   }
   if (cfg->adaptive) {
@@ -805,7 +868,8 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
       if (rc) return rc;
       hipLaunchKernelGGL(k_mark_unsorted, one, one, 0, s, st->ctl);
       LAUNCH_CHECK();
-      rc = cond_sort(ctx, cfg, st, cur, S);
+      sorted_host = 0;
+      rc = cond_sort(ctx, cfg, st, cur, S, &sorted_host);
       if (rc) return rc;
     }
   }

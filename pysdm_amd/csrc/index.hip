@@ -1019,35 +1019,57 @@ __device__ __forceinline__ int64_t sort_key(const int64_t *__restrict__ idx,
   return cell_idx[cell_id[idx[i]]];
 }
 
-__global__ void __launch_bounds__(SDM_WAVE)
-k_sort_hist(int32_t *__restrict__ H, const int64_t *__restrict__ idx,
-            const int64_t *__restrict__ cell_id, const int64_t *__restrict__ cell_idx,
-            const int64_t *__restrict__ p_length, int64_t n_cell, int64_t tile) {
-  const int64_t length = *p_length;
-  const int64_t first = (int64_t)blockIdx.x * tile;
-  int32_t *row = H + (int64_t)blockIdx.x * n_cell;
-  for (int64_t i = first + threadIdx.x; i < first + tile && i < length; i += SDM_WAVE)
-    atomicAdd(&row[sort_key(idx, cell_id, cell_idx, i)], 1);
+// every kernel of the sort exits at once when the length word is 0 (the fused step gates the
+// whole sort on the device that way)
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_sort_zero(int32_t *__restrict__ H, int64_t n, const int64_t *__restrict__ p_length) {
+  if (*p_length == 0) return;
+  for (int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * SDM_BLOCK)
+    H[i] = 0;
 }
 
-// per key: exclusive scan down the tiles; totals -> count[c]
-__global__ void __launch_bounds__(SDM_BLOCK)
-k_sort_colscan(int32_t *__restrict__ H, int64_t *__restrict__ count, int64_t n_cell, int nb) {
-  const int64_t c = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
-  if (c >= n_cell) return;
-  int32_t run = 0;
-  for (int b = 0; b < nb; ++b) {
-    const int32_t t = H[(int64_t)b * n_cell + c];
-    H[(int64_t)b * n_cell + c] = run;
-    run += t;
+// H[key][tile]: per-tile histogram of the keys; keys cached for the scatter pass
+__global__ void __launch_bounds__(SDM_WAVE)
+k_sort_hist(int32_t *__restrict__ H, int32_t *__restrict__ keys, const int64_t *__restrict__ idx,
+            const int64_t *__restrict__ cell_id, const int64_t *__restrict__ cell_idx,
+            const int64_t *__restrict__ p_length, int nb, int64_t tile) {
+  const int64_t length = *p_length;
+  const int64_t first = (int64_t)blockIdx.x * tile;
+  for (int64_t i = first + threadIdx.x; i < first + tile && i < length; i += SDM_WAVE) {
+    const int32_t key = (int32_t)sort_key(idx, cell_id, cell_idx, i);
+    keys[i] = key;
+    atomicAdd(&H[(int64_t)key * nb + blockIdx.x], 1);
   }
-  count[c] = run;
+}
+
+// one workgroup per key: exclusive scan along the tiles; total -> count[key]
+__global__ void __launch_bounds__(BIN_THREADS)
+k_sort_colscan(int32_t *__restrict__ H, int64_t *__restrict__ count, int nb,
+               const int64_t *__restrict__ p_length) {
+  if (*p_length == 0) return;
+  int32_t *row = H + (int64_t)blockIdx.x * nb;
+  const int per = (nb + BIN_THREADS - 1) / BIN_THREADS;
+  const int t0 = threadIdx.x * per;
+  int sum = 0;
+  for (int k = 0; k < per; ++k)
+    if (t0 + k < nb) sum += row[t0 + k];
+  int all;
+  int run = block_excl_scan(sum, &all);
+  for (int k = 0; k < per; ++k)
+    if (t0 + k < nb) {
+      const int v = row[t0 + k];
+      row[t0 + k] = run;
+      run += v;
+    }
+  if (threadIdx.x == 0) count[blockIdx.x] = all;
 }
 
 // cell_start[0..n_cell] = exclusive scan of count (single block, chunked)
 __global__ void __launch_bounds__(1024)
 k_sort_cellstart(const int64_t *__restrict__ count, int64_t *__restrict__ cell_start,
-                 int64_t n_cell) {
+                 int64_t n_cell, const int64_t *__restrict__ p_length) {
+  if (*p_length == 0) return;
   __shared__ int64_t sm[1024];
   __shared__ int64_t carry;
   if (threadIdx.x == 0) carry = 0;
@@ -1074,18 +1096,17 @@ k_sort_cellstart(const int64_t *__restrict__ count, int64_t *__restrict__ cell_s
 
 __global__ void __launch_bounds__(SDM_WAVE)
 k_sort_scatter(int64_t *__restrict__ new_idx, int32_t *__restrict__ H,
-               const int64_t *__restrict__ idx, const int64_t *__restrict__ cell_id,
-               const int64_t *__restrict__ cell_idx, const int64_t *__restrict__ cell_start,
-               const int64_t *__restrict__ p_length, int64_t n_cell, int64_t tile, int key_bits) {
+               const int32_t *__restrict__ keys, const int64_t *__restrict__ idx,
+               const int64_t *__restrict__ cell_start, const int64_t *__restrict__ p_length,
+               int nb, int64_t tile, int key_bits) {
   const int64_t length = *p_length;
   const int64_t first = (int64_t)blockIdx.x * tile;
-  int32_t *row = H + (int64_t)blockIdx.x * n_cell;
   const int lane = threadIdx.x;
   for (int64_t base = first; base < first + tile && base < length; base += SDM_WAVE) {
     const int64_t i = base + lane;
     const bool in = i < first + tile && i < length;
     const int64_t v = in ? idx[i] : 0;
-    const int64_t key = in ? cell_idx[cell_id[v]] : -1;
+    const int32_t key = in ? keys[i] : -1;
     // peers = lanes holding the same key
     unsigned long long peers = __ballot(in);
     for (int b = 0; b < key_bits; ++b) {
@@ -1097,7 +1118,8 @@ k_sort_scatter(int64_t *__restrict__ new_idx, int32_t *__restrict__ H,
       const int rank = __popcll(peers & ((1ull << lane) - 1));
       const int leader = 63 - __clzll(peers);
       int32_t basepos = 0;
-      if (lane == leader) basepos = atomicAdd(&row[key], __popcll(peers));
+      if (lane == leader)
+        basepos = atomicAdd(&H[(int64_t)key * nb + blockIdx.x], __popcll(peers));
       basepos = __shfl(basepos, leader, 64);
       new_idx[cell_start[key] + basepos + rank] = v;
     }
@@ -1128,7 +1150,8 @@ size_t sdm_sort_scratch(int64_t length_bound, int64_t n_cell) {
   int64_t tile;
   int nb;
   sort_geometry(length_bound, n_cell, &tile, &nb);
-  return carve_size(sizeof(int32_t) * (size_t)nb * n_cell) + carve_size(sizeof(int64_t) * n_cell);
+  return carve_size(sizeof(int32_t) * (size_t)nb * n_cell) + carve_size(sizeof(int64_t) * n_cell) +
+         carve_size(sizeof(int32_t) * length_bound);
 }
 
 int sdm_counting_sort_async(sdm_ctx *ctx, char *scratch, int64_t *new_idx, const int64_t *idx,
@@ -1147,20 +1170,23 @@ int sdm_counting_sort_async(sdm_ctx *ctx, char *scratch, int64_t *new_idx, const
   Carver cv(scratch);
   int32_t *H = cv.take<int32_t>((size_t)nb * n_cell);
   int64_t *count = cv.take<int64_t>(n_cell);
+  int32_t *keys = cv.take<int32_t>(length_bound);
   int key_bits = 1;
   while ((1ll << key_bits) < n_cell) ++key_bits;
-  HIP_TRY(hipMemsetAsync(H, 0, sizeof(int32_t) * (size_t)nb * n_cell, ctx->stream));
-  hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(SDM_WAVE), 0, ctx->stream, H, idx, cell_id,
-                     cell_idx, p_length, n_cell, tile);
+  hipLaunchKernelGGL(k_sort_zero, dim3(1024), dim3(SDM_BLOCK), 0, ctx->stream, H,
+                     (int64_t)nb * n_cell, p_length);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_sort_colscan, dim3(grid_for(n_cell)), dim3(SDM_BLOCK), 0, ctx->stream, H,
-                     count, n_cell, nb);
+  hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(SDM_WAVE), 0, ctx->stream, H, keys, idx, cell_id,
+                     cell_idx, p_length, nb, tile);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_sort_colscan, dim3((unsigned)n_cell), dim3(BIN_THREADS), 0, ctx->stream, H,
+                     count, nb, p_length);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_sort_cellstart, dim3(1), dim3(1024), 0, ctx->stream, count, cell_start,
-                     n_cell);
+                     n_cell, p_length);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(SDM_WAVE), 0, ctx->stream, new_idx, H, idx,
-                     cell_id, cell_idx, cell_start, p_length, n_cell, tile, key_bits);
+  hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(SDM_WAVE), 0, ctx->stream, new_idx, H, keys,
+                     idx, cell_start, p_length, nb, tile, key_bits);
   LAUNCH_CHECK();
   return SDM_OK;
 }
@@ -1171,6 +1197,10 @@ extern "C" int sdm_counting_sort_by_cell_id(sdm_ctx *ctx, int64_t *new_idx, cons
                                             int64_t n_cell) {
   ARG_TRY(ctx && cell_start && n_cell >= 1 && length >= 0);
   ARG_TRY(length == 0 || (new_idx && idx && cell_id && cell_idx));
+  if (length == 0) {  // nothing to sort: every cell empty
+    HIP_TRY(hipMemsetAsync(cell_start, 0, sizeof(int64_t) * (n_cell + 1), ctx->stream));
+    return SDM_OK;
+  }
   int rc = sdm_reserve(ctx, sdm_sort_scratch(length, n_cell));
   if (rc) return rc;
   int64_t *p_length = ctx->dscal + 8;
