@@ -251,8 +251,10 @@ typedef struct sdm_step_state {
   /* device control block, int64[8]: {valid_n_sd, working_length, sorted, healthy,
    * n_overflow, idx_swapped, reserved, reserved}; kept device-resident between calls */
   int64_t *ctl;
-  /* optional [n_sd] x 16 B mirror {int64 multiplicity, double mass} kept by the library (one
-   * random line per gather instead of two); caller-owned like all state, NULL = do not use.
+  /* optional mirror kept by the library, caller-owned like all state (NULL = do not use):
+   * [n_sd] x 32 B.  Records are {int64 multiplicity, double mass} (16-B stride) or, with the
+   * geometric kernel / Berry / Straub breakup, {multiplicity, mass, radius, terminal velocity}
+   * (32-B stride): one random line per gather, derived attributes evaluated once per change.
    * (Re)initialised from the SoA columns when SDM_STEP_FRESH_CTL is passed.                   */
   void *nm;
   uint64_t rng_offset;        /* doubles already drawn from the coll. stream (host-tracked) */

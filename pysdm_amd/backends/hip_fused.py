@@ -67,8 +67,8 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
         self.idx = view["idx"]
         self.tmp_idx = view["caretaker"].tmp_idx
         self.ctl = torch.zeros(8, dtype=torch.int64, device=self.idx.data.device)
-        # {multiplicity, mass} mirror, 16 B per super-droplet (see sdm_step_state.nm)
-        self.nm = torch.empty(2 * part.n_sd, dtype=torch.int64, device=self.idx.data.device)
+        # per-droplet mirror records, up to 32 B each (see sdm_step_state.nm)
+        self.nm = torch.empty(4 * part.n_sd, dtype=torch.int64, device=self.idx.data.device)
         self._ctl_initialised = False
         self._stamps = None
         self.result = StepResult()

@@ -21,7 +21,12 @@ int sdm_adaptive_end_async(sdm_ctx *ctx, const double *dt_left, int64_t n_cell,
 
 #define TID() ((int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x)
 
-struct __align__(16) NM { int64_t n; double m; };
+// per-super-droplet mirror record: {multiplicity, mass} (16 B) or, when radius / terminal velocity
+// are needed (geometric kernel, Berry / Straub breakup), {multiplicity, mass, radius, velocity}
+// (32 B): the derived attributes are then evaluated once per change of a droplet instead of once
+// per candidate pair and sub-step (attributes/physics/{radius,terminal_velocity}.py semantics)
+struct SD { int64_t n; double m, r, u; };
+struct Collided;
 
 struct FusedArgs {
   // state
@@ -57,7 +62,11 @@ struct FusedArgs {
   const int64_t *idx_prev;  // previous permutation (source of the dead tail)
   // {multiplicity, mass} of each super-droplet side by side (one random line per gather instead
   // of two); a mirror of the SoA columns kept current by the update code, NULL = not in use
-  NM *nm;
+  double *nm;
+  int nm_wide;  // 0: 16-B records, 1: 32-B records
+  // breakup: colliding pairs listed by the pair kernels, resolved by k_resolve_dense
+  struct Collided *list;
+  unsigned long long *list_count;
 };
 
 // wave-aggregated int64 counter add: one atomic per wave when all contributing lanes share cid
@@ -96,6 +105,48 @@ __device__ __forceinline__ double norm_factor_of(const sdm_step_cfg &cfg,
                           (double)(sd_num / 2);
 }
 
+__device__ __forceinline__ void derive_ru(const sdm_step_cfg &cfg, const FusedArgs &A, SD &v) {
+  const double inv = 1 / (3.14159265358979323846 * 4 / 3);
+  v.r = radius_of_volume(volume_of_mass(v.m, cfg.rho_w), inv);
+  v.u = A.gk_a ? gk_interpolate(v.r, cfg.gk_factor, A.gk_a, A.gk_b, cfg.gk_table_len) : 0.0;
+}
+
+// state of super-droplet `id`: from the mirror if there is one, else from the SoA columns
+__device__ __forceinline__ SD sd_load(const sdm_step_cfg &cfg, const FusedArgs &A, int64_t id,
+                                      bool need_ru) {
+  SD v;
+  if (A.nm && A.nm_wide) {
+    const double4 w = ((const double4 *)A.nm)[id];
+    v.n = __double_as_longlong(w.x); v.m = w.y; v.r = w.z; v.u = w.w;
+  } else {
+    if (A.nm) {
+      const double2 w = ((const double2 *)A.nm)[id];
+      v.n = __double_as_longlong(w.x); v.m = w.y;
+    } else {
+      v.n = A.multiplicity[id];
+      v.m = (A.attributes + (int64_t)cfg.mass_attr * cfg.n_sd)[id];
+    }
+    v.r = v.u = 0.0;
+    if (need_ru) derive_ru(cfg, A, v);
+  }
+  return v;
+}
+
+// refresh the mirror record of `id` from the SoA columns (after an update)
+__device__ __forceinline__ void sd_refresh(const sdm_step_cfg &cfg, const FusedArgs &A,
+                                           int64_t id) {
+  if (!A.nm) return;
+  SD v;
+  v.n = A.multiplicity[id];
+  v.m = (A.attributes + (int64_t)cfg.mass_attr * cfg.n_sd)[id];
+  if (A.nm_wide) {
+    derive_ru(cfg, A, v);
+    ((double4 *)A.nm)[id] = make_double4(__longlong_as_double(v.n), v.m, v.r, v.u);
+  } else {
+    ((double2 *)A.nm)[id] = make_double2(__longlong_as_double(v.n), v.m);
+  }
+}
+
 // ---- per-cell adaptive init (collisions_methods.py:355-356) -----------------------------------
 __global__ void __launch_bounds__(SDM_BLOCK) k_cells_pre(sdm_step_cfg cfg, FusedArgs A) {
   const int64_t c = TID();
@@ -109,19 +160,11 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_cells_pre(sdm_step_cfg cfg, Fused
 // evaluated for pairs that actually collide (they are pure functions of the pair's state before
 // the update, so evaluating them lazily gives the values the reference computes for all pairs)
 __device__ __forceinline__ void breakup_params(const sdm_step_cfg &cfg, const FusedArgs &A,
-                                               double mj, double mk, double u_b, double &ec,
-                                               double &fm) {
+                                               const SD &sj, const SD &sk, double u_b,
+                                               double &ec, double &fm) {
+  const double mj = sj.m, mk = sk.m;
   const double vj = volume_of_mass(mj, cfg.rho_w), vk = volume_of_mass(mk, cfg.rho_w);
-  double rj = 0, rk = 0, uj = 0, uk = 0;
-  if (cfg.ec != SDM_EC_CONST || cfg.frag == SDM_FRAG_STRAUB2010) {
-    const double inv = 1 / (3.14159265358979323846 * 4 / 3);
-    rj = radius_of_volume(vj, inv);
-    rk = radius_of_volume(vk, inv);
-    if (A.gk_a) {
-      uj = gk_interpolate(rj, cfg.gk_factor, A.gk_a, A.gk_b, cfg.gk_table_len);
-      uk = gk_interpolate(rk, cfg.gk_factor, A.gk_a, A.gk_b, cfg.gk_table_len);
-    }
-  }
+  const double rj = sj.r, rk = sk.r, uj = sj.u, uk = sk.u;
     switch (cfg.ec) {
       case SDM_EC_CONST: ec = cfg.ec_param[0]; break;
       case SDM_EC_BERRY1967: {
@@ -231,22 +274,15 @@ __device__ __forceinline__ PairInfo pair_prob_body(const sdm_step_cfg &cfg, cons
   R.off = (uint8_t)(i - 2 * d);
   const bool traced = A.rec != nullptr;
   int64_t j = traced ? tj : A.idx[i], k = traced ? tk : A.idx[i + 1];
-  const double *mass = A.attributes + (int64_t)cfg.mass_attr * cfg.n_sd;
-  int64_t nj, nk;
-  double mj, mk;
-  if (A.nm) {
-    const NM a = A.nm[j], b = A.nm[k];
-    nj = a.n; mj = a.m; nk = b.n; mk = b.m;
-  } else {
-    nj = A.multiplicity[j]; nk = A.multiplicity[k];
-    mj = mass[j]; mk = mass[k];
-  }
+  const bool need_r = KERNEL == SDM_KERNEL_GEOMETRIC;
+  SD sj = sd_load(cfg, A, j, need_r), sk = sd_load(cfg, A, k, need_r);
+  int64_t nj = sj.n, nk = sk.n;
   // sort_within_pair_by_attr (pair_methods.py:126-140)
   const bool swap = nj < nk;
   if (swap) {
     const int64_t t = j; j = k; k = t;
     const int64_t tn = nj; nj = nk; nk = tn;
-    const double tm = mj; mj = mk; mk = tm;
+    const SD ts = sj; sj = sk; sk = ts;
   }
   if (swap || traced) {
     A.idx[i] = j;
@@ -254,18 +290,8 @@ __device__ __forceinline__ PairInfo pair_prob_body(const sdm_step_cfg &cfg, cons
   }
   R.j = j; R.k = k; R.nj = nj; R.nk = nk;
   R.cid_j = cfg.n_cell == 1 ? 0 : A.cell_id[j];
-  const double vj = volume_of_mass(mj, cfg.rho_w), vk = volume_of_mass(mk, cfg.rho_w);
-  double rj = 0, rk = 0, uj = 0, uk = 0;
-  const bool need_r = KERNEL == SDM_KERNEL_GEOMETRIC;
-  if (need_r) {
-    const double inv = 1 / (3.14159265358979323846 * 4 / 3);
-    rj = radius_of_volume(vj, inv);
-    rk = radius_of_volume(vk, inv);
-    if (A.gk_a) {
-      uj = gk_interpolate(rj, cfg.gk_factor, A.gk_a, A.gk_b, cfg.gk_table_len);
-      uk = gk_interpolate(rk, cfg.gk_factor, A.gk_a, A.gk_b, cfg.gk_table_len);
-    }
-  }
+  const double vj = volume_of_mass(sj.m, cfg.rho_w), vk = volume_of_mass(sk.m, cfg.rho_w);
+  const double rj = sj.r, rk = sk.r, uj = sj.u, uk = sk.u;
   double K;
   if (KERNEL == SDM_KERNEL_GOLOVIN) {
     K = (vj + vk) * cfg.kernel_param[0];
@@ -292,41 +318,23 @@ __device__ __forceinline__ PairInfo pair_prob_body(const sdm_step_cfg &cfg, cons
 
 // compute_gamma + collision_coalescence[_breakup] for slot d (all lanes of the wave must call).
 // p = the (already dt-scaled) probability; u = the slot's `rand`; j/k valid if `known`.
+// one colliding pair: bounce / coalescence / breakup decision and the update
+// (collisions_methods.py:247-311).  Wave-collective (counter_add): every lane calls it.
+struct Collided { int64_t j, k, cid; double g, u_b; };
+
 template <bool BREAKUP>
-__device__ __forceinline__ void pair_update_body(const sdm_step_cfg &cfg, const FusedArgs &A,
-                                                 int64_t d, bool in_range, double p, double u,
-                                                 double u_b, bool known, int64_t off,
-                                                 int64_t j, int64_t k) {
-  bool collide = false;
-  int64_t cid = 0, nk = 0, gi = 0, gc = 0;
-  double g = 0;
-  if (in_range) {
-    g = ceil(p - u);  // collisions_methods.py:560
-    // pair_indices' skip (gamma == 0) also covers "no pair": then prob == 0, gamma = -0.0
-    if (g != 0 && off < 2) {
-      collide = true;
-      if (!known) {
-        j = A.idx[2 * d + off];
-        k = A.idx[2 * d + 1 + off];
-      }
-      nk = A.multiplicity[k];
-      const int64_t prop = A.multiplicity[j] / nk;
-      gi = (int64_t)g;
-      gc = gi < prop ? gi : prop;
-      cid = cfg.n_cell == 1 ? 0 : A.cell_id[j];
-      g = (double)gc;
-    }
-  }
-  counter_add(A.collision_rate, cid, gc * nk, collide);
-  counter_add(A.collision_rate_deficit, cid, (gi - gc) * nk, collide);
-  collide = collide && g != 0;
+__device__ __forceinline__ void resolve_collision(const sdm_step_cfg &cfg, const FusedArgs &A,
+                                                  bool collide, int64_t j, int64_t k,
+                                                  int64_t cid, double g, double u_b) {
+  const int64_t nk = collide ? A.multiplicity[k] : 0;
   bool coal = collide;
   if (BREAKUP && collide) {
     const double eb = cfg.eb_const;
     double ec, fm;
     {
-      const double *mass0 = A.attributes + (int64_t)cfg.mass_attr * cfg.n_sd;
-      breakup_params(cfg, A, mass0[j], mass0[k], u_b, ec, fm);
+      const bool need_ru = cfg.ec != SDM_EC_CONST || cfg.frag == SDM_FRAG_STRAUB2010;
+      const SD sj = sd_load(cfg, A, j, need_ru), sk = sd_load(cfg, A, k, need_ru);
+      breakup_params(cfg, A, sj, sk, u_b, ec, fm);
     }
     if (u_b - (ec + (1 - ec) * eb) > 0) {
       collide = false;  // bounce
@@ -391,15 +399,59 @@ __device__ __forceinline__ void pair_update_body(const sdm_step_cfg &cfg, const 
   if (collide) {
     const int64_t n_j = A.multiplicity[j], n_k = A.multiplicity[k];
     if (n_k == 0 || n_j == 0) A.ctl[CTL_HEALTHY] = 0;
-    if (A.nm) {
-      const double *mass = A.attributes + (int64_t)cfg.mass_attr * cfg.n_sd;
-      NM a, b;
-      a.n = n_j; a.m = mass[j];
-      b.n = n_k; b.m = mass[k];
-      A.nm[j] = a;
-      A.nm[k] = b;
+    sd_refresh(cfg, A, j);
+    sd_refresh(cfg, A, k);
+  }
+}
+
+
+template <bool BREAKUP>
+__device__ __forceinline__ void pair_update_body(const sdm_step_cfg &cfg, const FusedArgs &A,
+                                                 int64_t d, bool in_range, double p, double u,
+                                                 double u_b, bool known, int64_t off,
+                                                 int64_t j, int64_t k) {
+  bool collide = false;
+  int64_t cid = 0, nk = 0, gi = 0, gc = 0;
+  double g = 0;
+  if (in_range) {
+    g = ceil(p - u);  // collisions_methods.py:560
+    // pair_indices' skip (gamma == 0) also covers "no pair": then prob == 0, gamma = -0.0
+    if (g != 0 && off < 2) {
+      collide = true;
+      if (!known) {
+        j = A.idx[2 * d + off];
+        k = A.idx[2 * d + 1 + off];
+      }
+      nk = A.multiplicity[k];
+      const int64_t prop = A.multiplicity[j] / nk;
+      gi = (int64_t)g;
+      gc = gi < prop ? gi : prop;
+      cid = cfg.n_cell == 1 ? 0 : A.cell_id[j];
+      g = (double)gc;
     }
   }
+  counter_add(A.collision_rate, cid, gc * nk, collide);
+  counter_add(A.collision_rate_deficit, cid, (gi - gc) * nk, collide);
+  collide = collide && g != 0;
+  if (BREAKUP) {
+    // breakup: the (rare, transcendental-heavy) resolution runs densely packed in
+    // k_resolve_dense; here the colliding pairs are only listed
+    const unsigned long long m = __ballot(collide);
+    if (m != 0) {
+      const int lane = lane_id(), leader = __ffsll((long long)m) - 1;
+      unsigned long long base = 0;
+      if (lane == leader) base = atomicAdd((unsigned long long *)A.list_count,
+                                           (unsigned long long)__popcll(m));
+      base = __shfl((long long)base, leader, 64);
+      if (collide) {
+        Collided c;
+        c.j = j; c.k = k; c.cid = cid; c.g = g; c.u_b = u_b;
+        A.list[base + __popcll(m & ((1ull << lane) - 1))] = c;
+      }
+    }
+    return;
+  }
+  resolve_collision<false>(cfg, A, collide, j, k, cid, g, u_b);
 }
 
 // ---- non-adaptive: everything about a pair in one kernel -------------------------------------
@@ -511,6 +563,18 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_update(sdm_step_cfg cfg, Fus
   pair_update_body<BREAKUP>(cfg, A, d, in_range, p, u, u_b, false, off, 0, 0);
 }
 
+// ---- breakup: dense resolution of the listed colliding pairs ----------------------------------
+__global__ void __launch_bounds__(SDM_BLOCK) k_resolve_dense(sdm_step_cfg cfg, FusedArgs A) {
+  const int64_t n = (int64_t)*A.list_count;
+  if ((int64_t)blockIdx.x * SDM_BLOCK >= n) return;
+  const int64_t t = TID();
+  const bool active = t < n;
+  Collided c;
+  c.j = c.k = c.cid = 0; c.g = 0; c.u_b = 0;
+  if (active) c = A.list[t];
+  resolve_collision<true>(cfg, A, active, c.j, c.k, c.cid, c.g, c.u_b);
+}
+
 // ---- control-word kernels -------------------------------------------------------------------
 // conditional counting sort (multi-cell): the sort cores read the length from gate_len (0
 // disables them); whether to run is decided on the device by ctl[CTL_SORTED].
@@ -532,15 +596,9 @@ k_sort_commit(int64_t *__restrict__ idx, const int64_t *__restrict__ sorted_buf,
 __global__ void k_sort_done(int64_t *ctl) { ctl[CTL_SORTED] = 1; }
 __global__ void k_mark_unsorted(int64_t *ctl) { ctl[CTL_SORTED] = 0; }
 
-__global__ void __launch_bounds__(SDM_BLOCK)
-k_nm_init(NM *__restrict__ nm, const int64_t *__restrict__ multiplicity,
-          const double *__restrict__ mass, int64_t n) {
+__global__ void __launch_bounds__(SDM_BLOCK) k_nm_init(sdm_step_cfg cfg, FusedArgs A) {
   const int64_t i = TID();
-  if (i >= n) return;
-  NM v;
-  v.n = multiplicity[i];
-  v.m = mass[i];
-  nm[i] = v;
+  if (i < cfg.n_sd) sd_refresh(cfg, A, i);
 }
 
 // single cell: the sort is the identity, only cell_start = {0, length} has to be right
@@ -567,6 +625,8 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_fill_f64(double *p, double v, int
 // ---------------------------------------------------------------------------------------------
 struct FusedScratch {
   double *prob, *dt_todo, *cell_min, *block_min;
+  Collided *list;
+  unsigned long long *list_count;
   uint8_t *pair_off;
   int32_t *pair_cid;
   int64_t *sorted_buf, *cs_tmp, *gate_len, *cctl, *end2;
@@ -581,6 +641,8 @@ static FusedScratch layout(char *base, const sdm_step_cfg *cfg) {
   const bool split = cfg->adaptive != 0;  // prob etc. cross a kernel boundary only then
   S.prob = cv.take<double>(split ? P : 1);
   S.dt_todo = cv.take<double>(C);
+  S.list = cv.take<Collided>(cfg->enable_breakup ? P : 1);
+  S.list_count = cv.take<unsigned long long>(2);
   S.cell_min = cv.take<double>(C);
   S.block_min = cv.take<double>(grid_for((cfg->n_sd + 1) / 2) + 1);
   S.pair_off = cv.take<uint8_t>(split ? P : 1);
@@ -701,6 +763,8 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   A.pair_cid = S.pair_cid;
   A.dt_todo = S.dt_todo;
   A.cell_min = S.cell_min;
+  A.list = S.list;
+  A.list_count = S.list_count;
   A.block_min = S.block_min;
   A.n_block_min = (int)grid_for((N + 1) / 2);
 
@@ -711,10 +775,12 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   hipStream_t s = ctx->stream;
   const dim3 blk(SDM_BLOCK), one(1);
 
-  A.nm = (NM *)st->nm;
+  A.nm = (double *)st->nm;
+  A.nm_wide = cfg->kernel == SDM_KERNEL_GEOMETRIC ||
+              (cfg->enable_breakup &&
+               (cfg->ec != SDM_EC_CONST || cfg->frag == SDM_FRAG_STRAUB2010));
   if (st->nm && (flags & 2)) {
-    hipLaunchKernelGGL(k_nm_init, dim3(grid_for(N)), blk, 0, s, (NM *)st->nm, st->multiplicity,
-                       st->attributes + (int64_t)cfg->mass_attr * N, N);
+    hipLaunchKernelGGL(k_nm_init, dim3(grid_for(N)), blk, 0, s, *cfg, A);
     LAUNCH_CHECK();
   }
   if (C == 1 && (flags & 2)) {
@@ -787,6 +853,8 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
       if (rc) return rc;
     }
     A.idx = cur;
+    if (cfg->enable_breakup)
+      HIP_TRY(hipMemsetAsync(S.list_count, 0, sizeof(unsigned long long), s));
     // (e)+(f) probabilities, gamma, update
     if (!cfg->adaptive) {
       PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
@@ -816,6 +884,11 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
           hipLaunchKernelGGL(k_pair_update<false>, dim3(grid_for(P)), blk, 0, s, *cfg, A);
         LAUNCH_CHECK();
       }
+    }
+    if (cfg->enable_breakup) {
+      PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
+      hipLaunchKernelGGL(k_resolve_dense, dim3(grid_for(P)), blk, 0, s, *cfg, A);
+      LAUNCH_CHECK();
     }
     // (g) sanitize (particle_attributes.py:67-73), decided on the device by the healthy word
     {
