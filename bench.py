@@ -76,7 +76,7 @@ def cpu_baseline(workload, n_sd, adaptive, seconds_budget=15.0):
         substeps = int(dynamic.stats_n_substep.to_ndarray().sum()) - substeps0
         pairs = substeps * (particulator.n_sd // n_cell // 2)
     else:
-        pairs = steps * (n_sd // 2)
+        pairs = steps * (particulator.n_sd // 2)
     return {
         "value": pairs / elapsed,
         "unit": "candidate SD-pairs/s",

@@ -275,6 +275,11 @@ typedef struct sdm_step_result {
 #define SDM_STEP_FRESH_CTL 2
 int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *state,
                        sdm_step_result *result, int flags);
+/* n_steps time steps back to back (`Particulator.run(n_steps)` with the collision dynamic alone,
+ * PySDM/particulator.py:50-56); state->idx / tmp_idx are exchanged in place as needed, result
+ * holds totals (idx_swapped = parity over the run).                                          */
+int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *state,
+                      sdm_step_result *result, int flags, int64_t n_steps);
 
 #ifdef __cplusplus
 }

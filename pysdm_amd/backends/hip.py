@@ -360,5 +360,5 @@ class HIP(BackendMethods):  # pylint: disable=too-many-public-methods
         return FusedStep(self, dynamic, parts)
 
     @staticmethod
-    def collision_step(fused_step):
-        fused_step()
+    def collision_step(fused_step, n_steps=1):
+        fused_step(n_steps)

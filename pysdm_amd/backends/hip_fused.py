@@ -71,6 +71,7 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
         self.nm = torch.empty(4 * part.n_sd, dtype=torch.int64, device=self.idx.data.device)
         self._ctl_initialised = False
         self._stamps = None
+        self._state_cache = None
         self.result = StepResult()
 
     def _push_host_state(self):
@@ -82,43 +83,60 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
         self.ctl.copy_(host)
         self._ctl_initialised = True
 
-    def __call__(self):
+    def _state(self):
+        """the C view of the device state (rebuilt per call: cheap next to a time step only if
+        kept short, hence the cached constant part)"""
         dyn, attrs = self.dynamic, self.particulator.attributes
+        state = self._state_cache
+        if state is None:
+            state = StepState()
+            state.multiplicity = _p(attrs["multiplicity"].data)
+            state.attributes = _p(attrs.get_extensive_attribute_storage().data)
+            state.cell_id = _p(attrs["cell id"].data)
+            state.cell_idx = _p(attrs.cell_idx.data)
+            state.cell_start = _p(attrs._fused_view()["cell_start"].data)  # pylint: disable=protected-access
+            state.dt_left = _p(dyn.dt_left.data)
+            state.stats_dt_min = _p(dyn.stats_dt_min.data)
+            state.stats_n_substep = _p(dyn.stats_n_substep.data)
+            state.collision_rate = _p(dyn.collision_rate.data)
+            state.collision_rate_deficit = _p(dyn.collision_rate_deficit.data)
+            state.coalescence_rate = _p(dyn.coalescence_rate.data)
+            if dyn.enable_breakup:
+                state.breakup_rate = _p(dyn.breakup_rate.data)
+                state.breakup_rate_deficit = _p(dyn.breakup_rate_deficit.data)
+            if self.gk is not None:
+                state.gk_a, state.gk_b = _p(self.gk.a.data), _p(self.gk.b.data)
+            state.ctl = _p(self.ctl)
+            state.nm = _p(self.nm)
+            self._state_cache = state
+        state.idx = _p(self.idx.data)
+        state.tmp_idx = _p(self.tmp_idx.data)
+        state.rng_offset = dyn.rnd_opt_coll.rnd.offset
+        if dyn.enable_breakup:
+            state.rng_offset_breakup = dyn.rnd_opt_proc.rnd.offset
+        return state
+
+    def __call__(self, n_steps=1):
+        dyn = self.dynamic
         flags = int(self.read_back)
         # anything else that touched multiplicities / attributes since the last fused call
         # (method-by-method calls, uploads) invalidates the device-side bookkeeping
         if self._stamps != self._timestamps():
             self._ctl_initialised = False
+            self._state_cache = None
         if not self._ctl_initialised:
             self._push_host_state()
             flags |= 2
-        state = StepState()
-        state.idx = _p(self.idx.data)
-        state.tmp_idx = _p(self.tmp_idx.data)
-        state.multiplicity = _p(attrs["multiplicity"].data)
-        state.attributes = _p(attrs.get_extensive_attribute_storage().data)
-        state.cell_id = _p(attrs["cell id"].data)
-        state.cell_idx = _p(attrs.cell_idx.data)
-        state.cell_start = _p(attrs._fused_view()["cell_start"].data)  # pylint: disable=protected-access
-        state.dt_left = _p(dyn.dt_left.data)
-        state.stats_dt_min = _p(dyn.stats_dt_min.data)
-        state.stats_n_substep = _p(dyn.stats_n_substep.data)
-        state.collision_rate = _p(dyn.collision_rate.data)
-        state.collision_rate_deficit = _p(dyn.collision_rate_deficit.data)
-        state.coalescence_rate = _p(dyn.coalescence_rate.data)
-        if dyn.enable_breakup:
-            state.breakup_rate = _p(dyn.breakup_rate.data)
-            state.breakup_rate_deficit = _p(dyn.breakup_rate_deficit.data)
-        if self.gk is not None:
-            state.gk_a, state.gk_b = _p(self.gk.a.data), _p(self.gk.b.data)
-        state.ctl = _p(self.ctl)
-        state.nm = _p(self.nm)
-        state.rng_offset = dyn.rnd_opt_coll.rnd.offset
-        if dyn.enable_breakup:
-            state.rng_offset_breakup = dyn.rnd_opt_proc.rnd.offset
+        state = self._state()
         ctx = _Context.get()
-        check(ctx.lib.sdm_collision_step(ctx.handle, ctypes.byref(self.cfg), ctypes.byref(state),
-                                         ctypes.byref(self.result), flags))
+        if n_steps == 1:
+            check(ctx.lib.sdm_collision_step(ctx.handle, ctypes.byref(self.cfg),
+                                             ctypes.byref(state), ctypes.byref(self.result),
+                                             flags))
+        else:
+            check(ctx.lib.sdm_collision_run(ctx.handle, ctypes.byref(self.cfg),
+                                            ctypes.byref(state), ctypes.byref(self.result),
+                                            flags, ctypes.c_int64(n_steps)))
         res = self.result
         if res.idx_swapped:
             self.idx.data, self.tmp_idx.data = self.tmp_idx.data, self.idx.data

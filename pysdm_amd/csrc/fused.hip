@@ -962,3 +962,41 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   st->rng_offset_breakup = off_b;
   return SDM_OK;
 }
+
+// n_steps consecutive time steps in one call (no host-side work between them): what
+// `Particulator.run(n_steps)` amounts to when the collision dynamic is the only dynamic and nothing
+// observes the intermediate states (PySDM/particulator.py:50-56).  state->idx / tmp_idx are
+// exchanged in place whenever a step leaves the permutation in the other buffer; the result holds
+// the totals, idx_swapped the parity over the whole run.
+extern "C" int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st,
+                                 sdm_step_result *res, int flags, int64_t n_steps) {
+  ARG_TRY(res && st && n_steps >= 0);
+  sdm_step_result total;
+  memset(&total, 0, sizeof(total));
+  total.valid_n_sd = -1;
+  total.rng_offset = st->rng_offset;
+  total.rng_offset_breakup = st->rng_offset_breakup;
+  bool pairs_known = true;
+  for (int64_t step = 0; step < n_steps; ++step) {
+    sdm_step_result one;
+    const bool last = step == n_steps - 1;
+    // read the control block back only after the last step
+    const int rc = sdm_collision_step(ctx, cfg, st, &one, (last ? (flags & 1) : 0) |
+                                                          (step == 0 ? (flags & 2) : 0));
+    if (rc) return rc;
+    if (one.idx_swapped) {
+      int64_t *t = st->idx;
+      st->idx = st->tmp_idx;
+      st->tmp_idx = t;
+      total.idx_swapped ^= 1;
+    }
+    total.n_substeps += one.n_substeps;
+    if (one.n_pairs < 0) pairs_known = false; else total.n_pairs += one.n_pairs;
+    total.valid_n_sd = one.valid_n_sd;
+    total.rng_offset = one.rng_offset;
+    total.rng_offset_breakup = one.rng_offset_breakup;
+  }
+  if (!pairs_known) total.n_pairs = -1;
+  *res = total;
+  return SDM_OK;
+}

@@ -485,6 +485,14 @@ class Collision:  # pylint: disable=too-many-instance-attributes
             )
         return self._fused_state is not False
 
+    def run_steps(self, n_steps):
+        """n_steps consecutive `__call__`s in one backend call; False if not available"""
+        if not self.enable or not self._use_fused():
+            return False
+        with self.particulator.timers[self.DYNAMIC_KEY]:
+            self.particulator.backend.collision_step(self._fused_state, n_steps)
+        return True
+
     def __call__(self):
         if not self.enable:
             return

@@ -53,6 +53,13 @@ class Particulator:  # pylint: disable=too-many-instance-attributes
         self.null = self.Storage.empty(0, dtype=float)
 
     def run(self, steps):
+        # a collision dynamic on its own with nobody observing the intermediate states: hand the
+        # whole loop to the backend (same sequence of time steps, no Python in between)
+        if steps > 1 and len(self.dynamics) == 1 and not self.observers:
+            (key, dynamic), = self.dynamics.items()
+            if getattr(dynamic, "run_steps", None) is not None and dynamic.run_steps(steps):
+                self.n_steps += steps
+                return
         for _ in range(steps):
             for key, dynamic in self.dynamics.items():
                 with self.timers[key]:
