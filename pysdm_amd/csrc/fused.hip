@@ -234,6 +234,28 @@ struct PairInfo {
   double prob, dt_optimal;
 };
 
+// collision probability of one (multiplicity-sorted) pair in slot d: kernel, max multiplicity,
+// normalisation (collision.py:249-254; cell of RAW super-droplet #d: reference quirk)
+template <int KERNEL>
+__device__ __forceinline__ double pair_prob_value(const sdm_step_cfg &cfg, const FusedArgs &A,
+                                                  int64_t d, const SD &sj, const SD &sk) {
+  const double vj = volume_of_mass(sj.m, cfg.rho_w), vk = volume_of_mass(sk.m, cfg.rho_w);
+  double K;
+  if (KERNEL == SDM_KERNEL_GOLOVIN) {
+    K = (vj + vk) * cfg.kernel_param[0];
+  } else if (KERNEL == SDM_KERNEL_GEOMETRIC) {
+    const double s = sj.r + sk.r;
+    K = (s * s) * cfg.kernel_param[0];
+    K *= fabs(sj.u - sk.u);
+  } else {
+    K = cfg.kernel_param[0];
+  }
+  double prob = (double)sj.n;
+  prob *= K;
+  prob *= norm_factor_of(cfg, A.cell_start, cfg.n_cell == 1 ? 0 : A.cell_idx[A.cell_id[d]]);
+  return prob;
+}
+
 // pairing (find_pairs + sort_within_pair), kernel, probability, [Ec, fragment mass], [optimal dt]
 // for pair slot d; `u_b` = the slot's draw of the breakup streams
 template <int KERNEL, bool BREAKUP>
@@ -290,22 +312,7 @@ __device__ __forceinline__ PairInfo pair_prob_body(const sdm_step_cfg &cfg, cons
   }
   R.j = j; R.k = k; R.nj = nj; R.nk = nk;
   R.cid_j = cfg.n_cell == 1 ? 0 : A.cell_id[j];
-  const double vj = volume_of_mass(sj.m, cfg.rho_w), vk = volume_of_mass(sk.m, cfg.rho_w);
-  const double rj = sj.r, rk = sk.r, uj = sj.u, uk = sk.u;
-  double K;
-  if (KERNEL == SDM_KERNEL_GOLOVIN) {
-    K = (vj + vk) * cfg.kernel_param[0];
-  } else if (KERNEL == SDM_KERNEL_GEOMETRIC) {
-    const double s = rj + rk;
-    K = (s * s) * cfg.kernel_param[0];
-    K *= fabs(uj - uk);
-  } else {
-    K = cfg.kernel_param[0];
-  }
-  // collision.py:249-254: prob = max(n) ; *= K ; normalize (cell of RAW SD #d: reference quirk)
-  double prob = (double)nj;
-  prob *= K;
-  prob *= norm_factor_of(cfg, A.cell_start, cfg.n_cell == 1 ? 0 : A.cell_idx[A.cell_id[d]]);
+  const double prob = pair_prob_value<KERNEL>(cfg, A, d, sj, sk);
   R.prob = prob;
   if (cfg.adaptive && prob != 0) {
     // collisions_methods.py:359-368
@@ -563,6 +570,197 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_update(sdm_step_cfg cfg, Fus
   pair_update_body<BREAKUP>(cfg, A, d, in_range, p, u, u_b, false, off, 0, 0);
 }
 
+// ---- multi-cell fast path: one workgroup per cell, the whole sub-step of the cell in LDS ---------
+// For cells of at most CELL_CAP super-droplets: shuffle_local's events, hit lists and the backward
+// walks live in LDS (no binning passes, no global scatter); pairing needs no per-droplet cell-id
+// gathers (a sorted segment holds one cell: same key <=> same cell id); the per-cell minimum of the
+// optimal sub-step is a workgroup reduction, so probability, gamma and update are one kernel also
+// in adaptive mode.  Global random traffic left: one mirror record per droplet.
+#define CELL_CAP 6144
+#define CELL_THREADS 1024
+#define CELL_MAXPOS (CELL_CAP / CELL_THREADS)
+#define CELL_MAXPAIR (CELL_CAP / 2 / CELL_THREADS)
+#define CELL_LDS_BYTES (5 * CELL_CAP * 4 + 2 * CELL_CAP * 2)
+
+struct CellArgs {
+  const int64_t *idx_in;
+  int64_t *idx_out;
+  u128 s_u01;  // PCG64 state at draw 0 of the sub-step's u01 window
+  int n_tail_blocks;
+};
+
+template <int KERNEL, bool BREAKUP>
+__global__ void __launch_bounds__(CELL_THREADS)
+k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int32_t *s0 = (int32_t *)smem, *s1 = s0 + CELL_CAP, *head = s1 + CELL_CAP;
+  int32_t *val = head + CELL_CAP, *out = val + CELL_CAP;
+  int16_t *jown = (int16_t *)(out + CELL_CAP), *next = jown + CELL_CAP;
+  __shared__ double red[CELL_THREADS / SDM_WAVE];
+  __shared__ int64_t s_cid, s_base;
+  __shared__ u128 s_rng[3];  // generator states at the cell's first position / first pair slot
+  const int64_t C = cfg.n_cell, N = cfg.n_sd;
+  const int tid = threadIdx.x;
+  if ((int64_t)blockIdx.x >= C) {  // dead tail [cell_start[C], N) is carried over unchanged
+    const int64_t from = A.cell_start[C];
+    for (int64_t i = from + ((int64_t)blockIdx.x - C) * CELL_THREADS + tid; i < N;
+         i += (int64_t)X.n_tail_blocks * CELL_THREADS)
+      X.idx_out[i] = X.idx_in[i];
+    return;
+  }
+  const int64_t lo = A.cell_start[blockIdx.x], hi = A.cell_start[blockIdx.x + 1];
+  const int n = (int)(hi - lo);
+  if (n == 0) return;
+  if (n > CELL_CAP) {  // never taken: the host enables this path only below the cap
+    if (tid == 0) A.ctl[7] = 1;
+    for (int li = tid; li < n; li += CELL_THREADS) X.idx_out[lo + li] = X.idx_in[lo + li];
+    return;
+  }
+  const int64_t W = A.ctl[CTL_WORK];
+  for (int li = tid; li < n; li += CELL_THREADS) {
+    val[li] = (int32_t)X.idx_in[lo + li];
+    s0[li] = -1; s1[li] = -1; head[li] = -1;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    s_cid = A.cell_id[val[0]];
+    s_base = A.cell_start[A.cell_idx[s_cid]];
+  }
+  // long jump-aheads once per workgroup (three wavefronts, one each); threads then only jump by
+  // their small offset inside the cell
+  if (tid == 64) s_rng[0] = pcg_jump(X.s_u01, A.rng_tab, (uint64_t)lo);
+  if (tid == 128) s_rng[1] = pcg_jump(A.s_rand, A.rng_tab, (uint64_t)(lo >> 1));
+  if (BREAKUP && tid == 192) s_rng[2] = pcg_jump(A.s_rand_b, A.rng_tab, (uint64_t)(lo >> 1));
+  __syncthreads();
+  // shuffle_local events of this cell (index_methods.py:35-41): consecutive positions per thread
+  {
+    const int chunk = (n + CELL_THREADS - 1) / CELL_THREADS;
+    const int li0 = tid * chunk;
+    if (li0 < n) {
+      u128 state = pcg_jump(s_rng[0], A.rng_tab, (uint64_t)li0);
+      const u128 mult = pcg_mult();
+      for (int e = 0; e < chunk && li0 + e < n; ++e) {
+        const int li = li0 + e;
+        state = state * mult + A.rng_inc;
+        const double u = pcg_output(state);
+        int jt = -1;
+        if (li > 0) {
+          const int64_t t = (int64_t)((double)lo + u * (double)(hi - lo)) - lo;
+          jt = (int)(t > n - 1 ? n - 1 : (t < 0 ? 0 : t));
+          if (atomicCAS(&s0[jt], -1, li) != -1)
+            if (atomicCAS(&s1[jt], -1, li) != -1)
+              next[li] = (int16_t)atomicExch(&head[jt], li);
+        }
+        jown[li] = (int16_t)jt;
+      }
+    }
+  }
+  __syncthreads();
+  // backward walks (see index.hip), entirely in LDS
+  for (int li = tid; li < n; li += CELL_THREADS) {
+    int e = 0, q = li;
+    for (;;) {
+      int best = INT32_MAX;
+      const int jq = jown[q];
+      if (q > e && jq >= 0) best = q;
+      const int a = s0[q], b = s1[q];
+      if (a > e && a < best) best = a;
+      if (b > e && b < best) best = b;
+      for (int t = head[q]; t >= 0; t = next[t])
+        if (t > e && t < best) best = t;
+      if (best == INT32_MAX) break;
+      q = (best == q) ? jq : best;
+      e = best;
+    }
+    out[li] = val[q];
+  }
+  __syncthreads();
+  // pairs: positions p with (p - cell_start[cell_idx[cid]]) even and p + 1 in the same segment
+  const int64_t cid = s_cid;
+  const int lp0 = (int)((lo - s_base) & 1);
+  int64_t pj[CELL_MAXPAIR], pk[CELL_MAXPAIR];
+  double pprob[CELL_MAXPAIR];
+  bool pvalid[CELL_MAXPAIR];
+  double my_min = INFINITY;
+#pragma unroll
+  for (int r = 0; r < CELL_MAXPAIR; ++r) {
+    const int lp = lp0 + 2 * (tid + r * CELL_THREADS);
+    const int64_t p = lo + lp;
+    pvalid[r] = lp + 1 < n && p < W - 1;
+    pj[r] = pk[r] = 0;
+    pprob[r] = 0.0;
+    if (pvalid[r]) {
+      int64_t j = out[lp], k = out[lp + 1];
+      const bool need_r = KERNEL == SDM_KERNEL_GEOMETRIC;
+      SD sj = sd_load(cfg, A, j, need_r), sk = sd_load(cfg, A, k, need_r);
+      if (sj.n < sk.n) {  // sort_within_pair_by_attr
+        const int64_t t = j; j = k; k = t;
+        const SD ts = sj; sj = sk; sk = ts;
+        out[lp] = (int32_t)j;
+        out[lp + 1] = (int32_t)k;
+      }
+      pj[r] = j; pk[r] = k;
+      const double prob = pair_prob_value<KERNEL>(cfg, A, p >> 1, sj, sk);
+      pprob[r] = prob;
+      if (cfg.adaptive && prob != 0) {
+        const int64_t prop = sj.n / sk.n;
+        const double t = cfg.dt * (double)prop / prob;
+        const double dt_opt = t > cfg.dt_min ? t : cfg.dt_min;
+        my_min = dt_opt < my_min ? dt_opt : my_min;
+      }
+    }
+  }
+  double scale = 1.0 / (double)cfg.substeps;
+  if (cfg.adaptive) {  // workgroup minimum of the optimal sub-step (collisions_methods.py:357-368)
+    const double m = wave_min_f64(my_min);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    double bmin = red[0];
+    for (int w = 1; w < CELL_THREADS / SDM_WAVE; ++w) bmin = red[w] < bmin ? red[w] : bmin;
+    if (tid == 0) A.cell_min[cid] = bmin;  // k_cells_adaptive does the per-cell bookkeeping
+    const double l = A.dt_left[cid];
+    double todo = l < cfg.dt_max ? l : cfg.dt_max;
+    if (bmin < todo) todo = bmin;
+    scale = todo / cfg.dt;
+  }
+  // gamma + update (all lanes take part: wave-aggregated counters)
+#pragma unroll
+  for (int r = 0; r < CELL_MAXPAIR; ++r) {
+    const int lp = lp0 + 2 * (tid + r * CELL_THREADS);
+    const int64_t d = (lo + lp) >> 1;
+    double p = pprob[r], u = 0.0, u_b = 0.0;
+    if (pvalid[r]) {
+      if (p != 0) { if (cfg.adaptive) p *= scale; else p /= (double)cfg.substeps; }
+      const uint64_t dd = (uint64_t)(d - (lo >> 1));  // slot offset inside the cell
+      u128 st = pcg_jump(s_rng[1], A.rng_tab, dd);
+      st = st * pcg_mult() + A.rng_inc;
+      u = pcg_output(st);
+      if (BREAKUP) {
+        u128 sb = pcg_jump(s_rng[2], A.rng_tab, dd);
+        sb = sb * pcg_mult() + A.rng_inc;
+        u_b = pcg_output(sb);
+      }
+    }
+    pair_update_body<BREAKUP>(cfg, A, d, pvalid[r], p, u, u_b, true, 0, pj[r], pk[r]);
+  }
+  __syncthreads();
+  for (int li = tid; li < n; li += CELL_THREADS) X.idx_out[lo + li] = out[li];
+}
+
+// largest cell of a sorted state -> ctl[6]
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_max_cell(const int64_t *__restrict__ cell_start, int64_t n_cell, int64_t *ctl) {
+  const int64_t c = TID();
+  const int64_t sz = c < n_cell ? cell_start[c + 1] - cell_start[c] : 0;
+  int64_t m = sz;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int64_t t = __shfl_xor((long long)m, o, 64);
+    m = t > m ? t : m;
+  }
+  if (lane_id() == 0) atomicMax((long long *)&ctl[6], (long long)m);
+}
+
 // ---- breakup: dense resolution of the listed colliding pairs ----------------------------------
 __global__ void __launch_bounds__(SDM_BLOCK) k_resolve_dense(sdm_step_cfg cfg, FusedArgs A) {
   const int64_t n = (int64_t)*A.list_count;
@@ -793,13 +991,36 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   }
   int64_t work_host = -1;
   int sorted_host = -1;  // host's knowledge of ctl[CTL_SORTED]
+  int64_t max_cell = -1;  // upper bound of the cell sizes during this call (-1: unknown)
   if (cfg->adaptive || read_back) {
-    HIP_TRY(hipMemcpyAsync(ctx->mailbox + 8, st->ctl, sizeof(int64_t) * 4, hipMemcpyDeviceToHost,
+    if (C > 1 && cfg->croupier_local) {
+      // meaningful only if the state is sorted (checked below): cells can only shrink in a call
+      HIP_TRY(hipMemsetAsync(st->ctl + 6, 0, sizeof(int64_t), s));
+      hipLaunchKernelGGL(k_max_cell, dim3(grid_for(C)), blk, 0, s, st->cell_start, C, st->ctl);
+      LAUNCH_CHECK();
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->mailbox + 8, st->ctl, sizeof(int64_t) * 8, hipMemcpyDeviceToHost,
                            s));
     HIP_TRY(hipStreamSynchronize(s));
     work_host = ctx->mailbox[8 + CTL_WORK];
     sorted_host = (int)ctx->mailbox[8 + CTL_SORTED];
     if (C == 1 && (flags & 2)) sorted_host = 1;
+    if (C > 1 && cfg->croupier_local && sorted_host == 1 && !(flags & 2))
+      max_cell = ctx->mailbox[8 + 6];
+  }
+  const bool cell_path = max_cell >= 0 && max_cell <= CELL_CAP;
+  if (cell_path) {
+    static bool attr_done = false;  // > 64 KiB of dynamic LDS must be opted into, per kernel
+    if (!attr_done) {
+      const int lds = CELL_LDS_BYTES;
+#define CELL_ATTR(K, B) HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step<K, B>, \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds))
+      CELL_ATTR(SDM_KERNEL_GOLOVIN, false); CELL_ATTR(SDM_KERNEL_GOLOVIN, true);
+      CELL_ATTR(SDM_KERNEL_GEOMETRIC, false); CELL_ATTR(SDM_KERNEL_GEOMETRIC, true);
+      CELL_ATTR(SDM_KERNEL_CONSTANT, false); CELL_ATTR(SDM_KERNEL_CONSTANT, true);
+#undef CELL_ATTR
+      attr_done = true;
+    }
   }
   for (;;) {
     if (!cfg->adaptive && n_sub >= cfg->substeps) break;
@@ -828,7 +1049,46 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
     const int64_t *p_shuffle_len = cfg->croupier_local ? st->cell_start + C : st->ctl + CTL_WORK;
     const uint64_t u01_off = draw_off + (uint64_t)(cfg->optimized_random ? n_sub : 0);
     const bool split = C == 1 && cfg->croupier_local && sdm_shuffle_can_split(N, false);
-    if (split) {
+    if (cell_path) {
+      // one workgroup per cell does the whole sub-step of its cell (see k_cell_step)
+      if (cfg->enable_breakup)
+        HIP_TRY(hipMemsetAsync(S.list_count, 0, sizeof(unsigned long long), s));
+      if (cfg->adaptive) {
+        PhaseScope ph(ctx, SDM_PHASE_CELLS_PRE);
+        hipLaunchKernelGGL(k_cells_pre, dim3(grid_for(C)), blk, 0, s, *cfg, A);
+        LAUNCH_CHECK();
+      }
+      CellArgs X;
+      X.idx_in = cur;
+      X.idx_out = alt;
+      X.s_u01 = sdm_pcg_advance_host(rng_state, rng_inc, u01_off);
+      X.n_tail_blocks = 64;
+      A.idx = alt;
+      {
+        PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
+        const dim3 grid((unsigned)(C + X.n_tail_blocks)), cblk(CELL_THREADS);
+        const bool brk = cfg->enable_breakup != 0;
+#define CELL_LAUNCH(K)                                                                        \
+  do {                                                                                        \
+    if (brk) hipLaunchKernelGGL((k_cell_step<K, true>), grid, cblk, CELL_LDS_BYTES, s, *cfg, A, X); \
+    else hipLaunchKernelGGL((k_cell_step<K, false>), grid, cblk, CELL_LDS_BYTES, s, *cfg, A, X);    \
+  } while (0)
+        switch (cfg->kernel) {
+          case SDM_KERNEL_GOLOVIN: CELL_LAUNCH(SDM_KERNEL_GOLOVIN); break;
+          case SDM_KERNEL_GEOMETRIC: CELL_LAUNCH(SDM_KERNEL_GEOMETRIC); break;
+          default: CELL_LAUNCH(SDM_KERNEL_CONSTANT);
+        }
+#undef CELL_LAUNCH
+        LAUNCH_CHECK();
+      }
+      if (cfg->adaptive) {
+        PhaseScope ph(ctx, SDM_PHASE_CELLS_ADAPTIVE);
+        hipLaunchKernelGGL(k_cells_adaptive, dim3(grid_for(C)), blk, 0, s, *cfg, A);
+        LAUNCH_CHECK();
+      }
+      { int64_t *t = cur; cur = alt; alt = t; }
+      ++swaps;
+    } else if (split) {
       // single cell: event records only; the pair kernels walk them (2 positions per thread)
       ShuffleViews views;
       rc = sdm_shuffle_build_async(ctx, S.shuffle, cur, st->cell_start, C, p_shuffle_len, N,
@@ -843,8 +1103,10 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
                              N, !cfg->croupier_local, N, cfg->rng_state_inc, u01_off);
       if (rc) return rc;
     }
-    { int64_t *t = cur; cur = alt; alt = t; }
-    ++swaps;
+    if (!cell_path) {
+      int64_t *t = cur; cur = alt; alt = t;
+      ++swaps;
+    }
     if (!cfg->croupier_local && C > 1) {
       hipLaunchKernelGGL(k_mark_unsorted, one, one, 0, s, st->ctl);
       LAUNCH_CHECK();
@@ -853,10 +1115,12 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
       if (rc) return rc;
     }
     A.idx = cur;
-    if (cfg->enable_breakup)
+    if (cfg->enable_breakup && !cell_path)
       HIP_TRY(hipMemsetAsync(S.list_count, 0, sizeof(unsigned long long), s));
     // (e)+(f) probabilities, gamma, update
-    if (!cfg->adaptive) {
+    if (cell_path) {
+      // done by k_cell_step above
+    } else if (!cfg->adaptive) {
       PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
       DISPATCH_PAIR(k_pair_all, dim3(grid_for((N + 1) / 2)));
       LAUNCH_CHECK();

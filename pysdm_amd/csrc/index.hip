@@ -629,30 +629,26 @@ extern "C" int sdm_shuffle_local(sdm_ctx *ctx, int64_t *idx, const double *u01,
 // sort_by_key (index_methods.py:46-48): idx[:] = argsort(keys, kind="stable")[::-1]
 // n = number of cells; O(n^2 / threads) rank counting, keys staged through LDS tiles.
 // ---------------------------------------------------------------------------------------
+// one workgroup per key i: rank(i) = #{j : key_j < key_i or (key_j == key_i and j < i)}
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_sort_by_key(int64_t *__restrict__ idx, const double *__restrict__ keys, int64_t n) {
-  __shared__ double tile[SDM_BLOCK];
-  const int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
-  const double ki = i < n ? keys[i] : 0.0;
-  int64_t rank = 0;
-  for (int64_t base = 0; base < n; base += SDM_BLOCK) {
-    const int64_t jj = base + threadIdx.x;
-    tile[threadIdx.x] = jj < n ? keys[jj] : 0.0;
-    __syncthreads();
-    const int m = (int)((n - base) < SDM_BLOCK ? (n - base) : SDM_BLOCK);
-    if (i < n)
-      for (int t = 0; t < m; ++t) {
-        const double kj = tile[t];
-        rank += (kj < ki) || (kj == ki && (base + t) < i);
-      }
-    __syncthreads();
+  __shared__ int sm[SDM_BLOCK / SDM_WAVE];
+  const int64_t i = blockIdx.x;
+  const double ki = keys[i];
+  int rank = 0;
+  for (int64_t j = threadIdx.x; j < n; j += SDM_BLOCK) {
+    const double kj = keys[j];
+    rank += (kj < ki) || (kj == ki && j < i);
   }
-  if (i < n) idx[n - 1 - rank] = i;
+  rank = wave_sum_i32(rank);
+  if (lane_id() == 0) sm[threadIdx.x / SDM_WAVE] = rank;
+  __syncthreads();
+  if (threadIdx.x == 0) idx[n - 1 - (sm[0] + sm[1] + sm[2] + sm[3])] = i;
 }
 
 int sdm_sort_by_key_async(sdm_ctx *ctx, int64_t *idx, const double *keys, int64_t n) {
   if (n <= 0) return SDM_OK;
-  hipLaunchKernelGGL(k_sort_by_key, dim3(grid_for(n)), dim3(SDM_BLOCK), 0, ctx->stream, idx,
+  hipLaunchKernelGGL(k_sort_by_key, dim3((unsigned)n), dim3(SDM_BLOCK), 0, ctx->stream, idx,
                      keys, n);
   LAUNCH_CHECK();
   return SDM_OK;
@@ -1029,17 +1025,29 @@ k_sort_zero(int32_t *__restrict__ H, int64_t n, const int64_t *__restrict__ p_le
     H[i] = 0;
 }
 
-// H[key][tile]: per-tile histogram of the keys; keys cached for the scatter pass
+// H[key][tile]: per-tile histogram of the keys; keys cached for the scatter pass.  Equal keys
+// inside a 64-chunk share one atomic (input that is already grouped by cell -- every re-sort
+// after the first -- then needs one atomic per chunk)
 __global__ void __launch_bounds__(SDM_WAVE)
 k_sort_hist(int32_t *__restrict__ H, int32_t *__restrict__ keys, const int64_t *__restrict__ idx,
             const int64_t *__restrict__ cell_id, const int64_t *__restrict__ cell_idx,
-            const int64_t *__restrict__ p_length, int nb, int64_t tile) {
+            const int64_t *__restrict__ p_length, int nb, int64_t tile, int key_bits) {
   const int64_t length = *p_length;
   const int64_t first = (int64_t)blockIdx.x * tile;
-  for (int64_t i = first + threadIdx.x; i < first + tile && i < length; i += SDM_WAVE) {
-    const int32_t key = (int32_t)sort_key(idx, cell_id, cell_idx, i);
-    keys[i] = key;
-    atomicAdd(&H[(int64_t)key * nb + blockIdx.x], 1);
+  const int lane = threadIdx.x;
+  for (int64_t base = first; base < first + tile && base < length; base += SDM_WAVE) {
+    const int64_t i = base + lane;
+    const bool in = i < first + tile && i < length;
+    const int32_t key = in ? (int32_t)sort_key(idx, cell_id, cell_idx, i) : -1;
+    if (in) keys[i] = key;
+    unsigned long long peers = __ballot(in);
+    for (int b = 0; b < key_bits; ++b) {
+      const bool bit = (key >> b) & 1;
+      const unsigned long long m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    if (in && lane == 63 - __clzll(peers))
+      atomicAdd(&H[(int64_t)key * nb + blockIdx.x], __popcll(peers));
   }
 }
 
@@ -1177,7 +1185,7 @@ int sdm_counting_sort_async(sdm_ctx *ctx, char *scratch, int64_t *new_idx, const
                      (int64_t)nb * n_cell, p_length);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(SDM_WAVE), 0, ctx->stream, H, keys, idx, cell_id,
-                     cell_idx, p_length, nb, tile);
+                     cell_idx, p_length, nb, tile, key_bits);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_sort_colscan, dim3((unsigned)n_cell), dim3(BIN_THREADS), 0, ctx->stream, H,
                      count, nb, p_length);
