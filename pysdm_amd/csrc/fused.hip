@@ -684,7 +684,7 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   double my_min = INFINITY;
 #pragma unroll
   for (int r = 0; r < CELL_MAXPAIR; ++r) {
-    const int lp = lp0 + 2 * (tid + r * CELL_THREADS);
+    const int lp = lp0 + 2 * (tid * CELL_MAXPAIR + r);  // consecutive pair slots per thread
     const int64_t p = lo + lp;
     pvalid[r] = lp + 1 < n && p < W - 1;
     pj[r] = pk[r] = 0;
@@ -723,24 +723,28 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     if (bmin < todo) todo = bmin;
     scale = todo / cfg.dt;
   }
-  // gamma + update (all lanes take part: wave-aggregated counters)
+  // gamma + update (all lanes take part: wave-aggregated counters).  A thread's pair slots are
+  // consecutive, so are their draws: one jump-ahead, then single generator steps
+  u128 st = 0, sb = 0;
+  {
+    const uint64_t dd0 = (uint64_t)(((lo + lp0 + 2 * (int64_t)(tid * CELL_MAXPAIR)) >> 1) -
+                                    (lo >> 1));
+    st = pcg_jump(s_rng[1], A.rng_tab, dd0);
+    if (BREAKUP) sb = pcg_jump(s_rng[2], A.rng_tab, dd0);
+  }
 #pragma unroll
   for (int r = 0; r < CELL_MAXPAIR; ++r) {
-    const int lp = lp0 + 2 * (tid + r * CELL_THREADS);
+    const int lp = lp0 + 2 * (tid * CELL_MAXPAIR + r);
     const int64_t d = (lo + lp) >> 1;
-    double p = pprob[r], u = 0.0, u_b = 0.0;
-    if (pvalid[r]) {
-      if (p != 0) { if (cfg.adaptive) p *= scale; else p /= (double)cfg.substeps; }
-      const uint64_t dd = (uint64_t)(d - (lo >> 1));  // slot offset inside the cell
-      u128 st = pcg_jump(s_rng[1], A.rng_tab, dd);
-      st = st * pcg_mult() + A.rng_inc;
-      u = pcg_output(st);
-      if (BREAKUP) {
-        u128 sb = pcg_jump(s_rng[2], A.rng_tab, dd);
-        sb = sb * pcg_mult() + A.rng_inc;
-        u_b = pcg_output(sb);
-      }
+    st = st * pcg_mult() + A.rng_inc;
+    const double u = pcg_output(st);
+    double u_b = 0.0;
+    if (BREAKUP) {
+      sb = sb * pcg_mult() + A.rng_inc;
+      u_b = pcg_output(sb);
     }
+    double p = pprob[r];
+    if (pvalid[r] && p != 0) { if (cfg.adaptive) p *= scale; else p /= (double)cfg.substeps; }
     pair_update_body<BREAKUP>(cfg, A, d, pvalid[r], p, u, u_b, true, 0, pj[r], pk[r]);
   }
   __syncthreads();
