@@ -183,7 +183,8 @@ def main():
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(traffic_file):
             with open(traffic_file, encoding="utf-8") as f:
-                traffic = json.load(f).get(dominant)
+                # measured offline with rocprofv3 --pmc (see profiles/README.md); per workload
+                traffic = json.load(f).get(args.workload, {}).get(dominant)
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
