@@ -162,6 +162,12 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
         self.particulator.attributes._fused_commit(  # pylint: disable=protected-access
             valid_n_sd=int(words[0]), sorted_flag=bool(words[2])
         )
+        if words[7] != 0:
+            raise RuntimeError(
+                "libsdm_hip: device-side failure in the fused collision step "
+                + {1: "(cell larger than the per-cell kernel's capacity)",
+                   2: "(grid barrier of the compaction kernel timed out)"}.get(int(words[7]), "")
+            )
         if words[4] > 0 and self.dynamic.warn_overflows:
             warnings.warn("overflow")
             self.ctl[4] = 0

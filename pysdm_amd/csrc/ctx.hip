@@ -236,7 +236,8 @@ k_ew_f64(int op, double *out, const double *a, const double *b, double s, int64_
     case SDM_EW_DIV: r = x / y; break;
     case SDM_EW_POW: {
       const double sg = (x > 0) - (x < 0);
-      r = (x != x) ? x : sg * pow(fabs(x), s);
+      // exponent 2 (Geometric kernel, Berry Ec): the exact square, as numpy / libm give it
+      r = (x != x) ? x : sg * (s == 2.0 ? x * x : pow(fabs(x), s));
       break;
     }
     case SDM_EW_DIV_IF_NOT_ZERO: r = (y != 0.0) ? x / y : x; break;

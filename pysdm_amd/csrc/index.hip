@@ -850,7 +850,12 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
     __syncthreads();
     if (threadIdx.x == 0) block_dead[tile] = sm[0] + sm[1] + sm[2] + sm[3];
   }
-  if (!grid_barrier(bar, 1 * COMPACT_GRID)) return;
+#define BARRIER_OR_FAIL(k)                                   \
+  if (!grid_barrier(bar, (k) * COMPACT_GRID)) {              \
+    if (threadIdx.x == 0) fctl[7] = 2; /* surfaced by the host as an error */ \
+    return;                                                  \
+  }
+  BARRIER_OR_FAIL(1)
   // phase B: workgroup 0 scans the tile counts (exclusive) and publishes the totals
   if (blockIdx.x == 0) {
     if (threadIdx.x == 0) carry = 0;
@@ -878,7 +883,7 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
       ctl[2] = 0;
     }
   }
-  if (!grid_barrier(bar, 2 * COMPACT_GRID)) return;
+  BARRIER_OR_FAIL(2)
   const int64_t total_dead = ((volatile int64_t *)ctl)[3], new_len = ((volatile int64_t *)ctl)[1];
   // phase C: holes of the surviving prefix, live elements of the tail (from the end backwards)
   if (total_dead != 0)
@@ -902,7 +907,7 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
         }
       }
     }
-  if (!grid_barrier(bar, 3 * COMPACT_GRID)) return;
+  BARRIER_OR_FAIL(3)
   // phase D: apply
   if (total_dead != 0) {
     const int64_t n_holes = ((volatile int64_t *)ctl)[2];
@@ -912,7 +917,8 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
       if (t < n_holes) idx[((volatile int32_t *)holes)[t]] = ((volatile int64_t *)fillers)[t];
     }
   }
-  if (!grid_barrier(bar, 4 * COMPACT_GRID)) return;
+  BARRIER_OR_FAIL(4)
+#undef BARRIER_OR_FAIL
   // every workgroup is past the last barrier once it arrives here: the last one re-arms the
   // barrier words and commits the control words
   __shared__ bool last;

@@ -313,3 +313,55 @@ def check_moments(kit):
             if not skip:
                 expk = np.where(exp0 != 0, expk / np.where(exp0 != 0, exp0, 1), 0)
             np.testing.assert_allclose(mom.to_ndarray()[k], expk, rtol=1e-12)
+
+
+def check_storage_ops(kit):
+    """the Storage contract used on the path (impl_numba/storage.py:63-213) against numpy"""
+    rng = np.random.default_rng(11)
+    a = rng.uniform(-2, 2, 1001)
+    b = rng.uniform(0.5, 3, 1001)
+    b[::7] = 0.0
+
+    def sto(x):
+        return kit.Storage.from_ndarray(x.copy())
+
+    x = sto(a); x += sto(b); np.testing.assert_array_equal(x.to_ndarray(), a + b)
+    x = sto(a); x += 1.5; np.testing.assert_array_equal(x.to_ndarray(), a + 1.5)
+    x = sto(a); x += (2.5, "*", sto(b)); np.testing.assert_array_equal(x.to_ndarray(), a + 2.5 * b)
+    x = sto(a); x -= sto(b); np.testing.assert_array_equal(x.to_ndarray(), a - b)
+    x = sto(a); x *= sto(b); np.testing.assert_array_equal(x.to_ndarray(), a * b)
+    x = sto(a); x *= -1.15; np.testing.assert_array_equal(x.to_ndarray(), a * -1.15)
+    x = sto(a); x /= 3.0; np.testing.assert_array_equal(x.to_ndarray(), a / 3.0)
+    x = sto(a); x **= 2; np.testing.assert_array_equal(x.to_ndarray(), np.sign(a) * np.abs(a) ** 2)
+    x = sto(a); x **= 1 / 3
+    np.testing.assert_allclose(x.to_ndarray(), np.sign(a) * np.abs(a) ** (1 / 3), rtol=1e-15)
+    x = sto(a); x.divide_if_not_zero(sto(b))
+    np.testing.assert_array_equal(x.to_ndarray(), np.where(b != 0, a / np.where(b != 0, b, 1), a))
+    x = sto(a); x.floor(); np.testing.assert_array_equal(x.to_ndarray(), np.floor(a))
+    x = sto(a); x.abs(); np.testing.assert_array_equal(x.to_ndarray(), np.abs(a))
+    x = sto(a); x.exp(); np.testing.assert_allclose(x.to_ndarray(), np.exp(a), rtol=1e-15)
+    x = sto(a); x.product(sto(a), sto(b)); np.testing.assert_array_equal(x.to_ndarray(), a * b)
+    x = sto(a); x.ratio(sto(a), sto(b + 1)); np.testing.assert_array_equal(x.to_ndarray(), a / (b + 1))
+    x = sto(a); x.sum(sto(a), sto(b)); np.testing.assert_array_equal(x.to_ndarray(), a + b)
+    x = sto(a); x.fill(7.25); assert (x.to_ndarray() == 7.25).all()
+    x = sto(a); x.fill(sto(b)); np.testing.assert_array_equal(x.to_ndarray(), b)
+    assert sto(a).amin() == a.min() and sto(a).amax() == a.max()
+    with_nan = a.copy(); with_nan[5] = np.nan
+    assert np.isnan(sto(with_nan).amin())
+    view = sto(a)[10:20]
+    view *= 2.0
+    np.testing.assert_array_equal(view.to_ndarray(), a[10:20] * 2)
+    assert isinstance(sto(a)[3], float) and sto(a)[3] == a[3]
+    empty_f = kit.Storage.empty(4, dtype=float).to_ndarray()
+    empty_i = kit.Storage.empty(4, dtype=int).to_ndarray()
+    assert np.isnan(empty_f).all() and (empty_i == -1).all()
+    ints = kit.Storage.from_ndarray(np.arange(-5, 6))
+    ints += kit.Storage.from_ndarray(np.ones(11, dtype=np.int64))
+    np.testing.assert_array_equal(ints.to_ndarray(), np.arange(-4, 7))
+    origin = kit.Storage.from_ndarray(np.array([[5, -1, 7], [9, 3, -2]], dtype=np.int64))
+    origin %= kit.Storage.from_ndarray(np.array([4, 5], dtype=np.int64))
+    np.testing.assert_array_equal(origin.to_ndarray(), np.array([[1, 3, 3], [4, 3, 3]]))
+    import pytest
+    for bad in (lambda: sto(a) + sto(b), lambda: sto(a) * 2, lambda: sto(a) ** 2):
+        with pytest.raises(TypeError):
+            bad()
