@@ -262,14 +262,17 @@ API void oracle_scale_prob_for_adaptive_sdm_gamma(
     const int64_t *cell_id, double *dt_left, int64_t n_cell, double dt, double dt_min,
     double dt_max, const uint8_t *flag, int64_t *stats_n_substep, double *stats_dt_min) {
   double *dt_todo = (double *)malloc(sizeof(double) * (size_t)(n_cell > 0 ? n_cell : 1));
-  for (int64_t c = 0; c < n_cell; ++c) dt_todo[c] = dt_left[c] < dt_max ? dt_left[c] : dt_max;
+  /* Python min(a, b) = b if b < a else a */
+  for (int64_t c = 0; c < n_cell; ++c) dt_todo[c] = dt_max < dt_left[c] ? dt_max : dt_left[c];
   for (int64_t i = 0; i < length / 2; ++i) {
     int64_t j, k;
     if (pair_indices(i, idx, flag, prob, &j, &k)) continue;
     const int64_t prop = multiplicity[j] / multiplicity[k];
     double dt_optimal = dt * (double)prop / prob[i];
     const int64_t cid = cell_id[j];
-    dt_optimal = dt_optimal > dt_min ? dt_optimal : dt_min; /* max(dt_optimal, dt_min) */
+    /* Python max(a, b) = b if b > a else a (a NaN dt_min -- used by the reference's tests --
+     * leaves dt_optimal unclamped) */
+    dt_optimal = dt_min > dt_optimal ? dt_min : dt_optimal;
     dt_todo[cid] = dt_todo[cid] < dt_optimal ? dt_todo[cid] : dt_optimal;
     /* Python min(a, b) = b if b < a else a: a NaN stats_dt_min (initial fill) stays NaN */
     stats_dt_min[cid] = dt_optimal < stats_dt_min[cid] ? dt_optimal : stats_dt_min[cid];

@@ -184,7 +184,7 @@ k_adaptive_init(double *__restrict__ dt_todo, double *__restrict__ cell_min,
   const int64_t c = TID();
   if (c >= n_cell) return;
   const double l = dt_left[c];
-  dt_todo[c] = l < dt_max ? l : dt_max;
+  dt_todo[c] = dt_max < l ? dt_max : l;  // Python min(l, dt_max)
   cell_min[c] = INFINITY;
 }
 
@@ -202,7 +202,7 @@ k_adaptive_min(const double *__restrict__ prob, const int64_t *__restrict__ idx,
   if (active) {
     const int64_t prop = multiplicity[j] / multiplicity[k];
     dt_optimal = dt * (double)prop / prob[i];
-    dt_optimal = dt_optimal > dt_min ? dt_optimal : dt_min;
+    dt_optimal = dt_min > dt_optimal ? dt_min : dt_optimal;  // Python max(): NaN dt_min = no clamp
     cid = cell_id[j];
   }
   // wave-aggregate when every active lane sits in the same cell (the common case)
@@ -258,7 +258,7 @@ extern "C" int sdm_scale_prob_for_adaptive_sdm_gamma(
     const int64_t *cell_id, double *dt_left, int64_t n_cell, double dt, double dt_min,
     double dt_max, const uint8_t *flag, int64_t *stats_n_substep, double *stats_dt_min) {
   ARG_TRY(ctx && length >= 0 && n_cell >= 1 && dt_left && stats_n_substep && stats_dt_min);
-  ARG_TRY(dt_min > 0);
+  ARG_TRY(!(dt_min <= 0));  // NaN = "no lower bound" (the reference's tests pass it)
   int rc = sdm_reserve(ctx, 2 * carve_size(sizeof(double) * n_cell));
   if (rc) return rc;
   Carver cv(ctx->arena);

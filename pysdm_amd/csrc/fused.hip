@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_cells_pre(sdm_step_cfg cfg, Fused
   const int64_t c = TID();
   if (c >= cfg.n_cell) return;
   const double l = A.dt_left[c];
-  A.dt_todo[c] = l < cfg.dt_max ? l : cfg.dt_max;
+  A.dt_todo[c] = cfg.dt_max < l ? cfg.dt_max : l;  // Python min(l, dt_max)
   A.cell_min[c] = INFINITY;
 }
 
@@ -318,7 +318,7 @@ __device__ __forceinline__ PairInfo pair_prob_body(const sdm_step_cfg &cfg, cons
     // collisions_methods.py:359-368
     const int64_t prop = nj / nk;
     double t = cfg.dt * (double)prop / prob;
-    R.dt_optimal = t > cfg.dt_min ? t : cfg.dt_min;
+    R.dt_optimal = cfg.dt_min > t ? cfg.dt_min : t;
   }
   return R;
 }
@@ -705,7 +705,7 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
       if (cfg.adaptive && prob != 0) {
         const int64_t prop = sj.n / sk.n;
         const double t = cfg.dt * (double)prop / prob;
-        const double dt_opt = t > cfg.dt_min ? t : cfg.dt_min;
+        const double dt_opt = cfg.dt_min > t ? cfg.dt_min : t;
         my_min = dt_opt < my_min ? dt_opt : my_min;
       }
     }
@@ -719,7 +719,7 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     for (int w = 1; w < CELL_THREADS / SDM_WAVE; ++w) bmin = red[w] < bmin ? red[w] : bmin;
     if (tid == 0) A.cell_min[cid] = bmin;  // k_cells_adaptive does the per-cell bookkeeping
     const double l = A.dt_left[cid];
-    double todo = l < cfg.dt_max ? l : cfg.dt_max;
+    double todo = cfg.dt_max < l ? cfg.dt_max : l;
     if (bmin < todo) todo = bmin;
     scale = todo / cfg.dt;
   }
@@ -920,7 +920,7 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   ARG_TRY(cfg->kernel != SDM_KERNEL_GEOMETRIC || (st->gk_a && st->gk_b && cfg->gk_table_len > 0));
   ARG_TRY(cfg->adaptive || cfg->substeps >= 1);
   ARG_TRY(cfg->mass_attr >= 0 && cfg->mass_attr < cfg->n_attr);
-  ARG_TRY(cfg->dt_min > 0);
+  ARG_TRY(!(cfg->dt_min <= 0));
   const bool read_back = (flags & 1) != 0;
 
   const int64_t N = cfg->n_sd, P = N / 2, C = cfg->n_cell;

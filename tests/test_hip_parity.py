@@ -5,6 +5,7 @@ point bit-exact on the coalescence-only paths, 1e-12 relative where device trans
 import numpy as np
 import pytest
 
+from . import known_answers as ka
 from . import micro_cases as mc
 from .trajectory import golden_files, run_and_compare, setup_from_golden, snapshot
 
@@ -60,3 +61,8 @@ def test_fused_equals_oracle_beyond_goldens(name, hip_backend_class, oracle_back
         if key == "idx":  # beyond `length`: dead storage (see trajectory.compare)
             value, ref = value[:length], ref[:length]
         np.testing.assert_array_equal(value, ref, err_msg=key)
+
+
+@pytest.mark.parametrize("check", ka.ALL_CHECKS)
+def test_reference_known_answers(check, kit):
+    check(kit)

@@ -2,6 +2,7 @@
 against the known-answer tables of the reference's own unit tests.  CPU only."""
 import pytest
 
+from . import known_answers as ka
 from . import micro_cases as mc
 
 EXACT_ON_CPU = {"volume", "radius", "velocity", "golovin", "geometric", "berry1967",
@@ -25,3 +26,8 @@ def test_physics_goldens(kit):
     # numpy evaluates log/exp through its own SIMD loops, glibc's differ in the last bit: the
     # transcendental-heavy fragmentation volumes are compared at 1e-14, the rest bit-exactly
     mc.check_physics(kit, exact=EXACT_ON_CPU, rtol=1e-14)
+
+
+@pytest.mark.parametrize("check", ka.ALL_CHECKS)
+def test_reference_known_answers(check, kit):
+    check(kit)
