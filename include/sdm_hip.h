@@ -163,6 +163,19 @@ int sdm_straub_fragmentation(sdm_ctx *ctx, double *n_fragment, const double *CW,
                              double *Nr3, double *Nr4, double *Nrt, double *d34,
                              const double consts[6]);
 
+/* f-2 rows: :477-485 gauss (consts = {VEDDER_1987_A, VEDDER_1987_b}), :487-499 feingold1988,
+ * :98-112 slams -- each followed by the limiters :76-95                                       */
+int sdm_gauss_fragmentation(sdm_ctx *ctx, double *n_fragment, double mu, double sigma,
+                            double *frag_volume, const double *x_plus_y, const double *rand,
+                            int64_t n, double vmin, double nfmax, const double consts[2]);
+int sdm_feingold1988_fragmentation(sdm_ctx *ctx, double *n_fragment, double scale,
+                                   double *frag_volume, const double *x_plus_y,
+                                   const double *rand, int64_t n, double fragtol, double vmin,
+                                   double nfmax);
+int sdm_slams_fragmentation(sdm_ctx *ctx, double *n_fragment, double *frag_volume,
+                            const double *x_plus_y, double *probs, const double *rand, int64_t n,
+                            double vmin, double nfmax);
+
 /* ---- f-1 moments, PySDM/backends/impl_numba/methods/moments_methods.py:14-99 ------------ */
 int sdm_moments(sdm_ctx *ctx, double *moment_0, double *moments, const int64_t *multiplicity,
                 const double *attr_data, const int64_t *cell_id, const int64_t *idx,
@@ -170,6 +183,14 @@ int sdm_moments(sdm_ctx *ctx, double *moment_0, double *moments, const int64_t *
                 double min_x, double max_x, const double *x_attr,
                 const double *weighting_attribute, double weighting_rank,
                 int skip_division_by_m0);
+/* moments_methods.py:100-182: per (bin, cell) moments; x_bins has n_bins + 1 edges, the first
+ * bin with x_bins[k] <= x < x_bins[k+1] takes the SD; moment_0 / moments are (n_bins, n_cell)   */
+int sdm_spectrum_moments(sdm_ctx *ctx, double *moment_0, double *moments,
+                         const int64_t *multiplicity, const double *attr_data,
+                         const int64_t *cell_id, const int64_t *idx, int64_t length, double rank,
+                         const double *x_bins, int64_t n_bins, int64_t n_cell,
+                         const double *x_attr, const double *weighting_attribute,
+                         double weighting_rank);
 
 /* ---- a-20 Storage element-wise ops, PySDM/backends/impl_numba/storage_impl.py ----------- */
 /* out[i] = a[i] (op) b[i]  or  a[i] (op) scalar when b == NULL.  out may alias a.            */

@@ -341,6 +341,33 @@ class OracleBackend(BackendMethods):  # pylint: disable=too-many-public-methods
             _f64(-1.0 if nfmax is None else nfmax), _p(x_plus_y.data),
         )
 
+    def _limiters(self, n_fragment, frag_volume, x_plus_y, vmin, nfmax):
+        lib().oracle_fragmentation_limiters(
+            _p(n_fragment.data), _p(frag_volume.data), _i64(len(frag_volume.data)), _f64(vmin),
+            _f64(-1.0 if nfmax is None else nfmax), _p(x_plus_y.data),
+        )
+
+    def gauss_fragmentation(self, *, n_fragment, mu, sigma, frag_volume, x_plus_y, rand, vmin,
+                            nfmax):
+        const = self.formulae.constants
+        consts = np.asarray([const.VEDDER_1987_A, const.VEDDER_1987_b], dtype=np.float64)
+        lib().oracle_gauss_fragmentation(_f64(mu), _f64(sigma), _p(frag_volume.data),
+                                         _p(rand.data), _i64(len(frag_volume.data)), _p(consts))
+        self._limiters(n_fragment, frag_volume, x_plus_y, vmin, nfmax)
+
+    def feingold1988_fragmentation(self, *, n_fragment, scale, frag_volume, x_plus_y, rand,
+                                   fragtol, vmin, nfmax):
+        lib().oracle_feingold1988_fragmentation(
+            _f64(scale), _p(frag_volume.data), _p(x_plus_y.data), _p(rand.data),
+            _i64(len(frag_volume.data)), _f64(fragtol))
+        self._limiters(n_fragment, frag_volume, x_plus_y, vmin, nfmax)
+
+    def slams_fragmentation(self, n_fragment, frag_volume, x_plus_y, probs, rand, vmin, nfmax):
+        lib().oracle_slams_fragmentation(
+            _p(n_fragment.data), _p(frag_volume.data), _p(x_plus_y.data), _p(probs.data),
+            _p(rand.data), _i64(len(frag_volume.data)))
+        self._limiters(n_fragment, frag_volume, x_plus_y, vmin, nfmax)
+
     def straub_fragmentation(self, *, n_fragment, CW, gam, ds, frag_volume, v_max, x_plus_y, rand,
                              vmin, nfmax, Nr1, Nr2, Nr3, Nr4, Nrt, d34):
         n = len(frag_volume.data)
@@ -369,4 +396,16 @@ class OracleBackend(BackendMethods):  # pylint: disable=too-many-public-methods
             _i64(len(ranks.data)), _i64(len(moment_0.data)), _f64(min_x), _f64(max_x),
             _p(x_attr.data), _p(weighting_attribute.data), _f64(weighting_rank),
             _int(int(skip_division_by_m0)),
+        )
+
+    @staticmethod
+    def spectrum_moments(*, moment_0, moments, multiplicity, attr_data, cell_id, idx, length, rank,
+                         x_bins, x_attr, weighting_attribute, weighting_rank):
+        assert moments.shape[0] == x_bins.shape[0] - 1
+        assert moment_0.shape == moments.shape
+        lib().oracle_spectrum_moments(
+            _p(moment_0.data), _p(moments.data), _p(multiplicity.data), _p(attr_data.data),
+            _p(cell_id.data), _p(idx.data), _i64(int(length)), _f64(rank), _p(x_bins.data),
+            _i64(moments.shape[0]), _i64(moments.shape[1]), _p(x_attr.data),
+            _p(weighting_attribute.data), _f64(weighting_rank),
         )

@@ -619,6 +619,43 @@ API void oracle_fragmentation_limiters(double *n_fragment, double *frag_volume, 
   }
 }
 
+/* PySDM/physics/trivia.py:95-108 (Vedder 1987) */
+static inline double erfinv_approx(double c, double VA, double Vb) {
+  return 2 * sqrt(VA) * sinh(asinh(atanh(c) / 2 / Vb / pow(VA, 1.5)) / 3);
+}
+
+/* :477-485 gauss ; consts = {VEDDER_1987_A, VEDDER_1987_b} */
+API void oracle_gauss_fragmentation(double mu, double sigma, double *frag_volume,
+                                    const double *rand, int64_t n, const double *consts) {
+  for (int64_t i = 0; i < n; ++i)
+    frag_volume[i] = mu + sigma * erfinv_approx(rand[i], consts[0], consts[1]);
+}
+
+/* :487-499 + PySDM/physics/fragmentation_function/feingold1988.py:13-15 */
+API void oracle_feingold1988_fragmentation(double scale, double *frag_volume,
+                                           const double *x_plus_y, const double *rand, int64_t n,
+                                           double fragtol) {
+  for (int64_t i = 0; i < n; ++i) {
+    const double a = 1 - rand[i] * scale / x_plus_y[i];
+    frag_volume[i] = -scale * log(a > fragtol ? a : fragtol);
+  }
+}
+
+/* :98-112 slams */
+API void oracle_slams_fragmentation(double *n_fragment, double *frag_volume,
+                                    const double *x_plus_y, double *probs, const double *rand,
+                                    int64_t n) {
+  for (int64_t i = 0; i < n; ++i) {
+    probs[i] = 0.0;
+    n_fragment[i] = 1;
+    for (int k = 0; k < 22; ++k) {
+      probs[i] += 0.91 * pow((double)(k + 2), -1.56);
+      if (rand[i] < probs[i]) { n_fragment[i] = k + 2; break; }
+    }
+    frag_volume[i] = x_plus_y[i] / n_fragment[i];
+  }
+}
+
 /* :136-144 */
 API void oracle_exp_fragmentation(double scale, double *frag_volume, const double *rand,
                                   int64_t n, double tol) {
@@ -626,11 +663,6 @@ API void oracle_exp_fragmentation(double scale, double *frag_volume, const doubl
     const double a = 1 - rand[i];
     frag_volume[i] = -scale * log(a > tol ? a : tol);
   }
-}
-
-/* PySDM/physics/trivia.py:95-108 (Vedder 1987) */
-static inline double erfinv_approx(double c, double VA, double Vb) {
-  return 2 * sqrt(VA) * sinh(asinh(atanh(c) / 2 / Vb / pow(VA, 1.5)) / 3);
 }
 
 /* :321-377 with helpers :12-48 and PySDM/physics/fragmentation_function/straub2010nf.py:13-45.
@@ -717,4 +749,27 @@ API void oracle_moments(double *moment_0, double *moments, const int64_t *multip
     for (int64_t c = 0; c < n_cell; ++c)
       for (int64_t k = 0; k < n_ranks; ++k)
         moments[k * n_cell + c] = moment_0[c] != 0 ? moments[k * n_cell + c] / moment_0[c] : 0;
+}
+
+/* f-1  spectrum_moments, moments_methods.py:100-147: the first bin k with
+ * x_bins[k] <= x < x_bins[k+1] takes the SD; moment_0 and moments are (n_bins, n_cell) */
+API void oracle_spectrum_moments(double *moment_0, double *moments, const int64_t *multiplicity,
+                                 const double *attr_data, const int64_t *cell_id,
+                                 const int64_t *idx, int64_t length, double rank,
+                                 const double *x_bins, int64_t n_bins, int64_t n_cell,
+                                 const double *x_attr, const double *weighting_attribute,
+                                 double weighting_rank) {
+  for (int64_t k = 0; k < n_bins * n_cell; ++k) moment_0[k] = moments[k] = 0;
+  for (int64_t idx_i = 0; idx_i < length; ++idx_i) {
+    const int64_t i = idx[idx_i];
+    for (int64_t k = 0; k < n_bins; ++k)
+      if (x_bins[k] <= x_attr[i] && x_attr[i] < x_bins[k + 1]) {
+        const double w = (double)multiplicity[i] * pow(weighting_attribute[i], weighting_rank);
+        moment_0[k * n_cell + cell_id[i]] += w;
+        moments[k * n_cell + cell_id[i]] += w * pow(attr_data[i], rank);
+        break;
+      }
+  }
+  for (int64_t k = 0; k < n_bins * n_cell; ++k)
+    moments[k] = moment_0[k] != 0 ? moments[k] / moment_0[k] : 0;
 }

@@ -143,6 +143,17 @@ class Radius(DerivedAttribute):
         self.data **= 1 / 3
 
 
+class Area(DerivedAttribute):  # cf. PySDM/attributes/physics/area.py
+    def __init__(self, builder):
+        self.volume = builder.get_attribute("volume")
+        super().__init__(builder, name="area", dependencies=(self.volume,))
+
+    def recalculate(self):
+        self.data.product(self.volume.get(), 1 / self.formulae.constants.PI_4_3)
+        self.data **= 2 / 3
+        self.data *= self.formulae.constants.PI_4_3 * 3
+
+
 class TerminalVelocity(DerivedAttribute):
     def __init__(self, builder, name="terminal velocity"):
         self.radius = builder.get_attribute("radius")
@@ -161,6 +172,7 @@ ATTRIBUTE_CLASSES = {
     "water mass": WaterMass,
     "volume": Volume,
     "radius": Radius,
+    "area": Area,
     "terminal velocity": TerminalVelocity,
     # no RelaxedVelocity dynamic on this path: the fall velocity IS the terminal velocity
     "relative fall velocity": lambda builder: TerminalVelocity(builder, "relative fall velocity"),

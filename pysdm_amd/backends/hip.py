@@ -329,6 +329,30 @@ class HIP(BackendMethods):  # pylint: disable=too-many-public-methods
               c_i64(frag_volume.data.numel()), c_f64(vmin),
               c_f64(-1.0 if nfmax is None else nfmax), c_f64(tol))
 
+    def gauss_fragmentation(self, *, n_fragment, mu, sigma, frag_volume, x_plus_y, rand, vmin,
+                            nfmax):
+        const = self.formulae.constants
+        _call("sdm_gauss_fragmentation", _ptr(n_fragment.data), c_f64(mu), c_f64(sigma),
+              _ptr(frag_volume.data), _ptr(x_plus_y.data), _ptr(rand.data),
+              c_i64(frag_volume.data.numel()), c_f64(vmin),
+              c_f64(-1.0 if nfmax is None else nfmax),
+              (c_f64 * 2)(const.VEDDER_1987_A, const.VEDDER_1987_b))
+
+    @staticmethod
+    def feingold1988_fragmentation(*, n_fragment, scale, frag_volume, x_plus_y, rand, fragtol,
+                                   vmin, nfmax):
+        _call("sdm_feingold1988_fragmentation", _ptr(n_fragment.data), c_f64(scale),
+              _ptr(frag_volume.data), _ptr(x_plus_y.data), _ptr(rand.data),
+              c_i64(frag_volume.data.numel()), c_f64(fragtol), c_f64(vmin),
+              c_f64(-1.0 if nfmax is None else nfmax))
+
+    @staticmethod
+    def slams_fragmentation(n_fragment, frag_volume, x_plus_y, probs, rand, vmin, nfmax):
+        _call("sdm_slams_fragmentation", _ptr(n_fragment.data), _ptr(frag_volume.data),
+              _ptr(x_plus_y.data), _ptr(probs.data), _ptr(rand.data),
+              c_i64(frag_volume.data.numel()), c_f64(vmin),
+              c_f64(-1.0 if nfmax is None else nfmax))
+
     def straub_consts(self):
         const = self.formulae.constants
         return (c_f64 * 6)(const.CM, const.STRAUB_E_D1, const.STRAUB_MU2, const.VEDDER_1987_A,
@@ -352,6 +376,17 @@ class HIP(BackendMethods):  # pylint: disable=too-many-public-methods
               _ptr(ranks.data), c_i64(ranks.data.numel()), c_i64(moment_0.data.numel()),
               c_f64(min_x), c_f64(max_x), _ptr(x_attr.data), _ptr(weighting_attribute.data),
               c_f64(weighting_rank), c_int(int(skip_division_by_m0)))
+
+    @staticmethod
+    def spectrum_moments(*, moment_0, moments, multiplicity, attr_data, cell_id, idx, length, rank,
+                         x_bins, x_attr, weighting_attribute, weighting_rank):
+        assert moments.shape[0] == x_bins.shape[0] - 1
+        assert moment_0.shape == moments.shape
+        _call("sdm_spectrum_moments", _ptr(moment_0.data), _ptr(moments.data),
+              _ptr(multiplicity.data), _ptr(attr_data.data), _ptr(cell_id.data), _ptr(idx.data),
+              c_i64(int(length)), c_f64(rank), _ptr(x_bins.data), c_i64(moments.shape[0]),
+              c_i64(moments.shape[1]), _ptr(x_attr.data), _ptr(weighting_attribute.data),
+              c_f64(weighting_rank))
 
     # ---- the fused per-time-step route ----------------------------------------------------------
     def make_collision_step(self, dynamic, parts):

@@ -636,6 +636,90 @@ extern "C" int sdm_exp_fragmentation(sdm_ctx *ctx, double *n_fragment, double sc
   return SDM_OK;
 }
 
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_gauss_fragmentation(double *__restrict__ n_fragment, double mu, double sigma,
+                      double *__restrict__ frag_volume, const double *__restrict__ x_plus_y,
+                      const double *__restrict__ rand, int64_t n, double vmin, double nfmax,
+                      double VA, double Vb) {
+  const int64_t i = TID();
+  if (i >= n) return;
+  double fv = mu + sigma * erfinv_approx(rand[i], VA, Vb), nf;
+  fragmentation_limiters(nf, fv, vmin, nfmax, x_plus_y[i]);
+  frag_volume[i] = fv;
+  n_fragment[i] = nf;
+}
+
+extern "C" int sdm_gauss_fragmentation(sdm_ctx *ctx, double *n_fragment, double mu, double sigma,
+                                       double *frag_volume, const double *x_plus_y,
+                                       const double *rand, int64_t n, double vmin, double nfmax,
+                                       const double consts[2]) {
+  ARG_TRY(ctx && n >= 0 && consts);
+  if (n == 0) return SDM_OK;
+  ARG_TRY(n_fragment && frag_volume && x_plus_y && rand);
+  hipLaunchKernelGGL(k_gauss_fragmentation, GRID1D(n), n_fragment, mu, sigma, frag_volume,
+                     x_plus_y, rand, n, vmin, nfmax, consts[0], consts[1]);
+  LAUNCH_CHECK();
+  return SDM_OK;
+}
+
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_feingold1988_fragmentation(double *__restrict__ n_fragment, double scale,
+                             double *__restrict__ frag_volume,
+                             const double *__restrict__ x_plus_y,
+                             const double *__restrict__ rand, int64_t n, double fragtol,
+                             double vmin, double nfmax) {
+  const int64_t i = TID();
+  if (i >= n) return;
+  const double a = 1 - rand[i] * scale / x_plus_y[i];
+  double fv = -scale * log(a > fragtol ? a : fragtol), nf;
+  fragmentation_limiters(nf, fv, vmin, nfmax, x_plus_y[i]);
+  frag_volume[i] = fv;
+  n_fragment[i] = nf;
+}
+
+extern "C" int sdm_feingold1988_fragmentation(sdm_ctx *ctx, double *n_fragment, double scale,
+                                              double *frag_volume, const double *x_plus_y,
+                                              const double *rand, int64_t n, double fragtol,
+                                              double vmin, double nfmax) {
+  ARG_TRY(ctx && n >= 0);
+  if (n == 0) return SDM_OK;
+  ARG_TRY(n_fragment && frag_volume && x_plus_y && rand);
+  hipLaunchKernelGGL(k_feingold1988_fragmentation, GRID1D(n), n_fragment, scale, frag_volume,
+                     x_plus_y, rand, n, fragtol, vmin, nfmax);
+  LAUNCH_CHECK();
+  return SDM_OK;
+}
+
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_slams_fragmentation(double *__restrict__ n_fragment, double *__restrict__ frag_volume,
+                      const double *__restrict__ x_plus_y, double *__restrict__ probs,
+                      const double *__restrict__ rand, int64_t n, double vmin, double nfmax) {
+  const int64_t i = TID();
+  if (i >= n) return;
+  double p = 0.0, nf = 1;
+  for (int k = 0; k < 22; ++k) {
+    p += 0.91 * pow((double)(k + 2), -1.56);
+    if (rand[i] < p) { nf = k + 2; break; }
+  }
+  probs[i] = p;
+  double fv = x_plus_y[i] / nf;
+  fragmentation_limiters(nf, fv, vmin, nfmax, x_plus_y[i]);
+  frag_volume[i] = fv;
+  n_fragment[i] = nf;
+}
+
+extern "C" int sdm_slams_fragmentation(sdm_ctx *ctx, double *n_fragment, double *frag_volume,
+                                       const double *x_plus_y, double *probs, const double *rand,
+                                       int64_t n, double vmin, double nfmax) {
+  ARG_TRY(ctx && n >= 0);
+  if (n == 0) return SDM_OK;
+  ARG_TRY(n_fragment && frag_volume && x_plus_y && probs && rand);
+  hipLaunchKernelGGL(k_slams_fragmentation, GRID1D(n), n_fragment, frag_volume, x_plus_y, probs,
+                     rand, n, vmin, nfmax);
+  LAUNCH_CHECK();
+  return SDM_OK;
+}
+
 struct StraubConsts { double k[6]; };
 
 __global__ void __launch_bounds__(SDM_BLOCK)
@@ -675,6 +759,15 @@ extern "C" int sdm_straub_fragmentation(sdm_ctx *ctx, double *n_fragment, const 
 }
 
 // ---- moments (moments_methods.py:14-99) ----------------------------------------------------
+// After a collision step the state is sorted by cell (or is one cell), so a wave's 64 SDs nearly
+// always share their cell: the wave then folds its terms with shuffles and issues one atomic per
+// (wave, rank) instead of 64 to the same address.  Mixed waves fall back to per-lane atomics.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_moments(double *__restrict__ moment_0, double *__restrict__ moments,
           const int64_t *__restrict__ multiplicity, const double *__restrict__ attr_data,
@@ -683,16 +776,75 @@ k_moments(double *__restrict__ moment_0, double *__restrict__ moments,
           double max_x, const double *__restrict__ x_attr,
           const double *__restrict__ weighting_attribute, double weighting_rank) {
   const int64_t t = TID();
+  bool live = t < length;
+  int64_t i = 0;
+  if (live) {
+    i = idx[t];
+    const double x = x_attr[i];
+    live = min_x <= x && x < max_x;
+  }
+  const int c = live ? (int)cell_id[i] : -1;
+  int lo = live ? c : 0x7fffffff, hi = c;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = min(lo, __shfl_xor(lo, o, 64));
+    hi = max(hi, __shfl_xor(hi, o, 64));
+  }
+  if (hi < 0) return;  // nothing in range in this wave
+  const double w = !live ? 0.0 : (double)multiplicity[i] *
+                   (weighting_rank == 0 ? 1.0 : pow(weighting_attribute[i], weighting_rank));
+  const bool uniform = lo == hi;
+  const bool leader = (threadIdx.x & 63) == 0;
+  if (uniform) {
+    const double s = wave_sum_f64(w);
+    if (leader) atomicAdd(&moment_0[hi], s);
+  } else if (live) {
+    atomicAdd(&moment_0[c], w);
+  }
+  for (int64_t k = 0; k < n_ranks; ++k) {
+    const double term = live ? w * pow(attr_data[i], ranks[k]) : 0.0;
+    if (uniform) {
+      const double s = wave_sum_f64(term);
+      if (leader) atomicAdd(&moments[k * n_cell + hi], s);
+    } else if (live) {
+      atomicAdd(&moments[k * n_cell + c], term);
+    }
+  }
+}
+
+// ---- spectrum_moments (moments_methods.py:100-147) -----------------------------------------
+// bin edges staged in LDS; the first matching bin wins exactly as in the reference's scan
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_spectrum_moments(double *__restrict__ moment_0, double *__restrict__ moments,
+                   const int64_t *__restrict__ multiplicity,
+                   const double *__restrict__ attr_data, const int64_t *__restrict__ cell_id,
+                   const int64_t *__restrict__ idx, int64_t length, double rank,
+                   const double *__restrict__ x_bins, int n_bins, int64_t n_cell,
+                   const double *__restrict__ x_attr,
+                   const double *__restrict__ weighting_attribute, double weighting_rank) {
+  extern __shared__ double edges[];
+  for (int k = threadIdx.x; k <= n_bins; k += blockDim.x) edges[k] = x_bins[k];
+  __syncthreads();
+  const int64_t t = TID();
   if (t >= length) return;
   const int64_t i = idx[t];
   const double x = x_attr[i];
-  if (!(min_x <= x && x < max_x)) return;
-  const double w = (double)multiplicity[i] *
-                   (weighting_rank == 0 ? 1.0 : pow(weighting_attribute[i], weighting_rank));
-  const int64_t c = cell_id[i];
-  atomicAdd(&moment_0[c], w);
-  for (int64_t k = 0; k < n_ranks; ++k)
-    atomicAdd(&moments[k * n_cell + c], w * pow(attr_data[i], ranks[k]));
+  int bin = -1;
+  for (int k = 0; k < n_bins; ++k)
+    if (edges[k] <= x && x < edges[k + 1]) { bin = k; break; }
+  if (bin < 0) return;
+  const double w = (double)multiplicity[i] * pow(weighting_attribute[i], weighting_rank);
+  const int64_t at = bin * n_cell + cell_id[i];
+  atomicAdd(&moment_0[at], w);
+  atomicAdd(&moments[at], w * pow(attr_data[i], rank));
+}
+
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_spectrum_divide(const double *__restrict__ moment_0, double *__restrict__ moments, int64_t n) {
+  const int64_t t = TID();
+  if (t >= n) return;
+  const double m0 = moment_0[t];
+  moments[t] = m0 != 0 ? moments[t] / m0 : 0.0;
 }
 
 __global__ void __launch_bounds__(SDM_BLOCK)
@@ -728,5 +880,29 @@ extern "C" int sdm_moments(sdm_ctx *ctx, double *moment_0, double *moments,
                        n_cell);
     LAUNCH_CHECK();
   }
+  return SDM_OK;
+}
+
+extern "C" int sdm_spectrum_moments(sdm_ctx *ctx, double *moment_0, double *moments,
+                                    const int64_t *multiplicity, const double *attr_data,
+                                    const int64_t *cell_id, const int64_t *idx, int64_t length,
+                                    double rank, const double *x_bins, int64_t n_bins,
+                                    int64_t n_cell, const double *x_attr,
+                                    const double *weighting_attribute, double weighting_rank) {
+  ARG_TRY(ctx && moment_0 && moments && x_bins && n_cell >= 1 && length >= 0);
+  ARG_TRY(n_bins >= 1 && n_bins < 8000);  // the edges live in LDS
+  HIP_TRY(hipMemsetAsync(moment_0, 0, sizeof(double) * n_bins * n_cell, ctx->stream));
+  HIP_TRY(hipMemsetAsync(moments, 0, sizeof(double) * n_bins * n_cell, ctx->stream));
+  if (length > 0) {
+    ARG_TRY(multiplicity && attr_data && cell_id && idx && x_attr && weighting_attribute);
+    hipLaunchKernelGGL(k_spectrum_moments, dim3((unsigned)((length + SDM_BLOCK - 1) / SDM_BLOCK)),
+                       dim3(SDM_BLOCK), sizeof(double) * (n_bins + 1), ctx->stream, moment_0,
+                       moments, multiplicity, attr_data, cell_id, idx, length, rank, x_bins,
+                       (int)n_bins, n_cell, x_attr, weighting_attribute, weighting_rank);
+    LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_spectrum_divide, GRID1D(n_bins * n_cell), moment_0, moments,
+                     n_bins * n_cell);
+  LAUNCH_CHECK();
   return SDM_OK;
 }

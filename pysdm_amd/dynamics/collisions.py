@@ -137,6 +137,74 @@ class Geometric:
                 "needs_gk": True}
 
 
+class ParameterizedKernel:
+    """gravitational kernel with Berry's parameterised collection efficiency
+    (collision_kernels/impl/parameterized.py:8-30)"""
+
+    def __init__(self, params):
+        self.params = params
+        self.particulator = None
+        self.pair_tmp = None
+
+    def register(self, builder):
+        self.particulator = builder.particulator
+        builder.request_attribute("radius")
+        builder.request_attribute("relative fall velocity")
+        self.pair_tmp = self.particulator.PairwiseStorage.empty(
+            self.particulator.n_sd // 2, dtype=float
+        )
+
+    def __call__(self, output, is_first_in_pair):
+        attributes = self.particulator.attributes
+        self.particulator.backend.linear_collection_efficiency(
+            params=self.params,
+            output=output,
+            radii=attributes["radius"],
+            is_first_in_pair=is_first_in_pair,
+            unit=si.um,
+        )
+        output **= 2
+        output *= const.PI
+        self.pair_tmp.max(attributes["radius"], is_first_in_pair)
+        self.pair_tmp **= 2
+        output *= self.pair_tmp
+        self.pair_tmp.distance(attributes["relative fall velocity"], is_first_in_pair)
+        output *= self.pair_tmp
+
+
+class Electric(ParameterizedKernel):  # collision_kernels/electric.py (3000 V/cm, Berry 1967)
+    def __init__(self):
+        super().__init__((1, 1, -7, 1.78, -20.5, 1.73, 0.26, 1.47, 1, 0.82, -0.003, 4.4, 8))
+
+
+class Hydrodynamic(ParameterizedKernel):  # collision_kernels/hydrodynamic.py
+    def __init__(self):
+        super().__init__((1, 1, -27, 1.65, -58, 1.9, 15, 1.13, 16.7, 1, 0.004, 4, 8))
+
+
+class SimpleGeometric:  # collision_kernels/simple_geometric.py (no fall velocity)
+    def __init__(self, C):
+        self.particulator = None
+        self.pair_tmp = None
+        self.C = C
+
+    def register(self, builder):
+        self.particulator = builder.particulator
+        builder.request_attribute("radius")
+        builder.request_attribute("area")
+        self.pair_tmp = self.particulator.PairwiseStorage.empty(
+            self.particulator.n_sd // 2, dtype=float
+        )
+
+    def __call__(self, output, is_first_in_pair):
+        output[:] = self.C
+        self.pair_tmp.sum(self.particulator.attributes["radius"], is_first_in_pair)
+        self.pair_tmp **= 2
+        output *= self.pair_tmp
+        self.pair_tmp.distance(self.particulator.attributes["area"], is_first_in_pair)
+        output *= self.pair_tmp
+
+
 # ---- efficiencies ---------------------------------------------------------------------------
 class ConstEc:
     def __init__(self, Ec=1.0):
@@ -197,6 +265,13 @@ class Berry1967(Parameterized):  # pylint: disable=too-few-public-methods
         super().__init__((1, 1, -27, 1.65, -58, 1.9, 15, 1.13, 16.7, 1, 0.004, 4, 8))
 
 
+class SpecifiedEff(Parameterized):  # coalescence_efficiencies/specified_eff.py
+    # pylint: disable=too-many-arguments
+    def __init__(self, *, A=1, B=1, D1=-27, D2=1.65, E1=-58, E2=1.9, F1=15, F2=1.13, G1=16.7,
+                 G2=1, G3=0.004, Mf=4, Mg=8):
+        super().__init__((A, B, D1, D2, E1, E2, F1, F2, G1, G2, G3, Mf, Mg))
+
+
 class Straub2010Ec:
     def __init__(self):
         self.particulator = None
@@ -254,6 +329,20 @@ class AlwaysN:
         return {"frag": 0, "frag_param": (float(self.N), 0.0)}
 
 
+class ConstantMass:  # breakup_fragmentations/constant_mass.py
+    def __init__(self, c):
+        self.particulator = None
+        self.C = c
+
+    def register(self, builder):
+        self.particulator = builder.particulator
+
+    def __call__(self, nf, frag_mass, u01, is_first_in_pair):
+        frag_mass[:] = self.C
+        nf.sum(self.particulator.attributes["water mass"], is_first_in_pair)
+        nf /= self.C
+
+
 class VolumeBasedFragmentationFunction:
     def __init__(self):
         self.particulator = None
@@ -300,6 +389,69 @@ class Exponential(VolumeBasedFragmentationFunction):
     def fused_descriptor(self):
         return {"frag": 1, "frag_param": (float(self.scale), 0.0), "frag_vmin": float(self.vmin),
                 "frag_nfmax": -1.0 if self.nfmax is None else float(self.nfmax)}
+
+
+class _SumOfVolumes(VolumeBasedFragmentationFunction):
+    def __init__(self, vmin, nfmax):
+        super().__init__()
+        self.vmin = vmin
+        self.nfmax = nfmax
+        self.sum_of_volumes = None
+
+    def register(self, builder):
+        super().register(builder)
+        self.sum_of_volumes = self.particulator.PairwiseStorage.empty(
+            self.particulator.n_sd // 2, dtype=float
+        )
+
+    def _sum(self, is_first_in_pair):
+        self.sum_of_volumes.sum(self.particulator.attributes["volume"], is_first_in_pair)
+        return self.sum_of_volumes
+
+
+class Gaussian(_SumOfVolumes):  # breakup_fragmentations/gaussian.py (mu, sigma: volumes)
+    def __init__(self, mu, sigma, vmin=0.0, nfmax=None):
+        super().__init__(vmin, nfmax)
+        self.mu = mu
+        self.sigma = sigma
+
+    def compute_fragment_number_and_volumes(self, nf, frag_volume, u01, is_first_in_pair):
+        self.particulator.backend.gauss_fragmentation(
+            n_fragment=nf, mu=self.mu, sigma=self.sigma, frag_volume=frag_volume,
+            x_plus_y=self._sum(is_first_in_pair), rand=u01, vmin=self.vmin, nfmax=self.nfmax,
+        )
+
+
+class Feingold1988(_SumOfVolumes):  # breakup_fragmentations/feingold1988.py
+    def __init__(self, scale, fragtol=1e-3, vmin=0.0, nfmax=None):
+        super().__init__(vmin, nfmax)
+        self.scale = scale
+        self.fragtol = fragtol
+
+    def compute_fragment_number_and_volumes(self, nf, frag_volume, u01, is_first_in_pair):
+        self.particulator.backend.feingold1988_fragmentation(
+            n_fragment=nf, scale=self.scale, frag_volume=frag_volume,
+            x_plus_y=self._sum(is_first_in_pair), rand=u01, fragtol=self.fragtol,
+            vmin=self.vmin, nfmax=self.nfmax,
+        )
+
+
+class SLAMS(_SumOfVolumes):  # breakup_fragmentations/slams.py
+    def __init__(self, vmin=0.0, nfmax=None):
+        super().__init__(vmin, nfmax)
+        self.p_vec = None
+
+    def register(self, builder):
+        super().register(builder)
+        self.p_vec = self.particulator.PairwiseStorage.empty(
+            self.particulator.n_sd // 2, dtype=float
+        )
+
+    def compute_fragment_number_and_volumes(self, nf, frag_volume, u01, is_first_in_pair):
+        self.particulator.backend.slams_fragmentation(
+            n_fragment=nf, frag_volume=frag_volume, x_plus_y=self._sum(is_first_in_pair),
+            probs=self.p_vec, rand=u01, vmin=self.vmin, nfmax=self.nfmax,
+        )
 
 
 class Straub2010Nf(VolumeBasedFragmentationFunction):

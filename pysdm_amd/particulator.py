@@ -175,6 +175,24 @@ class Particulator:  # pylint: disable=too-many-instance-attributes
             skip_division_by_m0=skip_division_by_m0,
         )
 
+    def spectrum_moments(self, *, moment_0, moments, attr, rank, attr_bins,
+                         attr_name="water mass", weighting_attribute="water mass",
+                         weighting_rank=0):
+        self.backend.spectrum_moments(
+            moment_0=moment_0,
+            moments=moments,
+            multiplicity=self.attributes["multiplicity"],
+            attr_data=self.attributes[attr],
+            cell_id=self.attributes["cell id"],
+            idx=self.attributes._fused_view()["idx"],  # pylint: disable=protected-access
+            length=self.attributes.super_droplet_count,
+            rank=rank,
+            x_bins=attr_bins,
+            x_attr=self.attributes[attr_name],
+            weighting_attribute=self.attributes[weighting_attribute],
+            weighting_rank=weighting_rank,
+        )
+
     def adaptive_sdm_end(self, dt_left):
         return self.backend.adaptive_sdm_end(dt_left, self.attributes.cell_start)
 

@@ -423,6 +423,29 @@ def gen_frag():
         eff(pw, flag)
         out[f"ec/{name}"] = pw.to_ndarray()
 
+    # remaining kernels / efficiencies
+    from PySDM.dynamics.collisions.collision_kernels import (
+        Electric, Hydrodynamic, SimpleGeometric,
+    )
+    from PySDM.dynamics.collisions.coalescence_efficiencies import SpecifiedEff
+    from PySDM.attributes.physics.area import Area  # noqa: F401
+
+    area_s = IndexedStorage.empty(idx, (n_sd,), float)
+    area_s.product(vol_s, 1 / const.PI_4_3)
+    area_s **= 2 / 3
+    area_s *= const.PI_4_3 * 3
+    part.attributes["area"] = area_s
+    out["derived/area"] = area_s.to_ndarray(raw=True)
+    for name, kern in (("electric", Electric()), ("hydrodynamic", Hydrodynamic()),
+                       ("simple_geometric", SimpleGeometric(C=2.5))):
+        kern.register(_Builder)
+        kern(pw, flag)
+        out[f"kernel/{name}"] = pw.to_ndarray()
+    eff = SpecifiedEff(A=0.8, B=0.9, D1=-20)
+    eff.register(_Builder)
+    eff(pw, flag)
+    out["ec/specified"] = pw.to_ndarray()
+
     # fragmentations
     u01 = rng.uniform(0, 1, n_sd // 2)
     u01[:4] = [0.0, 1e-12, 1 - 1e-12, 0.999999]
@@ -444,7 +467,27 @@ def gen_frag():
         ),
         "straub_ss": Straub2010Nf(vmin=(0.01 * si.mm) ** 3 * np.pi / 6, nfmax=10000),
     }
+    from PySDM.dynamics.collisions.breakup_fragmentations import (
+        ConstantMass, Feingold1988, Gaussian, SLAMS,
+    )
+
+    frag_cases.update({
+        "constant_mass": ConstantMass(c=float(const.rho_w * formulae.trivia.volume(radius=20 * si.um))),
+        "gaussian": Gaussian(mu=formulae.trivia.volume(radius=50 * si.um),
+                             sigma=formulae.trivia.volume(radius=30 * si.um)),
+        "gaussian_lim": Gaussian(mu=formulae.trivia.volume(radius=50 * si.um),
+                                 sigma=formulae.trivia.volume(radius=30 * si.um),
+                                 vmin=formulae.trivia.volume(radius=5 * si.um), nfmax=20),
+        "feingold1988": Feingold1988(scale=formulae.trivia.volume(radius=40 * si.um)),
+        "slams": SLAMS(),
+        "slams_lim": SLAMS(vmin=formulae.trivia.volume(radius=5 * si.um), nfmax=5),
+    })
+    feingold_backend = CPU(Formulae(
+        terminal_velocity="GunnKinzer1949", fragmentation_function="Feingold1988"
+    ))
     for name, frag in frag_cases.items():
+        # Feingold's closed form lives in the formulae object the backend was built with
+        part.backend = feingold_backend if name.startswith("feingold") else backend
         frag.register(_Builder)
         frag(nf, fm, u01_s, flag)
         out[f"frag/{name}/nf"] = nf.to_ndarray()

@@ -250,13 +250,22 @@ def check_physics(kit, exact, rtol):  # pylint: disable=too-many-locals
         def request_attribute(_):
             pass
 
+    area = kit.IndexedStorage.empty(idx, (n_sd,), float)
+    area.product(vol, 1 / kit.backend.formulae.constants.PI_4_3)
+    area **= 2 / 3
+    area *= kit.backend.formulae.constants.PI_4_3 * 3
+    cmp("area", area.to_ndarray(raw=True), g["derived/area"])
+    part.attributes["area"] = area
     pw = kit.PairwiseStorage.empty(n_sd // 2, dtype=float)
     for name, kern in (("golovin", C.Golovin(b=1.5e3)),
-                       ("geometric", C.Geometric(collection_efficiency=1.0))):
+                       ("geometric", C.Geometric(collection_efficiency=1.0)),
+                       ("electric", C.Electric()), ("hydrodynamic", C.Hydrodynamic()),
+                       ("simple_geometric", C.SimpleGeometric(C=2.5))):
         kern.register(Builder)
         kern(pw, flag)
         cmp(name, pw.to_ndarray(), g["kernel/" + name])
-    for name, eff in (("berry1967", C.Berry1967()), ("straub2010", C.Straub2010Ec())):
+    for name, eff in (("berry1967", C.Berry1967()), ("straub2010", C.Straub2010Ec()),
+                      ("specified", C.SpecifiedEff(A=0.8, B=0.9, D1=-20))):
         eff.register(Builder)
         eff(pw, flag)
         cmp(name, pw.to_ndarray(), g["ec/" + name])
@@ -264,13 +273,20 @@ def check_physics(kit, exact, rtol):  # pylint: disable=too-many-locals
     nf = kit.PairwiseStorage.empty(n_sd // 2, dtype=float)
     fm = kit.PairwiseStorage.empty(n_sd // 2, dtype=float)
     tv = kit.backend.formulae.trivia.volume
+    um = 1e-6  # the goldens were made with `N * si.um`, which is not the literal `Ne-6`
     cases = {
         "always_n_4": C.AlwaysN(n=4),
-        "exp_100um": C.Exponential(scale=tv(100e-6)),
-        "exp_100um_lim": C.Exponential(scale=tv(100e-6), vmin=tv(5e-6), nfmax=10),
+        "exp_100um": C.Exponential(scale=tv(100 * um)),
+        "exp_100um_lim": C.Exponential(scale=tv(100 * um), vmin=tv(5 * um), nfmax=10),
         "straub": C.Straub2010Nf(),
-        "straub_lim": C.Straub2010Nf(vmin=tv(30.531e-6) * 1e-3, nfmax=10),
+        "straub_lim": C.Straub2010Nf(vmin=tv(30.531 * um) * 1e-3, nfmax=10),
         "straub_ss": C.Straub2010Nf(vmin=(0.01e-3) ** 3 * np.pi / 6, nfmax=10000),
+        "constant_mass": C.ConstantMass(c=float(g["const/rho_w"]) * tv(20 * um)),
+        "gaussian": C.Gaussian(mu=tv(50 * um), sigma=tv(30 * um)),
+        "gaussian_lim": C.Gaussian(mu=tv(50 * um), sigma=tv(30 * um), vmin=tv(5 * um), nfmax=20),
+        "feingold1988": C.Feingold1988(scale=tv(40 * um)),
+        "slams": C.SLAMS(),
+        "slams_lim": C.SLAMS(vmin=tv(5 * um), nfmax=5),
     }
     for name, frag in cases.items():
         frag.register(Builder)
