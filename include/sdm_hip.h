@@ -176,6 +176,18 @@ int sdm_slams_fragmentation(sdm_ctx *ctx, double *n_fragment, double *frag_volum
                             const double *x_plus_y, double *probs, const double *rand, int64_t n,
                             double vmin, double nfmax);
 
+/* fragmentation_methods.py:260-319,379-474 (Low & List 1982): frag_volume per pair from the
+ * filament / sheet / disk modes; rand, Rf, Rs, Rd are updated in place as in the reference;
+ * consts = {CM, PI, VEDDER_1987_A, VEDDER_1987_b}; limiters (:75-93) applied afterwards.      */
+int sdm_ll82_fragmentation(sdm_ctx *ctx, double *n_fragment, const double *CKE, const double *W,
+                           const double *W2, const double *St, const double *ds,
+                           const double *dl, const double *dcoal, double *frag_volume,
+                           const double *x_plus_y, double *rand, int64_t n, double vmin,
+                           double nfmax, double *Rf, double *Rs, double *Rd, double tol,
+                           const double consts[4]);
+/* fragmentation_methods.py:305-319: Ec[i] = 1 where dl[i] < 0.4 mm */
+int sdm_ll82_coalescence_check(sdm_ctx *ctx, double *Ec, const double *dl, int64_t n);
+
 /* ---- f-1 moments, PySDM/backends/impl_numba/methods/moments_methods.py:14-99 ------------ */
 int sdm_moments(sdm_ctx *ctx, double *moment_0, double *moments, const int64_t *multiplicity,
                 const double *attr_data, const int64_t *cell_id, const int64_t *idx,

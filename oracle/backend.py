@@ -368,6 +368,21 @@ class OracleBackend(BackendMethods):  # pylint: disable=too-many-public-methods
             _p(rand.data), _i64(len(frag_volume.data)))
         self._limiters(n_fragment, frag_volume, x_plus_y, vmin, nfmax)
 
+    def ll82_fragmentation(self, *, n_fragment, CKE, W, W2, St, ds, dl, dcoal, frag_volume,
+                           x_plus_y, rand, vmin, nfmax, Rf, Rs, Rd, tol=1e-8):
+        const = self.formulae.constants
+        consts = np.asarray([const.CM, const.PI, const.VEDDER_1987_A, const.VEDDER_1987_b],
+                            dtype=np.float64)
+        lib().oracle_ll82_fragmentation(
+            _p(CKE.data), _p(W.data), _p(W2.data), _p(St.data), _p(ds.data), _p(dl.data),
+            _p(dcoal.data), _p(frag_volume.data), _p(rand.data), _p(Rf.data), _p(Rs.data),
+            _p(Rd.data), _i64(len(frag_volume.data)), _f64(tol), _p(consts))
+        self._limiters(n_fragment, frag_volume, x_plus_y, vmin, nfmax)
+
+    @staticmethod
+    def ll82_coalescence_check(*, Ec, dl):
+        lib().oracle_ll82_coalescence_check(_p(Ec.data), _p(dl.data), _i64(len(Ec.data)))
+
     def straub_fragmentation(self, *, n_fragment, CW, gam, ds, frag_volume, v_max, x_plus_y, rand,
                              vmin, nfmax, Nr1, Nr2, Nr3, Nr4, Nrt, d34):
         n = len(frag_volume.data)

@@ -641,6 +641,210 @@ API void oracle_feingold1988_fragmentation(double scale, double *frag_volume,
   }
 }
 
+
+/* Python's max(a, b) = b if b > a else a ; min(a, b) = b if b < a else a */
+#define PYMAX(a, b) ((b) > (a) ? (b) : (a))
+#define PYMIN(a, b) ((b) < (a) ? (b) : (a))
+#define LL_PI 3.141592653589793
+
+/* Low & List 1982 fragment-size parameters, PySDM/physics/fragmentation_function/lowlist82.py
+ * (each returns H, mu, sigma in cm units; the fixed-point loops run 10 rounds as there) */
+struct LL82P { double H, mu, sigma; };
+
+static struct LL82P ll82_gauss_fixed_point(double H, double mu, double upper) {
+  /* :22-30, :108-116, :150-158: sigma <- sqrt(2/pi)/H / (1 + erf((upper - mu)/(sqrt2 sigma))) */
+  double sigma = 1 / H;
+  for (int r = 0; r < 10; ++r)
+    sigma = 1 / H * sqrt(2 / LL_PI) / (1 + erf((upper - mu) / (sqrt(2.0) * sigma)));
+  struct LL82P p = {H, mu, sigma};
+  return p;
+}
+
+static struct LL82P ll82_f1(double CM, double dl, double dcoal) { /* :15-30 */
+  const double dlCM = dl / CM;
+  return ll82_gauss_fixed_point(50.8 * pow(dlCM, -0.718), dlCM, dcoal / CM);
+}
+
+static struct LL82P ll82_f2(double CM, double ds) { /* :33-38 */
+  const double dsCM = ds / CM;
+  const double H = 4.18 * pow(dsCM, -1.17);
+  struct LL82P p = {H, dsCM, 1 / (sqrt(2 * LL_PI) * H)};
+  return p;
+}
+
+static struct LL82P ll82_f3(double CM, double ds, double dl) { /* :41-98 */
+  const double dsCM = ds / CM, dlCM = dl / CM;
+  double Ff1 = (-2.25e4 * pow(dlCM - 0.403, 2.0) - 37.9) * pow(dsCM, 2.5) +
+               9.67 * pow(dlCM - 0.170, 2.0) + 4.95;
+  Ff1 = PYMAX(0.0, Ff1);
+  const double Ff2 = 1.02e4 * pow(dsCM, 2.83) + 2;
+  const double ds0 = PYMAX(0.04, pow(Ff1 / 2.83, 1 / 1.02e4));
+  const double Ff = dsCM > ds0 ? PYMAX(2.0, Ff1) : PYMAX(2.0, Ff2);
+  const double Dff3 = 0.241 * dsCM + 0.0129;
+  const double Pf301 = 1.68e5 * pow(dsCM, 2.33);
+  const double Pf302 = PYMAX(0.0, (43.4 * pow(dlCM + 1.81, 2.0) - 159.0) / dsCM -
+                                      3870 * pow(dlCM - 0.285, 2.0) - 58.1);
+  const double alpha = (dsCM - ds0) / (0.2 * ds0);
+  const double Pf303 = alpha * Pf301 + (1 - alpha) * Pf302;
+  const double Pf0 = dsCM < ds0 ? Pf301 : (dsCM > 1.2 * ds0 ? Pf302 : Pf303);
+  double sigma = 10 * Dff3;
+  double mu = log(Dff3) + sigma * sigma;
+  double H = Pf0 * Dff3 / exp(-0.5 * (sigma * sigma));
+  for (int r = 0; r < 10; ++r) {
+    if (sigma == 0.0 || H == 0) {
+      struct LL82P z = {0.0, log(ds0), log(ds0)};
+      return z;
+    }
+    sigma = sqrt(2 / LL_PI) * (Ff - 2) / H / (1 - erf((log(0.01) - mu) / sqrt(2.0) / sigma));
+    mu = log(Dff3) + sigma * sigma;
+    H = Pf0 * Dff3 / exp(-0.5 * (sigma * sigma));
+  }
+  struct LL82P p = {H, mu, sigma};
+  return p;
+}
+
+static struct LL82P ll82_s1(double CM, double dl, double ds, double dcoal) { /* :100-116 */
+  return ll82_gauss_fixed_point(100 * exp(-3.25 * (ds / CM)), dl / CM, dcoal / CM);
+}
+
+static struct LL82P ll82_s2(double CM, double dl, double ds, double St) { /* :118-143 */
+  const double dsCM = ds / CM, dlCM = dl / CM;
+  const double Dss2 = 0.254 * pow(dsCM, 0.413) * exp(3.53 * pow(dsCM, 2.51) * (dlCM - dsCM));
+  const double bstar = 14.2 * exp(-17.2 * dsCM);
+  const double Ps20 = 0.23 * pow(dsCM, -3.93) * pow(dlCM, bstar);
+  double sigma = 10 * Dss2;
+  double mu = log(Dss2) + sigma * sigma;
+  double H = Ps20 * Dss2 / exp(-0.5 * (sigma * sigma));
+  const double Fs = 5 * erf((St - 2.52e-6) / (1.85e-6)) + 6;
+  for (int r = 0; r < 10; ++r) {
+    sigma = sqrt(2 / LL_PI) * (Fs - 1) / H / (1 - erf((log(0.01) - mu) / sqrt(2.0) / sigma));
+    mu = log(Dss2) + sigma * sigma;
+    H = Ps20 * Dss2 / exp(-0.5 * (sigma * sigma));
+  }
+  struct LL82P p = {H, mu, sigma};
+  return p;
+}
+
+static struct LL82P ll82_d1(double CM, double W1, double dl, double dcoal, double CKE) {
+  /* :145-160 */
+  const double mu = (dl / CM) * (1 - exp(-3.70 * (3.10 - W1)));
+  return ll82_gauss_fixed_point(1.58e-5 * pow(CKE, -1.22), mu, dcoal / CM);
+}
+
+static struct LL82P ll82_d2(double CM, double ds, double dl, double CKE) { /* :162-193 */
+  const double dsCM = ds / CM, dlCM = dl / CM;
+  const double Ddd2 = exp(-17.4 * dsCM - 0.671 * (dlCM - dsCM)) * dsCM;
+  const double bstar = 0.007 * pow(dsCM, -2.54);
+  const double Pd20 = 0.0884 * pow(dsCM, -2.52) * pow(dlCM - dsCM, bstar);
+  double sigma = 10 * Ddd2;
+  double mu = log(Ddd2) + sigma * sigma;
+  double H = Pd20 * Ddd2 / exp(-0.5 * (sigma * sigma));
+  const double Fd = PYMAX(1.0, 297.5 + 23.7 * log(CKE));
+  struct LL82P z = {0.0, log(Ddd2), log(Ddd2)};
+  if (Fd == 1.0) return z;
+  for (int r = 0; r < 10; ++r) {
+    if (sigma == 0.0 || H <= 0.1) return z;
+    if (sigma >= 1.0) return z;
+    sigma = sqrt(2 / LL_PI) * (Fd - 1) / H / (1 - erf((log(0.01) - mu) / sqrt(2.0) / sigma));
+    mu = log(Ddd2) + sigma * sigma;
+    H = Pd20 * Ddd2 / exp(-0.5 * (sigma * sigma));
+  }
+  struct LL82P p = {H, mu, sigma};
+  return p;
+}
+
+/* one pair of fragmentation_methods.py:379-474 (+ ll82_Nr :51-72); *rand, *Rf, *Rs, *Rd are
+ * updated in place as the reference does; K = {CM, PI, VEDDER_1987_A, VEDDER_1987_b} */
+static double ll82_fragment_volume(double CKE, double W, double W2, double St, double ds, double dl,
+                                 double dcoal, double *rand, double *Rf, double *Rs, double *Rd,
+                                 double tol, const double *K) {
+  const double CM = K[0], PI = K[1], VA = K[2], Vb = K[3];
+  if (dl <= 0.4e-3) return pow(dcoal, 3.0) * PI / 6;
+  if (ds == 0.0 || dl == 0.0) return 1e-18;
+  *Rf = CKE >= 0.893e-6 ? 1.11e-4 * pow(CKE, -0.654) : 1.0;
+  *Rs = W >= 0.86 ? 0.685 * (1 - exp(-1.63 * (W2 - 0.86))) : 0.0;
+  *Rd = (*Rs + *Rf) > 1.0 ? 0.0 : 1.0 - *Rs - *Rf;
+  double d;  /* fragment diameter in cm */
+  if (*rand <= *Rf) {  /* filament breakup */
+    const struct LL82P p1 = ll82_f1(CM, dl, dcoal), p2 = ll82_f2(CM, ds), p3 = ll82_f3(CM, ds, dl);
+    const double H1 = p1.H * p1.mu, H2 = p2.H * p2.mu, H3 = p3.H * exp(p3.mu);
+    const double Hsum = H1 + H2 + H3;
+    *rand = *rand / *Rf;
+    if (*rand <= H1 / Hsum) {
+      const double X = PYMAX(*rand * Hsum / H1, tol);
+      d = p1.mu + sqrt(2.0) * p1.sigma * erfinv_approx(2 * X - 1, VA, Vb);
+    } else if (*rand <= (H1 + H2) / Hsum) {
+      const double X = (*rand * Hsum - H1) / H2;
+      d = p2.mu + sqrt(2.0) * p2.sigma * erfinv_approx(2 * X - 1, VA, Vb);
+    } else {
+      const double X = PYMIN((*rand * Hsum - H1 - H2) / H3, 1.0 - tol);
+      d = exp(p3.mu + sqrt(2.0) * p3.sigma * erfinv_approx(2 * X - 1, VA, Vb));
+    }
+  } else if (*rand <= *Rf + *Rs) {  /* sheet breakup */
+    const struct LL82P p1 = ll82_s1(CM, dl, ds, dcoal), p2 = ll82_s2(CM, dl, ds, St);
+    const double H1 = p1.H * p1.mu, H2 = p2.H * exp(p2.mu);
+    const double Hsum = H1 + H2;
+    *rand = (*rand - *Rf) / (*Rs);
+    if (*rand <= H1 / Hsum) {
+      const double X = PYMAX(*rand * Hsum / H1, tol);
+      d = p1.mu + sqrt(2.0) * p1.sigma * erfinv_approx(2 * X - 1, VA, Vb);
+    } else {
+      const double X = PYMIN((*rand * Hsum - H1) / H2, 1.0 - tol);
+      d = exp(p2.mu + sqrt(2.0) * p2.sigma * erfinv_approx(2 * X - 1, VA, Vb));
+    }
+  } else {  /* disk breakup */
+    const struct LL82P p1 = ll82_d1(CM, W, dl, dcoal, CKE), p2 = ll82_d2(CM, ds, dl, CKE);
+    const double H1 = p1.H * p1.mu, H2 = p2.H;
+    const double Hsum = H1 + H2;
+    *rand = (*rand - *Rf - *Rs) / *Rd;
+    if (*rand <= H1 / Hsum) {
+      const double X = PYMAX(*rand * Hsum / H1, tol);
+      d = p1.mu + sqrt(2.0) * p1.sigma * erfinv_approx(2 * X - 1, VA, Vb);
+    } else {
+      const double X = PYMIN((*rand * Hsum - H1) / H2, 1 - tol);
+      d = exp(p2.mu + sqrt(2.0) * p2.sigma * erfinv_approx(2 * X - 1, VA, Vb));
+    }
+  }
+  d = d * 0.01;  /* cm -> m */
+  return pow(d, 3.0) * PI / 6;
+}
+
+/* fragmentation_methods.py:379-474 */
+API void oracle_ll82_fragmentation(const double *CKE, const double *W, const double *W2,
+                                   const double *St, const double *ds, const double *dl,
+                                   const double *dcoal, double *frag_volume, double *rand,
+                                   double *Rf, double *Rs, double *Rd, int64_t n, double tol,
+                                   const double *consts) {
+  for (int64_t i = 0; i < n; ++i)
+    frag_volume[i] = ll82_fragment_volume(CKE[i], W[i], W2[i], St[i], ds[i], dl[i], dcoal[i],
+                                          &rand[i], &Rf[i], &Rs[i], &Rd[i], tol, consts);
+}
+
+/* test hook: the seven parameter triples of lowlist82.py, selected by name index
+ * 0 f1(dl,dcoal) 1 f2(ds) 2 f3(ds,dl) 3 s1(dl,ds,dcoal) 4 s2(dl,ds,St) 5 d1(W1,dl,dcoal,CKE)
+ * 6 d2(ds,dl,CKE) -- pinned by tests/unit_tests/physics/test_fragmentation_functions.py:76-173 */
+API void oracle_ll82_params(int which, double a, double b, double c, double d, double CM,
+                            double *out) {
+  struct LL82P p = {0, 0, 0};
+  switch (which) {
+    case 0: p = ll82_f1(CM, a, b); break;
+    case 1: p = ll82_f2(CM, a); break;
+    case 2: p = ll82_f3(CM, a, b); break;
+    case 3: p = ll82_s1(CM, a, b, c); break;
+    case 4: p = ll82_s2(CM, a, b, c); break;
+    case 5: p = ll82_d1(CM, a, b, c, d); break;
+    case 6: p = ll82_d2(CM, a, b, c); break;
+    default: break;
+  }
+  out[0] = p.H; out[1] = p.mu; out[2] = p.sigma;
+}
+
+/* fragmentation_methods.py:305-319 */
+API void oracle_ll82_coalescence_check(double *Ec, const double *dl, int64_t n) {
+  for (int64_t i = 0; i < n; ++i)
+    if (dl[i] < 0.4e-3) Ec[i] = 1.0;
+}
+
 /* :98-112 slams */
 API void oracle_slams_fragmentation(double *n_fragment, double *frag_volume,
                                     const double *x_plus_y, double *probs, const double *rand,

@@ -353,6 +353,21 @@ class HIP(BackendMethods):  # pylint: disable=too-many-public-methods
               c_i64(frag_volume.data.numel()), c_f64(vmin),
               c_f64(-1.0 if nfmax is None else nfmax))
 
+    def ll82_fragmentation(self, *, n_fragment, CKE, W, W2, St, ds, dl, dcoal, frag_volume,
+                           x_plus_y, rand, vmin, nfmax, Rf, Rs, Rd, tol=1e-8):
+        const = self.formulae.constants
+        _call("sdm_ll82_fragmentation", _ptr(n_fragment.data), _ptr(CKE.data), _ptr(W.data),
+              _ptr(W2.data), _ptr(St.data), _ptr(ds.data), _ptr(dl.data), _ptr(dcoal.data),
+              _ptr(frag_volume.data), _ptr(x_plus_y.data), _ptr(rand.data),
+              c_i64(frag_volume.data.numel()), c_f64(vmin),
+              c_f64(-1.0 if nfmax is None else nfmax), _ptr(Rf.data), _ptr(Rs.data),
+              _ptr(Rd.data), c_f64(tol),
+              (c_f64 * 4)(const.CM, const.PI, const.VEDDER_1987_A, const.VEDDER_1987_b))
+
+    @staticmethod
+    def ll82_coalescence_check(*, Ec, dl):
+        _call("sdm_ll82_coalescence_check", _ptr(Ec.data), _ptr(dl.data), c_i64(Ec.data.numel()))
+
     def straub_consts(self):
         const = self.formulae.constants
         return (c_f64 * 6)(const.CM, const.STRAUB_E_D1, const.STRAUB_MU2, const.VEDDER_1987_A,

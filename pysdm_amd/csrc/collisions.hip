@@ -720,6 +720,64 @@ extern "C" int sdm_slams_fragmentation(sdm_ctx *ctx, double *n_fragment, double 
   return SDM_OK;
 }
 
+struct LL82Consts { double k[4]; };
+
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_ll82_fragmentation(double *__restrict__ n_fragment, const double *__restrict__ CKE,
+                     const double *__restrict__ W, const double *__restrict__ W2,
+                     const double *__restrict__ St, const double *__restrict__ ds,
+                     const double *__restrict__ dl, const double *__restrict__ dcoal,
+                     double *__restrict__ frag_volume, const double *__restrict__ x_plus_y,
+                     double *__restrict__ rand, int64_t n, double vmin, double nfmax,
+                     double *__restrict__ Rf, double *__restrict__ Rs, double *__restrict__ Rd,
+                     double tol, LL82Consts K) {
+  const int64_t i = TID();
+  if (i >= n) return;
+  double r = rand[i], rf = Rf[i], rs = Rs[i], rd = Rd[i];
+  double fv = ll82_fragment_volume(CKE[i], W[i], W2[i], St[i], ds[i], dl[i], dcoal[i], &r, &rf,
+                                   &rs, &rd, tol, K.k);
+  rand[i] = r; Rf[i] = rf; Rs[i] = rs; Rd[i] = rd;
+  double nf;
+  fragmentation_limiters(nf, fv, vmin, nfmax, x_plus_y[i]);
+  frag_volume[i] = fv;
+  n_fragment[i] = nf;
+}
+
+extern "C" int sdm_ll82_fragmentation(sdm_ctx *ctx, double *n_fragment, const double *CKE,
+                                      const double *W, const double *W2, const double *St,
+                                      const double *ds, const double *dl, const double *dcoal,
+                                      double *frag_volume, const double *x_plus_y, double *rand,
+                                      int64_t n, double vmin, double nfmax, double *Rf,
+                                      double *Rs, double *Rd, double tol,
+                                      const double consts[4]) {
+  ARG_TRY(ctx && n >= 0 && consts);
+  if (n == 0) return SDM_OK;
+  ARG_TRY(n_fragment && CKE && W && W2 && St && ds && dl && dcoal && frag_volume && x_plus_y &&
+          rand && Rf && Rs && Rd);
+  LL82Consts K;
+  memcpy(K.k, consts, sizeof(K.k));
+  hipLaunchKernelGGL(k_ll82_fragmentation, GRID1D(n), n_fragment, CKE, W, W2, St, ds, dl, dcoal,
+                     frag_volume, x_plus_y, rand, n, vmin, nfmax, Rf, Rs, Rd, tol, K);
+  LAUNCH_CHECK();
+  return SDM_OK;
+}
+
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_ll82_coalescence_check(double *__restrict__ Ec, const double *__restrict__ dl, int64_t n) {
+  const int64_t i = TID();
+  if (i < n && dl[i] < 0.4e-3) Ec[i] = 1.0;
+}
+
+extern "C" int sdm_ll82_coalescence_check(sdm_ctx *ctx, double *Ec, const double *dl,
+                                          int64_t n) {
+  ARG_TRY(ctx && n >= 0);
+  if (n == 0) return SDM_OK;
+  ARG_TRY(Ec && dl);
+  hipLaunchKernelGGL(k_ll82_coalescence_check, GRID1D(n), Ec, dl, n);
+  LAUNCH_CHECK();
+  return SDM_OK;
+}
+
 struct StraubConsts { double k[6]; };
 
 __global__ void __launch_bounds__(SDM_BLOCK)

@@ -311,6 +311,74 @@ class Straub2010Ec:
         return {"ec": 2, "needs_gk": True}
 
 
+def _ll82_surface_and_kinetic(arr, attrs, extensive, is_first_in_pair, const):
+    """Sc, St and CKE of a colliding pair as both Low & List classes compute them
+    (coalescence_efficiencies/lowlist1982.py:46-80, breakup_fragmentations/lowlist82.py:53-78);
+    `extensive` is "water mass" for Ec and "volume" for Nf"""
+    arr["Sc"].sum(attrs[extensive], is_first_in_pair)
+    arr["Sc"] **= 2 / 3
+    arr["Sc"] *= const.PI * const.sgm_w * (6 / const.PI) ** (2 / 3)
+    arr["St"].min(attrs["radius"], is_first_in_pair)
+    arr["St"] *= 2
+    arr["St"] **= 2
+    arr["tmp"].max(attrs["radius"], is_first_in_pair)
+    arr["tmp"] *= 2
+    arr["tmp"] **= 2
+    arr["St"] += arr["tmp"]
+    arr["St"] *= const.PI * const.sgm_w
+    arr["tmp"].sum(attrs[extensive], is_first_in_pair)
+    arr["tmp2"].distance(attrs["relative fall velocity"], is_first_in_pair)
+    arr["tmp2"] **= 2
+    arr["CKE"].multiply(attrs[extensive], is_first_in_pair)
+    arr["CKE"].divide_if_not_zero(arr["tmp"])
+    arr["CKE"] *= arr["tmp2"]
+    arr["CKE"] *= const.rho_w / 2
+
+
+class LowList1982Ec:  # coalescence_efficiencies/lowlist1982.py
+    def __init__(self):
+        self.particulator = None
+        self.arrays = {}
+        self.const = None
+
+    def register(self, builder):
+        self.particulator = builder.particulator
+        self.const = self.particulator.formulae.constants
+        builder.request_attribute("radius")
+        builder.request_attribute("water mass")
+        builder.request_attribute("relative fall velocity")
+        for key in ("Sc", "St", "dS", "tmp", "tmp2", "CKE", "Et", "ds", "dl"):
+            self.arrays[key] = self.particulator.PairwiseStorage.empty(
+                self.particulator.n_sd // 2, dtype=float
+            )
+
+    def __call__(self, output, is_first_in_pair):
+        arr, attrs = self.arrays, self.particulator.attributes
+        arr["ds"].min(attrs["radius"], is_first_in_pair)
+        arr["ds"] *= 2
+        arr["dl"].max(attrs["radius"], is_first_in_pair)
+        arr["dl"] *= 2
+        _ll82_surface_and_kinetic(arr, attrs, "water mass", is_first_in_pair, self.const)
+        arr["dS"].fill(arr["St"])
+        arr["dS"] -= arr["Sc"]
+        arr["Et"].fill(arr["CKE"])
+        arr["Et"] += arr["dS"]
+        a = 0.778
+        b = 2.61e6 / si.J**2 * si.m**2
+        arr["tmp2"].fill(arr["Et"])
+        arr["tmp2"] **= 2
+        arr["tmp2"] *= -1.0 * b * self.const.sgm_w
+        arr["tmp2"] /= arr["Sc"]
+        output.fill(arr["ds"])
+        output /= arr["dl"]
+        output += 1.0
+        output **= -2.0
+        output *= a
+        arr["tmp2"].exp()
+        output *= arr["tmp2"]
+        self.particulator.backend.ll82_coalescence_check(Ec=output, dl=arr["dl"])
+
+
 # ---- fragmentation functions ----------------------------------------------------------------
 class AlwaysN:
     def __init__(self, n):
@@ -451,6 +519,48 @@ class SLAMS(_SumOfVolumes):  # breakup_fragmentations/slams.py
         self.particulator.backend.slams_fragmentation(
             n_fragment=nf, frag_volume=frag_volume, x_plus_y=self._sum(is_first_in_pair),
             probs=self.p_vec, rand=u01, vmin=self.vmin, nfmax=self.nfmax,
+        )
+
+
+class LowList1982Nf(_SumOfVolumes):  # breakup_fragmentations/lowlist82.py
+    def __init__(self, vmin=0.0, nfmax=None):
+        super().__init__(vmin, nfmax)
+        self.arrays = {}
+        self.ll82_tmp = {}
+        self.const = None
+
+    def register(self, builder):
+        super().register(builder)
+        self.const = self.particulator.formulae.constants
+        builder.request_attribute("radius")
+        builder.request_attribute("relative fall velocity")
+        half = self.particulator.n_sd // 2
+        for key in ("Sc", "St", "tmp", "tmp2", "CKE", "We", "W2", "ds", "dl", "dcoal"):
+            self.arrays[key] = self.particulator.PairwiseStorage.empty(half, dtype=float)
+        for key in ("Rf", "Rs", "Rd"):
+            self.ll82_tmp[key] = self.particulator.PairwiseStorage.empty(half, dtype=float)
+
+    def compute_fragment_number_and_volumes(self, nf, frag_volume, u01, is_first_in_pair):
+        arr, attrs = self.arrays, self.particulator.attributes
+        arr["ds"].min(attrs["radius"], is_first_in_pair)
+        arr["ds"] *= 2
+        arr["dl"].max(attrs["radius"], is_first_in_pair)
+        arr["dl"] *= 2
+        arr["dcoal"].sum(attrs["volume"], is_first_in_pair)
+        arr["dcoal"] /= self.const.PI / 6
+        arr["dcoal"] **= 1 / 3
+        _ll82_surface_and_kinetic(arr, attrs, "volume", is_first_in_pair, self.const)
+        arr["We"].fill(arr["CKE"])
+        arr["W2"].fill(arr["CKE"])
+        arr["We"].divide_if_not_zero(arr["Sc"])
+        arr["W2"].divide_if_not_zero(arr["St"])
+        for key in ("Rf", "Rs", "Rd"):
+            self.ll82_tmp[key] *= 0.0
+        self.particulator.backend.ll82_fragmentation(
+            n_fragment=nf, CKE=arr["CKE"], W=arr["We"], W2=arr["W2"], St=arr["St"],
+            ds=arr["ds"], dl=arr["dl"], dcoal=arr["dcoal"], frag_volume=frag_volume,
+            x_plus_y=self._sum(is_first_in_pair), rand=u01, vmin=self.vmin, nfmax=self.nfmax,
+            Rf=self.ll82_tmp["Rf"], Rs=self.ll82_tmp["Rs"], Rd=self.ll82_tmp["Rd"],
         )
 
 

@@ -445,6 +445,12 @@ def gen_frag():
     eff.register(_Builder)
     eff(pw, flag)
     out["ec/specified"] = pw.to_ndarray()
+    from PySDM.dynamics.collisions.coalescence_efficiencies import LowList1982Ec
+
+    eff = LowList1982Ec()
+    eff.register(_Builder)
+    eff(pw, flag)
+    out["ec/lowlist1982"] = pw.to_ndarray()
 
     # fragmentations
     u01 = rng.uniform(0, 1, n_sd // 2)
@@ -468,7 +474,7 @@ def gen_frag():
         "straub_ss": Straub2010Nf(vmin=(0.01 * si.mm) ** 3 * np.pi / 6, nfmax=10000),
     }
     from PySDM.dynamics.collisions.breakup_fragmentations import (
-        ConstantMass, Feingold1988, Gaussian, SLAMS,
+        ConstantMass, Feingold1988, Gaussian, LowList1982Nf, SLAMS,
     )
 
     frag_cases.update({
@@ -481,15 +487,25 @@ def gen_frag():
         "feingold1988": Feingold1988(scale=formulae.trivia.volume(radius=40 * si.um)),
         "slams": SLAMS(),
         "slams_lim": SLAMS(vmin=formulae.trivia.volume(radius=5 * si.um), nfmax=5),
+        "lowlist": LowList1982Nf(),
+        "lowlist_lim": LowList1982Nf(vmin=formulae.trivia.volume(radius=5 * si.um), nfmax=50),
     })
+    lowlist_backend = CPU(Formulae(
+        terminal_velocity="GunnKinzer1949", fragmentation_function="LowList1982Nf"
+    ))
     feingold_backend = CPU(Formulae(
         terminal_velocity="GunnKinzer1949", fragmentation_function="Feingold1988"
     ))
     for name, frag in frag_cases.items():
         # Feingold's closed form lives in the formulae object the backend was built with
-        part.backend = feingold_backend if name.startswith("feingold") else backend
+        part.backend = (feingold_backend if name.startswith("feingold") else
+                        lowlist_backend if name.startswith("lowlist") else backend)
         frag.register(_Builder)
-        frag(nf, fm, u01_s, flag)
+        # Low & List rescales its random numbers in place: hand each case a fresh copy
+        frag(nf, fm, Storage.from_ndarray(u01.copy()), flag)
+        if name.startswith("lowlist"):
+            for key in ("Rf", "Rs", "Rd"):
+                out[f"frag/{name}/{key}"] = frag.ll82_tmp[key].to_ndarray()
         out[f"frag/{name}/nf"] = nf.to_ndarray()
         out[f"frag/{name}/mass"] = fm.to_ndarray()
         out[f"frag/{name}/vmin"] = np.asarray(getattr(frag, "vmin", 0.0))
@@ -783,8 +799,72 @@ def gen_shards():
         save(f"shard_golovin_4x4_r{rank}of{world}", **out)
 
 
+# ------------------------------------------------------------------------------------------
+# f-1: moments and spectrum_moments of the reference backend on a small multi-cell state
+# ------------------------------------------------------------------------------------------
+def gen_moments():
+    out = {}
+    rng = np.random.default_rng(2024)
+    backend = CPU(Formulae())
+    Index, IndexedStorage, _, _ = _storages(backend)
+    Storage = backend.Storage
+    n_sd, n_cell, length = 1200, 5, 1100
+    perm = rng.permutation(n_sd).astype(np.int64)
+    idx = Index.from_ndarray(perm)
+    idx.length = Storage.INT(length)
+    mult = rng.integers(1, 10**6, n_sd).astype(np.int64)
+    vol = np.exp(rng.uniform(np.log(1e-16), np.log(1e-10), n_sd))
+    mass = vol * 1000.0
+    cell = rng.integers(0, n_cell, n_sd).astype(np.int64)
+    out.update({"perm": perm, "mult": mult, "vol": vol, "mass": mass, "cell": cell,
+                "dims": np.asarray([n_sd, n_cell, length])})
+    common = {
+        "multiplicity": IndexedStorage.from_ndarray(idx, mult),
+        "cell_id": IndexedStorage.from_ndarray(idx, cell),
+        "idx": idx, "length": length,
+    }
+    ranks = np.array([0.0, 1.0, 2.0, 1 / 3, 3.0])
+    out["ranks"] = ranks
+    for tag, (lo, hi, wrank, skip) in {
+        "all": (-np.inf, np.inf, 0, False),
+        "range": (1e-14, 1e-11, 0, False),
+        "weighted": (1e-15, 1e-11, 1, False),
+        "skipdiv": (1e-14, 1e-11, 0, True),
+    }.items():
+        m0 = Storage.empty((n_cell,), dtype=float)
+        mom = Storage.empty((len(ranks), n_cell), dtype=float)
+        backend.moments(
+            moment_0=m0, moments=mom, attr_data=IndexedStorage.from_ndarray(idx, vol),
+            ranks=Storage.from_ndarray(ranks), min_x=lo, max_x=hi,
+            x_attr=IndexedStorage.from_ndarray(idx, vol),
+            weighting_attribute=IndexedStorage.from_ndarray(idx, mass), weighting_rank=wrank,
+            skip_division_by_m0=skip, **common,
+        )
+        out[f"moments/{tag}/args"] = np.asarray([lo, hi, wrank, int(skip)], dtype=float)
+        out[f"moments/{tag}/m0"] = m0.to_ndarray()
+        out[f"moments/{tag}/mom"] = mom.to_ndarray()
+    bins = np.exp(np.linspace(np.log(1e-15), np.log(2e-11), 33))
+    out["spectrum/bins"] = bins
+    for tag, (rank, wrank) in {"r1": (1.0, 0), "r0_w1": (0.0, 1), "r2": (2.0, 0)}.items():
+        m0 = Storage.empty((len(bins) - 1, n_cell), dtype=float)
+        mom = Storage.empty((len(bins) - 1, n_cell), dtype=float)
+        backend.spectrum_moments(
+            moment_0=m0, moments=mom, attr_data=IndexedStorage.from_ndarray(idx, vol),
+            rank=rank, x_bins=Storage.from_ndarray(bins),
+            x_attr=IndexedStorage.from_ndarray(idx, vol),
+            weighting_attribute=IndexedStorage.from_ndarray(idx, mass), weighting_rank=wrank,
+            **common,
+        )
+        out[f"spectrum/{tag}/args"] = np.asarray([rank, wrank], dtype=float)
+        out[f"spectrum/{tag}/m0"] = m0.to_ndarray()
+        out[f"spectrum/{tag}/mom"] = mom.to_ndarray()
+    save("moments", **out)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["micro", "frag", "traj", "breakup", "shards"]
+    what = sys.argv[1:] or ["micro", "frag", "traj", "breakup", "shards", "moments"]
+    if "moments" in what:
+        gen_moments()
     if "shards" in what:
         gen_shards()
     if "micro" in what:

@@ -185,6 +185,137 @@ def check_single_breakup_known_answers(kit):
             or gamma == 0
 
 
-ALL_CHECKS = (check_scale_prob_known_answers, check_adaptivity_paper_diagram,
+def _two_drop_setup(kit, component, volume, fragmentation_function=None, water_mass=None):
+    """the arrangement shared by the reference's component tests: two droplets, one pair
+    (tests/unit_tests/dynamics/collisions/test_fragmentations.py:44-71 and siblings)"""
+    from pysdm_amd.environments import Box  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.formulae import Formulae  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.particulator import Builder  # pylint: disable=import-outside-toplevel
+
+    kwargs = {} if fragmentation_function is None else {
+        "fragmentation_function": fragmentation_function}
+    n_sd = len(volume if volume is not None else water_mass)
+    builder = Builder(n_sd, kit.backend.__class__(Formulae(**kwargs)),
+                      environment=Box(dv=None, dt=None))
+    component.register(builder)
+    attributes = {"multiplicity": np.ones(n_sd)}
+    if volume is not None:
+        attributes["volume"] = np.asarray(volume)
+    else:
+        attributes["water mass"] = np.asarray(water_mass)
+    particulator = builder.build(attributes=attributes)
+    flag = particulator.PairIndicator(length=n_sd)
+    flag.indicator = particulator.Storage.from_ndarray(np.asarray([True, False]))
+    return particulator, flag
+
+
+UM3 = 1e-18  # si.um**3
+RHO_W = 1000.0
+
+
+def _fragmentation_classes():
+    from pysdm_amd.dynamics import collisions as C  # pylint: disable=import-outside-toplevel
+
+    return C
+
+
+def _run_fragmentation(kit, make, volume, u01=0.5, vmin=None):
+    sut = make()
+    if vmin is not None:
+        sut.vmin = vmin
+    particulator, flag = _two_drop_setup(kit, sut, volume, sut.__class__.__name__)
+    nf = particulator.PairwiseStorage.from_ndarray(np.zeros(1))
+    frag_mass = particulator.PairwiseStorage.from_ndarray(np.zeros(1))
+    rand = particulator.PairwiseStorage.from_ndarray(np.asarray([u01], dtype=float))
+    sut(nf, frag_mass, rand, flag)
+    return nf.to_ndarray(), frag_mass.to_ndarray()
+
+
+def check_reference_fragmentation_tests(kit):
+    """test_fragmentations.py:30-262 re-typed: call, vmin / vmax / nfmax limiters, and the
+    100-point sweep over u01 for two rain-size drops"""
+    C = _fragmentation_classes()
+    volume = np.asarray([440.0 * UM3, 6660.0 * UM3])
+    total = np.sum(volume) * RHO_W
+    # :30-84 call
+    for make in (lambda: C.AlwaysN(n=2), lambda: C.Exponential(scale=1e6 * UM3),
+                 lambda: C.Feingold1988(scale=1e6 * UM3),
+                 lambda: C.Gaussian(mu=2e6 * UM3, sigma=1e6 * UM3), C.SLAMS, C.Straub2010Nf,
+                 C.LowList1982Nf):
+        nf, frag_mass = _run_fragmentation(kit, make, volume, vmin=1 * UM3)
+        assert (nf > 0.99).all() and (frag_mass > 0).all()
+        np.testing.assert_approx_equal(nf[0] * frag_mass[0], total)
+    # :86-146 vmin limiter: one fragment holding all the mass
+    for make in (lambda: C.Exponential(scale=1 * UM3, vmin=6660.0 * UM3),
+                 lambda: C.Feingold1988(scale=1 * UM3, vmin=6660.0 * UM3),
+                 lambda: C.Gaussian(mu=2 * UM3, sigma=1 * UM3, vmin=6660.0 * UM3),
+                 lambda: C.SLAMS(vmin=6660.0 * UM3), lambda: C.Straub2010Nf(vmin=6660.0 * UM3)):
+        nf, frag_mass = _run_fragmentation(kit, make, volume)
+        np.testing.assert_array_equal([1.0], nf)
+        np.testing.assert_array_equal([(6660.0 + 440.0) * UM3 * RHO_W], frag_mass)
+    # :148-204 vmax limiter
+    for make in (lambda: C.Exponential(scale=1.0 * 1e-6), lambda: C.Feingold1988(scale=1.0 * 1e-6),
+                 lambda: C.Gaussian(mu=1.0 * 1e-6, sigma=1e6 * UM3), C.SLAMS, C.Straub2010Nf):
+        nf, frag_mass = _run_fragmentation(kit, make, volume, vmin=1 * UM3)
+        assert (nf > 0.999).all()
+        assert (frag_mass < (6661.0 + 440.0) * UM3 * RHO_W).all()
+        np.testing.assert_approx_equal(nf[0] * frag_mass[0], total)
+    # :206-262 nfmax limiter
+    for make in (lambda: C.Exponential(scale=1.0 * UM3, nfmax=2),
+                 lambda: C.Feingold1988(scale=1.0 * UM3, nfmax=2),
+                 lambda: C.Gaussian(mu=1.0 * UM3, sigma=1e6 * UM3, nfmax=2),
+                 lambda: C.SLAMS(nfmax=2), lambda: C.Straub2010Nf(nfmax=2)):
+        nf, frag_mass = _run_fragmentation(kit, make, volume, vmin=1 * UM3)
+        assert (nf < 2.0 + 1e-6).all()
+        assert (frag_mass > ((6660.0 + 440.0) / 2 - 1) * UM3).all()
+        np.testing.assert_approx_equal(nf[0] * frag_mass[0], total)
+    # :264-340 distribution sweep (4 mm and 2 mm drops)
+    rain = np.asarray([(4 / 3) * np.pi * (0.2e-2 / 2) ** 3, (4 / 3) * np.pi * (0.4e-2 / 2) ** 3])
+    for make in (lambda: C.Exponential(scale=1e6 * UM3), lambda: C.Gaussian(mu=2e6 * UM3,
+                                                                            sigma=1e6 * UM3),
+                 C.SLAMS, C.Straub2010Nf, C.LowList1982Nf):
+        for rn in np.linspace(1e-6, 1 - 1e-6, 25):
+            nf, frag_mass = _run_fragmentation(kit, make, rain, u01=rn, vmin=1 * UM3)
+            assert (nf > 0.99).all() and (frag_mass > 0).all(), (make().__class__.__name__, rn)
+            np.testing.assert_approx_equal(nf[0] * frag_mass[0], np.sum(rain) * RHO_W)
+    # :342-400 nf and fragment mass of ConstantMass / AlwaysN
+    for make in (lambda: C.ConstantMass(c=4 * UM3), lambda: C.AlwaysN(n=250)):
+        sut = make()
+        water_mass = np.asarray([400.0 * UM3, 600.0 * UM3])
+        particulator, flag = _two_drop_setup(kit, sut, None, water_mass=water_mass)
+        nf = particulator.PairwiseStorage.from_ndarray(np.zeros(1))
+        frag_mass = particulator.PairwiseStorage.from_ndarray(np.zeros(1))
+        rand = particulator.PairwiseStorage.from_ndarray(np.asarray([0.5]))
+        sut(nf, frag_mass, rand, flag)
+        np.testing.assert_array_equal(nf.to_ndarray(), [250])
+        np.testing.assert_array_almost_equal(frag_mass.to_ndarray(), [np.sum(water_mass) / 250])
+
+
+def check_reference_efficiency_and_kernel_tests(kit):
+    """test_efficiencies.py:21-56 (values in [0, 1]) and test_kernels.py:32-89 (SimpleGeometric
+    zero for C = 0 and for equal sizes, positive otherwise)"""
+    C = _fragmentation_classes()
+    volume = np.asarray([440.0 * UM3, 6660.0 * UM3])
+    for sut in (C.Berry1967(), C.ConstEc(Ec=0.5), C.SpecifiedEff(A=0.8, B=0.6), C.Straub2010Ec(),
+                C.LowList1982Ec(), C.ConstEb(Eb=0.3)):
+        particulator, flag = _two_drop_setup(kit, sut, volume)
+        eff = particulator.PairwiseStorage.from_ndarray(np.asarray([-1.0]))
+        sut(eff, flag)
+        values = eff.to_ndarray()
+        assert np.min(values) >= 0 and np.max(values) <= 1, sut.__class__.__name__
+    for c_value, vol, positive in ((0.0, [44.0, 666.0], False), (1.0, [44.0, 666.0], True),
+                                   (1.0, [1.0, 2.0], True), (1.0, [1.0, 1.0], False)):
+        sut = C.SimpleGeometric(C=c_value)
+        particulator, flag = _two_drop_setup(kit, sut, np.asarray(vol))
+        output = particulator.PairwiseStorage.from_ndarray(np.zeros(1))
+        sut(output, is_first_in_pair=flag)
+        if positive:
+            assert (output.to_ndarray() > 0).all()
+        else:
+            np.testing.assert_array_equal(output.to_ndarray(), [0.0])
+
+
+ALL_CHECKS = (check_reference_fragmentation_tests, check_reference_efficiency_and_kernel_tests,
+              check_scale_prob_known_answers, check_adaptivity_paper_diagram,
               check_gamma_formula_grid, check_same_multiplicity_split,
               check_single_breakup_known_answers)
