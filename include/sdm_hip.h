@@ -188,6 +188,31 @@ int sdm_ll82_fragmentation(sdm_ctx *ctx, double *n_fragment, const double *CKE, 
 /* fragmentation_methods.py:305-319: Ec[i] = 1 where dl[i] < 0.4 mm */
 int sdm_ll82_coalescence_check(sdm_ctx *ctx, double *Ec, const double *dl, int64_t n);
 
+/* ---- f-3 displacement, PySDM/backends/impl_numba/methods/displacement_methods.py ---------- */
+/* :14-129: displacement[dim, :] from the Arakawa-C Courant field of direction `dim` (shape =
+ * grid with one more point along dim; row-major) interpolated to the SD's position in its cell;
+ * scheme 0 = ImplicitInSpace, 1 = ExplicitInSpace (physics/particle_advection/);
+ * displacement, cell_origin, position_in_cell are (n_dims, n_sd) row-major                     */
+int sdm_calculate_displacement(sdm_ctx *ctx, int dim, int n_dims, int scheme,
+                               double *displacement, const double *courant,
+                               const int64_t *courant_shape, const int64_t *cell_origin,
+                               const double *position_in_cell, int64_t n_sd, double n_substeps);
+/* :131-166,192-218: SDs moving down through `level` (in cells, along the last dimension) get
+ * idx[i] = n_sd and healthy[0] = 0; *rainfall_mass (host) = sum |m| * n over them; syncs        */
+int sdm_flag_precipitated(sdm_ctx *ctx, const int64_t *cell_origin,
+                          const double *position_in_cell, const double *water_mass,
+                          const int64_t *multiplicity, int64_t *idx, int64_t length,
+                          int64_t n_sd, int n_dims, int64_t *healthy, double level,
+                          const double *displacement, double *rainfall_mass);
+/* :168-190,220-238: SDs below 0 or above `top` along the last dimension are flagged out         */
+int sdm_flag_out_of_column(sdm_ctx *ctx, const int64_t *cell_origin,
+                           const double *position_in_cell, int64_t *idx, int64_t length,
+                           int64_t n_sd, int n_dims, int64_t *healthy, double top);
+/* Storage.floor(other) into an int64 storage and float -= int64 (storage_impl.py:44-47 and
+ * storage.py:76-78 as used by dynamics/displacement.py:146-150)                                */
+int sdm_floor_to_i64(sdm_ctx *ctx, int64_t *out, const double *a, int64_t n);
+int sdm_subtract_i64(sdm_ctx *ctx, double *out, const int64_t *b, int64_t n);
+
 /* ---- f-1 moments, PySDM/backends/impl_numba/methods/moments_methods.py:14-99 ------------ */
 int sdm_moments(sdm_ctx *ctx, double *moment_0, double *moments, const int64_t *multiplicity,
                 const double *attr_data, const int64_t *cell_id, const int64_t *idx,

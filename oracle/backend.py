@@ -401,6 +401,37 @@ class OracleBackend(BackendMethods):  # pylint: disable=too-many-public-methods
             _f64(-1.0 if nfmax is None else nfmax), _p(x_plus_y.data),
         )
 
+    # ---- displacement (displacement_methods.py) --------------------------------------------------
+    def calculate_displacement(self, *, dim, displacement, courant, cell_origin, position_in_cell,
+                               n_substeps):
+        n_dims = len(courant.shape)
+        if n_dims not in (1, 2, 3):
+            raise NotImplementedError()
+        shape = np.asarray(courant.shape, dtype=np.int64)
+        lib().oracle_calculate_displacement(
+            _int(dim), _int(n_dims), _int(self.formulae.particle_advection.scheme_id),
+            _p(displacement.data), _p(courant.data), _p(shape), _p(cell_origin.data),
+            _p(position_in_cell.data), _i64(displacement.shape[1]), _f64(n_substeps))
+
+    @staticmethod
+    def flag_precipitated(*, cell_origin, position_in_cell, water_mass, multiplicity, idx, length,
+                          healthy, precipitation_counting_level_index, displacement) -> float:
+        fun = lib().oracle_flag_precipitated
+        fun.restype = ctypes.c_double
+        return fun(
+            _p(cell_origin.data), _p(position_in_cell.data), _p(water_mass.data),
+            _p(multiplicity.data), _p(idx.data), _i64(int(length)), _i64(len(idx.data)),
+            _int(cell_origin.shape[0]), _p(healthy.data),
+            _f64(precipitation_counting_level_index), _p(displacement.data))
+
+    @staticmethod
+    def flag_out_of_column(cell_origin, position_in_cell, idx, length, healthy,
+                           domain_top_level_index):
+        lib().oracle_flag_out_of_column(
+            _p(cell_origin.data), _p(position_in_cell.data), _p(idx.data), _i64(int(length)),
+            _i64(len(idx.data)), _int(cell_origin.shape[0]), _p(healthy.data),
+            _f64(domain_top_level_index))
+
     # ---- moments ------------------------------------------------------------------------------
     @staticmethod
     def moments(*, moment_0, moments, multiplicity, attr_data, cell_id, idx, length, ranks, min_x,

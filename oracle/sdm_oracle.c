@@ -929,6 +929,66 @@ API void oracle_straub_fragmentation(const double *CW, const double *gam, const 
 }
 
 /* ------------------------------------------------------------------------------------------
+ * f-3  displacement, PySDM/backends/impl_numba/methods/displacement_methods.py
+ * ---------------------------------------------------------------------------------------- */
+/* :14-129 + physics/particle_advection/{implicit,explicit}_in_space.py: Arakawa-C Courant
+ * numbers left and right of the droplet in direction `dim`, interpolated to its position.
+ * courant has the grid's shape with one more point along `dim`; scheme 0 implicit, 1 explicit */
+API void oracle_calculate_displacement(int dim, int n_dims, int scheme, double *displacement,
+                                       const double *courant, const int64_t *courant_shape,
+                                       const int64_t *cell_origin, const double *position_in_cell,
+                                       int64_t n_sd, double n_substeps) {
+  for (int64_t droplet = 0; droplet < n_sd; ++droplet) {
+    int64_t l = 0, r = 0;
+    for (int d = 0; d < n_dims; ++d) {
+      const int64_t o = cell_origin[d * n_sd + droplet];
+      l = l * courant_shape[d] + o;
+      r = r * courant_shape[d] + o + (d == dim);
+    }
+    const double x = position_in_cell[dim * n_sd + droplet];
+    const double c_l = courant[l] / n_substeps, c_r = courant[r] / n_substeps;
+    double v = c_l * (1 - x) + c_r * x;
+    if (scheme == 0) v = v / (1 - c_r + c_l);
+    displacement[dim * n_sd + droplet] = v;
+  }
+}
+
+/* :131-166, :192-218: SDs that fall through the counting level are flagged out (idx = n_sd),
+ * returns the mass of water they carried (summed in idx order) */
+API double oracle_flag_precipitated(const int64_t *cell_origin, const double *position_in_cell,
+                                    const double *water_mass, const int64_t *multiplicity,
+                                    int64_t *idx, int64_t length, int64_t n_sd, int n_dims,
+                                    int64_t *healthy, double level, const double *displacement) {
+  double rainfall_mass = 0.0;
+  const int64_t last = (int64_t)(n_dims - 1) * n_sd;
+  for (int64_t i = 0; i < length; ++i) {
+    const int64_t k = idx[i];
+    const double z = (double)cell_origin[last + k] + position_in_cell[last + k];
+    if (displacement[last + k] < 0 && z < level) {
+      rainfall_mass += fabs(water_mass[k]) * (double)multiplicity[k];
+      idx[i] = n_sd;
+      healthy[0] = 0;
+    }
+  }
+  return rainfall_mass;
+}
+
+/* :168-190, :220-238 */
+API void oracle_flag_out_of_column(const int64_t *cell_origin, const double *position_in_cell,
+                                   int64_t *idx, int64_t length, int64_t n_sd, int n_dims,
+                                   int64_t *healthy, double top) {
+  const int64_t last = (int64_t)(n_dims - 1) * n_sd;
+  for (int64_t i = 0; i < length; ++i) {
+    const int64_t k = idx[i];
+    const double z = (double)cell_origin[last + k] + position_in_cell[last + k];
+    if (z < 0 || z > top) {
+      idx[i] = n_sd;
+      healthy[0] = 0;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
  * f-1  moments, PySDM/backends/impl_numba/methods/moments_methods.py:14-99 (serial order)
  * ---------------------------------------------------------------------------------------- */
 API void oracle_moments(double *moment_0, double *moments, const int64_t *multiplicity,

@@ -99,6 +99,14 @@ class CellOrigin(CellAttribute):
         )
 
 
+class PositionInCell(CellAttribute):  # PySDM/attributes/numerics/position_in_cell.py
+    def __init__(self, builder):
+        super().__init__(
+            builder, name="position in cell", dtype=float,
+            n_vector_components=builder.particulator.mesh.dim,
+        )
+
+
 class SignedWaterMass(ExtensiveAttribute):
     def __init__(self, builder):
         super().__init__(builder, name="signed water mass")
@@ -168,6 +176,7 @@ ATTRIBUTE_CLASSES = {
     "multiplicity": Multiplicity,
     "cell id": CellId,
     "cell origin": CellOrigin,
+    "position in cell": PositionInCell,
     "signed water mass": SignedWaterMass,
     "water mass": WaterMass,
     "volume": Volume,
@@ -322,7 +331,7 @@ def make_particle_attributes(particulator, req_attr, attributes):
                 f" but no initial values given"
             )
         req_attr[name].init(attributes[name])
-    for name in ("multiplicity", "cell id", "cell origin"):
+    for name in ("multiplicity", "cell id", "cell origin", "position in cell"):
         if name not in req_attr:
             continue
         attr = req_attr[name]

@@ -90,7 +90,13 @@ class Storage(sb.StorageBase):
     def _ew(self, op, a, b=None, scalar=0.0):
         out = self.data
         n = out.numel()
-        if self.dtype is Storage.FLOAT:
+        if op == sb.EW_FLOOR and self.dtype is Storage.INT and a.dtype == torch.float64:
+            _call("sdm_floor_to_i64", _ptr(out), _ptr(a), c_i64(n))
+        elif (op == sb.EW_SUB and self.dtype is Storage.FLOAT and b is not None
+              and b.dtype == torch.int64):
+            assert a.data_ptr() == out.data_ptr()
+            _call("sdm_subtract_i64", _ptr(out), _ptr(b), c_i64(n))
+        elif self.dtype is Storage.FLOAT:
             _call("sdm_elementwise_f64", c_int(op), _ptr(out), _ptr(a), _ptr(b),
                   c_f64(float(scalar)), c_i64(n))
         elif self.dtype is Storage.INT:
@@ -381,6 +387,36 @@ class HIP(BackendMethods):  # pylint: disable=too-many-public-methods
               c_f64(-1.0 if nfmax is None else nfmax), _ptr(Nr1.data), _ptr(Nr2.data),
               _ptr(Nr3.data), _ptr(Nr4.data), _ptr(Nrt.data), _ptr(d34.data),
               self.straub_consts())
+
+    # ---- displacement (displacement_methods.py) ------------------------------------------------
+    def calculate_displacement(self, *, dim, displacement, courant, cell_origin, position_in_cell,
+                               n_substeps):
+        n_dims = len(courant.shape)
+        if n_dims not in (1, 2, 3):
+            raise NotImplementedError()
+        _call("sdm_calculate_displacement", c_int(dim), c_int(n_dims),
+              c_int(self.formulae.particle_advection.scheme_id), _ptr(displacement.data),
+              _ptr(courant.data), (c_i64 * 3)(*courant.shape, *([1] * (3 - n_dims))),
+              _ptr(cell_origin.data), _ptr(position_in_cell.data),
+              c_i64(displacement.shape[1]), c_f64(n_substeps))
+
+    @staticmethod
+    def flag_precipitated(*, cell_origin, position_in_cell, water_mass, multiplicity, idx, length,
+                          healthy, precipitation_counting_level_index, displacement) -> float:
+        result = c_f64()
+        _call("sdm_flag_precipitated", _ptr(cell_origin.data), _ptr(position_in_cell.data),
+              _ptr(water_mass.data), _ptr(multiplicity.data), _ptr(idx.data), c_i64(int(length)),
+              c_i64(idx.data.numel()), c_int(cell_origin.shape[0]), _ptr(healthy.data),
+              c_f64(precipitation_counting_level_index), _ptr(displacement.data),
+              ctypes.byref(result))
+        return result.value
+
+    @staticmethod
+    def flag_out_of_column(cell_origin, position_in_cell, idx, length, healthy,
+                           domain_top_level_index):
+        _call("sdm_flag_out_of_column", _ptr(cell_origin.data), _ptr(position_in_cell.data),
+              _ptr(idx.data), c_i64(int(length)), c_i64(idx.data.numel()),
+              c_int(cell_origin.shape[0]), _ptr(healthy.data), c_f64(domain_top_level_index))
 
     # ---- moments (moments_methods.py) ---------------------------------------------------------
     @staticmethod

@@ -7,7 +7,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
 objs=()
 pids=()
-for f in ctx index collisions fused; do
+for f in ctx index collisions fused displacement; do
   stale=0
   [ -f $f.o ] || stale=1
   for dep in $f.hip common.h physics.h index.h shuffle_device.h ../../include/sdm_hip.h; do

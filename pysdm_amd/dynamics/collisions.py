@@ -182,6 +182,26 @@ class Hydrodynamic(ParameterizedKernel):  # collision_kernels/hydrodynamic.py
         super().__init__((1, 1, -27, 1.65, -58, 1.9, 15, 1.13, 16.7, 1, 0.004, 4, 8))
 
 
+class Linear:
+    """K = a + b (v_j + v_k), collision_kernels/linear.py.  The reference file is an unfinished
+    stub (its TODO #744): it calls `output.sum_pair`, which PairwiseStorage does not have, so it
+    cannot be run there; this is the evident intent with the pairwise `sum`."""
+
+    def __init__(self, a, b):
+        self.a = a
+        self.b = b
+        self.particulator = None
+
+    def register(self, builder):
+        self.particulator = builder.particulator
+        builder.request_attribute("volume")
+
+    def __call__(self, output, is_first_in_pair):
+        output.sum(self.particulator.attributes["volume"], is_first_in_pair)
+        output *= self.b
+        output += self.a
+
+
 class SimpleGeometric:  # collision_kernels/simple_geometric.py (no fall velocity)
     def __init__(self, C):
         self.particulator = None

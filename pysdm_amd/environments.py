@@ -23,6 +23,10 @@ class Mesh:
         self.n_dims = len(grid) if n_dims is None else n_dims
 
     @property
+    def dz(self):
+        return self.size[-1] / self.grid[-1]
+
+    @property
     def dimension(self):
         return self.n_dims
 

@@ -2,7 +2,7 @@
 
 Collision-path subset of PySDM/formulae.py:27-67 (same keyword names: `seed`, `constants`,
 `terminal_velocity`, `fragmentation_function`, `handle_all_breakups`,
-`particle_shape_and_density`); everything unrelated to the path is absent.
+`particle_shape_and_density`, `particle_advection`); everything unrelated to the path is absent.
 """
 from types import SimpleNamespace
 
@@ -37,6 +37,24 @@ class _LiquidSpheres:  # PySDM/physics/particle_shape_and_density/liquid_spheres
         return _const.rho_w * volume
 
 
+class _ImplicitInSpace:  # PySDM/physics/particle_advection/implicit_in_space.py:11-13
+    __name__ = "ImplicitInSpace"
+    scheme_id = 0  # SDM scheme code of sdm_calculate_displacement
+
+    @staticmethod
+    def displacement(position_in_cell, c_l, c_r):
+        return (c_l * (1 - position_in_cell) + c_r * position_in_cell) / (1 - c_r + c_l)
+
+
+class _ExplicitInSpace:  # PySDM/physics/particle_advection/explicit_in_space.py:11-13
+    __name__ = "ExplicitInSpace"
+    scheme_id = 1
+
+    @staticmethod
+    def displacement(position_in_cell, c_l, c_r):
+        return c_l * (1 - position_in_cell) + c_r * position_in_cell
+
+
 class Formulae:  # pylint: disable=too-few-public-methods,too-many-arguments
     def __init__(
         self,
@@ -48,6 +66,7 @@ class Formulae:  # pylint: disable=too-few-public-methods,too-many-arguments
         particle_shape_and_density="LiquidSpheres",
         terminal_velocity="GunnKinzer1949",
         handle_all_breakups=False,
+        particle_advection="ImplicitInSpace",
     ):
         if particle_shape_and_density != "LiquidSpheres":
             raise NotImplementedError(particle_shape_and_density)
@@ -67,6 +86,10 @@ class Formulae:  # pylint: disable=too-few-public-methods,too-many-arguments
         self.trivia = _Trivia()
         self.particle_shape_and_density = _LiquidSpheres()
         self.terminal_velocity = terminal_velocity
+        schemes = {"ImplicitInSpace": _ImplicitInSpace, "ExplicitInSpace": _ExplicitInSpace}
+        if particle_advection not in schemes:
+            raise NotImplementedError(particle_advection)
+        self.particle_advection = schemes[particle_advection]()
 
     @property
     def terminal_velocity_class(self):

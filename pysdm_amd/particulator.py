@@ -193,6 +193,47 @@ class Particulator:  # pylint: disable=too-many-instance-attributes
             weighting_rank=weighting_rank,
         )
 
+    # ---- displacement (particulator.py:401-440) ---------------------------------------------------
+    def remove_precipitated(self, *, displacement, precipitation_counting_level_index) -> float:
+        view = self.attributes._fused_view()  # pylint: disable=protected-access
+        rainfall_mass = self.backend.flag_precipitated(
+            cell_origin=self.attributes["cell origin"],
+            position_in_cell=self.attributes["position in cell"],
+            water_mass=self.attributes["water mass"],
+            multiplicity=self.attributes["multiplicity"],
+            idx=view["idx"],
+            length=self.attributes.super_droplet_count,
+            healthy=view["healthy"],
+            precipitation_counting_level_index=precipitation_counting_level_index,
+            displacement=displacement,
+        )
+        self.attributes.sanitize()
+        return rainfall_mass
+
+    def flag_out_of_column(self):
+        view = self.attributes._fused_view()  # pylint: disable=protected-access
+        self.backend.flag_out_of_column(
+            cell_origin=self.attributes["cell origin"],
+            position_in_cell=self.attributes["position in cell"],
+            idx=view["idx"],
+            length=self.attributes.super_droplet_count,
+            healthy=view["healthy"],
+            domain_top_level_index=self.mesh.grid[-1],
+        )
+        self.attributes.sanitize()
+
+    def calculate_displacement(self, *, displacement, courant, cell_origin, position_in_cell,
+                               n_substeps):
+        for dim in range(len(self.environment.mesh.grid)):
+            self.backend.calculate_displacement(
+                dim=dim,
+                displacement=displacement,
+                courant=courant[dim],
+                cell_origin=cell_origin,
+                position_in_cell=position_in_cell,
+                n_substeps=n_substeps,
+            )
+
     def adaptive_sdm_end(self, dt_left):
         return self.backend.adaptive_sdm_end(dt_left, self.attributes.cell_start)
 

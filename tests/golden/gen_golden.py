@@ -861,8 +861,80 @@ def gen_moments():
     save("moments", **out)
 
 
+# ------------------------------------------------------------------------------------------
+# f-3: displacement (advection by a Courant field + sedimentation), alone and ahead of collisions
+# ------------------------------------------------------------------------------------------
+def gen_displacement():
+    from PySDM.dynamics import Displacement
+
+    cases = {
+        # name: grid, size[m], dt, scheme, sedimentation, adaptive, collide, n_sd, steps
+        "disp1d_implicit_sed": ((12,), (1200.0,), 4.0, "ImplicitInSpace", True, True, False, 300, 6),
+        "disp2d_implicit_sed": ((6, 5), (600.0, 500.0), 5.0, "ImplicitInSpace", True, True, False,
+                                400, 6),
+        "disp2d_explicit": ((6, 5), (600.0, 500.0), 5.0, "ExplicitInSpace", False, False, False,
+                            400, 4),
+        "disp3d_implicit": ((3, 4, 5), (30.0, 40.0, 50.0), 1.0, "ImplicitInSpace", False, True,
+                            False, 350, 4),
+        "disp2d_collide": ((4, 4), (400.0, 400.0), 5.0, "ImplicitInSpace", True, True, True,
+                           512, 8),
+    }
+    for name, (grid, size, dt, scheme, sed, adaptive, collide, n_sd, steps) in cases.items():
+        rng = np.random.default_rng(abs(hash(name)) % 2**31 if False else len(name) * 7919)
+        formulae = Formulae(seed=44, particle_advection=scheme,
+                            terminal_velocity="GunnKinzer1949")
+        env = Box(dt=dt, dv=None)
+        env.mesh = Mesh(grid, size)
+        builder = Builder(n_sd=n_sd, backend=CPU(formulae), environment=env)
+        disp = Displacement(enable_sedimentation=sed, adaptive=adaptive,
+                            precipitation_counting_level_index=0)
+        builder.add_dynamic(disp)
+        if collide:
+            builder.add_dynamic(Coalescence(collision_kernel=Geometric(), adaptive=True))
+        positions = rng.uniform(0, 1, (len(grid), n_sd)) * np.asarray(grid).reshape(-1, 1)
+        cell_id, cell_origin, position_in_cell = env.mesh.cellular_attributes(positions)
+        radius = np.exp(rng.uniform(np.log(10e-6), np.log(1.5e-3), n_sd))
+        volume = formulae.trivia.volume(radius=radius)
+        mult = rng.integers(1, 10**5, n_sd).astype(float)
+        particulator = builder.build({
+            "volume": volume.copy(), "multiplicity": mult.copy(), "cell id": cell_id.copy(),
+            "cell origin": cell_origin.copy(), "position in cell": position_in_cell.copy(),
+        })
+        courant = tuple(
+            rng.uniform(-0.45, 0.45, tuple(g + (1 if a == d else 0) for a, g in enumerate(grid)))
+            for d in range(len(grid))
+        )
+        disp = particulator.dynamics["Displacement"]
+        disp.upload_courant_field(courant)
+        out = {"grid": np.asarray(grid), "size": np.asarray(size),
+               "cfg": np.asarray([n_sd, dt, int(scheme == "ExplicitInSpace"), int(sed),
+                                  int(adaptive), int(collide), steps]),
+               "init/volume": volume, "init/multiplicity": mult, "init/positions": positions,
+               "n_substeps": np.asarray(disp._n_substeps)}
+        for d, component in enumerate(courant):
+            out[f"courant/{d}"] = component
+        for step in range(1, steps + 1):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                particulator.run(1)
+            attrs = particulator.attributes
+            attrs.sanitize()
+            length = attrs.super_droplet_count
+            idx = attrs._ParticleAttributes__idx.to_ndarray()
+            out[f"step{step}/length"] = np.asarray(length)
+            out[f"step{step}/idx"] = idx
+            out[f"step{step}/precipitation"] = np.asarray(disp.precipitation_mass_in_last_step)
+            for key, tag in (("cell origin", "cell_origin"), ("position in cell", "position"),
+                             ("cell id", "cell_id"), ("multiplicity", "multiplicity"),
+                             ("water mass", "mass")):
+                out[f"step{step}/{tag}"] = attrs[key].to_ndarray(raw=True)
+        save(f"traj_{name}", **out)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["micro", "frag", "traj", "breakup", "shards", "moments"]
+    what = sys.argv[1:] or ["micro", "frag", "traj", "breakup", "shards", "moments", "displacement"]
+    if "displacement" in what:
+        gen_displacement()
     if "moments" in what:
         gen_moments()
     if "shards" in what:

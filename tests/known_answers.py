@@ -303,6 +303,11 @@ def check_reference_efficiency_and_kernel_tests(kit):
         sut(eff, flag)
         values = eff.to_ndarray()
         assert np.min(values) >= 0 and np.max(values) <= 1, sut.__class__.__name__
+    sut = C.Linear(a=2.0, b=3.0)  # no reference run exists (stub there): analytic answer
+    particulator, flag = _two_drop_setup(kit, sut, np.asarray([44.0, 666.0]))
+    output = particulator.PairwiseStorage.from_ndarray(np.zeros(1))
+    sut(output, flag)
+    np.testing.assert_allclose(output.to_ndarray(), [2.0 + 3.0 * 710.0], rtol=1e-14)
     for c_value, vol, positive in ((0.0, [44.0, 666.0], False), (1.0, [44.0, 666.0], True),
                                    (1.0, [1.0, 2.0], True), (1.0, [1.0, 1.0], False)):
         sut = C.SimpleGeometric(C=c_value)

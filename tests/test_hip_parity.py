@@ -5,6 +5,7 @@ point bit-exact on the coalescence-only paths, 1e-12 relative where device trans
 import numpy as np
 import pytest
 
+from . import displacement_cases
 from . import known_answers as ka
 from . import micro_cases as mc
 from .trajectory import golden_files, run_and_compare, setup_from_golden, snapshot
@@ -67,3 +68,11 @@ def test_fused_equals_oracle_beyond_goldens(name, hip_backend_class, oracle_back
 @pytest.mark.parametrize("check", ka.ALL_CHECKS)
 def test_reference_known_answers(check, kit):
     check(kit)
+
+
+@pytest.mark.parametrize("fused", [False, None], ids=["methods", "fused"])
+@pytest.mark.parametrize("name", displacement_cases.CASES)
+def test_displacement_goldens(name, fused, hip_backend_class):
+    if fused is None and "collide" not in name:
+        pytest.skip("no collision dynamic in this case")
+    displacement_cases.run_case(name, hip_backend_class, fused=fused)

@@ -2,6 +2,7 @@
 recorded from the reference itself (tests/golden/gen_golden.py).  CPU only."""
 import pytest
 
+from . import displacement_cases
 from .trajectory import golden_files, run_and_compare
 
 
@@ -26,3 +27,8 @@ def test_breakup(name, oracle_backend_class):
     # log/exp/sinh..., which numpy (SIMD loops, used by the reference run that made the goldens)
     # and glibc (the C oracle) round differently in the last bit, so attributes get 1e-12
     run_and_compare(name, oracle_backend_class, float_rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", displacement_cases.CASES)
+def test_displacement_goldens(name, oracle_backend_class):
+    displacement_cases.run_case(name, oracle_backend_class)
