@@ -15,7 +15,7 @@ import subprocess
 import numpy as np
 
 from pysdm_amd.backends import storage_base as sb
-from pysdm_amd.backends.impl_common import BackendMethods, RandomCommon
+from pysdm_amd.backends.impl_common import BackendMethods, RandomCommon, advection_scheme_id
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsdm_oracle.so")
@@ -409,7 +409,7 @@ class OracleBackend(BackendMethods):  # pylint: disable=too-many-public-methods
             raise NotImplementedError()
         shape = np.asarray(courant.shape, dtype=np.int64)
         lib().oracle_calculate_displacement(
-            _int(dim), _int(n_dims), _int(self.formulae.particle_advection.scheme_id),
+            _int(dim), _int(n_dims), _int(advection_scheme_id(self.formulae)),
             _p(displacement.data), _p(courant.data), _p(shape), _p(cell_origin.data),
             _p(position_in_cell.data), _i64(displacement.shape[1]), _f64(n_substeps))
 

@@ -17,7 +17,7 @@ from .. import _lib
 from .._lib import c_f64, c_i64, c_int, c_ptr, check
 from ..formulae import Formulae
 from . import storage_base as sb
-from .impl_common import BackendMethods, RandomCommon
+from .impl_common import BackendMethods, RandomCommon, advection_scheme_id
 
 _TORCH_DTYPE = {np.float64: torch.float64, np.int64: torch.int64, np.bool_: torch.bool}
 
@@ -395,7 +395,7 @@ class HIP(BackendMethods):  # pylint: disable=too-many-public-methods
         if n_dims not in (1, 2, 3):
             raise NotImplementedError()
         _call("sdm_calculate_displacement", c_int(dim), c_int(n_dims),
-              c_int(self.formulae.particle_advection.scheme_id), _ptr(displacement.data),
+              c_int(advection_scheme_id(self.formulae)), _ptr(displacement.data),
               _ptr(courant.data), (c_i64 * 3)(*courant.shape, *([1] * (3 - n_dims))),
               _ptr(cell_origin.data), _ptr(position_in_cell.data),
               c_i64(displacement.shape[1]), c_f64(n_substeps))

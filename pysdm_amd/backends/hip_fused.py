@@ -9,6 +9,7 @@ import torch
 
 from .. import _lib
 from .._lib import StepCfg, StepResult, StepState, c_ptr, check
+from . import state_access
 from .hip import _Context, pcg64_state_inc
 
 
@@ -58,12 +59,13 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
         cfg.rng_state_inc = (ctypes.c_uint64 * 4)(*pcg64_state_inc(backend.formulae.seed))
         self.gk = None
         if parts.get("needs_gk", False):
-            self.gk = attrs.get_attribute_object("relative fall velocity").approximation
+            self.gk = state_access.attribute_object(
+                attrs, "relative fall velocity").approximation
             cfg.gk_table_len = self.gk.a.data.numel()
             cfg.gk_factor = float(self.gk.factor)
         self.cfg = cfg
 
-        view = attrs._fused_view()  # pylint: disable=protected-access
+        view = state_access.view(attrs)
         self.idx = view["idx"]
         self.tmp_idx = view["caretaker"].tmp_idx
         self.ctl = torch.zeros(8, dtype=torch.int64, device=self.idx.data.device)
@@ -75,7 +77,7 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
         self.result = StepResult()
 
     def _push_host_state(self):
-        view = self.particulator.attributes._fused_view()  # pylint: disable=protected-access
+        view = state_access.view(self.particulator.attributes)
         host = torch.tensor(
             [view["valid_n_sd"], len(view["idx"]), int(view["sorted"]),
              int(bool(view["healthy"])), 0, 0, 0, 0], dtype=torch.int64,
@@ -94,7 +96,7 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
             state.attributes = _p(attrs.get_extensive_attribute_storage().data)
             state.cell_id = _p(attrs["cell id"].data)
             state.cell_idx = _p(attrs.cell_idx.data)
-            state.cell_start = _p(attrs._fused_view()["cell_start"].data)  # pylint: disable=protected-access
+            state.cell_start = _p(state_access.view(attrs)["cell_start"].data)
             state.dt_left = _p(dyn.dt_left.data)
             state.stats_dt_min = _p(dyn.stats_dt_min.data)
             state.stats_n_substep = _p(dyn.stats_n_substep.data)
@@ -149,19 +151,18 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
             self.total_pairs += res.n_pairs
         if self.read_back:
             self._commit(ctx)
-        self.particulator.mark_collision_outputs_updated()
+        state_access.mark_collision_outputs_updated(self.particulator.attributes)
         self._stamps = self._timestamps()
 
     def _timestamps(self):
         attrs = self.particulator.attributes
         names = ["multiplicity", "cell id"] + list(attrs.get_extensive_attribute_keys())
-        return tuple(attrs.get_attribute_object(name).timestamp for name in names)
+        return tuple(state_access.attribute_object(attrs, name).timestamp for name in names)
 
     def _commit(self, _ctx):
         words = self.ctl.cpu().numpy()
-        self.particulator.attributes._fused_commit(  # pylint: disable=protected-access
-            valid_n_sd=int(words[0]), sorted_flag=bool(words[2])
-        )
+        state_access.commit(self.particulator.attributes, valid_n_sd=int(words[0]),
+                            sorted_flag=bool(words[2]))
         if words[7] != 0:
             raise RuntimeError(
                 "libsdm_hip: device-side failure in the fused collision step "

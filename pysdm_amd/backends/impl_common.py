@@ -163,3 +163,15 @@ def make_PairIndicator(backend):
             self.length = len(cell_id)
 
     return PairIndicator
+
+
+def advection_scheme_id(formulae):
+    """SDM scheme code of sdm_calculate_displacement for `formulae.particle_advection` (this
+    package's or PySDM's own object: PySDM/physics/particle_advection/*.py)"""
+    scheme = formulae.particle_advection
+    code = getattr(scheme, "scheme_id", None)
+    if code is None:
+        # PySDM wraps the chosen class in a namespace that keeps its name (formulae.py:144-160)
+        name = getattr(scheme, "__name__", type(scheme).__name__)
+        code = {"ImplicitInSpace": 0, "ExplicitInSpace": 1}[name]
+    return code

@@ -19,6 +19,7 @@ from collections import namedtuple
 import numpy as np
 
 from ..attributes import Multiplicity
+from . import register_dynamic
 from ..physics import constants as const
 from ..physics.constants import si
 
@@ -653,6 +654,7 @@ class Straub2010Nf(VolumeBasedFragmentationFunction):
 
 
 # ---- the dynamic ----------------------------------------------------------------------------
+@register_dynamic()
 class Collision:  # pylint: disable=too-many-instance-attributes
     DYNAMIC_KEY = "Collision"
 

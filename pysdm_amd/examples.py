@@ -97,4 +97,5 @@ def make_box(backend_class, name, *, n_sd=None, adaptive=None, fused=None, seed=
     builder = Builder(n_sd=n_sd, backend=backend_class(formulae), environment=env)
     dynamic = cfg["make"](adaptive, fused)
     builder.add_dynamic(dynamic)
-    return builder.build(attributes), dynamic
+    particulator = builder.build(attributes)
+    return particulator, particulator.dynamics["Collision"]

@@ -291,8 +291,8 @@ class Builder:
         names, self.req_attr_names, self.req_attr = self.req_attr_names, None, {}
         for name in names:
             self._resolve_attribute(name)
-        for dynamic in self.particulator.dynamics.values():
-            dynamic.register(self)
+        for key, dynamic in self.particulator.dynamics.items():
+            self.particulator.dynamics[key] = dynamic.instantiate(builder=self)
         for attribute in attributes:
             self.request_attribute(attribute)
 

@@ -40,3 +40,29 @@ def test_error_reporting_without_a_gpu_call():
     # a NULL ctx is rejected before anything touches the device
     assert lib.sdm_ctx_set_stream(None, None) == -1
     assert b"bad argument" in lib.sdm_last_error()
+
+
+def test_hip_backend_and_oracle_backend_are_interface_twins(oracle_backend_class):
+    """every backend method the front-end may call exists on both with the same parameters:
+    what the oracle passes under the unmodified reference front-end (test_reference_plugin.py)
+    carries over to HIP"""
+    import inspect  # pylint: disable=import-outside-toplevel
+
+    from pysdm_amd.backends.hip import HIP, Storage  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.backends.storage_base import StorageBase  # pylint: disable=import-outside-toplevel
+
+    def public(cls):
+        return {name: member for name, member in inspect.getmembers(cls, callable)
+                if not name.startswith("_")}
+
+    hip, oracle = public(HIP), public(oracle_backend_class)
+    device_only = {"make_collision_step", "collision_step", "straub_consts", "synchronize"}
+    assert set(hip) - device_only == set(oracle) - device_only
+    for name in set(hip) - device_only:
+        if inspect.isclass(hip[name]):
+            continue
+        params = [[p for p in inspect.signature(side[name]).parameters if p != "self"]
+                  for side in (hip, oracle)]
+        assert params[0] == params[1], name
+    assert issubclass(Storage, StorageBase) and issubclass(oracle_backend_class.Storage,
+                                                           StorageBase)

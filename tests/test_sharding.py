@@ -48,6 +48,7 @@ def _worker(rank, world, port, errors):
         dynamic = Coalescence(collision_kernel=Golovin(b=1.5e3), adaptive=bool(full["cfg"][2]))
         builder.add_dynamic(dynamic)
         particulator = builder.build(local)
+        dynamic = particulator.dynamics["Collision"]
         for step in (1, 3, 10):
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")

@@ -90,6 +90,7 @@ def setup_from_golden(name, backend_class, fused=None):
     builder = Builder(n_sd=n_sd, backend=backend, environment=env)
     builder.add_dynamic(dynamic)
     particulator = builder.build(attributes)
+    dynamic = particulator.dynamics["Collision"]  # the built copy (builder.py:130-131)
     steps = sorted({int(k.split("/")[0][4:]) for k in gold.files if k.startswith("step")})
     return particulator, dynamic, gold, steps
 
