@@ -99,3 +99,50 @@ def make_box(backend_class, name, *, n_sd=None, adaptive=None, fused=None, seed=
     builder.add_dynamic(dynamic)
     particulator = builder.build(attributes)
     return particulator, particulator.dynamics["Collision"]
+
+
+def single_eddy_courant(grid, size, dt, w_max=0.6):
+    """Courant numbers of the non-divergent single-eddy flow of the 2-D kinematic set-up
+    (stream function psi = -w_max X/pi sin(pi z/Z) cos(2 pi x/X), as in
+    examples/PySDM_examples/Szumowski_et_al_1998/.., Arabas_et_al_2015) on the Arakawa-C faces:
+    differences of psi at the cell corners, so the discrete divergence vanishes"""
+    (n_x, n_z), (len_x, len_z) = grid, size
+    d_x, d_z = len_x / n_x, len_z / n_z
+    x = np.linspace(0, len_x, n_x + 1).reshape(-1, 1)
+    z = np.linspace(0, len_z, n_z + 1).reshape(1, -1)
+    psi = -w_max * len_x / np.pi * np.sin(np.pi * z / len_z) * np.cos(2 * np.pi * x / len_x)
+    courant_x = -(psi[:, 1:] - psi[:, :-1]) / d_z * dt / d_x  # (n_x + 1, n_z)
+    courant_z = (psi[1:, :] - psi[:-1, :]) / d_x * dt / d_z   # (n_x, n_z + 1)
+    return courant_x, courant_z
+
+
+def make_kinematic_flow(backend_class, *, n_sd=2**22, grid=(32, 32), size=(1500.0, 1500.0), dt=5.0,
+                        fused=None, seed=44, sedimentation=True):
+    """configs[3] with the step that precedes collisions in the 2-D kinematic set-up:
+    `Displacement` (single-eddy flow + sedimentation) followed by adaptive Geometric coalescence.
+    Returns (particulator, displacement, collision)"""
+    from .dynamics.displacement import Displacement  # pylint: disable=import-outside-toplevel
+
+    cfg = CONFIGS["kinematic2d"]
+    formulae = Formulae(seed=seed)
+    n_cell = int(np.prod(grid))
+    env = Box(dt=dt, dv=None)
+    env.mesh = Mesh(grid, size)
+    dv_total = env.mesh.dv * n_cell
+    spectrum = ExponentialSpectrum(norm_factor=cfg["n_part"] * dv_total * n_sd / cfg["n_sd"],
+                                   scale=TRIVIA.volume(radius=cfg["radius"]))
+    volume, multiplicity = ConstantMultiplicity(spectrum).sample(n_sd)
+    rng = np.random.default_rng(7)
+    order = rng.permutation(n_sd)
+    positions = rng.uniform(0, 1, (2, n_sd)) * np.asarray(grid).reshape(2, 1)
+    cell_id, cell_origin, position_in_cell = env.mesh.cellular_attributes(positions)
+    builder = Builder(n_sd=n_sd, backend=backend_class(formulae), environment=env)
+    builder.add_dynamic(Displacement(enable_sedimentation=sedimentation))
+    builder.add_dynamic(cfg["make"](True, fused))
+    particulator = builder.build({
+        "volume": volume[order], "multiplicity": multiplicity[order], "cell id": cell_id,
+        "cell origin": cell_origin, "position in cell": position_in_cell,
+    })
+    displacement = particulator.dynamics["Displacement"]
+    displacement.upload_courant_field(single_eddy_courant(grid, size, dt))
+    return particulator, displacement, particulator.dynamics["Collision"]

@@ -7,7 +7,7 @@ import warnings
 import numpy as np
 import pytest
 
-from pysdm_amd.examples import CONFIGS, make_box
+from pysdm_amd.examples import CONFIGS, make_box, make_kinematic_flow
 
 from .trajectory import snapshot
 
@@ -74,3 +74,34 @@ def test_full_size_routes_agree(name, adaptive, steps, hip_backend_class):
         run(particulator, steps)
         snaps.append(snapshot(particulator, dynamic))
     assert_same(snaps[0], snaps[1])
+
+
+def test_full_size_displacement_then_collisions(hip_backend_class, oracle_backend_class):
+    """configs[3] with its preceding step: 2^22 super-droplets advected by the single-eddy flow
+    and sedimenting through a 32 x 32 grid (precipitation leaves through the bottom), then the
+    adaptive Geometric collision step on the unsorted state; HIP (fused collision route) against
+    the oracle"""
+    results = []
+    for backend_class in (hip_backend_class, oracle_backend_class):
+        particulator, displacement, collision = make_kinematic_flow(backend_class)
+        rain = []
+        for _ in range(2):
+            run(particulator, 1)
+            rain.append(displacement.precipitation_mass_in_last_step)
+        attrs = particulator.attributes
+        snap = snapshot(particulator, collision)
+        snap["cell_origin"] = attrs["cell origin"].to_ndarray(raw=True)
+        snap["cell_id"] = attrs["cell id"].to_ndarray(raw=True)
+        results.append((snap, attrs["position in cell"].to_ndarray(raw=True), rain))
+    (hip, hip_pos, hip_rain), (ref, ref_pos, ref_rain) = results
+    length = int(hip["length"])
+    assert length == int(ref["length"]) and length < 2**22  # some rain left the domain
+    live = hip["idx"][:length]
+    np.testing.assert_array_equal(live, ref["idx"][:length])
+    for key in ("cell_origin", "cell_id", "multiplicity", "attributes"):
+        np.testing.assert_array_equal(hip[key][..., live], ref[key][..., live], err_msg=key)
+    for key in ("cell_start", "collision_rate", "coalescence_rate", "stats_n_substep"):
+        np.testing.assert_array_equal(hip[key], ref[key], err_msg=key)
+    np.testing.assert_allclose(hip_pos[:, live], ref_pos[:, live], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(hip_rain, ref_rain, rtol=1e-12)
+    assert hip_rain[0] > 0
