@@ -6,7 +6,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdm_hip.so")
+# SDM_HIP_LIB: another build of the same library (tuning variants); still no fallback
+LIB_PATH = os.environ.get("SDM_HIP_LIB") or os.path.join(_HERE, "libsdm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sdm_hip.h")
 
 c_i64 = ctypes.c_int64

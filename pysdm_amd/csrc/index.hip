@@ -232,13 +232,27 @@ int sdm_shuffle_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *
 // so the backward walk needs no separate gather of the initial content.  u01 comes either from
 // memory or from the PCG64 stream evaluated in place (16 consecutive draws per thread).
 // ---------------------------------------------------------------------------------------
-#define BIN_POS 2048     // positions per bin (K4 workgroup)
-#define BIN_SHIFT 11
-#define BIN_THREADS 256
+// Tile shapes (overridable at compile time for tuning runs: -DBIN_SHIFT=.. -DEV_TILE=.. ..).
+// Measured on MI355X at n_sd = 2^20 (profiles/README.md, "tile shapes"): 256 -> 1024 threads and
+// 2048 -> 4096 positions per bin took the build from 42 to 35 us; smaller or larger event tiles,
+// 8 PCG64 steps per thread and 8192-position bins were all slower.
+#ifndef BIN_SHIFT
+#define BIN_SHIFT 12
+#endif
+#define BIN_POS (1 << BIN_SHIFT)  // positions per bin (K4 workgroup)
+#ifndef BIN_THREADS
+#define BIN_THREADS 1024
+#endif
+#ifndef EV_TILE
 #define EV_TILE 4096     // events per K1 / K3 workgroup
-#define EV_PER_THREAD 16 // K3: 256 threads
-#define K1_THREADS 1024  // K1: sequential PCG64 steps per thread kept short
-#define K1_PER_THREAD 4
+#endif
+#define EV_PER_THREAD (EV_TILE / BIN_THREADS)  // K3
+#ifndef K1_PER_THREAD
+#define K1_PER_THREAD 4  // K1: sequential PCG64 steps per thread kept short
+#endif
+#define K1_THREADS (EV_TILE / K1_PER_THREAD)
+static_assert(EV_PER_THREAD * BIN_THREADS == EV_TILE && K1_THREADS * K1_PER_THREAD == EV_TILE &&
+              K1_THREADS <= 1024 && BIN_THREADS % 64 == 0, "tile shapes");
 
 // PackRec and the backward walk live in shuffle_device.h (shared with the fused pair kernels)
 
