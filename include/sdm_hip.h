@@ -339,6 +339,44 @@ int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st
 int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *state,
                       sdm_step_result *result, int flags, int64_t n_steps);
 
+/* ---- the fused displacement step (f-3) ------------------------------------------------------
+ * One call = one `Displacement.__call__` (PySDM/dynamics/displacement.py:100-121): all its
+ * sub-steps, each { displacement of every dimension, sedimentation, position update,
+ * precipitation flagging + removal, out-of-column flagging + removal, cell origin / position
+ * renormalisation, periodic boundary, cell id } in four launches plus the two gated compactions,
+ * without returning to the host in between.                                                   */
+typedef struct sdm_disp_cfg {
+  int64_t n_sd;
+  int32_t n_dims;               /* 1..3 */
+  int32_t scheme;               /* 0 ImplicitInSpace, 1 ExplicitInSpace */
+  int32_t enable_sedimentation;
+  int32_t n_substeps;
+  int64_t grid[3];              /* cells per dimension (unused dimensions: 1) */
+  int64_t strides[3];           /* mesh.strides: cell id = sum origin[d] * strides[d] */
+  double dt_over_dz;            /* dt / n_substeps / dz (displacement.py:131-133) */
+  double level;                 /* precipitation_counting_level_index */
+} sdm_disp_cfg;
+
+typedef struct sdm_disp_state {
+  const double *courant[3];     /* component d: grid shape with grid[d] + 1 points along d */
+  double *displacement;         /* (n_dims, n_sd) */
+  double *position_in_cell;     /* (n_dims, n_sd) */
+  int64_t *cell_origin;         /* (n_dims, n_sd) */
+  int64_t *cell_id;             /* (n_sd) */
+  const double *fall_velocity;  /* (n_sd) "relative fall velocity"; NULL without sedimentation */
+  const double *water_mass;     /* (n_sd) */
+  const int64_t *multiplicity;  /* (n_sd) */
+  int64_t *idx;                 /* (n_sd) permutation; removed super-droplets are compacted out */
+  int64_t *ctl;                 /* 8 device words {valid n_sd, working length, sorted, healthy,..}
+                                   set by the caller: {n_valid, n_valid, *, 1}; on return valid =
+                                   work = survivors, sorted = 0, healthy = 1 */
+} sdm_disp_state;
+
+/* *rainfall_mass = mass of water that left through the counting level in this step (sum over the
+ * sub-steps, in sub-step order), *valid_n_sd = surviving super-droplets; synchronises once.      */
+int sdm_displacement_step(sdm_ctx *ctx, const sdm_disp_cfg *cfg, const sdm_disp_state *state,
+                          double *rainfall_mass, int64_t *valid_n_sd);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,22 @@ class StepResult(ctypes.Structure):  # == sdm_step_result
     ]
 
 
+class DispCfg(ctypes.Structure):  # == sdm_disp_cfg
+    _fields_ = [
+        ("n_sd", c_i64), ("n_dims", ctypes.c_int32), ("scheme", ctypes.c_int32),
+        ("enable_sedimentation", ctypes.c_int32), ("n_substeps", ctypes.c_int32),
+        ("grid", c_i64 * 3), ("strides", c_i64 * 3), ("dt_over_dz", c_f64), ("level", c_f64),
+    ]
+
+
+class DispState(ctypes.Structure):  # == sdm_disp_state
+    _fields_ = [
+        ("courant", c_ptr * 3), ("displacement", c_ptr), ("position_in_cell", c_ptr),
+        ("cell_origin", c_ptr), ("cell_id", c_ptr), ("fall_velocity", c_ptr),
+        ("water_mass", c_ptr), ("multiplicity", c_ptr), ("idx", c_ptr), ("ctl", c_ptr),
+    ]
+
+
 def declared_symbols():
     """every function the header declares"""
     with open(HEADER_PATH, encoding="utf-8") as header:

@@ -439,6 +439,50 @@ class HIP(BackendMethods):  # pylint: disable=too-many-public-methods
               c_i64(moments.shape[1]), _ptr(x_attr.data), _ptr(weighting_attribute.data),
               c_f64(weighting_rank))
 
+    # ---- the fused displacement step (sdm_displacement_step) ---------------------------------------
+    def displacement_step(self, dynamic):
+        """one `Displacement.__call__` in one library call; returns the precipitated mass"""
+        from . import state_access  # pylint: disable=import-outside-toplevel
+
+        part = dynamic.particulator
+        attrs = part.attributes
+        view = state_access.view(attrs)
+        n_valid = attrs.super_droplet_count  # asserts a healthy state, as flag_precipitated does
+        mesh = part.mesh
+        n_dims = len(mesh.grid)
+        cfg = _lib.DispCfg()
+        cfg.n_sd, cfg.n_dims = part.n_sd, n_dims
+        cfg.scheme = advection_scheme_id(self.formulae)
+        cfg.enable_sedimentation = int(dynamic.enable_sedimentation)
+        cfg.n_substeps = int(dynamic._n_substeps)  # pylint: disable=protected-access
+        cfg.grid = (c_i64 * 3)(*[int(g) for g in mesh.grid], *([1] * (3 - n_dims)))
+        strides = np.asarray(mesh.strides).ravel()
+        cfg.strides = (c_i64 * 3)(*[int(v) for v in strides], *([0] * (3 - n_dims)))
+        if dynamic.enable_sedimentation:
+            cfg.dt_over_dz = part.dt / cfg.n_substeps / mesh.dz
+        cfg.level = float(dynamic.precipitation_counting_level_index)
+        state = _lib.DispState()
+        for dim in range(n_dims):
+            state.courant[dim] = dynamic.courant[dim].data.data_ptr()
+        state.displacement = dynamic.displacement.data.data_ptr()
+        state.position_in_cell = attrs["position in cell"].data.data_ptr()
+        state.cell_origin = attrs["cell origin"].data.data_ptr()
+        state.cell_id = attrs["cell id"].data.data_ptr()
+        if dynamic.enable_sedimentation:
+            state.fall_velocity = attrs["relative fall velocity"].data.data_ptr()
+        state.water_mass = attrs["water mass"].data.data_ptr()
+        state.multiplicity = attrs["multiplicity"].data.data_ptr()
+        idx = view["idx"]
+        state.idx = idx.data.data_ptr()
+        ctl = torch.tensor([n_valid, n_valid, 0, 1, 0, 0, 0, 0], dtype=torch.int64).to(
+            idx.data.device)
+        state.ctl = ctl.data_ptr()
+        rainfall, survivors = c_f64(), c_i64()
+        _call("sdm_displacement_step", ctypes.byref(cfg), ctypes.byref(state),
+              ctypes.byref(rainfall), ctypes.byref(survivors))
+        state_access.commit(attrs, valid_n_sd=survivors.value, sorted_flag=False)
+        return rainfall.value
+
     # ---- the fused per-time-step route ----------------------------------------------------------
     def make_collision_step(self, dynamic, parts):
         from .hip_fused import FusedStep  # pylint: disable=import-outside-toplevel

@@ -15,9 +15,6 @@ int sdm_shuffle_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *
                       int64_t n_total, const uint64_t *rng_state_inc, uint64_t rng_offset);
 int sdm_sort_by_key_async(sdm_ctx *ctx, int64_t *idx, const double *keys, int64_t n);
 size_t sdm_compact_scratch(int64_t n);
-int sdm_compact_async(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity, int64_t *idx,
-                      const int64_t *p_length, int64_t length_bound, int64_t flag,
-                      int64_t *fctl, int64_t *ctl, int64_t *cell_start_single);
 size_t sdm_sort_scratch(int64_t length_bound, int64_t n_cell);
 int sdm_counting_sort_async(sdm_ctx *ctx, char *scratch, int64_t *new_idx, const int64_t *idx,
                             const int64_t *cell_id, const int64_t *cell_idx,
@@ -30,4 +27,4 @@ int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
                             uint64_t rng_offset, ShuffleViews *views);
 int sdm_compact_fused_async(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity,
                             int64_t *idx, int64_t length_bound, int64_t flag, int64_t *fctl,
-                            int64_t *ctl, int64_t *cell_start_single);
+                            int64_t *ctl, int64_t *cell_start_single, bool flag_only = false);

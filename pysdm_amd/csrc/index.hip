@@ -698,130 +698,8 @@ __device__ __forceinline__ bool sd_dead(const int64_t *__restrict__ multiplicity
 #define FCTL_SORTED 2
 #define FCTL_HEALTHY 3
 
-__device__ __forceinline__ bool last_block_done(unsigned int *ticket) {
-  __shared__ bool is_last;
-  __threadfence();  // this block's writes first
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned int t = atomicAdd(ticket, 1u);
-    is_last = (t == gridDim.x - 1);
-    if (is_last) *ticket = 0;  // re-arm for the next launch
-  }
-  __syncthreads();
-  if (is_last) __threadfence();  // acquire: drop stale L1 lines before reading others' results
-  return is_last;
-}
-
-// per-block dead counts; the last block to finish scans them (exclusive) and publishes totals
-__global__ void __launch_bounds__(SDM_BLOCK)
-k_compact_count(const int64_t *__restrict__ multiplicity, const int64_t *__restrict__ idx,
-                const int64_t *__restrict__ p_length, int64_t flag,
-                const int64_t *__restrict__ fctl, int32_t *__restrict__ block_dead, int nb,
-                int64_t *__restrict__ ctl, unsigned int *__restrict__ ticket) {
-  if (fctl && fctl[FCTL_HEALTHY] != 0) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ctl[1] = fctl[FCTL_WORK]; ctl[2] = 0; ctl[3] = 0; }
-    return;
-  }
-  const int64_t length = fctl ? fctl[FCTL_VALID] : *p_length;
-  const int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
-  __shared__ int sm[SDM_BLOCK];
-  const bool dead = i < length && sd_dead(multiplicity, idx, i, flag);
-  const int c = __popcll(__ballot(dead));
-  if (lane_id() == 0) sm[threadIdx.x / SDM_WAVE] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) block_dead[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
-  if (!last_block_done(ticket)) return;
-  // exclusive scan of block_dead[0:nb) by this (last) block, SDM_BLOCK entries per round
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < nb; base += SDM_BLOCK) {
-    const int b = base + threadIdx.x;
-    const int v = b < nb ? ((volatile int32_t *)block_dead)[b] : 0;
-    sm[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 1; o < SDM_BLOCK; o <<= 1) {
-      const int t = threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
-      __syncthreads();
-      sm[threadIdx.x] += t;
-      __syncthreads();
-    }
-    const int incl = sm[threadIdx.x];
-    if (b < nb) block_dead[b] = carry + incl - v;
-    __syncthreads();
-    if (threadIdx.x == SDM_BLOCK - 1) carry += incl;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    ctl[3] = carry;
-    ctl[1] = length - carry;
-    ctl[2] = 0;
-  }
-}
-
-__global__ void __launch_bounds__(SDM_BLOCK)
-k_compact_lists(const int64_t *__restrict__ multiplicity, const int64_t *__restrict__ idx,
-                const int64_t *__restrict__ p_length, int64_t flag,
-                const int64_t *__restrict__ fctl, const int32_t *__restrict__ block_off,
-                int64_t *__restrict__ ctl, int32_t *__restrict__ holes,
-                int64_t *__restrict__ fillers) {
-  const int64_t total_dead = ctl[3];
-  if (total_dead == 0) return;
-  const int64_t length = fctl ? fctl[FCTL_VALID] : *p_length, new_len = ctl[1];
-  const int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
-  __shared__ int sm[SDM_BLOCK / SDM_WAVE];
-  const bool in = i < length;
-  const bool dead = in && sd_dead(multiplicity, idx, i, flag);
-  const unsigned long long m = __ballot(dead);
-  const int lane = lane_id(), w = threadIdx.x / SDM_WAVE;
-  if (lane == 0) sm[w] = __popcll(m);
-  __syncthreads();
-  int before = block_off[blockIdx.x];
-  for (int k = 0; k < w; ++k) before += sm[k];
-  const int64_t dp = before + __popcll(m & ((1ull << lane) - 1));  // dead in [0, i)
-  if (!in) return;
-  if (i == new_len) ctl[2] = dp;  // holes in the surviving prefix
-  if (i < new_len) {
-    if (dead) holes[dp] = (int32_t)i;
-  } else if (!dead) {
-    const int64_t r = (length - 1 - i) - (total_dead - dp);  // live elements after i
-    fillers[r] = idx[i];
-  }
-}
-
-__global__ void __launch_bounds__(SDM_BLOCK)
-k_compact_apply(int64_t *__restrict__ idx, const int64_t *__restrict__ p_length, int64_t flag,
-                int64_t *__restrict__ fctl, const int64_t *__restrict__ ctl,
-                const int32_t *__restrict__ holes, const int64_t *__restrict__ fillers,
-                int64_t *__restrict__ cell_start_single, unsigned int *__restrict__ ticket) {
-  if (fctl && fctl[FCTL_HEALTHY] != 0) return;
-  const int64_t new_len = ctl[1];
-  if (ctl[3] != 0) {
-    const int64_t length = fctl ? fctl[FCTL_VALID] : *p_length, n_holes = ctl[2];
-    const int64_t t = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
-    // threads [0, length - new_len): one tail slot each, and (if t < n_holes) one hole each
-    if (t < length - new_len) {
-      idx[new_len + t] = flag;
-      if (t < n_holes) idx[holes[t]] = fillers[t];
-    }
-  }
-  if (!fctl) return;
-  if (!last_block_done(ticket)) return;
-  if (threadIdx.x == 0) {
-    fctl[FCTL_VALID] = new_len;
-    fctl[FCTL_WORK] = new_len;
-    fctl[FCTL_HEALTHY] = 1;
-    if (cell_start_single) {
-      cell_start_single[0] = 0;
-      cell_start_single[1] = new_len;
-    } else {
-      fctl[FCTL_SORTED] = 0;
-    }
-  }
-}
-
-// ---- single-launch variant for the fused step: exits at once while healthy; otherwise the
-// same four phases separated by a software grid barrier.  The grid is COMPACT_GRID workgroups
+// ---- one launch: exits at once while healthy; otherwise four phases (dead count per tile, scan
+// of the counts, holes / fillers, apply) separated by a software grid barrier.  The grid is COMPACT_GRID workgroups
 // (<= one per CU: always co-resident); every spin is bounded (bar[2] is set on time-out).
 #define COMPACT_GRID 256
 
@@ -843,6 +721,9 @@ __device__ __forceinline__ bool grid_barrier(unsigned int *bar, unsigned int tar
   return ok;
 }
 
+// FLAG_ONLY: the caller guarantees that no live super-droplet has zero multiplicity (it entered
+// with a healthy state and only flags positions), so the random gather of multiplicities is skipped
+template <bool FLAG_ONLY>
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restrict__ idx,
                      int64_t flag, int64_t *__restrict__ fctl, int32_t *__restrict__ block_dead,
@@ -852,12 +733,11 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
   if (fctl[FCTL_HEALTHY] != 0) return;
   const int64_t length = fctl[FCTL_VALID];
   __shared__ int sm[SDM_BLOCK];
-  __shared__ int carry;
   const int lane = lane_id(), w = threadIdx.x / SDM_WAVE;
   // phase A: dead count of every tile of SDM_BLOCK positions
   for (int tile = blockIdx.x; tile < nb; tile += COMPACT_GRID) {
     const int64_t i = (int64_t)tile * SDM_BLOCK + threadIdx.x;
-    const bool dead = i < length && sd_dead(multiplicity, idx, i, flag);
+    const bool dead = i < length && (FLAG_ONLY ? idx[i] == flag : sd_dead(multiplicity, idx, i, flag));
     const int c = __popcll(__ballot(dead));
     __syncthreads();
     if (lane == 0) sm[w] = c;
@@ -870,30 +750,40 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
     return;                                                  \
   }
   BARRIER_OR_FAIL(1)
-  // phase B: workgroup 0 scans the tile counts (exclusive) and publishes the totals
+  // phase B: workgroup 0 scans the tile counts (exclusive) and publishes the totals: every
+  // thread sums a contiguous chunk, the chunk sums are scanned across the workgroup, then each
+  // thread rewrites its chunk
   if (blockIdx.x == 0) {
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < nb; base += SDM_BLOCK) {
-      const int b = base + threadIdx.x;
-      const int v = b < nb ? ((volatile int32_t *)block_dead)[b] : 0;
-      sm[threadIdx.x] = v;
-      __syncthreads();
-      for (int o = 1; o < SDM_BLOCK; o <<= 1) {
-        const int t = threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
-        __syncthreads();
-        sm[threadIdx.x] += t;
-        __syncthreads();
-      }
-      const int incl = sm[threadIdx.x];
-      if (b < nb) block_dead[b] = carry + incl - v;
-      __syncthreads();
-      if (threadIdx.x == SDM_BLOCK - 1) carry += incl;
-      __syncthreads();
+    const int per = (nb + SDM_BLOCK - 1) / SDM_BLOCK;
+    const int b0 = threadIdx.x * per;
+    int sum = 0;
+    for (int k = 0; k < per; ++k)
+      if (b0 + k < nb) sum += ((volatile int32_t *)block_dead)[b0 + k];
+    // inclusive scan of the chunk sums: within waves by shuffles, across the four waves via LDS
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
     }
+    __syncthreads();
+    if (lane == 63) sm[w] = incl;
+    __syncthreads();
+    int base = 0, all = 0;
+    for (int k = 0; k < SDM_BLOCK / SDM_WAVE; ++k) {
+      if (k < w) base += sm[k];
+      all += sm[k];
+    }
+    int run = base + incl - sum;
+    for (int k = 0; k < per; ++k)
+      if (b0 + k < nb) {
+        const int v = ((volatile int32_t *)block_dead)[b0 + k];
+        block_dead[b0 + k] = run;
+        run += v;
+      }
     if (threadIdx.x == 0) {
-      ctl[3] = carry;
-      ctl[1] = length - carry;
+      ctl[3] = all;
+      ctl[1] = length - all;
       ctl[2] = 0;
     }
   }
@@ -904,7 +794,7 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
     for (int tile = blockIdx.x; tile < nb; tile += COMPACT_GRID) {
       const int64_t i = (int64_t)tile * SDM_BLOCK + threadIdx.x;
       const bool in = i < length;
-      const bool dead = in && sd_dead(multiplicity, idx, i, flag);
+      const bool dead = in && (FLAG_ONLY ? idx[i] == flag : sd_dead(multiplicity, idx, i, flag));
       const unsigned long long m = __ballot(dead);
       __syncthreads();
       if (lane == 0) sm[w] = __popcll(m);
@@ -956,16 +846,21 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
 // `bar`: 4 zero-initialised device words owned by the caller (persist across launches)
 int sdm_compact_fused_async(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity,
                             int64_t *idx, int64_t length_bound, int64_t flag, int64_t *fctl,
-                            int64_t *ctl, int64_t *cell_start_single) {
+                            int64_t *ctl, int64_t *cell_start_single, bool flag_only) {
   Carver cv(scratch);
   const int nb = (int)grid_for(length_bound);
   int32_t *block_dead = cv.take<int32_t>(nb + 1);
   int32_t *holes = cv.take<int32_t>(length_bound);
   int64_t *fillers = cv.take<int64_t>(length_bound);
   unsigned int *bar = (unsigned int *)(ctx->dscal + 12);
-  hipLaunchKernelGGL(k_compact_persistent, dim3(COMPACT_GRID), dim3(SDM_BLOCK), 0, ctx->stream,
-                     multiplicity, idx, flag, fctl, block_dead, nb, ctl, holes, fillers,
-                     cell_start_single, bar);
+  if (flag_only)
+    hipLaunchKernelGGL(k_compact_persistent<true>, dim3(COMPACT_GRID), dim3(SDM_BLOCK), 0,
+                       ctx->stream, multiplicity, idx, flag, fctl, block_dead, nb, ctl, holes,
+                       fillers, cell_start_single, bar);
+  else
+    hipLaunchKernelGGL(k_compact_persistent<false>, dim3(COMPACT_GRID), dim3(SDM_BLOCK), 0,
+                       ctx->stream, multiplicity, idx, flag, fctl, block_dead, nb, ctl, holes,
+                       fillers, cell_start_single, bar);
   LAUNCH_CHECK();
   return SDM_OK;
 }
@@ -975,49 +870,30 @@ size_t sdm_compact_scratch(int64_t n) {
          carve_size(sizeof(int64_t) * n);
 }
 
-// Without fctl: compacts idx[0:*p_length); ctl[1] receives the new length.  With fctl (fused
-// step): see the comment above FCTL_*; cell_start_single != NULL marks the single-cell case.
-// `ticket`: two zero-initialised device words.
-int sdm_compact_async(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity, int64_t *idx,
-                      const int64_t *p_length, int64_t length_bound, int64_t flag,
-                      int64_t *fctl, int64_t *ctl, int64_t *cell_start_single) {
-  if (length_bound <= 0) return SDM_OK;
-  Carver cv(scratch);
-  const int nb = (int)grid_for(length_bound);
-  int32_t *block_dead = cv.take<int32_t>(nb + 1);
-  int32_t *holes = cv.take<int32_t>(length_bound);
-  int64_t *fillers = cv.take<int64_t>(length_bound);
-  unsigned int *ticket = (unsigned int *)(ctx->dscal + 14);
-  const dim3 grid(nb), block(SDM_BLOCK);
-  hipLaunchKernelGGL(k_compact_count, grid, block, 0, ctx->stream, multiplicity, idx, p_length,
-                     flag, fctl, block_dead, nb, ctl, ticket);
-  LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_compact_lists, grid, block, 0, ctx->stream, multiplicity, idx, p_length,
-                     flag, fctl, block_dead, ctl, holes, fillers);
-  LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_compact_apply, grid, block, 0, ctx->stream, idx, p_length, flag, fctl,
-                     ctl, holes, fillers, cell_start_single, ticket + 1);
-  LAUNCH_CHECK();
-  return SDM_OK;
-}
-
 extern "C" int sdm_remove_zero_n_or_flagged(sdm_ctx *ctx, const int64_t *multiplicity,
                                             int64_t *idx, int64_t length, int64_t idx_len,
                                             int64_t *new_length) {
   ARG_TRY(ctx && new_length && length >= 0 && length <= idx_len && idx_len < INT32_MAX);
   if (length == 0) { *new_length = 0; return SDM_OK; }
   ARG_TRY(multiplicity && idx);
-  int rc = sdm_reserve(ctx, sdm_compact_scratch(length));
+  int rc = sdm_reserve(ctx, sdm_compact_scratch(length) + 512);
   if (rc) return rc;
-  int64_t *ctl = ctx->dscal;
-  HIP_TRY(hipMemcpyAsync(ctl, &length, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-  rc = sdm_compact_async(ctx, ctx->arena, multiplicity, idx, ctl, length, idx_len, nullptr, ctl,
-                         nullptr);
+  Carver cv(ctx->arena);
+  int64_t *fctl = cv.take<int64_t>(8);   // {valid, work, sorted, healthy = 0: "compact now", ..}
+  int64_t *cctl = cv.take<int64_t>(8);
+  const int64_t words[8] = {length, length, 0, 0, 0, 0, 0, 0};
+  memcpy(ctx->mailbox, words, sizeof(words));
+  HIP_TRY(hipMemcpyAsync(fctl, ctx->mailbox, sizeof(words), hipMemcpyHostToDevice, ctx->stream));
+  rc = sdm_compact_fused_async(ctx, ctx->arena + 512, multiplicity, idx, length, idx_len, fctl,
+                               cctl, nullptr);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(ctx->mailbox, ctl + 1, sizeof(int64_t), hipMemcpyDeviceToHost,
-                         ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->mailbox, fctl, sizeof(words), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  *new_length = ctx->mailbox[0];
+  if (ctx->mailbox[7] != 0) {
+    sdm_set_error("remove_zero_n_or_flagged: grid barrier of the compaction kernel timed out");
+    return SDM_E_HIP;
+  }
+  *new_length = ctx->mailbox[FCTL_VALID];
   return SDM_OK;
 }
 

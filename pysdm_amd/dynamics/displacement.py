@@ -4,8 +4,9 @@ and unsorts the state the collision step then re-sorts).
 
 Host-side mirror of PySDM/dynamics/displacement.py:19-153: same constructor keywords, attributes
 (`courant`, `displacement`, `precipitation_mass_in_last_step`) and method names; the per-droplet
-arithmetic runs in the backend (`calculate_displacement`, `flag_precipitated`,
-`flag_out_of_column`, Storage ops).
+arithmetic runs in the backend: method by method (`calculate_displacement`,
+`flag_precipitated`, `flag_out_of_column`, Storage ops) or, where the backend offers
+`displacement_step`, all sub-steps in one library call.
 """
 from collections import namedtuple
 
@@ -19,7 +20,7 @@ DEFAULTS = namedtuple("_", ("rtol", "adaptive"))(rtol=1e-2, adaptive=True)
 @register_dynamic()
 class Displacement:  # pylint: disable=too-many-instance-attributes
     def __init__(self, enable_sedimentation=False, precipitation_counting_level_index: int = 0,
-                 adaptive=DEFAULTS.adaptive, rtol=DEFAULTS.rtol):
+                 adaptive=DEFAULTS.adaptive, rtol=DEFAULTS.rtol, fused=None):
         self.particulator = None
         self.enable_sedimentation = enable_sedimentation
         self.dimension = None
@@ -32,6 +33,8 @@ class Displacement:  # pylint: disable=too-many-instance-attributes
         self.adaptive = adaptive
         self.rtol = rtol
         self._n_substeps = 1
+        # None: take the backend's one-call route if it has one; False: method by method
+        self.fused = fused
 
     def register(self, builder):
         builder.request_attribute("relative fall velocity")
@@ -75,6 +78,11 @@ class Displacement:  # pylint: disable=too-many-instance-attributes
         cell_origin = attributes["cell origin"]
         position_in_cell = attributes["position in cell"]
         self.precipitation_mass_in_last_step = 0.0
+        if self.fused is not False and hasattr(self.particulator.backend, "displacement_step"):
+            self.precipitation_mass_in_last_step = self.particulator.backend.displacement_step(self)
+            for key in ("position in cell", "cell origin", "cell id"):
+                attributes.mark_updated(key)
+            return
         for _ in range(self._n_substeps):
             self.calculate_displacement(self.displacement, self.courant, cell_origin,
                                         position_in_cell)

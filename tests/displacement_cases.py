@@ -29,7 +29,7 @@ def run_case(name, backend_class, fused=None):
     env.mesh = Mesh(grid, tuple(float(v) for v in gold["size"]))
     builder = Builder(n_sd=n_sd, backend=backend_class(formulae), environment=env)
     builder.add_dynamic(Displacement(enable_sedimentation=bool(sed), adaptive=bool(adaptive),
-                                     precipitation_counting_level_index=0))
+                                     precipitation_counting_level_index=0, fused=fused))
     if collide:
         builder.add_dynamic(Coalescence(collision_kernel=Geometric(), adaptive=True, fused=fused))
     cell_id, cell_origin, position_in_cell = env.mesh.cellular_attributes(gold["init/positions"])

@@ -73,6 +73,4 @@ def test_reference_known_answers(check, kit):
 @pytest.mark.parametrize("fused", [False, None], ids=["methods", "fused"])
 @pytest.mark.parametrize("name", displacement_cases.CASES)
 def test_displacement_goldens(name, fused, hip_backend_class):
-    if fused is None and "collide" not in name:
-        pytest.skip("no collision dynamic in this case")
     displacement_cases.run_case(name, hip_backend_class, fused=fused)
