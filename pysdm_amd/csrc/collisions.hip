@@ -826,48 +826,74 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;
 }
 
+// Every wave walks a contiguous chunk of positions and keeps running sums for "its current
+// cell" in registers, flushing them with one atomic per (cell change, rank): a single-cell state
+// of 2^20 super-droplets costs 2 k atomics per rank instead of 16 k on one address (which take
+// ~60 ns each there).  Up to MOM_MAXR ranks per pass.
+#define MOM_MAXR 4
+#define MOM_GRID 512
+
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_moments(double *__restrict__ moment_0, double *__restrict__ moments,
           const int64_t *__restrict__ multiplicity, const double *__restrict__ attr_data,
           const int64_t *__restrict__ cell_id, const int64_t *__restrict__ idx, int64_t length,
-          const double *__restrict__ ranks, int64_t n_ranks, int64_t n_cell, double min_x,
-          double max_x, const double *__restrict__ x_attr,
+          const double *__restrict__ ranks, int rank_first, int n_pass, int with_m0,
+          int64_t n_cell, double min_x, double max_x, const double *__restrict__ x_attr,
           const double *__restrict__ weighting_attribute, double weighting_rank) {
-  const int64_t t = TID();
-  bool live = t < length;
-  int64_t i = 0;
-  if (live) {
-    i = idx[t];
-    const double x = x_attr[i];
-    live = min_x <= x && x < max_x;
-  }
-  const int c = live ? (int)cell_id[i] : -1;
-  int lo = live ? c : 0x7fffffff, hi = c;
+  const int lane = threadIdx.x & 63;
+  const int64_t n_waves = (int64_t)gridDim.x * (SDM_BLOCK / SDM_WAVE);
+  const int64_t wave = (int64_t)blockIdx.x * (SDM_BLOCK / SDM_WAVE) + threadIdx.x / SDM_WAVE;
+  const int64_t chunk = (((length + n_waves - 1) / n_waves) + 63) & ~(int64_t)63;
+  const int64_t begin = wave * chunk;
+  const int64_t end = begin + chunk < length ? begin + chunk : length;
+  int cur = -1;  // cell of the running sums
+  double a0 = 0.0, acc[MOM_MAXR] = {0.0, 0.0, 0.0, 0.0};
+  auto flush = [&]() {
+    if (cur >= 0 && lane == 0) {
+      if (with_m0) atomicAdd(&moment_0[cur], a0);
+      for (int k = 0; k < n_pass; ++k)
+        atomicAdd(&moments[(int64_t)(rank_first + k) * n_cell + cur], acc[k]);
+    }
+    a0 = 0.0;
+    for (int k = 0; k < MOM_MAXR; ++k) acc[k] = 0.0;
+  };
+  for (int64_t t0 = begin; t0 < end; t0 += 64) {
+    const int64_t t = t0 + lane;
+    bool live = t < end;
+    int64_t i = 0;
+    if (live) {
+      i = idx[t];
+      const double x = x_attr[i];
+      live = min_x <= x && x < max_x;
+    }
+    const int c = live ? (int)cell_id[i] : -1;
+    int lo = live ? c : 0x7fffffff, hi = c;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    lo = min(lo, __shfl_xor(lo, o, 64));
-    hi = max(hi, __shfl_xor(hi, o, 64));
-  }
-  if (hi < 0) return;  // nothing in range in this wave
-  const double w = !live ? 0.0 : (double)multiplicity[i] *
-                   (weighting_rank == 0 ? 1.0 : pow(weighting_attribute[i], weighting_rank));
-  const bool uniform = lo == hi;
-  const bool leader = (threadIdx.x & 63) == 0;
-  if (uniform) {
-    const double s = wave_sum_f64(w);
-    if (leader) atomicAdd(&moment_0[hi], s);
-  } else if (live) {
-    atomicAdd(&moment_0[c], w);
-  }
-  for (int64_t k = 0; k < n_ranks; ++k) {
-    const double term = live ? w * pow(attr_data[i], ranks[k]) : 0.0;
-    if (uniform) {
-      const double s = wave_sum_f64(term);
-      if (leader) atomicAdd(&moments[k * n_cell + hi], s);
+    for (int o = 32; o > 0; o >>= 1) {
+      lo = min(lo, __shfl_xor(lo, o, 64));
+      hi = max(hi, __shfl_xor(hi, o, 64));
+    }
+    if (hi < 0) continue;  // nothing in range in this round
+    const double w = !live ? 0.0 : (double)multiplicity[i] *
+                     (weighting_rank == 0 ? 1.0 : pow(weighting_attribute[i], weighting_rank));
+    double term[MOM_MAXR];
+    for (int k = 0; k < MOM_MAXR; ++k)
+      term[k] = (live && k < n_pass) ? w * pow(attr_data[i], ranks[rank_first + k]) : 0.0;
+    if (lo == hi) {  // the usual case after a collision step: sorted by cell, or one cell
+      if (hi != cur) {
+        flush();
+        cur = hi;
+      }
+      a0 += wave_sum_f64(w);
+      for (int k = 0; k < MOM_MAXR; ++k)
+        if (k < n_pass) acc[k] += wave_sum_f64(term[k]);
     } else if (live) {
-      atomicAdd(&moments[k * n_cell + c], term);
+      if (with_m0) atomicAdd(&moment_0[c], w);
+      for (int k = 0; k < n_pass; ++k)
+        atomicAdd(&moments[(int64_t)(rank_first + k) * n_cell + c], term[k]);
     }
   }
+  flush();
 }
 
 // ---- spectrum_moments (moments_methods.py:100-147) -----------------------------------------
@@ -928,10 +954,15 @@ extern "C" int sdm_moments(sdm_ctx *ctx, double *moment_0, double *moments,
     HIP_TRY(hipMemsetAsync(moments, 0, sizeof(double) * n_ranks * n_cell, ctx->stream));
   if (length > 0) {
     ARG_TRY(multiplicity && cell_id && idx && x_attr && weighting_attribute);
-    hipLaunchKernelGGL(k_moments, GRID1D(length), moment_0, moments, multiplicity, attr_data,
-                       cell_id, idx, length, ranks, n_ranks, n_cell, min_x, max_x, x_attr,
-                       weighting_attribute, weighting_rank);
-    LAUNCH_CHECK();
+    const unsigned grid = grid_for(length) < MOM_GRID ? grid_for(length) : MOM_GRID;
+    for (int first = 0; first == 0 || first < n_ranks; first += MOM_MAXR) {
+      const int n_pass = (int)(n_ranks - first < MOM_MAXR ? n_ranks - first : MOM_MAXR);
+      hipLaunchKernelGGL(k_moments, dim3(grid), dim3(SDM_BLOCK), 0, ctx->stream, moment_0,
+                         moments, multiplicity, attr_data, cell_id, idx, length, ranks, first,
+                         n_pass, first == 0 ? 1 : 0, n_cell, min_x, max_x, x_attr,
+                         weighting_attribute, weighting_rank);
+      LAUNCH_CHECK();
+    }
   }
   if (!skip_division_by_m0 && n_ranks > 0) {
     hipLaunchKernelGGL(k_moments_divide, GRID1D(n_ranks * n_cell), moment_0, moments, n_ranks,

@@ -105,3 +105,29 @@ def test_full_size_displacement_then_collisions(hip_backend_class, oracle_backen
     np.testing.assert_allclose(hip_pos[:, live], ref_pos[:, live], rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(hip_rain, ref_rain, rtol=1e-12)
     assert hip_rain[0] > 0
+
+
+@pytest.mark.parametrize("n_sd,steps,thin", [(2**20, 12, None), (2**16, 12, 0.02),
+                                             (2**16, 40, 100.0)])
+def test_many_steps_in_one_call_equal_oracle(n_sd, steps, thin, hip_backend_class,
+                                             oracle_backend_class):
+    """`Particulator.run(n)` of the single-cell non-adaptive box = one `sdm_collision_run` call: n
+    time steps without the host in between.  `thin` (a cell volume): multiplicities of 1..3, so
+    that super-droplets die -- in every step (0.02) or once in a few steps (100) -- and the
+    device-gated compaction has to run in the middle of a call."""
+    snaps = []
+    for backend_class in (hip_backend_class, oracle_backend_class):
+        particulator, dynamic = make_box(backend_class, "shima", n_sd=n_sd, adaptive=False,
+                                         dt=200.0 if thin else None)
+        if thin:
+            mult = particulator.attributes["multiplicity"]
+            mult.upload((1 + np.arange(n_sd) % 3).astype(np.int64))
+            particulator.attributes.mark_updated("multiplicity")
+            particulator.environment.mesh.dv = thin * n_sd / 2**16
+        run(particulator, 1)
+        run(particulator, steps)
+        run(particulator, 5)
+        snaps.append(snapshot(particulator, dynamic))
+    assert_same(snaps[0], snaps[1])
+    if thin:
+        assert int(snaps[0]["length"]) < n_sd
