@@ -522,7 +522,8 @@ static size_t binned_scratch_bytes(int64_t n) {
 }
 
 // usable while the count matrix stays small and LDS holds the per-bin arrays of K3
-static bool binned_ok(int64_t n, bool global) { return !global && n >= 2 && bin_count(n) <= 2048; }
+// (8192 bins = 2^25 positions: K3 then holds 3 x 8193 + 3 x 4096 ints = 146 KB of the CU's 160 KB)
+static bool binned_ok(int64_t n, bool global) { return !global && n >= 2 && bin_count(n) <= 8192; }
 
 static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *idx0,
                                 const double *u01, const int64_t *cell_start, int64_t n_cell,
@@ -545,6 +546,9 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
   if (lds_scatter > 65536)  // gfx950 has 160 KiB of LDS per CU; > 64 KiB dynamic needs opting in
     HIP_TRY(hipFuncSetAttribute((const void *)k_bin_scatter,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scatter));
+  if (lds_build > 65536)
+    HIP_TRY(hipFuncSetAttribute((const void *)k_bin_build,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
   {
     PhaseScope ph(ctx, SDM_PHASE_SHUFFLE_BUILD);
     if (u01)

@@ -108,7 +108,7 @@ def test_full_size_displacement_then_collisions(hip_backend_class, oracle_backen
 
 
 @pytest.mark.parametrize("n_sd,steps,thin", [(2**20, 12, None), (2**16, 12, 0.02),
-                                             (2**16, 40, 100.0)])
+                                             (2**16, 40, 100.0), (2**24, 2, None)])
 def test_many_steps_in_one_call_equal_oracle(n_sd, steps, thin, hip_backend_class,
                                              oracle_backend_class):
     """`Particulator.run(n)` of the single-cell non-adaptive box = one `sdm_collision_run` call: n
