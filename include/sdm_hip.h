@@ -188,6 +188,14 @@ int sdm_ll82_fragmentation(sdm_ctx *ctx, double *n_fragment, const double *CKE, 
 /* fragmentation_methods.py:305-319: Ec[i] = 1 where dl[i] < 0.4 mm */
 int sdm_ll82_coalescence_check(sdm_ctx *ctx, double *Ec, const double *dl, int64_t n);
 
+/* terminal_velocity_methods.py:32-66: Rogers & Yau's three regimes (consts = {SMALL_K, MEDIUM_K,
+ * LARGE_K, SMALL_R_LIMIT, MEDIUM_R_LIMIT}) and the user-defined power series
+ * values[i] = sum_j prefactors[j] * radius[i]^(3 powers[j]) (host arrays of num_terms <= 16)      */
+int sdm_terminal_velocity(sdm_ctx *ctx, double *values, const double *radius, int64_t n,
+                          const double consts[5]);
+int sdm_power_series(sdm_ctx *ctx, double *values, const double *radius, int64_t n,
+                     int num_terms, const double *prefactors, const double *powers);
+
 /* ---- f-3 displacement, PySDM/backends/impl_numba/methods/displacement_methods.py ---------- */
 /* :14-129: displacement[dim, :] from the Arakawa-C Courant field of direction `dim` (shape =
  * grid with one more point along dim; row-major) interpolated to the SD's position in its cell;

@@ -401,6 +401,26 @@ class OracleBackend(BackendMethods):  # pylint: disable=too-many-public-methods
             _f64(-1.0 if nfmax is None else nfmax), _p(x_plus_y.data),
         )
 
+    # ---- terminal velocities other than the Gunn-Kinzer table (terminal_velocity_methods.py) ------
+    def _rogers_yau_consts(self):
+        const = self.formulae.constants
+        return np.asarray([const.ROGERS_YAU_TERM_VEL_SMALL_K, const.ROGERS_YAU_TERM_VEL_MEDIUM_K,
+                           const.ROGERS_YAU_TERM_VEL_LARGE_K,
+                           const.ROGERS_YAU_TERM_VEL_SMALL_R_LIMIT,
+                           const.ROGERS_YAU_TERM_VEL_MEDIUM_R_LIMIT], dtype=np.float64)
+
+    def terminal_velocity(self, *, values, radius):
+        # (raw arrays, as the reference passes `.data`)
+        lib().oracle_terminal_velocity(_p(values), _p(radius), _i64(len(values)),
+                                       _p(self._rogers_yau_consts()))
+
+    @staticmethod
+    def power_series(*, values, radius, num_terms, prefactors, powers):
+        lib().oracle_power_series(
+            _p(values), _p(radius), _i64(len(values)), _int(int(num_terms)),
+            _p(np.ascontiguousarray(prefactors, dtype=np.float64)),
+            _p(np.ascontiguousarray(powers, dtype=np.float64)))
+
     # ---- displacement (displacement_methods.py) --------------------------------------------------
     def calculate_displacement(self, *, dim, displacement, courant, cell_origin, position_in_cell,
                                n_substeps):

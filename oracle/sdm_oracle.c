@@ -928,6 +928,27 @@ API void oracle_straub_fragmentation(const double *CW, const double *gam, const 
   }
 }
 
+/* terminal_velocity_methods.py:32-45 with physics/terminal_velocity/rogers_yau.py:14-25;
+ * consts = {SMALL_K, MEDIUM_K, LARGE_K, SMALL_R_LIMIT, MEDIUM_R_LIMIT} */
+API void oracle_terminal_velocity(double *values, const double *radius, int64_t n,
+                                  const double *consts) {
+  for (int64_t i = 0; i < n; ++i) {
+    const double r = radius[i];
+    values[i] = r < consts[3] ? consts[0] * (r * r)
+                              : (r < consts[4] ? consts[1] * r : consts[2] * pow(r, 0.5));
+  }
+}
+
+/* terminal_velocity_methods.py:47-66 */
+API void oracle_power_series(double *values, const double *radius, int64_t n, int num_terms,
+                             const double *prefactors, const double *powers) {
+  for (int64_t i = 0; i < n; ++i) {
+    values[i] = 0.0;
+    for (int j = 0; j < num_terms; ++j)
+      values[i] = values[i] + prefactors[j] * pow(radius[i], powers[j] * 3);
+  }
+}
+
 /* ------------------------------------------------------------------------------------------
  * f-3  displacement, PySDM/backends/impl_numba/methods/displacement_methods.py
  * ---------------------------------------------------------------------------------------- */

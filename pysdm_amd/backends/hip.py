@@ -388,6 +388,23 @@ class HIP(BackendMethods):  # pylint: disable=too-many-public-methods
               _ptr(Nr3.data), _ptr(Nr4.data), _ptr(Nrt.data), _ptr(d34.data),
               self.straub_consts())
 
+    # ---- terminal velocities other than the Gunn-Kinzer table (terminal_velocity_methods.py) ------
+    def terminal_velocity(self, *, values, radius):
+        # (raw device arrays, as the reference passes `.data`)
+        const = self.formulae.constants
+        _call("sdm_terminal_velocity", _ptr(values), _ptr(radius), c_i64(values.numel()),
+              (c_f64 * 5)(const.ROGERS_YAU_TERM_VEL_SMALL_K, const.ROGERS_YAU_TERM_VEL_MEDIUM_K,
+                          const.ROGERS_YAU_TERM_VEL_LARGE_K,
+                          const.ROGERS_YAU_TERM_VEL_SMALL_R_LIMIT,
+                          const.ROGERS_YAU_TERM_VEL_MEDIUM_R_LIMIT))
+
+    @staticmethod
+    def power_series(*, values, radius, num_terms, prefactors, powers):
+        n_terms = int(num_terms)
+        _call("sdm_power_series", _ptr(values), _ptr(radius), c_i64(values.numel()),
+              c_int(n_terms), (c_f64 * n_terms)(*[float(v) for v in prefactors]),
+              (c_f64 * n_terms)(*[float(v) for v in powers]))
+
     # ---- displacement (displacement_methods.py) ------------------------------------------------
     def calculate_displacement(self, *, dim, displacement, courant, cell_origin, position_in_cell,
                                n_substeps):

@@ -816,6 +816,55 @@ extern "C" int sdm_straub_fragmentation(sdm_ctx *ctx, double *n_fragment, const 
   return SDM_OK;
 }
 
+// ---- terminal velocities besides the Gunn-Kinzer table (terminal_velocity_methods.py:32-66) ---
+struct TermVelConsts { double k[5]; };
+struct PowerSeriesTerms { double prefactor[16], power[16]; };
+
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_terminal_velocity(double *__restrict__ values, const double *__restrict__ radius, int64_t n,
+                    TermVelConsts K) {
+  const int64_t i = TID();
+  if (i >= n) return;
+  const double r = radius[i];
+  values[i] = r < K.k[3] ? K.k[0] * (r * r) : (r < K.k[4] ? K.k[1] * r : K.k[2] * pow(r, 0.5));
+}
+
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_power_series(double *__restrict__ values, const double *__restrict__ radius, int64_t n,
+               int num_terms, PowerSeriesTerms T) {
+  const int64_t i = TID();
+  if (i >= n) return;
+  double v = 0.0;
+  for (int j = 0; j < num_terms; ++j) v = v + T.prefactor[j] * pow(radius[i], T.power[j] * 3);
+  values[i] = v;
+}
+
+extern "C" int sdm_terminal_velocity(sdm_ctx *ctx, double *values, const double *radius,
+                                     int64_t n, const double consts[5]) {
+  ARG_TRY(ctx && n >= 0 && consts);
+  if (n == 0) return SDM_OK;
+  ARG_TRY(values && radius);
+  TermVelConsts K;
+  memcpy(K.k, consts, sizeof(K.k));
+  hipLaunchKernelGGL(k_terminal_velocity, GRID1D(n), values, radius, n, K);
+  LAUNCH_CHECK();
+  return SDM_OK;
+}
+
+extern "C" int sdm_power_series(sdm_ctx *ctx, double *values, const double *radius, int64_t n,
+                                int num_terms, const double *prefactors, const double *powers) {
+  ARG_TRY(ctx && n >= 0 && num_terms >= 0 && num_terms <= 16);
+  ARG_TRY(num_terms == 0 || (prefactors && powers));
+  if (n == 0) return SDM_OK;
+  ARG_TRY(values && radius);
+  PowerSeriesTerms T;
+  memset(&T, 0, sizeof(T));
+  for (int j = 0; j < num_terms; ++j) { T.prefactor[j] = prefactors[j]; T.power[j] = powers[j]; }
+  hipLaunchKernelGGL(k_power_series, GRID1D(n), values, radius, n, num_terms, T);
+  LAUNCH_CHECK();
+  return SDM_OK;
+}
+
 // ---- moments (moments_methods.py:14-99) ----------------------------------------------------
 // After a collision step the state is sorted by cell (or is one cell), so a wave's 64 SDs nearly
 // always share their cell: the wave then folds its terms with shuffles and issues one atomic per

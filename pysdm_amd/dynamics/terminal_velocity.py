@@ -77,3 +77,33 @@ class GunnKinzer1949:  # pylint: disable=too-few-public-methods
         self.particulator.backend.interpolation(
             output=output, radius=radius, factor=self.factor, b=self.a, c=self.b
         )
+
+
+class RogersYau:  # pylint: disable=too-few-public-methods
+    """Rogers & Yau eqs 8.5, 8.6, 8.8 (PySDM/dynamics/terminal_velocity/rogers_and_yau.py)"""
+
+    def __init__(self, particulator):
+        self.particulator = particulator
+
+    def __call__(self, output, radius):
+        self.particulator.backend.terminal_velocity(values=output.data, radius=radius.data)
+
+
+class PowerSeries:  # pylint: disable=too-few-public-methods
+    """sum of power laws in the particle volume with user-given coefficients
+    (PySDM/dynamics/terminal_velocity/power_series.py:18-35)"""
+
+    def __init__(self, particulator, *, prefactors=None, powers=None):
+        from ..physics import constants as const  # pylint: disable=import-outside-toplevel
+
+        self.particulator = particulator
+        self.prefactors = np.array(prefactors or [2.0e-1 * si.m / si.s / np.sqrt(si.m)])
+        self.powers = np.array(powers or [1 / 6])
+        assert len(self.prefactors) == len(self.powers)
+        for i, power in enumerate(self.powers):
+            self.prefactors[i] *= const.PI_4_3**power / si.um ** (3 * power)
+
+    def __call__(self, output, radius):
+        self.particulator.backend.power_series(
+            values=output.data, radius=radius.data, num_terms=len(self.powers),
+            prefactors=self.prefactors, powers=self.powers)

@@ -70,7 +70,7 @@ class Formulae:  # pylint: disable=too-few-public-methods,too-many-arguments
     ):
         if particle_shape_and_density != "LiquidSpheres":
             raise NotImplementedError(particle_shape_and_density)
-        if terminal_velocity != "GunnKinzer1949":
+        if terminal_velocity not in ("GunnKinzer1949", "RogersYau", "PowerSeries"):
             raise NotImplementedError(terminal_velocity)
         values = {
             k: getattr(_const, k)
@@ -93,9 +93,10 @@ class Formulae:  # pylint: disable=too-few-public-methods,too-many-arguments
 
     @property
     def terminal_velocity_class(self):
-        from .dynamics.terminal_velocity import GunnKinzer1949  # pylint: disable=import-outside-toplevel
+        from .dynamics import terminal_velocity as tv  # pylint: disable=import-outside-toplevel
 
-        return GunnKinzer1949
+        return {"GunnKinzer1949": tv.GunnKinzer1949, "RogersYau": tv.RogersYau,
+                "PowerSeries": tv.PowerSeries}[self.terminal_velocity]
 
     def __str__(self):
         return f"Formulae(seed={self.seed}, fragmentation_function={self.fragmentation_function})"

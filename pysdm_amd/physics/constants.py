@@ -50,3 +50,10 @@ VEDDER_1987_A = 993 / 880 / 3 / VEDDER_1987_b
 
 # PySDM/physics/constants.py:50-54
 default_random_seed = 44 if "CI" in os.environ else time.time_ns()
+
+# Rogers & Yau terminal velocity (PySDM/physics/constants_defaults.py:625-635)
+ROGERS_YAU_TERM_VEL_SMALL_K = 1.19e6 / si.cm / si.s
+ROGERS_YAU_TERM_VEL_MEDIUM_K = 8e3 / si.s
+ROGERS_YAU_TERM_VEL_LARGE_K = 2.01e3 * si.cm**0.5 / si.s
+ROGERS_YAU_TERM_VEL_SMALL_R_LIMIT = 35 * si.um
+ROGERS_YAU_TERM_VEL_MEDIUM_R_LIMIT = 600 * si.um

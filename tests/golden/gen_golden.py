@@ -423,6 +423,21 @@ def gen_frag():
         eff(pw, flag)
         out[f"ec/{name}"] = pw.to_ndarray()
 
+    # the other terminal-velocity formulations that go through backend methods
+    from PySDM.dynamics.terminal_velocity import PowerSeries, RogersYau
+
+    ry_backend = CPU(Formulae(terminal_velocity="RogersYau"))
+    ry_part = _Part()
+    ry_part.backend = ry_backend
+    vel_alt = ry_backend.Storage.empty((n_sd,), float)
+    rad_plain = ry_backend.Storage.from_ndarray(rad_s.to_ndarray(raw=True))
+    RogersYau(ry_part)(vel_alt, rad_plain)
+    out["derived/velocity_rogers_yau"] = vel_alt.to_ndarray()
+    PowerSeries(ry_part)(vel_alt, rad_plain)
+    out["derived/velocity_power_series"] = vel_alt.to_ndarray()
+    PowerSeries(ry_part, prefactors=[0.3, 1.1], powers=[1 / 6, 1 / 3])(vel_alt, rad_plain)
+    out["derived/velocity_power_series_2"] = vel_alt.to_ndarray()
+
     # remaining kernels / efficiencies
     from PySDM.dynamics.collisions.collision_kernels import (
         Electric, Hydrodynamic, SimpleGeometric,

@@ -242,6 +242,16 @@ def check_physics(kit, exact, rtol):  # pylint: disable=too-many-locals
     cmp("volume", vol.to_ndarray(raw=True), g["derived/volume"])
     cmp("radius", rad.to_ndarray(raw=True), g["derived/radius"])
     cmp("velocity", vel.to_ndarray(raw=True), g["derived/velocity"])
+    from pysdm_amd.dynamics.terminal_velocity import PowerSeries, RogersYau  # pylint: disable=import-outside-toplevel
+
+    alt = kit.Storage.empty(n_sd, dtype=float)
+    plain = kit.Storage.from_ndarray(g["derived/radius"])
+    RogersYau(part)(alt, plain)
+    cmp("velocity_rogers_yau", alt.to_ndarray(), g["derived/velocity_rogers_yau"])
+    PowerSeries(part)(alt, plain)
+    cmp("velocity_power_series", alt.to_ndarray(), g["derived/velocity_power_series"])
+    PowerSeries(part, prefactors=[0.3, 1.1], powers=[1 / 6, 1 / 3])(alt, plain)
+    cmp("velocity_power_series_2", alt.to_ndarray(), g["derived/velocity_power_series_2"])
     flag = kit.PairIndicator(n_sd)
     flag.indicator.upload(g["derived/flag"])
     part.attributes = {"volume": vol, "radius": rad, "relative fall velocity": vel,
