@@ -77,6 +77,9 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
         self.result = StepResult()
 
     def _push_host_state(self):
+        # the fused step's compaction only looks for flagged positions: hand it a state without
+        # unflagged zero multiplicities (what the reference's super_droplet_count asserts anyway)
+        self.particulator.attributes.sanitize()
         view = state_access.view(self.particulator.attributes)
         host = torch.tensor(
             [view["valid_n_sd"], len(view["idx"]), int(view["sorted"]),

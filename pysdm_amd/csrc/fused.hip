@@ -327,12 +327,15 @@ __device__ __forceinline__ PairInfo pair_prob_body(const sdm_step_cfg &cfg, cons
 // p = the (already dt-scaled) probability; u = the slot's `rand`; j/k valid if `known`.
 // one colliding pair: bounce / coalescence / breakup decision and the update
 // (collisions_methods.py:247-311).  Wave-collective (counter_add): every lane calls it.
-struct Collided { int64_t j, k, cid; double g, u_b; };
+// pos: position of j in the permutation the step leaves behind (k sits at pos + 1)
+struct Collided { int64_t j, k, cid, pos; double g, u_b; };
 
+// returns which member ended with zero multiplicity (bit 0: the one passed as j, bit 1: as k)
 template <bool BREAKUP>
-__device__ __forceinline__ void resolve_collision(const sdm_step_cfg &cfg, const FusedArgs &A,
-                                                  bool collide, int64_t j, int64_t k,
-                                                  int64_t cid, double g, double u_b) {
+__device__ __forceinline__ int resolve_collision(const sdm_step_cfg &cfg, const FusedArgs &A,
+                                                 bool collide, int64_t j, int64_t k,
+                                                 int64_t cid, double g, double u_b) {
+  const int64_t j_in = j, k_in = k;
   const int64_t nk = collide ? A.multiplicity[k] : 0;
   bool coal = collide;
   if (BREAKUP && collide) {
@@ -403,20 +406,36 @@ __device__ __forceinline__ void resolve_collision(const sdm_step_cfg &cfg, const
   }
   counter_add(A.coalescence_rate, cid, (int64_t)(g * (double)nk), coal);
   if (coal) coalesce_pair(j, k, g, A.multiplicity, A.attributes, cfg.n_attr, cfg.n_sd);
+  int died = 0;
   if (collide) {
-    const int64_t n_j = A.multiplicity[j], n_k = A.multiplicity[k];
-    if (n_k == 0 || n_j == 0) A.ctl[CTL_HEALTHY] = 0;
-    sd_refresh(cfg, A, j);
-    sd_refresh(cfg, A, k);
+    const int64_t n_j = A.multiplicity[j_in], n_k = A.multiplicity[k_in];
+    died = (n_j == 0 ? 1 : 0) | (n_k == 0 ? 2 : 0);
+    if (died) A.ctl[CTL_HEALTHY] = 0;
+    sd_refresh(cfg, A, j_in);
+    sd_refresh(cfg, A, k_in);
   }
+  return died;
+}
+
+// the compaction of the fused route looks at the permutation only (index.hip, FLAG_ONLY): a
+// super-droplet whose multiplicity reached zero is flagged where it sits, the way the reference
+// flags precipitated ones (displacement_methods.py:157-158)
+__device__ __forceinline__ void flag_dead(const sdm_step_cfg &cfg, int64_t *__restrict__ idx,
+                                          int64_t pos, int died) {
+  if (died & 1) idx[pos] = cfg.n_sd;
+  if (died & 2) idx[pos + 1] = cfg.n_sd;
 }
 
 
+// `pos`: position of j in A.idx after this step's permutation (listed with the pair for
+// k_resolve_dense); `flag_here`: flag dead members in A.idx right away (false: the caller holds the
+// permutation elsewhere and applies the returned mask itself)
 template <bool BREAKUP>
-__device__ __forceinline__ void pair_update_body(const sdm_step_cfg &cfg, const FusedArgs &A,
-                                                 int64_t d, bool in_range, double p, double u,
-                                                 double u_b, bool known, int64_t off,
-                                                 int64_t j, int64_t k) {
+__device__ __forceinline__ int pair_update_body(const sdm_step_cfg &cfg, const FusedArgs &A,
+                                                int64_t d, bool in_range, double p, double u,
+                                                double u_b, bool known, int64_t off,
+                                                int64_t j, int64_t k, int64_t pos,
+                                                bool flag_here) {
   bool collide = false;
   int64_t cid = 0, nk = 0, gi = 0, gc = 0;
   double g = 0;
@@ -452,13 +471,15 @@ __device__ __forceinline__ void pair_update_body(const sdm_step_cfg &cfg, const 
       base = __shfl((long long)base, leader, 64);
       if (collide) {
         Collided c;
-        c.j = j; c.k = k; c.cid = cid; c.g = g; c.u_b = u_b;
+        c.j = j; c.k = k; c.cid = cid; c.pos = pos; c.g = g; c.u_b = u_b;
         A.list[base + __popcll(m & ((1ull << lane) - 1))] = c;
       }
     }
-    return;
+    return 0;
   }
-  resolve_collision<false>(cfg, A, collide, j, k, cid, g, u_b);
+  const int died = resolve_collision<false>(cfg, A, collide, j, k, cid, g, u_b);
+  if (died && flag_here) flag_dead(cfg, A.idx, pos, died);
+  return died;
 }
 
 // ---- non-adaptive: everything about a pair in one kernel -------------------------------------
@@ -474,7 +495,8 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_all(sdm_step_cfg cfg, FusedA
   if (d < (cfg.n_sd + 1) / 2) R = pair_prob_body<KERNEL, BREAKUP>(cfg, A, d, W, u_b);
   double p = R.prob;
   if (p != 0) p /= (double)cfg.substeps;  // collision.py:279
-  pair_update_body<BREAKUP>(cfg, A, d, d < W / 2, p, u, u_b, true, R.off, R.j, R.k);
+  pair_update_body<BREAKUP>(cfg, A, d, d < W / 2, p, u, u_b, true, R.off, R.j, R.k,
+                            2 * d + R.off, true);
 }
 
 // ---- adaptive: probabilities first (per-cell min of the optimal dt is a global dependency) ---
@@ -567,7 +589,7 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_update(sdm_step_cfg cfg, Fus
       p *= A.dt_todo[cid] / cfg.dt;  // collisions_methods.py:369-372
     }
   }
-  pair_update_body<BREAKUP>(cfg, A, d, in_range, p, u, u_b, false, off, 0, 0);
+  pair_update_body<BREAKUP>(cfg, A, d, in_range, p, u, u_b, false, off, 0, 0, 2 * d + off, true);
 }
 
 // ---- multi-cell fast path: one workgroup per cell, the whole sub-step of the cell in LDS ---------
@@ -745,7 +767,10 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     }
     double p = pprob[r];
     if (pvalid[r] && p != 0) { if (cfg.adaptive) p *= scale; else p /= (double)cfg.substeps; }
-    pair_update_body<BREAKUP>(cfg, A, d, pvalid[r], p, u, u_b, true, 0, pj[r], pk[r]);
+    const int died = pair_update_body<BREAKUP>(cfg, A, d, pvalid[r], p, u, u_b, true, 0, pj[r],
+                                               pk[r], lo + lp, false);
+    if (died & 1) out[lp] = (int32_t)N;  // the permutation is still in LDS here
+    if (died & 2) out[lp + 1] = (int32_t)N;
   }
   __syncthreads();
   for (int li = tid; li < n; li += CELL_THREADS) X.idx_out[lo + li] = out[li];
@@ -772,9 +797,10 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_resolve_dense(sdm_step_cfg cfg, F
   const int64_t t = TID();
   const bool active = t < n;
   Collided c;
-  c.j = c.k = c.cid = 0; c.g = 0; c.u_b = 0;
+  c.j = c.k = c.cid = c.pos = 0; c.g = 0; c.u_b = 0;
   if (active) c = A.list[t];
-  resolve_collision<true>(cfg, A, active, c.j, c.k, c.cid, c.g, c.u_b);
+  const int died = resolve_collision<true>(cfg, A, active, c.j, c.k, c.cid, c.g, c.u_b);
+  if (died) flag_dead(cfg, A.idx, c.pos, died);
 }
 
 // ---- control-word kernels -------------------------------------------------------------------
@@ -1162,7 +1188,7 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
     {
       PhaseScope ph(ctx, SDM_PHASE_SANITIZE);
       rc = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl, S.cctl,
-                                   C == 1 ? st->cell_start : nullptr);
+                                   C == 1 ? st->cell_start : nullptr, true);
       if (rc) return rc;
       if (C > 1) sorted_host = -1;  // a compaction (decided on the device) un-sorts
     }
