@@ -417,6 +417,49 @@ __device__ __forceinline__ int resolve_collision(const sdm_step_cfg &cfg, const 
   return died;
 }
 
+// coalescence of a pair whose members' state is already in registers (one extensive attribute):
+// same arithmetic as coalesce_pair (physics.h, collisions_methods.py:44-59) without re-reading
+// anything; SoA columns and mirror records are written once.  Returns the died mask.
+__device__ __forceinline__ int coalesce_known(const sdm_step_cfg &cfg, const FusedArgs &A,
+                                              int64_t j, int64_t k, double g, SD sj, SD sk) {
+  double *mass = A.attributes + (int64_t)cfg.mass_attr * cfg.n_sd;
+  const double new_n = (double)sj.n - g * (double)sk.n;
+  if (new_n > 0) {
+    sj.n = (int64_t)new_n;
+    sk.m += g * sj.m;
+    A.multiplicity[j] = sj.n;
+    mass[k] = sk.m;
+    if (A.nm_wide) derive_ru(cfg, A, sk);
+  } else {
+    const int64_t half = sk.n / 2;
+    sj.n = half;
+    sk.n = sk.n - half;
+    const double v = g * sj.m + sk.m;
+    sj.m = sk.m = v;
+    A.multiplicity[j] = sj.n;
+    A.multiplicity[k] = sk.n;
+    mass[j] = v;
+    mass[k] = v;
+    if (A.nm_wide) {
+      derive_ru(cfg, A, sk);
+      sj.r = sk.r;
+      sj.u = sk.u;
+    }
+  }
+  if (A.nm) {
+    if (A.nm_wide) {
+      ((double4 *)A.nm)[j] = make_double4(__longlong_as_double(sj.n), sj.m, sj.r, sj.u);
+      ((double4 *)A.nm)[k] = make_double4(__longlong_as_double(sk.n), sk.m, sk.r, sk.u);
+    } else {
+      ((double2 *)A.nm)[j] = make_double2(__longlong_as_double(sj.n), sj.m);
+      ((double2 *)A.nm)[k] = make_double2(__longlong_as_double(sk.n), sk.m);
+    }
+  }
+  const int died = (sj.n == 0 ? 1 : 0) | (sk.n == 0 ? 2 : 0);
+  if (died) A.ctl[CTL_HEALTHY] = 0;
+  return died;
+}
+
 // the compaction of the fused route looks at the permutation only (index.hip, FLAG_ONLY): a
 // super-droplet whose multiplicity reached zero is flagged where it sits, the way the reference
 // flags precipitated ones (displacement_methods.py:157-158)
@@ -435,7 +478,8 @@ __device__ __forceinline__ int pair_update_body(const sdm_step_cfg &cfg, const F
                                                 int64_t d, bool in_range, double p, double u,
                                                 double u_b, bool known, int64_t off,
                                                 int64_t j, int64_t k, int64_t pos,
-                                                bool flag_here) {
+                                                bool flag_here, const SD *sj = nullptr,
+                                                const SD *sk = nullptr) {
   bool collide = false;
   int64_t cid = 0, nk = 0, gi = 0, gc = 0;
   double g = 0;
@@ -448,8 +492,8 @@ __device__ __forceinline__ int pair_update_body(const sdm_step_cfg &cfg, const F
         j = A.idx[2 * d + off];
         k = A.idx[2 * d + 1 + off];
       }
-      nk = A.multiplicity[k];
-      const int64_t prop = A.multiplicity[j] / nk;
+      nk = sk ? sk->n : A.multiplicity[k];
+      const int64_t prop = (sj ? sj->n : A.multiplicity[j]) / nk;
       gi = (int64_t)g;
       gc = gi < prop ? gi : prop;
       cid = cfg.n_cell == 1 ? 0 : A.cell_id[j];
@@ -477,7 +521,13 @@ __device__ __forceinline__ int pair_update_body(const sdm_step_cfg &cfg, const F
     }
     return 0;
   }
-  const int died = resolve_collision<false>(cfg, A, collide, j, k, cid, g, u_b);
+  int died;
+  if (sj && cfg.n_attr == 1) {  // members' state carried in registers by the caller
+    counter_add(A.coalescence_rate, cid, (int64_t)(g * (double)nk), collide);
+    died = collide ? coalesce_known(cfg, A, j, k, g, *sj, *sk) : 0;
+  } else {
+    died = resolve_collision<false>(cfg, A, collide, j, k, cid, g, u_b);
+  }
   if (died && flag_here) flag_dead(cfg, A.idx, pos, died);
   return died;
 }
@@ -611,10 +661,20 @@ struct CellArgs {
   int n_tail_blocks;
 };
 
+#ifdef CELL_PROFILE
+#define CELL_MARK(k) do { __syncthreads(); if (blockIdx.x == 7 && threadIdx.x == 0) cell_t[(k) + 1] = wall_clock64(); } while (0)
+#else
+#define CELL_MARK(k)
+#endif
+
 template <int KERNEL, bool BREAKUP>
 __global__ void __launch_bounds__(CELL_THREADS)
 k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef CELL_PROFILE
+  __shared__ long long cell_t[9];
+  if (blockIdx.x == 7 && threadIdx.x == 0) cell_t[0] = wall_clock64();
+#endif
   int32_t *s0 = (int32_t *)smem, *s1 = s0 + CELL_CAP, *head = s1 + CELL_CAP;
   int32_t *val = head + CELL_CAP, *out = val + CELL_CAP;
   int16_t *jown = (int16_t *)(out + CELL_CAP), *next = jown + CELL_CAP;
@@ -638,6 +698,7 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     for (int li = tid; li < n; li += CELL_THREADS) X.idx_out[lo + li] = X.idx_in[lo + li];
     return;
   }
+  CELL_MARK(0);
   const int64_t W = A.ctl[CTL_WORK];
   for (int li = tid; li < n; li += CELL_THREADS) {
     val[li] = (int32_t)X.idx_in[lo + li];
@@ -654,6 +715,7 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   if (tid == 128) s_rng[1] = pcg_jump(A.s_rand, A.rng_tab, (uint64_t)(lo >> 1));
   if (BREAKUP && tid == 192) s_rng[2] = pcg_jump(A.s_rand_b, A.rng_tab, (uint64_t)(lo >> 1));
   __syncthreads();
+  CELL_MARK(1);
   // shuffle_local events of this cell (index_methods.py:35-41): consecutive positions per thread
   {
     const int chunk = (n + CELL_THREADS - 1) / CELL_THREADS;
@@ -678,6 +740,7 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     }
   }
   __syncthreads();
+  CELL_MARK(2);
   // backward walks (see index.hip), entirely in LDS
   for (int li = tid; li < n; li += CELL_THREADS) {
     int e = 0, q = li;
@@ -697,41 +760,59 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     out[li] = val[q];
   }
   __syncthreads();
+  CELL_MARK(3);
   // pairs: positions p with (p - cell_start[cell_idx[cid]]) even and p + 1 in the same segment
   const int64_t cid = s_cid;
   const int lp0 = (int)((lo - s_base) & 1);
   int64_t pj[CELL_MAXPAIR], pk[CELL_MAXPAIR];
   double pprob[CELL_MAXPAIR];
   bool pvalid[CELL_MAXPAIR];
+  SD psj[CELL_MAXPAIR], psk[CELL_MAXPAIR];
   double my_min = INFINITY;
+  const bool need_r = KERNEL == SDM_KERNEL_GEOMETRIC;
+  // all gathers of the thread's pairs first (independent loads in flight together) ...
 #pragma unroll
   for (int r = 0; r < CELL_MAXPAIR; ++r) {
     const int lp = lp0 + 2 * (tid * CELL_MAXPAIR + r);  // consecutive pair slots per thread
-    const int64_t p = lo + lp;
-    pvalid[r] = lp + 1 < n && p < W - 1;
+    pvalid[r] = lp + 1 < n && lo + lp < W - 1;
     pj[r] = pk[r] = 0;
+    if (pvalid[r]) {
+      pj[r] = out[lp];
+      pk[r] = out[lp + 1];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < CELL_MAXPAIR; ++r) {
+    psj[r].n = psk[r].n = 1; psj[r].m = psk[r].m = psj[r].r = psk[r].r = psj[r].u = psk[r].u = 0;
+    if (pvalid[r]) {
+      psj[r] = sd_load(cfg, A, pj[r], need_r);
+      psk[r] = sd_load(cfg, A, pk[r], need_r);
+    }
+  }
+  // ... then sort within pair, kernel, probability
+#pragma unroll
+  for (int r = 0; r < CELL_MAXPAIR; ++r) {
+    const int lp = lp0 + 2 * (tid * CELL_MAXPAIR + r);
+    const int64_t p = lo + lp;
     pprob[r] = 0.0;
     if (pvalid[r]) {
-      int64_t j = out[lp], k = out[lp + 1];
-      const bool need_r = KERNEL == SDM_KERNEL_GEOMETRIC;
-      SD sj = sd_load(cfg, A, j, need_r), sk = sd_load(cfg, A, k, need_r);
-      if (sj.n < sk.n) {  // sort_within_pair_by_attr
-        const int64_t t = j; j = k; k = t;
-        const SD ts = sj; sj = sk; sk = ts;
-        out[lp] = (int32_t)j;
-        out[lp + 1] = (int32_t)k;
+      if (psj[r].n < psk[r].n) {  // sort_within_pair_by_attr
+        const int64_t t = pj[r]; pj[r] = pk[r]; pk[r] = t;
+        const SD ts = psj[r]; psj[r] = psk[r]; psk[r] = ts;
+        out[lp] = (int32_t)pj[r];
+        out[lp + 1] = (int32_t)pk[r];
       }
-      pj[r] = j; pk[r] = k;
-      const double prob = pair_prob_value<KERNEL>(cfg, A, p >> 1, sj, sk);
+      const double prob = pair_prob_value<KERNEL>(cfg, A, p >> 1, psj[r], psk[r]);
       pprob[r] = prob;
       if (cfg.adaptive && prob != 0) {
-        const int64_t prop = sj.n / sk.n;
+        const int64_t prop = psj[r].n / psk[r].n;
         const double t = cfg.dt * (double)prop / prob;
         const double dt_opt = cfg.dt_min > t ? cfg.dt_min : t;
         my_min = dt_opt < my_min ? dt_opt : my_min;
       }
     }
   }
+  CELL_MARK(4);
   double scale = 1.0 / (double)cfg.substeps;
   if (cfg.adaptive) {  // workgroup minimum of the optimal sub-step (collisions_methods.py:357-368)
     const double m = wave_min_f64(my_min);
@@ -745,6 +826,7 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     if (bmin < todo) todo = bmin;
     scale = todo / cfg.dt;
   }
+  CELL_MARK(5);
   // gamma + update (all lanes take part: wave-aggregated counters).  A thread's pair slots are
   // consecutive, so are their draws: one jump-ahead, then single generator steps
   u128 st = 0, sb = 0;
@@ -768,12 +850,22 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     double p = pprob[r];
     if (pvalid[r] && p != 0) { if (cfg.adaptive) p *= scale; else p /= (double)cfg.substeps; }
     const int died = pair_update_body<BREAKUP>(cfg, A, d, pvalid[r], p, u, u_b, true, 0, pj[r],
-                                               pk[r], lo + lp, false);
+                                               pk[r], lo + lp, false, &psj[r], &psk[r]);
     if (died & 1) out[lp] = (int32_t)N;  // the permutation is still in LDS here
     if (died & 2) out[lp + 1] = (int32_t)N;
   }
   __syncthreads();
+  CELL_MARK(6);
   for (int li = tid; li < n; li += CELL_THREADS) X.idx_out[lo + li] = out[li];
+#ifdef CELL_PROFILE
+  __syncthreads();
+  if (blockIdx.x == 7 && tid == 0) {
+    const long long t7 = wall_clock64();
+    printf("cell n=%d ticks(10ns): load %lld prep %lld events %lld walk %lld gather+prob %lld min %lld update %lld store %lld\n",
+           n, cell_t[1] - cell_t[0], cell_t[2] - cell_t[1], cell_t[3] - cell_t[2], cell_t[4] - cell_t[3],
+           cell_t[5] - cell_t[4], cell_t[6] - cell_t[5], cell_t[7] - cell_t[6], t7 - cell_t[7]);
+  }
+#endif
 }
 
 // largest cell of a sorted state -> ctl[6]
