@@ -8,6 +8,8 @@ tests/unit_tests/dynamics/collisions/test_sdm_single_cell.py:73-98 (same-multipl
 :215-258 (gamma formula grid); tests/unit_tests/dynamics/collisions/test_sdm_breakup.py:232-420
 (ten single-breakup answers).
 """
+import warnings
+
 import numpy as np
 
 from pysdm_amd.dynamics.collisions import DEFAULTS
@@ -320,7 +322,422 @@ def check_reference_efficiency_and_kernel_tests(kit):
             np.testing.assert_array_equal(output.to_ndarray(), [0.0])
 
 
-ALL_CHECKS = (check_reference_fragmentation_tests, check_reference_efficiency_and_kernel_tests,
+class _StubKernel:  # tests/unit_tests/dynamics/collisions/conftest.py:12-21
+    def __init__(self, value=0):
+        self.value = value
+
+    def register(self, builder):
+        pass
+
+    def __call__(self, output, is_first_in_pair):
+        _fill(output, self.value)
+
+
+def _fill(array, value, odd_zeros=False):
+    """conftest.py:24-37: upload a constant (or every other entry, zeros in between)"""
+    shape = array.shape[0]
+    if odd_zeros:
+        if isinstance(value, np.ndarray):
+            full = np.stack((value[::2], np.zeros_like(value[::2]))).flatten(order="F")
+            full = full.astype(np.float64)
+        else:
+            half = np.full(shape // 2, value).astype(np.float64)
+            full = np.stack((half, np.zeros_like(half))).flatten(order="F")
+            if shape % 2 != 0:
+                full = np.concatenate((full, np.zeros(1)))
+    else:
+        full = np.full(shape, value).astype(np.float64)
+    array.upload(full)
+
+
+def _box_with_coalescence(kit, attributes, *, seed=None, environment=None, substeps=1,
+                          optimized_random=False):
+    """conftest.py:46-60: Box(dv=1, dt=dt_coal_range[1]), stub kernel, non-adaptive, the
+    method-by-method route (the scenarios patch `compute_gamma` on the dynamic)"""
+    from pysdm_amd.dynamics.collisions import Coalescence  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.environments import Box  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.formulae import Formulae  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.particulator import Builder  # pylint: disable=import-outside-toplevel
+
+    env = environment or Box(dv=1, dt=DEFAULTS.dt_coal_range[1])
+    n_sd = len(attributes["multiplicity"])
+    kwargs = {} if seed is None else {"seed": seed}
+    builder = Builder(n_sd, kit.backend.__class__(Formulae(**kwargs)), environment=env)
+    builder.add_dynamic(Coalescence(collision_kernel=_StubKernel(), adaptive=False, fused=False,
+                                    substeps=substeps, optimized_random=optimized_random))
+    particulator = builder.build(attributes={k: np.asarray(v) for k, v in attributes.items()})
+    return particulator, particulator.dynamics["Collision"]
+
+
+def check_reference_single_cell_scenarios(kit):
+    """test_sdm_single_cell.py:16-214 re-typed (without the "heat"/"temperature" attributes, which
+    are off the path): forced gamma, multi-collision limits, odd droplets left alone, 32 steps"""
+    from pysdm_amd.dynamics.collisions import Coalescence  # pylint: disable=import-outside-toplevel
+
+    rho_w = kit.backend.formulae.constants.rho_w
+    pairs_v = (np.array([1.0, 1.0]), np.array([4.0, 2.0]))
+    pairs_n = (np.array([1, 1]), np.array([5, 1]), np.array([5, 3]))
+    # :16-79 single collision with gamma forced to one
+    for v_2 in pairs_v:
+        for n_2 in pairs_n:
+            particulator, sut = _box_with_coalescence(kit, {"multiplicity": n_2, "volume": v_2})
+            sut.compute_gamma = lambda prob, rand, is_first_in_pair, out: _fill(out, 1)
+            sut()
+            state = particulator.attributes
+            mult, vol = state["multiplicity"].to_ndarray(), state["volume"].to_ndarray()
+            np.testing.assert_approx_equal(np.sum(mult * vol), np.sum(n_2 * v_2))
+            assert np.sum(mult) == np.sum(n_2) - np.amin(n_2)
+            np.testing.assert_approx_equal(np.amax(vol), np.sum(v_2))
+            assert np.amax(mult) == max(np.amax(n_2) - np.amin(n_2), np.amin(n_2))
+    # :107-158 gamma limited by the multiplicity ratio
+    for p_value in (2, 4, 5, 7):
+        for v_2 in pairs_v:
+            for n_2 in pairs_n:
+                particulator, sut = _box_with_coalescence(kit, {"multiplicity": n_2,
+                                                                "volume": v_2})
+
+                def compute_gamma(prob, rand, is_first_in_pair, out, sut=sut, p_value=p_value):
+                    _fill(prob, p_value)
+                    Coalescence.compute_gamma(sut, prob, rand, is_first_in_pair, out=out)
+
+                sut.compute_gamma = compute_gamma
+                sut()
+                state = particulator.attributes
+                mult, vol = state["multiplicity"].to_ndarray(), state["volume"].to_ndarray()
+                gamma = min(p_value, max(n_2[0] // n_2[1], n_2[1] // n_2[1]))
+                assert np.amin(mult) >= 0
+                np.testing.assert_approx_equal(
+                    np.sum(mult * state["water mass"].to_ndarray()), np.sum(n_2 * v_2 * rho_w))
+                np.testing.assert_approx_equal(np.sum(mult * vol), np.sum(n_2 * v_2))
+                assert np.sum(mult) == np.sum(n_2) - gamma * np.amin(n_2)
+                np.testing.assert_approx_equal(
+                    np.amax(vol), gamma * v_2[np.argmax(n_2)] + v_2[np.argmax(n_2) - 1])
+                assert np.amax(mult) == max(np.amax(n_2) - gamma * np.amin(n_2), np.amin(n_2))
+    # :160-185 odd number of droplets
+    for v, n, p_value in ((np.array([1.0, 1, 1]), np.array([1, 1, 1]), 2),
+                          (np.array([1.0, 1, 1, 1, 1]), np.array([5, 1, 2, 1, 1]), 1),
+                          (np.array([1.0, 1, 1, 1, 1]), np.array([5, 1, 2, 1, 1]), 6)):
+        particulator, sut = _box_with_coalescence(kit, {"multiplicity": n, "volume": v})
+
+        def compute_gamma(prob, rand, is_first_in_pair, out, sut=sut, p_value=p_value):
+            _fill(prob, p_value, odd_zeros=True)
+            Coalescence.compute_gamma(sut, prob, rand, is_first_in_pair, out=out)
+
+        sut.compute_gamma = compute_gamma
+        sut()
+        state = particulator.attributes
+        assert np.amin(state["multiplicity"].to_ndarray()) >= 0
+        np.testing.assert_allclose(
+            np.sum(state["multiplicity"].to_ndarray() * state["volume"].to_ndarray()),
+            np.sum(n * v), rtol=1e-14)
+    # :187-214 32 steps with gamma = (rand > 0.5) on every other pair
+    rng = np.random.default_rng(5)
+    n_sd = 256
+    n, v = rng.integers(1, 64, size=n_sd), rng.uniform(size=n_sd)
+    particulator, sut = _box_with_coalescence(kit, {"multiplicity": n, "volume": v})
+    sut.compute_gamma = lambda prob, rand, is_first_in_pair, out: _fill(
+        out, rand.to_ndarray() > 0.5, odd_zeros=True)
+    for _ in range(32):
+        sut()
+        particulator.attributes.sanitize()
+    state = particulator.attributes
+    assert np.amin(state["multiplicity"].to_ndarray()) >= 0
+    np.testing.assert_approx_equal(
+        np.sum(state["multiplicity"].to_ndarray() * state["volume"].to_ndarray()), np.sum(n * v),
+        significant=8)
+
+
+def check_reference_random_reuse_and_multi_cell_call(kit):
+    """test_sdm_single_cell.py:260-307 (how often the generator is called) and
+    test_sdm_multi_cell.py:15-49 (a call on a 25 x 25 grid leaves the cell ids alone)"""
+    from pysdm_amd.environments import Box, Mesh  # pylint: disable=import-outside-toplevel
+
+    rng = np.random.default_rng(6)
+    n_sd, n_substeps = 256, 5
+    for optimized_random in (True, False):
+        for adaptive in (True, False):
+            attributes = {"multiplicity": rng.integers(1, 64, size=n_sd),
+                          "volume": rng.uniform(size=n_sd)}
+            _, sut = _box_with_coalescence(kit, attributes, substeps=n_substeps,
+                                           optimized_random=optimized_random)
+            calls = []
+            generator = sut.rnd_opt_coll.rnd
+            original = generator.__class__.__call__
+
+            class Counting(generator.__class__):  # pylint: disable=too-few-public-methods
+                def __call__(self, storage):
+                    calls.append(1)
+                    original(self, storage)
+
+            sut.rnd_opt_coll.rnd = Counting(n_sd, seed=44)
+            sut.stats_n_substep[:] = n_substeps
+            sut.adaptive = adaptive
+            sut()
+            if sut.rnd_opt_coll.optimized_random:
+                assert len(calls) == 2
+            elif adaptive:
+                assert 2 <= len(calls) <= 2 * n_substeps
+            else:
+                assert len(calls) == 2 * n_substeps
+    for n_sd in (2, 3, 8000):
+        for adaptive in (False, True):
+            grid = (25, 25)
+            env = Box(dv=1, dt=DEFAULTS.dt_coal_range[1])
+            env.mesh = Mesh(grid, size=grid)
+            positions = rng.uniform(0, 1, (2, n_sd)) * np.asarray(grid).reshape(2, 1)
+            cell_id, _, _ = env.mesh.cellular_attributes(positions)
+            particulator, sut = _box_with_coalescence(
+                kit, {"multiplicity": np.ones(n_sd), "volume": np.ones(n_sd), "cell id": cell_id},
+                environment=env)
+            sut.adaptive = adaptive
+            sut()
+            np.testing.assert_array_equal(
+                cell_id, particulator.attributes["cell id"].to_ndarray(raw=True))
+
+
+def _one_breakup_call(kit, *, n_init, v_init, gamma, frag_volume, rand=1.0, Eb=1.0,
+                      is_first_in_pair=None, n_calls=1, warn_overflows=False,
+                      handle_all_breakups=False):
+    """the arrangement shared by test_sdm_breakup.py:97-230,460-940: a NaN box, one backend call
+    `collision_coalescence_breakup` through the Particulator wrapper; returns
+    (multiplicities, volumes, breakup_rate, breakup_rate_deficit)"""
+    from pysdm_amd.environments import Box  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.formulae import Formulae  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.particulator import Builder  # pylint: disable=import-outside-toplevel
+
+    n_sd = len(n_init)
+    n_pairs = n_sd // 2
+    backend = kit.backend.__class__(Formulae(handle_all_breakups=handle_all_breakups))
+    builder = Builder(n_sd, backend, environment=Box(dv=np.nan, dt=np.nan))
+    particulator = builder.build(attributes={
+        "multiplicity": np.asarray(n_init), "volume": np.asarray(v_init, dtype=float)})
+
+    def pairwise(values):
+        values = np.asarray(values, dtype=float)
+        if values.ndim == 0:
+            values = np.full(n_pairs, float(values))
+        return particulator.PairwiseStorage.from_ndarray(values)
+
+    flag = particulator.PairIndicator(n_sd)
+    flag.indicator[:] = particulator.Storage.from_ndarray(np.asarray(
+        is_first_in_pair if is_first_in_pair is not None else [True, False] * n_pairs
+        + [False] * (n_sd % 2), dtype=bool))
+    breakup_rate = particulator.Storage.from_ndarray(np.array([0]))
+    deficit = particulator.Storage.from_ndarray(np.array([0]))
+    coalescence_rate = particulator.Storage.from_ndarray(np.array([0] * n_sd))
+    gamma_s, rand_s, eb_s = pairwise(gamma), pairwise(rand), pairwise(Eb)
+    frag_mass = pairwise(np.asarray(frag_volume, dtype=float) * RHO_W)
+    zeros = pairwise(0.0)
+    for _ in range(n_calls):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            particulator.collision_coalescence_breakup(
+                enable_breakup=True, gamma=gamma_s, rand=rand_s, Ec=zeros, Eb=eb_s,
+                fragment_mass=frag_mass, coalescence_rate=coalescence_rate,
+                breakup_rate=breakup_rate, breakup_rate_deficit=deficit, is_first_in_pair=flag,
+                warn_overflows=warn_overflows, max_multiplicity=DEFAULTS.max_multiplicity)
+    attrs = particulator.attributes
+    return (attrs["multiplicity"].to_ndarray(), attrs["volume"].to_ndarray(),
+            breakup_rate.to_ndarray(), deficit.to_ndarray())
+
+
+def check_reference_breakup_scenarios(kit):
+    """test_sdm_breakup.py re-typed: bounce (:85-144), breakup counters (:146-236), n breakups at
+    once = n single ones (:422-536), overflow guards (:538-690), non-integer fragment numbers
+    (:692-786), all breakups handled in a loop (:824-940)"""
+    um3 = 1e-18
+    # bounce: rand > Ec + (1 - Ec) Eb with Ec = Eb = 0 -> nothing happens
+    for rand in (1.0, 0.1):
+        mult, _, _, _ = _one_breakup_call(kit, n_init=[6, 6], v_init=[100 * um3] * 2, gamma=1.0,
+                                          frag_volume=[50 * um3 / RHO_W], rand=rand, Eb=0.0)
+        np.testing.assert_array_equal(mult, [6, 6])
+    # counters: breakup_rate = sum over pairs of gamma * smaller multiplicity
+    for n_init, first in (([1, 1], [True, False]), ([2, 1], [True, False]),
+                          ([2, 1, 2], [True, False, False]),
+                          ([2, 1, 2, 1], [True, False, True, False])):
+        _, _, rate, _ = _one_breakup_call(kit, n_init=n_init, v_init=[100 * um3] * len(n_init),
+                                          gamma=1.0, frag_volume=[2.0] * (len(n_init) // 2),
+                                          is_first_in_pair=first)
+        smaller = np.where(np.roll(first, shift=1), np.asarray(n_init), 0.0)
+        assert rate[0] == np.sum(1.0 * smaller)
+    # gamma = n in one call equals n calls with gamma = 1
+    for case in ({"n_init": [64, 2], "v_init": [128, 128], "frag_volume": [128]},
+                 {"n_init": [20, 4], "v_init": [1, 2], "frag_volume": [1.0]},
+                 {"n_init": [3, 1], "v_init": [1, 1], "frag_volume": [0.5]},
+                 {"n_init": [64, 2], "v_init": [8, 16], "frag_volume": [4.0]},
+                 {"n_init": [64, 2], "v_init": [6, 2], "frag_volume": [4.0]}):
+        for n_times in (1, 2, 3, 4, 5):
+            at_once = _one_breakup_call(kit, gamma=[n_times], **case)
+            one_by_one = _one_breakup_call(kit, gamma=[1], n_calls=n_times, **case)
+            np.testing.assert_array_almost_equal(at_once[0], one_by_one[0])
+            np.testing.assert_array_almost_equal(at_once[1], one_by_one[1])
+    # multiplicity overflow is refused, the deficit counted, mass conserved
+    mult, vol, _, deficit = _one_breakup_call(kit, n_init=[1, 3], v_init=[1, 1], gamma=[1.0],
+                                              frag_volume=[2e-10], warn_overflows=True)
+    assert deficit[0] > 0
+    np.testing.assert_almost_equal(np.sum(mult * vol), 4.0)
+    mult, vol, _, deficit = _one_breakup_call(kit, n_init=[1, 1], v_init=[1, 1], gamma=[46.0],
+                                              frag_volume=[0.5], warn_overflows=True)
+    assert deficit[0] > 0
+    assert np.sum(mult * vol) == 2.0
+    # non-integer numbers of fragments
+    for case in (
+        {"gamma": [1.0], "n_init": [1, 1], "v_init": [1, 1], "n_expected": [1, 1],
+         "v_expected": [1, 1], "expected_deficit": [0.0], "frag_volume": [1.25]},
+        {"gamma": [1.0], "n_init": [1, 1], "v_init": [1, 1], "n_expected": [1, 1],
+         "v_expected": [1, 1], "expected_deficit": [0.0], "frag_volume": [1 / 1.3]},
+        {"gamma": [2.0], "n_init": [2, 1], "v_init": [1, 1], "n_expected": [1, 3],
+         "v_expected": [1, 2 / 3], "expected_deficit": [1.0], "frag_volume": [1 / 1.4]},
+    ):
+        mult, vol, _, deficit = _one_breakup_call(
+            kit, n_init=case["n_init"], v_init=case["v_init"], gamma=case["gamma"],
+            frag_volume=case["frag_volume"])
+        np.testing.assert_array_equal(mult, case["n_expected"])
+        np.testing.assert_array_almost_equal(vol, case["v_expected"], decimal=6)
+        np.testing.assert_almost_equal(np.sum(mult * vol), np.sum(
+            np.asarray(case["n_init"]) * np.asarray(case["v_init"])), decimal=6)
+        np.testing.assert_equal(deficit, case["expected_deficit"])
+    # handle_all_breakups: the while loop of collisions_methods.py:196-243
+    for case in (
+        {"gamma": [2.0], "n_init": [1, 1], "v_init": [1, 1], "n_expected": [2, 2],
+         "v_expected": [0.5, 0.5], "expected_deficit": [0.0], "frag_volume": [0.5]},
+        {"gamma": [3.0], "n_init": [9, 2], "v_init": [1, 2], "n_expected": [2, 11],
+         "v_expected": [1, 1], "expected_deficit": [0.0], "frag_volume": [1.0]},
+    ):
+        mult, vol, _, deficit = _one_breakup_call(
+            kit, n_init=case["n_init"], v_init=case["v_init"], gamma=case["gamma"],
+            frag_volume=case["frag_volume"], warn_overflows=True, handle_all_breakups=True)
+        np.testing.assert_array_equal(mult, case["n_expected"])
+        np.testing.assert_array_almost_equal(vol, case["v_expected"], decimal=6)
+        np.testing.assert_equal(deficit, case["expected_deficit"])
+
+
+def check_reference_breakup_dynamic_tests(kit):
+    """test_sdm_breakup.py:34-83 (pure breakup with a constant kernel doubles two droplets ten
+    times whatever dt) and :788-822 (multiplicities stay positive over 100 steps of
+    Geometric + ConstEc(0.01) + exponential fragmentation)"""
+    from pysdm_amd.dynamics import collisions as C  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.environments import Box  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.formulae import Formulae  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.initialisation import ConstantMultiplicity  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.initialisation import Exponential as Spectrum  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.particulator import Builder  # pylint: disable=import-outside-toplevel
+
+    um3, cm3 = 1e-18, 1e-6
+    for dt in (1.0, 10.0):
+        attributes = {"multiplicity": np.asarray([1, 1]),
+                      "volume": np.asarray([100 * um3, 100 * um3])}
+        builder = Builder(2, kit.backend.__class__(Formulae(fragmentation_function="AlwaysN")),
+                          environment=Box(dv=1 * cm3, dt=dt))
+        builder.add_dynamic(C.Breakup(collision_kernel=C.ConstantK(1 * cm3),
+                                      fragmentation_function=C.AlwaysN(4), adaptive=False,
+                                      warn_overflows=False))
+        particulator = builder.build(attributes=attributes)
+        particulator.run(10)
+        np.testing.assert_array_equal(particulator.attributes["multiplicity"].to_ndarray(),
+                                      [1024, 1024])
+    n_sd = 2**5
+    formulae = Formulae(fragmentation_function="Exponential")
+    builder = Builder(n_sd=n_sd, backend=kit.backend.__class__(formulae),
+                      environment=Box(dv=1.0, dt=1.0))
+    spectrum = Spectrum(norm_factor=100 / cm3, scale=formulae.trivia.volume(radius=30.531e-6))
+    volume, multiplicity = ConstantMultiplicity(spectrum).sample(n_sd)
+    builder.add_dynamic(C.Collision(
+        collision_kernel=C.Geometric(), breakup_efficiency=C.ConstEb(Eb=1.0),
+        coalescence_efficiency=C.ConstEc(Ec=0.01),
+        fragmentation_function=C.Exponential(scale=formulae.trivia.volume(radius=100e-6)),
+        warn_overflows=False))
+    particulator = builder.build({"volume": volume, "multiplicity": multiplicity})
+    particulator.run(100)
+    assert (particulator.attributes["multiplicity"].to_ndarray() > 0).all()
+
+
+def check_reference_small_backend_tests(kit):
+    """the remaining one-call tests of tests/unit_tests/backends re-typed: test_pair_methods.py:67-125
+    (sum_pair, find_pairs at a cut length), test_moments_methods.py:8-46 (range filter edges),
+    test_collisions_methods.py:205-236 (cell caretaker after a flagged entry),
+    storage/test_basic_ops.py, storage/test_index.py, storage/test_setitem.py,
+    test_physics_methods.py:40-100 (LiquidSpheres mass <-> volume, signs kept)"""
+    backend, Storage = kit.backend, kit.Storage
+    # sum_pair
+    out = Storage.from_ndarray(np.asarray([0.0]))
+    flag = kit.PairIndicator(2)
+    flag.indicator = Storage.from_ndarray(np.asarray([True, False]))
+    backend.sum_pair(out, Storage.from_ndarray(np.asarray([44.0, 666.0])), flag,
+                     Storage.from_ndarray(np.asarray([0, 1])))
+    np.testing.assert_array_equal(out.to_ndarray(), [44.0 + 666.0])
+    # find_pairs never flags the last position of a cut index
+    for length in (1, 2, 3, 4):
+        flag = kit.PairIndicator(4)
+        flag.indicator = Storage.from_ndarray(np.asarray([True] * 4))
+        idx = kit.Index.identity_index(4)
+        idx.length = length
+        backend.find_pairs(Storage.from_ndarray(np.asarray([0, 0, 0, 0])), flag,
+                           Storage.from_ndarray(np.asarray([0, 0, 0, 0])),
+                           Storage.from_ndarray(np.asarray([0, 1, 2, 3])), idx)
+        assert not flag.indicator.to_ndarray()[length - 1]
+    # moments: [min_x, max_x)
+    for min_x, max_x, value, expected in ((0, 1, 0.5, 1), (0, 1, 0, 1), (0, 1, 1, 0),
+                                          (0, 1, -0.5, 0), (0, 1, 1.5, 0)):
+        def arr(x):
+            return Storage.from_ndarray(np.asarray((x,)))
+
+        moment_0, moments = arr(0.0), Storage.from_ndarray(np.full((1, 1), 0.0))
+        backend.moments(moment_0=moment_0, moments=moments, min_x=min_x, max_x=max_x,
+                        multiplicity=arr(1), attr_data=arr(0.0), cell_id=arr(0), idx=arr(0),
+                        length=1, ranks=arr(0.0), x_attr=arr(float(value)),
+                        weighting_attribute=arr(0.0), weighting_rank=0,
+                        skip_division_by_m0=False)
+        assert moment_0.to_ndarray()[0] == moments.to_ndarray()[0, 0] == expected
+    # cell caretaker: the flagged entry (4 == n_sd) is compacted out first, then sorted
+    cell_start = Storage.from_ndarray(np.asarray([-1, -1]))
+    idx = kit.Index.from_ndarray(np.asarray([0, 3, 2, 4], dtype=np.int64))
+    idx.remove_zero_n_or_flagged(kit.IndexedStorage.from_ndarray(idx, np.asarray([1, 1, 1, 1])))
+    caretaker = backend.make_cell_caretaker(idx.shape, idx.dtype, len(cell_start),
+                                            scheme="default")
+    caretaker(kit.IndexedStorage.from_ndarray(idx, np.asarray([0, 0, 0, 0])),
+              kit.Index.from_ndarray(np.asarray([0])), cell_start, idx)
+    np.testing.assert_array_equal(cell_start.to_ndarray(), [0, 3])
+    # Storage: += scalar / storage, exp incl. nan and inf, amax, item assignment
+    for addend in (2, [2]):
+        out = Storage.from_ndarray(np.asarray([1.0]))
+        out += Storage.from_ndarray(np.asarray(addend, dtype=float)) if isinstance(addend, list) \
+            else addend
+        np.testing.assert_array_equal(out.to_ndarray(), [3.0])
+    for data in ([1.0], [2.0, 3, 4], [-1, np.nan, np.inf]):
+        out = Storage.from_ndarray(np.asarray(data, dtype=float))
+        out.exp()
+        np.testing.assert_allclose(out.to_ndarray(), np.exp(np.asarray(data, dtype=float)),
+                                   rtol=1e-15)
+    for data, expected in (([1, 2], 2), ([0, 0], 0), ([999, 99, 9], 999)):
+        assert Storage.from_ndarray(np.asarray(data)).amax() == expected
+    arr3 = Storage.from_ndarray(np.zeros(3))
+    arr3[1] = 1
+    assert arr3[1] == 1 and arr3[0] == arr3[2] == 0
+    # Index.remove_zero_n_or_flagged
+    n_sd = 44
+    idx = kit.Index.identity_index(n_sd)
+    data = np.ones(n_sd).astype(np.int64)
+    data[0], data[n_sd // 2], data[-1] = 0, 0, 0
+    idx.remove_zero_n_or_flagged(kit.IndexedStorage.from_ndarray(idx, data))
+    assert len(idx) == n_sd - 3
+    assert (data[idx.to_ndarray()[: len(idx)]] > 0).all()
+    # mass <-> volume
+    rho_w = backend.formulae.constants.rho_w
+    values = np.asarray([1.0, -1.0])
+    volume_out = Storage.from_ndarray(np.zeros(2))
+    backend.volume_of_water_mass(volume=volume_out, mass=Storage.from_ndarray(values))
+    np.testing.assert_array_equal(volume_out.to_ndarray(), values / rho_w)
+    mass_out = Storage.from_ndarray(np.zeros(2))
+    backend.mass_of_water_volume(volume=Storage.from_ndarray(values), mass=mass_out)
+    np.testing.assert_array_equal(mass_out.to_ndarray(), values * rho_w)
+
+
+ALL_CHECKS = (check_reference_small_backend_tests,
+              check_reference_breakup_scenarios, check_reference_breakup_dynamic_tests,
+              check_reference_fragmentation_tests, check_reference_efficiency_and_kernel_tests,
+              check_reference_single_cell_scenarios,
+              check_reference_random_reuse_and_multi_cell_call,
               check_scale_prob_known_answers, check_adaptivity_paper_diagram,
               check_gamma_formula_grid, check_same_multiplicity_split,
               check_single_breakup_known_answers)
