@@ -79,7 +79,7 @@ class Formulae:  # pylint: disable=too-few-public-methods,too-many-arguments
         }
         values.update(constants or {})
         self.constants = SimpleNamespace(**values)
-        self.seed = seed or _const.default_random_seed
+        self.seed = seed if seed is not None else _const.default_random_seed
         self.fastmath = fastmath
         self.fragmentation_function = fragmentation_function
         self.handle_all_breakups = handle_all_breakups

@@ -733,7 +733,79 @@ def check_reference_small_backend_tests(kit):
     np.testing.assert_array_equal(mass_out.to_ndarray(), values * rho_w)
 
 
-ALL_CHECKS = (check_reference_small_backend_tests,
+def _exponential_box(kit, *, seed, n_sd, n_part, dv, radius, dt, dynamic):
+    from pysdm_amd.environments import Box  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.formulae import Formulae  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.initialisation import ConstantMultiplicity  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.initialisation import Exponential as Spectrum  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.particulator import Builder  # pylint: disable=import-outside-toplevel
+
+    formulae = Formulae(seed=seed)
+    builder = Builder(n_sd=n_sd, backend=kit.backend.__class__(formulae),
+                      environment=Box(dt=dt, dv=dv))
+    spectrum = Spectrum(norm_factor=n_part * dv, scale=formulae.trivia.volume(radius=radius))
+    volume, multiplicity = ConstantMultiplicity(spectrum).sample(n_sd)
+    builder.add_dynamic(dynamic)
+    return builder.build({"volume": volume, "multiplicity": multiplicity})
+
+
+def check_reference_box_smoke_tests(kit):
+    """tests/smoke_tests/box/shima_et_al_2009/test_lwc_constant.py (liquid water content stays at
+    1 g/m3 over 200 steps, the largest droplet keeps growing; local / global croupier, adaptive or
+    not) and berry_1967/test_coalescence.py (Geometric / Electric / Hydrodynamic kernels over 800
+    steps at 2^13 super-droplets: the largest droplet grows; plus the 2-droplet Golovin case)"""
+    from pysdm_amd.dynamics import collisions as C  # pylint: disable=import-outside-toplevel
+
+    for croupier in ("local", "global"):
+        for adaptive in (True, False):
+            n_sd, n_part, dv = 2**14, 2**23, 1e6
+            particulator = _exponential_box(
+                kit, seed=256, n_sd=n_sd, n_part=n_part, dv=dv, radius=30.531e-6, dt=1.0,
+                dynamic=C.Coalescence(collision_kernel=C.Golovin(b=1.5e3), croupier=croupier,
+                                      adaptive=adaptive))
+            x_max = 0
+            for step in (0, 100, 200):
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    particulator.run(step - particulator.n_steps)
+                mult = particulator.attributes["multiplicity"].to_ndarray()
+                vol = particulator.attributes["volume"].to_ndarray()
+                if step == 0:
+                    np.testing.assert_approx_equal(np.amin(mult), np.amax(mult), 1)
+                    np.testing.assert_approx_equal(mult[0], n_part * dv / n_sd, 1)
+                np.testing.assert_approx_equal(1000 * np.dot(mult, vol) / dv, 1e-3, 3)
+                assert x_max < np.amax(vol)
+                x_max = np.amax(vol)
+    for make_kernel in (C.Geometric, C.Electric, C.Hydrodynamic):
+        for croupier in ("local", "global"):
+            for adaptive in (True, False):
+                particulator = _exponential_box(
+                    kit, seed=0, n_sd=2**13, n_part=239e6, dv=10.0, radius=10e-6, dt=1.0,
+                    dynamic=C.Coalescence(collision_kernel=make_kernel(), croupier=croupier,
+                                          adaptive=adaptive))
+                x_max = 0
+                for step in (0, 800):
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        particulator.run(step - particulator.n_steps)
+                    largest = np.amax(particulator.attributes["volume"].to_ndarray())
+                    assert x_max < largest
+                    x_max = largest
+    particulator = _exponential_box(
+        kit, seed=0, n_sd=2, n_part=239e6, dv=10.0, radius=10e-6, dt=1.0,
+        dynamic=C.Coalescence(collision_kernel=C.Golovin(b=1.5e12), adaptive=False))
+    x_max = 0
+    for step in (0, 200):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            particulator.run(step - particulator.n_steps)
+        largest = np.amax(particulator.attributes["volume"].to_ndarray())
+        assert x_max < largest
+        x_max = largest
+    assert particulator.attributes.super_droplet_count == 1
+
+
+ALL_CHECKS = (check_reference_box_smoke_tests, check_reference_small_backend_tests,
               check_reference_breakup_scenarios, check_reference_breakup_dynamic_tests,
               check_reference_fragmentation_tests, check_reference_efficiency_and_kernel_tests,
               check_reference_single_cell_scenarios,
