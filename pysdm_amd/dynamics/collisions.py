@@ -93,6 +93,19 @@ class Golovin:
     def fused_descriptor(self):
         return {"kernel": 0, "kernel_param": (float(self.b), 0.0)}
 
+    def analytic_solution(self, x, t, x_0, N_0):
+        """number density n(x, t) / N_0 of Golovin (1963) for an exponential initial spectrum with
+        mean volume x_0 and concentration N_0 (collision_kernels/golovin.py:23-47); the scaled
+        Bessel function keeps large arguments finite"""
+        from scipy import special  # pylint: disable=import-outside-toplevel
+
+        tau = 1 - np.exp(-N_0 * self.b * x_0 * t)
+        sqrt_tau = np.sqrt(tau)
+        x = np.asarray(x, dtype=float)
+        result = ((1 - tau) / (x * sqrt_tau) * special.ive(1, 2 * x / x_0 * sqrt_tau)
+                  * np.exp(-(1 + tau - 2 * sqrt_tau) * x / x_0))
+        return result if result.ndim else float(result)
+
 
 class ConstantK:
     def __init__(self, a):

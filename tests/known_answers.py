@@ -805,7 +805,50 @@ def check_reference_box_smoke_tests(kit):
     assert particulator.attributes.super_droplet_count == 1
 
 
-ALL_CHECKS = (check_reference_box_smoke_tests, check_reference_small_backend_tests,
+def check_convergence_to_golovin_solution(kit):
+    """tests/smoke_tests/box/shima_et_al_2009/test_convergence.py:33-80 and
+    dynamics/collisions/test_kernels.py:13-29: after 3600 s of the Shima 2009 box (dt = 100 s,
+    adaptive) the mass density spectrum dm/dlnr - read out with `spectrum_moments`, as the
+    reference's ParticleVolumeVersusRadiusLogarithmSpectrum product does - approaches Golovin's
+    analytic solution as the number of super-droplets grows (error measure of
+    PySDM_examples/Shima_et_al_2009/error_measure.py)"""
+    from pysdm_amd.dynamics import collisions as C  # pylint: disable=import-outside-toplevel
+
+    kernel = C.Golovin(b=1.5e3)
+    x_0 = kit.backend.formulae.trivia.volume(radius=30.531e-6)
+    for x in (5e-10, np.full(10, 5e-10)):
+        assert np.all(np.isfinite(kernel.analytic_solution(x=x, t=1200, x_0=x_0, N_0=2**23)))
+    n_part, dv, rho, t_end = 2**23, 1e6, 1000.0, 3600
+    radius_edges = np.logspace(np.log10(10e-6), np.log10(5e3 * 1e-6), num=128, endpoint=True)
+    volume_edges = kit.backend.formulae.trivia.volume(radius=radius_edges)
+    d_m, d_r = np.diff(volume_edges), np.diff(radius_edges)
+    mid_x, mid_r = volume_edges[:-1] + d_m / 2, radius_edges[:-1] + d_r / 2
+    pdf_r = n_part * dv * kernel.analytic_solution(x=mid_x, t=t_end, x_0=x_0, N_0=n_part) \
+        * d_m / d_r * mid_r
+    y_true = pdf_r * kit.backend.formulae.trivia.volume(radius=mid_r) * rho / dv * 1e3  # g/m3
+    errors = []
+    for ln2_n_sd in (11, 14, 17):
+        particulator = _exponential_box(
+            kit, seed=44, n_sd=2**ln2_n_sd, n_part=n_part, dv=dv, radius=30.531e-6, dt=100.0,
+            dynamic=C.Coalescence(collision_kernel=C.Golovin(b=1.5e3), adaptive=True))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            particulator.run(t_end // 100)
+        moment_0 = kit.Storage.empty((len(radius_edges) - 1, 1), dtype=float)
+        moments = kit.Storage.empty((len(radius_edges) - 1, 1), dtype=float)
+        particulator.spectrum_moments(
+            moment_0=moment_0, moments=moments, attr="volume", rank=1,
+            attr_bins=kit.Storage.from_ndarray(volume_edges), attr_name="volume",
+            weighting_attribute="volume", weighting_rank=0)
+        spectrum = (moments.to_ndarray()[:, 0] * moment_0.to_ndarray()[:, 0]
+                    / np.diff(np.log(radius_edges)) / dv * rho * 1e3)
+        deviation = y_true - spectrum
+        errors.append(np.sum(np.abs((deviation[:-1] + deviation[1:]) * np.diff(mid_r * 1e6) / 2)))
+    assert errors[0] > errors[1] > errors[2], errors
+
+
+ALL_CHECKS = (check_convergence_to_golovin_solution,
+              check_reference_box_smoke_tests, check_reference_small_backend_tests,
               check_reference_breakup_scenarios, check_reference_breakup_dynamic_tests,
               check_reference_fragmentation_tests, check_reference_efficiency_and_kernel_tests,
               check_reference_single_cell_scenarios,
