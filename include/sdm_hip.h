@@ -323,6 +323,10 @@ typedef struct sdm_step_state {
    * (32-B stride): one random line per gather, derived attributes evaluated once per change.
    * (Re)initialised from the SoA columns when SDM_STEP_FRESH_CTL is passed.                   */
   void *nm;
+  /* library's bookkeeping between calls: live super-droplets as of the last read-back, so that
+   * a single-cell adaptive step need not ask the device again (-1 = unknown; set it to -1
+   * whenever SDM_STEP_FRESH_CTL is passed)                                                    */
+  int64_t known_valid;
   uint64_t rng_offset;        /* doubles already drawn from the coll. stream (host-tracked) */
   uint64_t rng_offset_breakup;/* doubles already drawn from the proc/frag streams */
 } sdm_step_state;
@@ -333,6 +337,7 @@ typedef struct sdm_step_result {
   int64_t valid_n_sd;         /* live super-droplets after the call (-1 if not read back) */
   int64_t idx_swapped;        /* 1 if state->idx / state->tmp_idx exchanged roles */
   uint64_t rng_offset, rng_offset_breakup; /* updated stream positions */
+  int64_t ctl[8];             /* the control block after the call (valid with SDM_STEP_READ_BACK) */
 } sdm_step_result;
 
 /* flags: bit 0 = read the control block back (fills result->valid_n_sd; synchronises);

@@ -42,14 +42,15 @@ class StepState(ctypes.Structure):  # == sdm_step_state
         ("stats_dt_min", c_ptr), ("stats_n_substep", c_ptr), ("collision_rate", c_ptr),
         ("collision_rate_deficit", c_ptr), ("coalescence_rate", c_ptr), ("breakup_rate", c_ptr),
         ("breakup_rate_deficit", c_ptr), ("gk_a", c_ptr), ("gk_b", c_ptr), ("ctl", c_ptr),
-        ("nm", c_ptr), ("rng_offset", c_u64), ("rng_offset_breakup", c_u64),
+        ("nm", c_ptr), ("known_valid", c_i64), ("rng_offset", c_u64),
+        ("rng_offset_breakup", c_u64),
     ]
 
 
 class StepResult(ctypes.Structure):  # == sdm_step_result
     _fields_ = [
         ("n_substeps", c_i64), ("n_pairs", c_i64), ("valid_n_sd", c_i64), ("idx_swapped", c_i64),
-        ("rng_offset", c_u64), ("rng_offset_breakup", c_u64),
+        ("rng_offset", c_u64), ("rng_offset_breakup", c_u64), ("ctl", c_i64 * 8),
     ]
 
 

@@ -113,6 +113,7 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
                 state.gk_a, state.gk_b = _p(self.gk.a.data), _p(self.gk.b.data)
             state.ctl = _p(self.ctl)
             state.nm = _p(self.nm)
+            state.known_valid = -1
             self._state_cache = state
         state.idx = _p(self.idx.data)
         state.tmp_idx = _p(self.tmp_idx.data)
@@ -153,7 +154,7 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
         if res.n_pairs >= 0:
             self.total_pairs += res.n_pairs
         if self.read_back:
-            self._commit(ctx)
+            self._commit(list(self.result.ctl))  # read back by the library at the end of the call
         state_access.mark_collision_outputs_updated(self.particulator.attributes)
         self._stamps = self._timestamps()
 
@@ -162,8 +163,7 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
         names = ["multiplicity", "cell id"] + list(attrs.get_extensive_attribute_keys())
         return tuple(state_access.attribute_object(attrs, name).timestamp for name in names)
 
-    def _commit(self, _ctx):
-        words = self.ctl.cpu().numpy()
+    def _commit(self, words):
         state_access.commit(self.particulator.attributes, valid_n_sd=int(words[0]),
                             sorted_flag=bool(words[2]))
         if words[7] != 0:
@@ -178,4 +178,4 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
 
     def sync(self):
         """bring the host-side bookkeeping up to date (needed after read_back=False steps)"""
-        self._commit(_Context.get())
+        self._commit(self.ctl.cpu().numpy())

@@ -1114,7 +1114,14 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   int64_t work_host = -1;
   int sorted_host = -1;  // host's knowledge of ctl[CTL_SORTED]
   int64_t max_cell = -1;  // upper bound of the cell sizes during this call (-1: unknown)
-  if (cfg->adaptive || read_back) {
+  if (flags & 2) st->known_valid = -1;
+  int64_t last_ctl[8] = {-1, -1, -1, -1, 0, 0, 0, 0};  // the control block as last read back
+  bool have_ctl = false;
+  if (C == 1 && st->known_valid >= 0 && cfg->adaptive) {
+    // one cell, nothing touched the state since the last read-back: no need to ask the device
+    work_host = st->known_valid;
+    sorted_host = 1;
+  } else if (cfg->adaptive || read_back) {
     if (C > 1 && cfg->croupier_local) {
       // meaningful only if the state is sorted (checked below): cells can only shrink in a call
       HIP_TRY(hipMemsetAsync(st->ctl + 6, 0, sizeof(int64_t), s));
@@ -1302,10 +1309,12 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
             hipLaunchKernelGGL(k_set_work, one, one, 0, s, st->ctl, S.end2 + 1);
             LAUNCH_CHECK();
           }
-          HIP_TRY(hipMemcpyAsync(ctx->mailbox + 8, st->ctl, sizeof(int64_t) * 4,
+          HIP_TRY(hipMemcpyAsync(ctx->mailbox + 8, st->ctl, sizeof(int64_t) * 8,
                                  hipMemcpyDeviceToHost, s));
           HIP_TRY(hipStreamSynchronize(s));
         }
+        memcpy(last_ctl, ctx->mailbox + 8, sizeof(last_ctl));
+        have_ctl = true;
         work_host = ctx->mailbox[8 + CTL_WORK];
         if (C == 1 || ctx->mailbox[8 + CTL_SORTED] != 0) { sorted_host = C == 1 ? sorted_host : 1; break; }
         // a compaction happened in this sub-step: sort by cell first (particle_attributes.py
@@ -1337,10 +1346,23 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   res->rng_offset = off;
   res->rng_offset_breakup = off_b;
   res->valid_n_sd = -1;
+  memset(res->ctl, 0, sizeof(res->ctl));
   if (read_back) {
-    HIP_TRY(hipMemcpyAsync(ctx->mailbox, st->ctl, sizeof(int64_t) * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    res->valid_n_sd = ctx->mailbox[CTL_VALID];
+    if (C == 1 && cfg->adaptive && have_ctl) {
+      // the last sub-step's read-back already holds everything; only the working length was
+      // reset since (k_reset_work: work = valid)
+      memcpy(res->ctl, last_ctl, sizeof(last_ctl));
+      res->ctl[CTL_WORK] = res->ctl[CTL_VALID];
+    } else {
+      HIP_TRY(hipMemcpyAsync(ctx->mailbox, st->ctl, sizeof(int64_t) * 8, hipMemcpyDeviceToHost,
+                             s));
+      HIP_TRY(hipStreamSynchronize(s));
+      memcpy(res->ctl, ctx->mailbox, sizeof(res->ctl));
+    }
+    res->valid_n_sd = res->ctl[CTL_VALID];
+    st->known_valid = res->valid_n_sd;
+  } else {
+    st->known_valid = -1;
   }
   // non-adaptive without read-back: the caller derives the pair count from its own length
   res->n_pairs = (cfg->adaptive || work_host >= 0) ? n_pairs : -1;
@@ -1379,6 +1401,7 @@ extern "C" int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step
     total.n_substeps += one.n_substeps;
     if (one.n_pairs < 0) pairs_known = false; else total.n_pairs += one.n_pairs;
     total.valid_n_sd = one.valid_n_sd;
+    memcpy(total.ctl, one.ctl, sizeof(total.ctl));
     total.rng_offset = one.rng_offset;
     total.rng_offset_breakup = one.rng_offset_breakup;
   }
