@@ -74,3 +74,43 @@ def test_reference_known_answers(check, kit):
 @pytest.mark.parametrize("name", displacement_cases.CASES)
 def test_displacement_goldens(name, fused, hip_backend_class):
     displacement_cases.run_case(name, hip_backend_class, fused=fused)
+
+
+def test_c_abi_example_equals_python_route(tmp_path, hip_backend_class):
+    """examples/shima_box_c_abi.cpp: the Shima box driven through include/sdm_hip.h from a plain
+    C++ program (no Python, no torch) gives bit for bit what the Python host code gives"""
+    import os  # pylint: disable=import-outside-toplevel
+    import struct  # pylint: disable=import-outside-toplevel
+    import subprocess  # pylint: disable=import-outside-toplevel
+
+    from pysdm_amd.backends.hip import pcg64_state_inc  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.examples import make_box  # pylint: disable=import-outside-toplevel
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    binary = os.path.join(root, "examples", "shima_box_c_abi")
+    if not os.path.exists(binary):
+        subprocess.check_call(["bash", os.path.join(root, "examples", "build.sh")])
+    n_sd, n_steps, seed = 2**14, 25, 44
+    particulator, dynamic = make_box(hip_backend_class, "shima", n_sd=n_sd, seed=seed)
+    attrs = particulator.attributes
+    multiplicity = attrs["multiplicity"].to_ndarray(raw=True)
+    mass = attrs["water mass"].to_ndarray(raw=True)
+    source, result = tmp_path / "box.in", tmp_path / "box.out"
+    with open(source, "wb") as handle:
+        handle.write(struct.pack("<qq", n_sd, n_steps))
+        handle.write(struct.pack("<ddd", particulator.dt, particulator.mesh.dv, 1.5e3))
+        handle.write(struct.pack("<4Q", *pcg64_state_inc(seed)))
+        handle.write(multiplicity.astype("<i8").tobytes())
+        handle.write(mass.astype("<f8").tobytes())
+    subprocess.check_call([binary, str(source), str(result)])
+    raw = np.fromfile(result, dtype=np.uint8)
+    n_live = int(raw[:8].view("<i8")[0])
+    idx = raw[8:8 + 8 * n_sd].view("<i8")
+    mult_c = raw[8 + 8 * n_sd:8 + 16 * n_sd].view("<i8")
+    mass_c = raw[8 + 16 * n_sd:8 + 24 * n_sd].view("<f8")
+    particulator.run(n_steps)
+    snap = snapshot(particulator, dynamic)
+    assert n_live == int(snap["length"])
+    np.testing.assert_array_equal(idx[:n_live], snap["idx"][:n_live])
+    np.testing.assert_array_equal(mult_c, snap["multiplicity"])
+    np.testing.assert_array_equal(mass_c, snap["attributes"][0])
