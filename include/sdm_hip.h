@@ -266,6 +266,10 @@ int sdm_reduce_f64(sdm_ctx *ctx, int kind, const double *a, int64_t n, double *r
 #define SDM_KERNEL_GOLOVIN 0    /* collision_kernels/golovin.py:14-16 ; kernel_param[0] = b */
 #define SDM_KERNEL_GEOMETRIC 1  /* collision_kernels/geometric.py:15-22 ; [0] = PI * E_coll */
 #define SDM_KERNEL_CONSTANT 2   /* collision_kernels/constantK.py ; [0] = a */
+#define SDM_KERNEL_PARAMETERIZED 3 /* collision_kernels/impl/parameterized.py:8-30 (Electric,
+                                      Hydrodynamic) ; kernel_berry_params, kernel_berry_unit */
+#define SDM_KERNEL_SIMPLE_GEOMETRIC 4 /* collision_kernels/simple_geometric.py ; [0] = C */
+#define SDM_KERNEL_LINEAR 5     /* collision_kernels/linear.py ; a + b (v_j + v_k), [0] = a [1] = b */
 #define SDM_EC_CONST 0          /* coalescence_efficiencies/constEc.py ; ec_param[0] = Ec */
 #define SDM_EC_BERRY1967 1      /* coalescence_efficiencies/berry1967.py */
 #define SDM_EC_STRAUB2010 2     /* coalescence_efficiencies/straub2010.py:27-50 */
@@ -294,6 +298,8 @@ typedef struct sdm_step_cfg {
   double straub_consts[6];    /* as sdm_straub_fragmentation */
   double berry_params[13];
   double berry_unit;
+  double kernel_berry_params[13]; /* SDM_KERNEL_PARAMETERIZED: the 13 parameters of its efficiency */
+  double kernel_berry_unit;
   int64_t max_multiplicity;
   uint64_t rng_state_inc[4];  /* PCG64 state/inc of seed (numpy.random.PCG64(seed).state) */
   int64_t gk_table_len;       /* Gunn-Kinzer table length (0 if unused) */

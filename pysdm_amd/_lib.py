@@ -30,6 +30,7 @@ class StepCfg(ctypes.Structure):  # == sdm_step_cfg
         ("frag_param", c_f64 * 2), ("frag_vmin", c_f64), ("frag_nfmax", c_f64),
         ("rho_w", c_f64), ("sgm_w", c_f64), ("straub_consts", c_f64 * 6),
         ("berry_params", c_f64 * 13), ("berry_unit", c_f64),
+        ("kernel_berry_params", c_f64 * 13), ("kernel_berry_unit", c_f64),
         ("max_multiplicity", c_i64), ("rng_state_inc", c_u64 * 4),
         ("gk_table_len", c_i64), ("gk_factor", c_f64),
     ]

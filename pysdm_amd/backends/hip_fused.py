@@ -55,6 +55,9 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
         cfg.straub_consts = backend.straub_consts()
         cfg.berry_params = (ctypes.c_double * 13)(*parts.get("berry_params", (0.0,) * 13))
         cfg.berry_unit = parts.get("berry_unit", 1.0)
+        cfg.kernel_berry_params = (ctypes.c_double * 13)(
+            *parts.get("kernel_berry_params", (0.0,) * 13))
+        cfg.kernel_berry_unit = parts.get("kernel_berry_unit", 1.0)
         cfg.max_multiplicity = int(dynamic.max_multiplicity)
         cfg.rng_state_inc = (ctypes.c_uint64 * 4)(*pcg64_state_inc(backend.formulae.seed))
         self.gk = None

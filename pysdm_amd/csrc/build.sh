@@ -26,3 +26,5 @@ done
 rm -f $OUT
 $HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined -o $OUT "${objs[@]}"
 echo "built $(realpath $OUT)"
+# the C-ABI example embeds the header's struct layouts: rebuild it with the library
+bash ../../examples/build.sh

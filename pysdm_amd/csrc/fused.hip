@@ -247,6 +247,25 @@ __device__ __forceinline__ double pair_prob_value(const sdm_step_cfg &cfg, const
     const double s = sj.r + sk.r;
     K = (s * s) * cfg.kernel_param[0];
     K *= fabs(sj.u - sk.u);
+  } else if (KERNEL == SDM_KERNEL_PARAMETERIZED) {  // parameterized.py:19-30, operation by operation
+    const double e = linear_collection_efficiency(cfg.kernel_berry_params, sj.r, sk.r,
+                                                  cfg.kernel_berry_unit);
+    K = e * e;
+    K *= 3.14159265358979323846;
+    const double r_max = sj.r > sk.r ? sj.r : sk.r;
+    K *= r_max * r_max;
+    K *= fabs(sj.u - sk.u);
+  } else if (KERNEL == SDM_KERNEL_SIMPLE_GEOMETRIC) {  // simple_geometric.py:21-27, area.py:14-17
+    const double pi_4_3 = 3.14159265358979323846 * 4 / 3;
+    const double aj = signed_pow(vj * (1 / pi_4_3), 2.0 / 3.0) * (pi_4_3 * 3);
+    const double ak = signed_pow(vk * (1 / pi_4_3), 2.0 / 3.0) * (pi_4_3 * 3);
+    const double s = sj.r + sk.r;
+    K = cfg.kernel_param[0];
+    K *= s * s;
+    K *= fabs(aj - ak);
+  } else if (KERNEL == SDM_KERNEL_LINEAR) {
+    K = (vj + vk) * cfg.kernel_param[1];
+    K += cfg.kernel_param[0];
   } else {
     K = cfg.kernel_param[0];
   }
@@ -296,7 +315,8 @@ __device__ __forceinline__ PairInfo pair_prob_body(const sdm_step_cfg &cfg, cons
   R.off = (uint8_t)(i - 2 * d);
   const bool traced = A.rec != nullptr;
   int64_t j = traced ? tj : A.idx[i], k = traced ? tk : A.idx[i + 1];
-  const bool need_r = KERNEL == SDM_KERNEL_GEOMETRIC;
+  const bool need_r = KERNEL == SDM_KERNEL_GEOMETRIC || KERNEL == SDM_KERNEL_PARAMETERIZED ||
+                      KERNEL == SDM_KERNEL_SIMPLE_GEOMETRIC;
   SD sj = sd_load(cfg, A, j, need_r), sk = sd_load(cfg, A, k, need_r);
   int64_t nj = sj.n, nk = sk.n;
   // sort_within_pair_by_attr (pair_methods.py:126-140)
@@ -769,7 +789,8 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   bool pvalid[CELL_MAXPAIR];
   SD psj[CELL_MAXPAIR], psk[CELL_MAXPAIR];
   double my_min = INFINITY;
-  const bool need_r = KERNEL == SDM_KERNEL_GEOMETRIC;
+  const bool need_r = KERNEL == SDM_KERNEL_GEOMETRIC || KERNEL == SDM_KERNEL_PARAMETERIZED ||
+                      KERNEL == SDM_KERNEL_SIMPLE_GEOMETRIC;
   // all gathers of the thread's pairs first (independent loads in flight together) ...
 #pragma unroll
   for (int r = 0; r < CELL_MAXPAIR; ++r) {
@@ -1018,6 +1039,18 @@ static int cond_sort(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st, 
         if (brk__) hipLaunchKernelGGL((KERN<SDM_KERNEL_GEOMETRIC, true>), GRID, blk, 0, s, *cfg, A); \
         else hipLaunchKernelGGL((KERN<SDM_KERNEL_GEOMETRIC, false>), GRID, blk, 0, s, *cfg, A); \
         break;                                                                                 \
+      case SDM_KERNEL_PARAMETERIZED:                                                               \
+        if (brk__) hipLaunchKernelGGL((KERN<SDM_KERNEL_PARAMETERIZED, true>), GRID, blk, 0, s, *cfg, A); \
+        else hipLaunchKernelGGL((KERN<SDM_KERNEL_PARAMETERIZED, false>), GRID, blk, 0, s, *cfg, A); \
+        break;                                                                                 \
+      case SDM_KERNEL_SIMPLE_GEOMETRIC:                                                               \
+        if (brk__) hipLaunchKernelGGL((KERN<SDM_KERNEL_SIMPLE_GEOMETRIC, true>), GRID, blk, 0, s, *cfg, A); \
+        else hipLaunchKernelGGL((KERN<SDM_KERNEL_SIMPLE_GEOMETRIC, false>), GRID, blk, 0, s, *cfg, A); \
+        break;                                                                                 \
+      case SDM_KERNEL_LINEAR:                                                               \
+        if (brk__) hipLaunchKernelGGL((KERN<SDM_KERNEL_LINEAR, true>), GRID, blk, 0, s, *cfg, A); \
+        else hipLaunchKernelGGL((KERN<SDM_KERNEL_LINEAR, false>), GRID, blk, 0, s, *cfg, A); \
+        break;                                                                                 \
       default:                                                                                 \
         if (brk__) hipLaunchKernelGGL((KERN<SDM_KERNEL_CONSTANT, true>), GRID, blk, 0, s, *cfg, A); \
         else hipLaunchKernelGGL((KERN<SDM_KERNEL_CONSTANT, false>), GRID, blk, 0, s, *cfg, A); \
@@ -1035,7 +1068,9 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
           st->stats_n_substep && st->collision_rate && st->collision_rate_deficit &&
           st->coalescence_rate && st->ctl);
   ARG_TRY(!cfg->enable_breakup || (st->breakup_rate && st->breakup_rate_deficit));
-  ARG_TRY(cfg->kernel != SDM_KERNEL_GEOMETRIC || (st->gk_a && st->gk_b && cfg->gk_table_len > 0));
+  ARG_TRY((cfg->kernel != SDM_KERNEL_GEOMETRIC && cfg->kernel != SDM_KERNEL_PARAMETERIZED) ||
+          (st->gk_a && st->gk_b && cfg->gk_table_len > 0));
+  ARG_TRY(cfg->kernel >= SDM_KERNEL_GOLOVIN && cfg->kernel <= SDM_KERNEL_LINEAR);
   ARG_TRY(cfg->adaptive || cfg->substeps >= 1);
   ARG_TRY(cfg->mass_attr >= 0 && cfg->mass_attr < cfg->n_attr);
   ARG_TRY(!(cfg->dt_min <= 0));
@@ -1096,7 +1131,8 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   const dim3 blk(SDM_BLOCK), one(1);
 
   A.nm = (double *)st->nm;
-  A.nm_wide = cfg->kernel == SDM_KERNEL_GEOMETRIC ||
+  A.nm_wide = cfg->kernel == SDM_KERNEL_GEOMETRIC || cfg->kernel == SDM_KERNEL_PARAMETERIZED ||
+              cfg->kernel == SDM_KERNEL_SIMPLE_GEOMETRIC ||
               (cfg->enable_breakup &&
                (cfg->ec != SDM_EC_CONST || cfg->frag == SDM_FRAG_STRAUB2010));
   if (st->nm && (flags & 2)) {
@@ -1147,6 +1183,9 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
       CELL_ATTR(SDM_KERNEL_GOLOVIN, false); CELL_ATTR(SDM_KERNEL_GOLOVIN, true);
       CELL_ATTR(SDM_KERNEL_GEOMETRIC, false); CELL_ATTR(SDM_KERNEL_GEOMETRIC, true);
       CELL_ATTR(SDM_KERNEL_CONSTANT, false); CELL_ATTR(SDM_KERNEL_CONSTANT, true);
+      CELL_ATTR(SDM_KERNEL_PARAMETERIZED, false); CELL_ATTR(SDM_KERNEL_PARAMETERIZED, true);
+      CELL_ATTR(SDM_KERNEL_SIMPLE_GEOMETRIC, false); CELL_ATTR(SDM_KERNEL_SIMPLE_GEOMETRIC, true);
+      CELL_ATTR(SDM_KERNEL_LINEAR, false); CELL_ATTR(SDM_KERNEL_LINEAR, true);
 #undef CELL_ATTR
       attr_done = true;
     }
@@ -1205,6 +1244,9 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
         switch (cfg->kernel) {
           case SDM_KERNEL_GOLOVIN: CELL_LAUNCH(SDM_KERNEL_GOLOVIN); break;
           case SDM_KERNEL_GEOMETRIC: CELL_LAUNCH(SDM_KERNEL_GEOMETRIC); break;
+          case SDM_KERNEL_PARAMETERIZED: CELL_LAUNCH(SDM_KERNEL_PARAMETERIZED); break;
+          case SDM_KERNEL_SIMPLE_GEOMETRIC: CELL_LAUNCH(SDM_KERNEL_SIMPLE_GEOMETRIC); break;
+          case SDM_KERNEL_LINEAR: CELL_LAUNCH(SDM_KERNEL_LINEAR); break;
           default: CELL_LAUNCH(SDM_KERNEL_CONSTANT);
         }
 #undef CELL_LAUNCH

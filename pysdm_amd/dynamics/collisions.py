@@ -186,6 +186,11 @@ class ParameterizedKernel:
         output *= self.pair_tmp
 
 
+    def fused_descriptor(self):
+        return {"kernel": 3, "kernel_berry_params": tuple(float(p) for p in self.params),
+                "kernel_berry_unit": si.um, "needs_gk": True}
+
+
 class Electric(ParameterizedKernel):  # collision_kernels/electric.py (3000 V/cm, Berry 1967)
     def __init__(self):
         super().__init__((1, 1, -7, 1.78, -20.5, 1.73, 0.26, 1.47, 1, 0.82, -0.003, 4.4, 8))
@@ -200,6 +205,9 @@ class Linear:
     """K = a + b (v_j + v_k), collision_kernels/linear.py.  The reference file is an unfinished
     stub (its TODO #744): it calls `output.sum_pair`, which PairwiseStorage does not have, so it
     cannot be run there; this is the evident intent with the pairwise `sum`."""
+
+    def fused_descriptor(self):
+        return {"kernel": 5, "kernel_param": (float(self.a), float(self.b))}
 
     def __init__(self, a, b):
         self.a = a
@@ -237,6 +245,9 @@ class SimpleGeometric:  # collision_kernels/simple_geometric.py (no fall velocit
         output *= self.pair_tmp
         self.pair_tmp.distance(self.particulator.attributes["area"], is_first_in_pair)
         output *= self.pair_tmp
+
+    def fused_descriptor(self):
+        return {"kernel": 4, "kernel_param": (float(self.C), 0.0)}
 
 
 # ---- efficiencies ---------------------------------------------------------------------------

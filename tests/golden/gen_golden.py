@@ -815,6 +815,38 @@ def gen_shards():
 
 
 # ------------------------------------------------------------------------------------------
+# f-2: trajectories with the remaining collision kernels
+# ------------------------------------------------------------------------------------------
+def gen_kernels():
+    # ---- the other kernels of the Berry 1967 set-up (f-2): Electric, Hydrodynamic, SimpleGeometric
+    from PySDM.dynamics.collisions.collision_kernels import (
+        Electric, Hydrodynamic, SimpleGeometric,
+    )
+
+    for name, make_kernel, n_sd, adaptive, dt in (
+        ("electric", Electric, 2**10, True, 10.0),
+        ("hydrodynamic", Hydrodynamic, 2**10, False, 1.0),
+        ("simplegeometric", lambda: SimpleGeometric(C=5e7), 2**10, True, 10.0),
+    ):
+        dv = 10.0 * n_sd / 2**13
+        x0 = Formulae().trivia.volume(radius=10e-6)
+        spectrum = spectra.Exponential(norm_factor=239e6 * dv, scale=x0)
+        volume, mult = ConstantMultiplicity(spectrum).sample(n_sd)
+        out = run_traj(
+            n_sd=n_sd, seed=44, dt=dt, dv=dv, volume=volume, multiplicity=mult,
+            make_dynamic=lambda a=adaptive, k=make_kernel: Coalescence(
+                collision_kernel=k(), adaptive=a
+            ),
+            record_steps=(1, 10, 60),
+            formulae_kwargs={"terminal_velocity": "GunnKinzer1949"},
+        )
+        out["init/volume"] = volume
+        out["init/multiplicity"] = mult
+        out["cfg"] = np.asarray([n_sd, 44, int(adaptive), dt, dv, 1.0])
+        save(f"traj_kernel_{name}", **out)
+
+
+# ------------------------------------------------------------------------------------------
 # f-1: moments and spectrum_moments of the reference backend on a small multi-cell state
 # ------------------------------------------------------------------------------------------
 def gen_moments():
@@ -947,7 +979,8 @@ def gen_displacement():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["micro", "frag", "traj", "breakup", "shards", "moments", "displacement"]
+    what = sys.argv[1:] or ["micro", "frag", "traj", "breakup", "shards", "moments", "displacement",
+                            "kernels"]
     if "displacement" in what:
         gen_displacement()
     if "moments" in what:
@@ -960,5 +993,7 @@ if __name__ == "__main__":
         gen_frag()
     if "traj" in what:
         gen_traj()
+    if "kernels" in what:
+        gen_kernels()
     if "breakup" in what:
         gen_breakup()

@@ -32,3 +32,8 @@ def test_breakup(name, oracle_backend_class):
 @pytest.mark.parametrize("name", displacement_cases.CASES)
 def test_displacement_goldens(name, oracle_backend_class):
     displacement_cases.run_case(name, oracle_backend_class)
+
+
+@pytest.mark.parametrize("name", golden_files("traj_kernel_*.npz"))
+def test_other_kernels_bit_exact(name, oracle_backend_class):
+    run_and_compare(name, oracle_backend_class)

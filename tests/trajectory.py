@@ -70,6 +70,12 @@ def setup_from_golden(name, backend_class, fused=None):
     elif name.startswith("traj_geometric"):
         dynamic = Coalescence(collision_kernel=Geometric(collection_efficiency=1),
                               adaptive=adaptive, fused=fused)
+    elif name.startswith("traj_kernel"):
+        from pysdm_amd.dynamics import collisions as C  # pylint: disable=import-outside-toplevel
+
+        kernel = {"electric": C.Electric, "hydrodynamic": C.Hydrodynamic,
+                  "simplegeometric": lambda: C.SimpleGeometric(C=5e7)}[name.split("_")[-1]]()
+        dynamic = Coalescence(collision_kernel=kernel, adaptive=adaptive, fused=fused)
     elif name.startswith("traj_multicell"):
         grid = tuple(int(g) for g in gold["grid"])
         env.mesh = Mesh(grid, size=tuple(float(g) for g in grid))
