@@ -276,6 +276,12 @@ int sdm_reduce_f64(sdm_ctx *ctx, int kind, const double *a, int64_t n, double *r
 #define SDM_FRAG_ALWAYS_N 0     /* breakup_fragmentations/always_n.py ; frag_param[0] = n */
 #define SDM_FRAG_EXPONENTIAL 1  /* breakup_fragmentations/exponential.py ; [0] = scale */
 #define SDM_FRAG_STRAUB2010 2   /* breakup_fragmentations/straub2010.py */
+#define SDM_FRAG_GAUSSIAN 3     /* gaussian.py ; frag_param = {mu, sigma} */
+#define SDM_FRAG_FEINGOLD1988 4 /* feingold1988.py ; frag_param = {scale, fragtol} */
+#define SDM_FRAG_SLAMS 5        /* slams.py */
+#define SDM_FRAG_CONSTANT_MASS 6 /* constant_mass.py ; frag_param[0] = c */
+#define SDM_FRAG_LOWLIST1982 7  /* lowlist82.py (straub_consts supplies CM, PI, Vedder's A, b) */
+#define SDM_EC_LOWLIST1982 3    /* coalescence_efficiencies/lowlist1982.py */
 
 typedef struct sdm_step_cfg {
   int64_t n_sd, n_cell, n_attr;

@@ -169,7 +169,35 @@ __device__ __forceinline__ void breakup_params(const sdm_step_cfg &cfg, const Fu
       case SDM_EC_CONST: ec = cfg.ec_param[0]; break;
       case SDM_EC_BERRY1967: {
         const double e = linear_collection_efficiency(cfg.berry_params, rj, rk, cfg.berry_unit);
-        ec = e * e;
+        ec = signed_sq(e);
+        break;
+      }
+      case SDM_EC_LOWLIST1982: {  // coalescence_efficiencies/lowlist1982.py:37-103 (mass-based)
+        const double PI = 3.14159265358979323846;
+        const double ds = (rj < rk ? rj : rk) * 2, dl = (rj > rk ? rj : rk) * 2;
+        double Sc = signed_pow(mj + mk, 2.0 / 3.0);
+        Sc *= cfg.ec_param[1];  // PI * sgm_w * (6/PI)**(2/3), one host-side constant
+        double St = ds * ds;
+        St += dl * dl;
+        St *= PI * cfg.sgm_w;
+        const double dS = St - Sc;
+        const double tmp = mj + mk;
+        double tmp2 = fabs(uj - uk);
+        tmp2 = tmp2 * tmp2;
+        double CKE = mj * mk;
+        if (tmp != 0.0) CKE /= tmp;
+        CKE *= tmp2;
+        CKE *= cfg.rho_w / 2;
+        const double Et = CKE + dS;
+        double e = signed_sq(Et);
+        e *= -1.0 * 2.61e6 * cfg.sgm_w;
+        e /= Sc;
+        double o = ds / dl;
+        o += 1.0;
+        o = signed_pow(o, -2.0);
+        o *= 0.778;
+        o *= exp(e);
+        ec = dl < 0.4e-3 ? 1.0 : o;
         break;
       }
       default: {  // coalescence_efficiencies/straub2010.py:27-50
@@ -195,6 +223,61 @@ __device__ __forceinline__ void breakup_params(const sdm_step_cfg &cfg, const Fu
         const double a = 1 - u_b;
         double fv = -cfg.frag_param[0] * log(a > 1e-5 ? a : 1e-5), nf;
         fragmentation_limiters(nf, fv, cfg.frag_vmin, cfg.frag_nfmax, vj + vk);
+        fm = cfg.rho_w * fv;
+        break;
+      }
+      case SDM_FRAG_GAUSSIAN: {  // fragmentation_methods.py:477-485
+        double fv = cfg.frag_param[0] + cfg.frag_param[1] *
+                    erfinv_approx(u_b, cfg.straub_consts[3], cfg.straub_consts[4]), nf;
+        fragmentation_limiters(nf, fv, cfg.frag_vmin, cfg.frag_nfmax, vj + vk);
+        fm = cfg.rho_w * fv;
+        break;
+      }
+      case SDM_FRAG_FEINGOLD1988: {  // :487-499, physics/fragmentation_function/feingold1988.py
+        const double a = 1 - u_b * cfg.frag_param[0] / (vj + vk);
+        double fv = -cfg.frag_param[0] * log(a > cfg.frag_param[1] ? a : cfg.frag_param[1]), nf;
+        fragmentation_limiters(nf, fv, cfg.frag_vmin, cfg.frag_nfmax, vj + vk);
+        fm = cfg.rho_w * fv;
+        break;
+      }
+      case SDM_FRAG_SLAMS: {  // :95-134
+        double p = 0.0, nf = 1;
+        for (int k = 0; k < 22; ++k) {
+          p += 0.91 * pow((double)(k + 2), -1.56);
+          if (u_b < p) { nf = k + 2; break; }
+        }
+        double fv = (vj + vk) / nf;
+        fragmentation_limiters(nf, fv, cfg.frag_vmin, cfg.frag_nfmax, vj + vk);
+        fm = cfg.rho_w * fv;
+        break;
+      }
+      case SDM_FRAG_CONSTANT_MASS: fm = cfg.frag_param[0]; break;  // constant_mass.py:11-14
+      case SDM_FRAG_LOWLIST1982: {  // breakup_fragmentations/lowlist82.py:37-103 (volume-based)
+        const double PI = 3.14159265358979323846;
+        const double x_plus_y = vj + vk;
+        const double ds = (rj < rk ? rj : rk) * 2, dl = (rj > rk ? rj : rk) * 2;
+        double dcoal = x_plus_y / (PI / 6);
+        dcoal = signed_pow(dcoal, 1.0 / 3.0);
+        double Sc = signed_pow(x_plus_y, 2.0 / 3.0);
+        Sc *= cfg.frag_param[0];  // PI * sgm_w * (6/PI)**(2/3), one host-side constant
+        double St = ds * ds;
+        St += dl * dl;
+        St *= PI * cfg.sgm_w;
+        double tmp2 = fabs(uj - uk);
+        tmp2 = tmp2 * tmp2;
+        double CKE = vj * vk;
+        if (x_plus_y != 0.0) CKE /= x_plus_y;
+        CKE *= tmp2;
+        CKE *= cfg.rho_w / 2;
+        double We = CKE, W2 = CKE;
+        if (Sc != 0.0) We /= Sc;
+        if (St != 0.0) W2 /= St;
+        const double K[4] = {cfg.straub_consts[0], cfg.straub_consts[5], cfg.straub_consts[3],
+                             cfg.straub_consts[4]};
+        double rand = u_b, Rf = 0.0, Rs = 0.0, Rd = 0.0, nf;
+        double fv = ll82_fragment_volume(CKE, We, W2, St, ds, dl, dcoal, &rand, &Rf, &Rs, &Rd,
+                                         1e-8, K);
+        fragmentation_limiters(nf, fv, cfg.frag_vmin, cfg.frag_nfmax, x_plus_y);
         fm = cfg.rho_w * fv;
         break;
       }
@@ -250,7 +333,7 @@ __device__ __forceinline__ double pair_prob_value(const sdm_step_cfg &cfg, const
   } else if (KERNEL == SDM_KERNEL_PARAMETERIZED) {  // parameterized.py:19-30, operation by operation
     const double e = linear_collection_efficiency(cfg.kernel_berry_params, sj.r, sk.r,
                                                   cfg.kernel_berry_unit);
-    K = e * e;
+    K = signed_sq(e);
     K *= 3.14159265358979323846;
     const double r_max = sj.r > sk.r ? sj.r : sk.r;
     K *= r_max * r_max;
@@ -362,7 +445,8 @@ __device__ __forceinline__ int resolve_collision(const sdm_step_cfg &cfg, const 
     const double eb = cfg.eb_const;
     double ec, fm;
     {
-      const bool need_ru = cfg.ec != SDM_EC_CONST || cfg.frag == SDM_FRAG_STRAUB2010;
+      const bool need_ru = cfg.ec != SDM_EC_CONST || cfg.frag == SDM_FRAG_STRAUB2010 ||
+                          cfg.frag == SDM_FRAG_LOWLIST1982;
       const SD sj = sd_load(cfg, A, j, need_ru), sk = sd_load(cfg, A, k, need_ru);
       breakup_params(cfg, A, sj, sk, u_b, ec, fm);
     }
@@ -1134,7 +1218,8 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   A.nm_wide = cfg->kernel == SDM_KERNEL_GEOMETRIC || cfg->kernel == SDM_KERNEL_PARAMETERIZED ||
               cfg->kernel == SDM_KERNEL_SIMPLE_GEOMETRIC ||
               (cfg->enable_breakup &&
-               (cfg->ec != SDM_EC_CONST || cfg->frag == SDM_FRAG_STRAUB2010));
+               (cfg->ec != SDM_EC_CONST || cfg->frag == SDM_FRAG_STRAUB2010 ||
+                cfg->frag == SDM_FRAG_LOWLIST1982));
   if (st->nm && (flags & 2)) {
     hipLaunchKernelGGL(k_nm_init, dim3(grid_for(N)), blk, 0, s, *cfg, A);
     LAUNCH_CHECK();

@@ -12,6 +12,12 @@ __device__ __forceinline__ double signed_pow(double x, double p) {
   return (x != x) ? x : sg * pow(fabs(x), p);
 }
 
+// `x **= 2` on a Storage: the sign survives (storage_impl.py:76-78), the square is exact
+__device__ __forceinline__ double signed_sq(double x) {
+  const double sg = (double)((x > 0) - (x < 0));
+  return (x != x) ? x : sg * (x * x);
+}
+
 // attributes/physics/volume.py:16-17 + liquid_spheres.py:18-19
 __device__ __forceinline__ double volume_of_mass(double m, double rho_w) { return m / rho_w; }
 

@@ -423,6 +423,10 @@ class LowList1982Ec:  # coalescence_efficiencies/lowlist1982.py
         output *= arr["tmp2"]
         self.particulator.backend.ll82_coalescence_check(Ec=output, dl=arr["dl"])
 
+    def fused_descriptor(self):
+        factor = self.const.PI * self.const.sgm_w * (6 / self.const.PI) ** (2 / 3)
+        return {"ec": 3, "ec_param": (0.0, factor), "needs_gk": True}
+
 
 # ---- fragmentation functions ----------------------------------------------------------------
 class AlwaysN:
@@ -454,6 +458,9 @@ class ConstantMass:  # breakup_fragmentations/constant_mass.py
         frag_mass[:] = self.C
         nf.sum(self.particulator.attributes["water mass"], is_first_in_pair)
         nf /= self.C
+
+    def fused_descriptor(self):
+        return {"frag": 6, "frag_param": (float(self.C), 0.0)}
 
 
 class VolumeBasedFragmentationFunction:
@@ -534,6 +541,11 @@ class Gaussian(_SumOfVolumes):  # breakup_fragmentations/gaussian.py (mu, sigma:
             x_plus_y=self._sum(is_first_in_pair), rand=u01, vmin=self.vmin, nfmax=self.nfmax,
         )
 
+    def fused_descriptor(self):
+        return {"frag": 3, "frag_param": (float(self.mu), float(self.sigma)),
+                "frag_vmin": float(self.vmin),
+                "frag_nfmax": -1.0 if self.nfmax is None else float(self.nfmax)}
+
 
 class Feingold1988(_SumOfVolumes):  # breakup_fragmentations/feingold1988.py
     def __init__(self, scale, fragtol=1e-3, vmin=0.0, nfmax=None):
@@ -547,6 +559,11 @@ class Feingold1988(_SumOfVolumes):  # breakup_fragmentations/feingold1988.py
             x_plus_y=self._sum(is_first_in_pair), rand=u01, fragtol=self.fragtol,
             vmin=self.vmin, nfmax=self.nfmax,
         )
+
+    def fused_descriptor(self):
+        return {"frag": 4, "frag_param": (float(self.scale), float(self.fragtol)),
+                "frag_vmin": float(self.vmin),
+                "frag_nfmax": -1.0 if self.nfmax is None else float(self.nfmax)}
 
 
 class SLAMS(_SumOfVolumes):  # breakup_fragmentations/slams.py
@@ -565,6 +582,10 @@ class SLAMS(_SumOfVolumes):  # breakup_fragmentations/slams.py
             n_fragment=nf, frag_volume=frag_volume, x_plus_y=self._sum(is_first_in_pair),
             probs=self.p_vec, rand=u01, vmin=self.vmin, nfmax=self.nfmax,
         )
+
+    def fused_descriptor(self):
+        return {"frag": 5, "frag_vmin": float(self.vmin),
+                "frag_nfmax": -1.0 if self.nfmax is None else float(self.nfmax)}
 
 
 class LowList1982Nf(_SumOfVolumes):  # breakup_fragmentations/lowlist82.py
@@ -607,6 +628,11 @@ class LowList1982Nf(_SumOfVolumes):  # breakup_fragmentations/lowlist82.py
             x_plus_y=self._sum(is_first_in_pair), rand=u01, vmin=self.vmin, nfmax=self.nfmax,
             Rf=self.ll82_tmp["Rf"], Rs=self.ll82_tmp["Rs"], Rd=self.ll82_tmp["Rd"],
         )
+
+    def fused_descriptor(self):
+        factor = self.const.PI * self.const.sgm_w * (6 / self.const.PI) ** (2 / 3)
+        return {"frag": 7, "frag_param": (factor, 0.0), "needs_gk": True, "frag_vmin": float(self.vmin),
+                "frag_nfmax": -1.0 if self.nfmax is None else float(self.nfmax)}
 
 
 class Straub2010Nf(VolumeBasedFragmentationFunction):

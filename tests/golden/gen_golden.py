@@ -789,6 +789,52 @@ def gen_breakup():
         save(f"traj_breakup_straub_rain_hab{int(hab)}", **out)
 
 
+def gen_breakup_more():
+    """f-2: the remaining fragmentation functions and the Low & List efficiency on the rain
+    spectrum (large drops: breakups happen), adaptive, Geometric kernel"""
+    from PySDM.dynamics.collisions.breakup_fragmentations import (
+        ConstantMass, Feingold1988, Gaussian, LowList1982Nf, SLAMS,
+    )
+    from PySDM.dynamics.collisions.coalescence_efficiencies import LowList1982Ec
+
+    triv = Formulae().trivia
+    n_sd = 2**9
+    rng = np.random.default_rng(99)
+    radii = np.exp(rng.uniform(np.log(0.1e-3), np.log(2.5e-3), n_sd))
+    volume = triv.volume(radius=radii)
+    mult = np.full(n_sd, 1000.0)
+    vmin = (0.01e-3) ** 3 * np.pi / 6
+    for name, fragf, ecf, fname in (
+        ("gaussian", lambda: Gaussian(mu=triv.volume(radius=0.4e-3),
+                                      sigma=triv.volume(radius=0.3e-3), vmin=vmin, nfmax=100),
+         lambda: ConstEc(Ec=0.5), "Gaussian"),
+        ("feingold", lambda: Feingold1988(scale=triv.volume(radius=0.5e-3), vmin=vmin,
+                                          nfmax=100),
+         lambda: ConstEc(Ec=0.5), "Feingold1988"),
+        ("slams", lambda: SLAMS(vmin=vmin, nfmax=100), lambda: ConstEc(Ec=0.5), "SLAMS"),
+        ("constmass", lambda: ConstantMass(c=float(1000.0 * triv.volume(radius=0.3e-3))),
+         lambda: ConstEc(Ec=0.5), "ConstantMass"),
+        ("lowlist", lambda: LowList1982Nf(vmin=vmin, nfmax=100), LowList1982Ec,
+         "LowList1982Nf"),
+    ):
+        out = run_traj(
+            n_sd=n_sd, seed=44, dt=10.0, dv=1e3, volume=volume, multiplicity=mult,
+            make_dynamic=lambda f=fragf, e=ecf: Collision(
+                collision_kernel=Geometric(), coalescence_efficiency=e(),
+                breakup_efficiency=ConstEb(1.0), fragmentation_function=f(),
+                adaptive=True, warn_overflows=False,
+            ),
+            record_steps=(1, 5, 20),
+            formulae_kwargs={"fragmentation_function": fname,
+                             "terminal_velocity": "GunnKinzer1949"},
+            breakup=True,
+        )
+        out["init/volume"] = volume
+        out["init/multiplicity"] = mult
+        out["cfg"] = np.asarray([n_sd, 44, 1, 10.0, 1e3, 0])
+        save(f"traj_breakup_rain_{name}", **out)
+
+
 def gen_shards():
     """sub-domain runs for the cell-sharding tests: a multi-cell case split into 2 contiguous
     blocks of cells; each block is run by the reference on its own (same seed), cell ids renumbered
@@ -980,7 +1026,7 @@ def gen_displacement():
 
 if __name__ == "__main__":
     what = sys.argv[1:] or ["micro", "frag", "traj", "breakup", "shards", "moments", "displacement",
-                            "kernels"]
+                            "kernels", "breakup_more"]
     if "displacement" in what:
         gen_displacement()
     if "moments" in what:
@@ -995,5 +1041,7 @@ if __name__ == "__main__":
         gen_traj()
     if "kernels" in what:
         gen_kernels()
+    if "breakup_more" in what:
+        gen_breakup_more()
     if "breakup" in what:
         gen_breakup()

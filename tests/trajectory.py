@@ -48,6 +48,25 @@ def _breakup_parts(name):
             Straub2010Ec, lambda: Straub2010Nf(vmin=(0.01e-3) ** 3 * np.pi / 6, nfmax=10000),
             "Straub2010Nf", True),
     }
+    if name.startswith("rain_") and name[5:] in ("gaussian", "feingold", "slams", "constmass",
+                                                   "lowlist"):
+        from pysdm_amd.dynamics import collisions as C  # pylint: disable=import-outside-toplevel
+
+        vmin = (0.01e-3) ** 3 * np.pi / 6
+        half = lambda: ConstEc(Ec=0.5)  # noqa: E731
+        return {  # gen_golden.py:gen_breakup_more
+            "gaussian": (half, lambda: C.Gaussian(mu=TRIVIA.volume(radius=0.4e-3),
+                                                  sigma=TRIVIA.volume(radius=0.3e-3), vmin=vmin,
+                                                  nfmax=100), "Gaussian", False),
+            "feingold": (half, lambda: C.Feingold1988(scale=TRIVIA.volume(radius=0.5e-3),
+                                                      vmin=vmin, nfmax=100), "Feingold1988",
+                         False),
+            "slams": (half, lambda: C.SLAMS(vmin=vmin, nfmax=100), "SLAMS", False),
+            "constmass": (half, lambda: C.ConstantMass(
+                c=float(1000.0 * TRIVIA.volume(radius=0.3e-3))), "ConstantMass", False),
+            "lowlist": (C.LowList1982Ec, lambda: C.LowList1982Nf(vmin=vmin, nfmax=100),
+                        "LowList1982Nf", False),
+        }[name[5:]]
     return table[name]
 
 
