@@ -8,6 +8,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 __global__ void k_calib_random(const double2 *__restrict__ table, const int32_t *__restrict__ perm,
@@ -41,8 +42,11 @@ __global__ void k_calib_stream(const double2 *__restrict__ table, double *__rest
   if (v.x + v.y == 12345.678) out[0] = 1.0;
 }
 
-int main() {
-  const int64_t n = 1 << 24;  // 16 Mi records = 256 MiB table (> 8 x 4 MB of L2, = Infinity Cache)
+int main(int argc, char **argv) {
+  // records of 16 B in the table: 2^24 = 256 MiB (default; > 8 x 4 MB of L2), 2^21 = 32 MiB (in the
+  // Infinity Cache), 2^17 = 2 MiB (in every L2) ...; the number of reads stays 2^24
+  const int64_t n = 1 << 24;
+  const int64_t table_n = argc > 1 ? (int64_t)1 << atoi(argv[1]) : n;
   std::vector<int32_t> perm(n);
   uint64_t s = 88172645463325252ull;
   for (int64_t i = 0; i < n; ++i) perm[i] = (int32_t)i;
@@ -60,6 +64,15 @@ int main() {
   for (int rep = 0; rep < 3; ++rep) {
     hipLaunchKernelGGL(k_calib_stream, dim3(n / 256), dim3(256), 0, 0, table, out, n);
     hipLaunchKernelGGL(k_calib_random, dim3(n / 256), dim3(256), 0, 0, table, dperm, out, n);
+  }
+  if (table_n != n) {  // smaller table: the same 2^24 reads folded into it
+    for (int64_t i = 0; i < n; ++i) perm[i] &= (int32_t)(table_n - 1);
+    hipMemcpy(dperm, perm.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice);
+    for (int rep = 0; rep < 4; ++rep)
+      hipLaunchKernelGGL(k_calib_random, dim3(n / 256), dim3(256), 0, 0, table, dperm, out, n);
+    hipDeviceSynchronize();
+    std::printf("table of 2^%d records\n", atoi(argv[1]));
+    return 0;
   }
   for (int rep = 0; rep < 3; ++rep) {
     hipLaunchKernelGGL(k_calib_halves, dim3(n / 8 / 256), dim3(256), 0, 0, table, dperm, out,
