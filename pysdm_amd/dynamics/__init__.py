@@ -1,22 +1,18 @@
 """Dynamics on and next to the collision path."""
-from copy import deepcopy
+import copy
 
 
-def _instantiate(self, *, builder):
-    copy = deepcopy(self)
-    copy.register(builder=builder)
-    return copy
+def builder_owned(cls):
+    """Class decorator: gives a dynamic the `instantiate(builder=...)` hook a Builder calls when it
+    builds.  The builder then works on its own deep copy, registered with it, so the object the
+    user created can be handed to several builders (semantics of
+    PySDM/dynamics/impl/register_dynamic.py; PySDM's own Builder calls the same hook, which is how
+    this package's dynamics also run under it)."""
 
+    def instantiate(self, *, builder):
+        own = copy.deepcopy(self)
+        own.register(builder=builder)
+        return own
 
-def register_dynamic():
-    """dynamics are deep-copied when a builder builds them, so that one instance can be handed
-    to several builders (PySDM/dynamics/impl/register_dynamic.py:7-22)"""
-
-    def decorator(cls):
-        if hasattr(cls, "instantiate"):
-            assert cls.instantiate is _instantiate
-        else:
-            setattr(cls, "instantiate", _instantiate)
-        return cls
-
-    return decorator
+    cls.instantiate = instantiate
+    return cls

@@ -19,7 +19,7 @@ from collections import namedtuple
 import numpy as np
 
 from ..attributes import Multiplicity
-from . import register_dynamic
+from . import builder_owned
 from ..physics import constants as const
 from ..physics.constants import si
 
@@ -704,7 +704,7 @@ class Straub2010Nf(VolumeBasedFragmentationFunction):
 
 
 # ---- the dynamic ----------------------------------------------------------------------------
-@register_dynamic()
+@builder_owned
 class Collision:  # pylint: disable=too-many-instance-attributes
     DYNAMIC_KEY = "Collision"
 

@@ -12,12 +12,12 @@ from collections import namedtuple
 
 import numpy as np
 
-from . import register_dynamic
+from . import builder_owned
 
 DEFAULTS = namedtuple("_", ("rtol", "adaptive"))(rtol=1e-2, adaptive=True)
 
 
-@register_dynamic()
+@builder_owned
 class Displacement:  # pylint: disable=too-many-instance-attributes
     def __init__(self, enable_sedimentation=False, precipitation_counting_level_index: int = 0,
                  adaptive=DEFAULTS.adaptive, rtol=DEFAULTS.rtol, fused=None):
