@@ -703,9 +703,19 @@ __device__ __forceinline__ bool sd_dead(const int64_t *__restrict__ multiplicity
 #define FCTL_HEALTHY 3
 
 // ---- one launch: exits at once while healthy; otherwise four phases (dead count per tile, scan
-// of the counts, holes / fillers, apply) separated by a software grid barrier.  The grid is COMPACT_GRID workgroups
-// (<= one per CU: always co-resident); every spin is bounded (bar[2] is set on time-out).
-#define COMPACT_GRID 256
+// of the counts, holes / fillers, apply) separated by a software grid barrier.  A tile is one
+// wavefront's worth of positions (ballots only, no LDS); the grid is COMPACT_GRID workgroups of
+// COMPACT_THREADS (always co-resident).  A grid barrier is one same-address atomic per workgroup
+// plus polling: measured 13.5 us with 256 workgroups, 5.1 us with 128, 3.0 us with 64 - hence
+// few, large ones (128 x 1024 threads measured best end to end).
+// Every spin is bounded (bar[2] is set on time-out).
+#ifndef COMPACT_GRID
+#define COMPACT_GRID 128
+#endif
+#ifndef COMPACT_THREADS
+#define COMPACT_THREADS 1024
+#endif
+#define COMPACT_WAVES (COMPACT_GRID * COMPACT_THREADS / SDM_WAVE)
 
 __device__ __forceinline__ bool grid_barrier(unsigned int *bar, unsigned int target) {
   __shared__ bool ok;
@@ -728,25 +738,24 @@ __device__ __forceinline__ bool grid_barrier(unsigned int *bar, unsigned int tar
 // FLAG_ONLY: the caller guarantees that no live super-droplet has zero multiplicity (it entered
 // with a healthy state and only flags positions), so the random gather of multiplicities is skipped
 template <bool FLAG_ONLY>
-__global__ void __launch_bounds__(SDM_BLOCK)
+__global__ void __launch_bounds__(COMPACT_THREADS)
 k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restrict__ idx,
-                     int64_t flag, int64_t *__restrict__ fctl, int32_t *__restrict__ block_dead,
-                     int nb, int64_t *__restrict__ ctl, int32_t *__restrict__ holes,
+                     int64_t flag, int64_t *__restrict__ fctl, int32_t *__restrict__ tile_dead,
+                     int n_tiles, int64_t *__restrict__ ctl, int32_t *__restrict__ holes,
                      int64_t *__restrict__ fillers, int64_t *__restrict__ cell_start_single,
                      unsigned int *__restrict__ bar) {
   if (fctl[FCTL_HEALTHY] != 0) return;
   const int64_t length = fctl[FCTL_VALID];
-  __shared__ int sm[SDM_BLOCK];
+  __shared__ int sm[COMPACT_THREADS / SDM_WAVE];
   const int lane = lane_id(), w = threadIdx.x / SDM_WAVE;
-  // phase A: dead count of every tile of SDM_BLOCK positions
-  for (int tile = blockIdx.x; tile < nb; tile += COMPACT_GRID) {
-    const int64_t i = (int64_t)tile * SDM_BLOCK + threadIdx.x;
-    const bool dead = i < length && (FLAG_ONLY ? idx[i] == flag : sd_dead(multiplicity, idx, i, flag));
+  const int wave = blockIdx.x * (COMPACT_THREADS / SDM_WAVE) + w;
+  // phase A: dead count of every tile of SDM_WAVE positions
+  for (int tile = wave; tile < n_tiles; tile += COMPACT_WAVES) {
+    const int64_t i = (int64_t)tile * SDM_WAVE + lane;
+    const bool dead =
+        i < length && (FLAG_ONLY ? idx[i] == flag : sd_dead(multiplicity, idx, i, flag));
     const int c = __popcll(__ballot(dead));
-    __syncthreads();
-    if (lane == 0) sm[w] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) block_dead[tile] = sm[0] + sm[1] + sm[2] + sm[3];
+    if (lane == 0) tile_dead[tile] = c;
   }
 #define BARRIER_OR_FAIL(k)                                   \
   if (!grid_barrier(bar, (k) * COMPACT_GRID)) {              \
@@ -758,31 +767,29 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
   // thread sums a contiguous chunk, the chunk sums are scanned across the workgroup, then each
   // thread rewrites its chunk
   if (blockIdx.x == 0) {
-    const int per = (nb + SDM_BLOCK - 1) / SDM_BLOCK;
+    const int per = (n_tiles + COMPACT_THREADS - 1) / COMPACT_THREADS;
     const int b0 = threadIdx.x * per;
     int sum = 0;
     for (int k = 0; k < per; ++k)
-      if (b0 + k < nb) sum += ((volatile int32_t *)block_dead)[b0 + k];
-    // inclusive scan of the chunk sums: within waves by shuffles, across the four waves via LDS
+      if (b0 + k < n_tiles) sum += ((volatile int32_t *)tile_dead)[b0 + k];
     int incl = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int t = __shfl_up(incl, o, 64);
       if (lane >= o) incl += t;
     }
-    __syncthreads();
     if (lane == 63) sm[w] = incl;
     __syncthreads();
     int base = 0, all = 0;
-    for (int k = 0; k < SDM_BLOCK / SDM_WAVE; ++k) {
+    for (int k = 0; k < COMPACT_THREADS / SDM_WAVE; ++k) {
       if (k < w) base += sm[k];
       all += sm[k];
     }
     int run = base + incl - sum;
     for (int k = 0; k < per; ++k)
-      if (b0 + k < nb) {
-        const int v = ((volatile int32_t *)block_dead)[b0 + k];
-        block_dead[b0 + k] = run;
+      if (b0 + k < n_tiles) {
+        const int v = ((volatile int32_t *)tile_dead)[b0 + k];
+        tile_dead[b0 + k] = run;
         run += v;
       }
     if (threadIdx.x == 0) {
@@ -795,17 +802,13 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
   const int64_t total_dead = ((volatile int64_t *)ctl)[3], new_len = ((volatile int64_t *)ctl)[1];
   // phase C: holes of the surviving prefix, live elements of the tail (from the end backwards)
   if (total_dead != 0)
-    for (int tile = blockIdx.x; tile < nb; tile += COMPACT_GRID) {
-      const int64_t i = (int64_t)tile * SDM_BLOCK + threadIdx.x;
+    for (int tile = wave; tile < n_tiles; tile += COMPACT_WAVES) {
+      const int64_t i = (int64_t)tile * SDM_WAVE + lane;
       const bool in = i < length;
-      const bool dead = in && (FLAG_ONLY ? idx[i] == flag : sd_dead(multiplicity, idx, i, flag));
+      const bool dead =
+          in && (FLAG_ONLY ? idx[i] == flag : sd_dead(multiplicity, idx, i, flag));
       const unsigned long long m = __ballot(dead);
-      __syncthreads();
-      if (lane == 0) sm[w] = __popcll(m);
-      __syncthreads();
-      int before = ((volatile int32_t *)block_dead)[tile];
-      for (int k = 0; k < w; ++k) before += sm[k];
-      const int64_t dp = before + __popcll(m & ((1ull << lane) - 1));
+      const int64_t dp = ((volatile int32_t *)tile_dead)[tile] + __popcll(m & ((1ull << lane) - 1));
       if (in) {
         if (i == new_len) ctl[2] = dp;
         if (i < new_len) {
@@ -819,8 +822,8 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
   // phase D: apply
   if (total_dead != 0) {
     const int64_t n_holes = ((volatile int64_t *)ctl)[2];
-    for (int64_t t = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x; t < length - new_len;
-         t += (int64_t)COMPACT_GRID * SDM_BLOCK) {
+    for (int64_t t = (int64_t)blockIdx.x * COMPACT_THREADS + threadIdx.x; t < length - new_len;
+         t += (int64_t)COMPACT_GRID * COMPACT_THREADS) {
       idx[new_len + t] = flag;
       if (t < n_holes) idx[((volatile int32_t *)holes)[t]] = ((volatile int64_t *)fillers)[t];
     }
@@ -852,26 +855,26 @@ int sdm_compact_fused_async(sdm_ctx *ctx, char *scratch, const int64_t *multipli
                             int64_t *idx, int64_t length_bound, int64_t flag, int64_t *fctl,
                             int64_t *ctl, int64_t *cell_start_single, bool flag_only) {
   Carver cv(scratch);
-  const int nb = (int)grid_for(length_bound);
-  int32_t *block_dead = cv.take<int32_t>(nb + 1);
+  const int n_tiles = (int)grid_for(length_bound, SDM_WAVE);
+  int32_t *tile_dead = cv.take<int32_t>(n_tiles + 1);
   int32_t *holes = cv.take<int32_t>(length_bound);
   int64_t *fillers = cv.take<int64_t>(length_bound);
   unsigned int *bar = (unsigned int *)(ctx->dscal + 12);
   if (flag_only)
-    hipLaunchKernelGGL(k_compact_persistent<true>, dim3(COMPACT_GRID), dim3(SDM_BLOCK), 0,
-                       ctx->stream, multiplicity, idx, flag, fctl, block_dead, nb, ctl, holes,
+    hipLaunchKernelGGL(k_compact_persistent<true>, dim3(COMPACT_GRID), dim3(COMPACT_THREADS), 0,
+                       ctx->stream, multiplicity, idx, flag, fctl, tile_dead, n_tiles, ctl, holes,
                        fillers, cell_start_single, bar);
   else
-    hipLaunchKernelGGL(k_compact_persistent<false>, dim3(COMPACT_GRID), dim3(SDM_BLOCK), 0,
-                       ctx->stream, multiplicity, idx, flag, fctl, block_dead, nb, ctl, holes,
+    hipLaunchKernelGGL(k_compact_persistent<false>, dim3(COMPACT_GRID), dim3(COMPACT_THREADS), 0,
+                       ctx->stream, multiplicity, idx, flag, fctl, tile_dead, n_tiles, ctl, holes,
                        fillers, cell_start_single, bar);
   LAUNCH_CHECK();
   return SDM_OK;
 }
 
 size_t sdm_compact_scratch(int64_t n) {
-  return carve_size(sizeof(int32_t) * (grid_for(n) + 1)) + carve_size(sizeof(int32_t) * n) +
-         carve_size(sizeof(int64_t) * n);
+  return carve_size(sizeof(int32_t) * (grid_for(n, SDM_WAVE) + 1)) +
+         carve_size(sizeof(int32_t) * n) + carve_size(sizeof(int64_t) * n);
 }
 
 extern "C" int sdm_remove_zero_n_or_flagged(sdm_ctx *ctx, const int64_t *multiplicity,
