@@ -142,3 +142,38 @@ def test_linear_kernel_routes_agree(hip_backend_class, oracle_backend_class):
             if key == "idx":
                 value, ref = value[:length], ref[:length]
             np.testing.assert_array_equal(value, ref, err_msg=key)
+
+
+def test_degenerate_sizes_through_the_abi(kit):
+    """empty and tiny inputs: zero-length arrays are accepted by every entry point that takes a
+    length, two super-droplets form one pair, three leave one alone, a null context is refused"""
+    import ctypes  # pylint: disable=import-outside-toplevel
+
+    from pysdm_amd import _lib  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.backends.hip import _Context  # pylint: disable=import-outside-toplevel
+
+    lib, ctx = _lib.load(), _Context.get()
+    null = ctypes.c_void_p(0)
+    zero = ctypes.c_int64(0)
+    for name, args in (
+        ("sdm_identity_index", (null, zero)),
+        ("sdm_elementwise_f64", (ctypes.c_int(0), null, null, null, ctypes.c_double(0), zero)),
+        ("sdm_elementwise_i64", (ctypes.c_int(0), null, null, null, zero, zero)),
+        ("sdm_volume_of_water_mass", (null, null, zero, ctypes.c_double(1000.0))),
+        ("sdm_floor_to_i64", (null, null, zero)),
+        ("sdm_subtract_i64", (null, null, zero)),
+        ("sdm_ll82_coalescence_check", (null, null, zero)),
+    ):
+        assert getattr(lib, name)(ctx.handle, *args) == 0, name
+    assert lib.sdm_identity_index(None, null, zero) == -1  # SDM_E_ARG, message available
+    assert b"bad argument" in lib.sdm_last_error()
+    for n_sd in (2, 3):
+        idx = kit.Index.identity_index(n_sd)
+        u01 = kit.Storage.from_ndarray(np.full(n_sd, 0.75))
+        idx.shuffle(u01)
+        assert sorted(idx.to_ndarray().tolist()) == list(range(n_sd))
+        flag = kit.PairIndicator(n_sd)
+        cell_start = kit.Storage.from_ndarray(np.asarray([0, n_sd]))
+        cell_id = kit.IndexedStorage.from_ndarray(idx, np.zeros(n_sd, dtype=np.int64))
+        flag.update(cell_start, kit.Index.identity_index(1), cell_id)
+        assert flag.indicator.to_ndarray().sum() == 1
