@@ -56,7 +56,7 @@ def build_workload(name, backend_class, rank, world, n_sd=None, adaptive=None):
     return make_box(backend_class, name, n_sd=n_sd, adaptive=adaptive, seed=44 + rank)
 
 
-def cpu_baseline(workload, n_sd, adaptive, seconds_budget=15.0):
+def cpu_baseline(workload, n_sd, adaptive, seconds_budget=12.0):
     """the oracle (kind "port": serial C restatement of the reference's Numba-backend algorithm,
     driven method by method like the reference) on one host core, same box, bounded sample"""
     from oracle.backend import OracleBackend
@@ -69,7 +69,7 @@ def cpu_baseline(workload, n_sd, adaptive, seconds_budget=15.0):
         particulator.run(1)
         steps += 1
         elapsed = time.perf_counter() - t0
-        if elapsed > seconds_budget or steps >= 200:
+        if elapsed > seconds_budget or steps >= 2000:
             break
     if dynamic.adaptive:  # candidate pairs = sum over sub-steps (all cells still full-length)
         n_cell = particulator.mesh.n_cell

@@ -88,3 +88,17 @@ def test_two_rank_sharded_run_matches_reference_subdomains():
     while not errors.empty():
         messages.append(errors.get())
     assert not failed and not messages, f"{failed} {messages}"
+
+
+def test_bench_cpu_baseline_leg_runs():
+    """bench.py's `cpu_baseline` (the oracle timed on the host) on a tiny box"""
+    import importlib.util  # pylint: disable=import-outside-toplevel
+
+    spec = importlib.util.spec_from_file_location(
+        "bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                              "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for workload, adaptive, n_sd in (("shima", False, 2**12), ("kinematic2d", True, 2**17)):
+        result = bench.cpu_baseline(workload, n_sd, adaptive, seconds_budget=0.3)
+        assert result["kind"] == "port" and result["cores"] == 1 and result["value"] > 0
