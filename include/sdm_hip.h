@@ -326,8 +326,9 @@ typedef struct sdm_step_state {
   int64_t *collision_rate, *collision_rate_deficit, *coalescence_rate;  /* [n_cell] */
   int64_t *breakup_rate, *breakup_rate_deficit;                        /* [n_cell] or NULL */
   const double *gk_a, *gk_b;  /* Gunn-Kinzer table (or NULL) */
-  /* device control block, int64[8]: {valid_n_sd, working_length, sorted, healthy,
-   * n_overflow, idx_swapped, reserved, reserved}; kept device-resident between calls */
+  /* device control block, int64[8]: {valid_n_sd, working_length, sorted, healthy, n_overflow,
+   * candidate pairs processed so far (single-cell non-adaptive steps), largest cell, error};
+   * kept device-resident between calls */
   int64_t *ctl;
   /* optional mirror kept by the library, caller-owned like all state (NULL = do not use):
    * [n_sd] x 32 B.  Records are {int64 multiplicity, double mass} (16-B stride) or, with the

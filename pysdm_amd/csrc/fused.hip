@@ -18,6 +18,7 @@ int sdm_adaptive_end_async(sdm_ctx *ctx, const double *dt_left, int64_t n_cell,
 #define CTL_SORTED 2
 #define CTL_HEALTHY 3
 #define CTL_OVERFLOW 4
+#define CTL_PAIRS 5  // candidate pairs processed by the single-cell non-adaptive pair kernel
 
 #define TID() ((int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x)
 
@@ -642,6 +643,7 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_all(sdm_step_cfg cfg, FusedA
   __shared__ u128 lds[2];
   const int64_t W = A.ctl[CTL_WORK];
   const int64_t d = TID();
+  if (d == 0) A.ctl[CTL_PAIRS] += W / 2;  // lets a caller count pairs without reading back per step
   const double u = stream_draw(A.s_rand, A.rng_inc, A.rng_tab, &lds[0]);
   const double u_b = BREAKUP ? stream_draw(A.s_rand_b, A.rng_inc, A.rng_tab, &lds[1]) : 0.0;
   PairInfo R;

@@ -131,3 +131,14 @@ def test_many_steps_in_one_call_equal_oracle(n_sd, steps, thin, hip_backend_clas
     assert_same(snaps[0], snaps[1])
     if thin:
         assert int(snaps[0]["length"]) < n_sd
+
+
+def test_shima_box_3600_steps_equal_oracle(hip_backend_class, oracle_backend_class):
+    """the whole Shima-2009 experiment (3600 steps of 1 s) in one library call at 2^16
+    super-droplets: permutation, multiplicities, masses and counters identical to the oracle's"""
+    snaps = []
+    for backend_class in (hip_backend_class, oracle_backend_class):
+        particulator, dynamic = make_box(backend_class, "shima", n_sd=2**16, adaptive=False)
+        run(particulator, 3600)
+        snaps.append(snapshot(particulator, dynamic))
+    assert_same(snaps[0], snaps[1])
