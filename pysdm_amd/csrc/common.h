@@ -13,6 +13,9 @@ typedef unsigned __int128 u128;
 #define SDM_MAX_EVENTS 8192
 #define SDM_WAVE 64
 
+#define SDM_CNT_SLOTS 128
+#define SDM_CNT_STRIDE 16  // int64 per slot: one 128-B line each
+
 struct ShufRec;  // shuffle.hip
 
 // ---- context ---------------------------------------------------------------------------
@@ -30,6 +33,8 @@ struct sdm_ctx {
   int64_t *mailbox;  // 16 x int64, hipHostMalloc
   // device control words for fine-grained calls (int64[16])
   int64_t *dscal;
+  // single-cell collision counters, spread over SDM_CNT_SLOTS cache lines (fused.hip)
+  int64_t *cnt_slots;
   // optional per-phase timing with HIP events on the ctx stream (bench / profiling only)
   bool timing;
   hipEvent_t *ev;      // pool of SDM_MAX_EVENTS events

@@ -26,6 +26,8 @@ extern "C" int sdm_ctx_create(sdm_ctx **out, int device) {
   HIP_TRY(hipHostMalloc((void **)&ctx->mailbox, sizeof(int64_t) * 16, hipHostMallocDefault));
   HIP_TRY(hipMalloc((void **)&ctx->dscal, sizeof(int64_t) * 16));
   HIP_TRY(hipMemset(ctx->dscal, 0, sizeof(int64_t) * 16));
+  HIP_TRY(hipMalloc((void **)&ctx->cnt_slots, sizeof(int64_t) * SDM_CNT_SLOTS * SDM_CNT_STRIDE));
+  HIP_TRY(hipMemset(ctx->cnt_slots, 0, sizeof(int64_t) * SDM_CNT_SLOTS * SDM_CNT_STRIDE));
   *out = ctx;
   return SDM_OK;
 }
@@ -38,6 +40,7 @@ extern "C" int sdm_ctx_destroy(sdm_ctx *ctx) {
   if (ctx->pcg_tab) (void)hipFree(ctx->pcg_tab);
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   if (ctx->dscal) (void)hipFree(ctx->dscal);
+  if (ctx->cnt_slots) (void)hipFree(ctx->cnt_slots);
   if (ctx->ev) {
     for (int i = 0; i < SDM_MAX_EVENTS; ++i) (void)hipEventDestroy(ctx->ev[i]);
     delete[] ctx->ev;

@@ -65,24 +65,66 @@ struct FusedArgs {
   // of two); a mirror of the SoA columns kept current by the update code, NULL = not in use
   double *nm;
   int nm_wide;  // 0: 16-B records, 1: 32-B records
+  // one cell: every wave of a step would add to the same few counter words, and same-address
+  // atomics serialise in L2 (~4 ns each: 70 us per step once most waves hold a colliding pair).
+  // The adds go to slot (workgroup % SDM_CNT_SLOTS) instead - one cache line per slot - and
+  // k_fold_counters adds the slots to the counters at the end of the call.  NULL: n_cell > 1
+  int64_t *slots;
   // breakup: colliding pairs listed by the pair kernels, resolved by k_resolve_dense
   struct Collided *list;
   unsigned long long *list_count;
 };
 
-// wave-aggregated int64 counter add: one atomic per wave when all contributing lanes share cid
-__device__ __forceinline__ void counter_add(int64_t *__restrict__ counter, int64_t cid,
-                                            int64_t v, bool active) {
+enum { CNT_COLLISION = 0, CNT_COLLISION_DEFICIT, CNT_COALESCENCE, CNT_BREAKUP, CNT_BREAKUP_DEFICIT,
+       CNT_KINDS };
+
+__device__ __forceinline__ int64_t *counter_of(const FusedArgs &A, int which) {
+  return which == CNT_COLLISION ? A.collision_rate
+         : which == CNT_COLLISION_DEFICIT ? A.collision_rate_deficit
+         : which == CNT_COALESCENCE ? A.coalescence_rate
+         : which == CNT_BREAKUP ? A.breakup_rate : A.breakup_rate_deficit;
+}
+
+// wave-aggregated int64 counter add: one atomic per wave when all contributing lanes share cid.
+// Wave-collective: lanes that have nothing to add call it with active = false.
+__device__ __forceinline__ void counter_add(const FusedArgs &A, int which, int64_t cid, int64_t v,
+                                            bool active) {
   active = active && v != 0;
   const unsigned long long am = __ballot(active);
   if (am == 0) return;
   const int first = __ffsll((long long)am) - 1;
+  if (A.slots) {  // one cell
+    const int64_t s = wave_sum_i64(active ? v : 0);
+    if (lane_id() == first)
+      atomicAdd((unsigned long long *)&A.slots[(blockIdx.x & (SDM_CNT_SLOTS - 1)) * SDM_CNT_STRIDE +
+                                               which], (unsigned long long)s);
+    return;
+  }
+  int64_t *__restrict__ counter = counter_of(A, which);
   const int64_t cid0 = __shfl((long long)cid, first, 64);
   if (__all(!active || cid == cid0)) {
     const int64_t s = wave_sum_i64(active ? v : 0);
     if (lane_id() == first) atomicAdd((unsigned long long *)&counter[cid0], (unsigned long long)s);
   } else if (active) {
     atomicAdd((unsigned long long *)&counter[cid], (unsigned long long)v);
+  }
+}
+
+// adds the slots to the (single) cell's counters and clears them; one workgroup of SDM_CNT_SLOTS
+__global__ void __launch_bounds__(SDM_CNT_SLOTS) k_fold_counters(FusedArgs A) {
+  __shared__ int64_t part[SDM_CNT_SLOTS / SDM_WAVE][CNT_KINDS];
+  int64_t *slot = A.slots + threadIdx.x * SDM_CNT_STRIDE;
+  for (int w = 0; w < CNT_KINDS; ++w) {
+    const int64_t v = slot[w];
+    if (v != 0) slot[w] = 0;
+    const int64_t s = wave_sum_i64(v);
+    if (lane_id() == 0) part[threadIdx.x / SDM_WAVE][w] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < CNT_KINDS) {
+    int64_t s = 0;
+    for (int w = 0; w < SDM_CNT_SLOTS / SDM_WAVE; ++w) s += part[w][threadIdx.x];
+    if (s != 0) counter_of(A, threadIdx.x)[0] += s;
   }
 }
 
@@ -442,6 +484,7 @@ __device__ __forceinline__ int resolve_collision(const sdm_step_cfg &cfg, const 
   const int64_t j_in = j, k_in = k;
   const int64_t nk = collide ? A.multiplicity[k] : 0;
   bool coal = collide;
+  int64_t n_breakup = 0, n_breakup_deficit = 0;  // added to the counters once, at the end
   if (BREAKUP && collide) {
     const double eb = cfg.eb_const;
     double ec, fm;
@@ -467,11 +510,8 @@ __device__ __forceinline__ int resolve_collision(const sdm_step_cfg &cfg, const 
                                         cfg.max_multiplicity, take_from_j, new_mult_k,
                                         gamma_j_k, ovf);
         gamma_deficit = g - (double)gamma_j_k;
-        if (gamma_j_k) atomicAdd((unsigned long long *)&A.breakup_rate[cid],
-                                 (unsigned long long)(gamma_j_k * nk));
-        if (gamma_deficit != 0)
-          atomicAdd((unsigned long long *)&A.breakup_rate_deficit[cid],
-                    (unsigned long long)(int64_t)(gamma_deficit * (double)nk));
+        n_breakup += gamma_j_k * nk;
+        if (gamma_deficit != 0) n_breakup_deficit += (int64_t)(gamma_deficit * (double)nk);
         apply_breakup_transfer(j, k, take_from_j, new_mult_k, A.multiplicity, A.attributes,
                                cfg.n_attr, cfg.n_sd);
       } else {
@@ -482,8 +522,7 @@ __device__ __forceinline__ int resolve_collision(const sdm_step_cfg &cfg, const 
             take_from_j = (double)mj;
             new_mult_k = (mass[j] + mass[k]) / fm * (double)mk;
             if (new_mult_k > (double)cfg.max_multiplicity) {
-              atomicAdd((unsigned long long *)&A.breakup_rate_deficit[cid],
-                        (unsigned long long)(int64_t)(gamma_deficit * (double)mk));
+              n_breakup_deficit += (int64_t)(gamma_deficit * (double)mk);
               ovf = true;
               break;
             }
@@ -497,19 +536,22 @@ __device__ __forceinline__ int resolve_collision(const sdm_step_cfg &cfg, const 
             gamma_j_k = (double)g_int;
           }
           const int64_t add = (int64_t)(gamma_j_k * (double)A.multiplicity[k]);
-          if (add) atomicAdd((unsigned long long *)&A.breakup_rate[cid], (unsigned long long)add);
+          n_breakup += add;
           gamma_deficit -= gamma_j_k;
           apply_breakup_transfer(j, k, take_from_j, new_mult_k, A.multiplicity, A.attributes,
                                  cfg.n_attr, cfg.n_sd);
         }
         const int64_t add = (int64_t)(gamma_deficit * (double)A.multiplicity[k]);
-        if (add) atomicAdd((unsigned long long *)&A.breakup_rate_deficit[cid],
-                           (unsigned long long)add);
+        n_breakup_deficit += add;
       }
       if (ovf) atomicAdd((unsigned long long *)&A.ctl[CTL_OVERFLOW], 1ull);
     }
   }
-  counter_add(A.coalescence_rate, cid, (int64_t)(g * (double)nk), coal);
+  if (BREAKUP) {
+    counter_add(A, CNT_BREAKUP, cid, n_breakup, true);
+    counter_add(A, CNT_BREAKUP_DEFICIT, cid, n_breakup_deficit, true);
+  }
+  counter_add(A, CNT_COALESCENCE, cid, (int64_t)(g * (double)nk), coal);
   if (coal) coalesce_pair(j, k, g, A.multiplicity, A.attributes, cfg.n_attr, cfg.n_sd);
   int died = 0;
   if (collide) {
@@ -605,8 +647,8 @@ __device__ __forceinline__ int pair_update_body(const sdm_step_cfg &cfg, const F
       g = (double)gc;
     }
   }
-  counter_add(A.collision_rate, cid, gc * nk, collide);
-  counter_add(A.collision_rate_deficit, cid, (gi - gc) * nk, collide);
+  counter_add(A, CNT_COLLISION, cid, gc * nk, collide);
+  counter_add(A, CNT_COLLISION_DEFICIT, cid, (gi - gc) * nk, collide);
   collide = collide && g != 0;
   if (BREAKUP) {
     // breakup: the (rare, transcendental-heavy) resolution runs densely packed in
@@ -628,7 +670,7 @@ __device__ __forceinline__ int pair_update_body(const sdm_step_cfg &cfg, const F
   }
   int died;
   if (sj && cfg.n_attr == 1) {  // members' state carried in registers by the caller
-    counter_add(A.coalescence_rate, cid, (int64_t)(g * (double)nk), collide);
+    counter_add(A, CNT_COALESCENCE, cid, (int64_t)(g * (double)nk), collide);
     died = collide ? coalesce_known(cfg, A, j, k, g, *sj, *sk) : 0;
   } else {
     died = resolve_collision<false>(cfg, A, collide, j, k, cid, g, u_b);
@@ -1145,8 +1187,9 @@ static int cond_sort(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st, 
 
 // flags: bit 0 = read the control block back at the end; bit 1 = the control block was freshly
 // pushed by the host (single-cell bookkeeping has to be initialised)
-extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st,
-                                  sdm_step_result *res, int flags) {
+// fold_counters: false when further steps of the same call follow (sdm_collision_run)
+static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st,
+                          sdm_step_result *res, int flags, bool fold_counters) {
   ARG_TRY(ctx && cfg && st && res);
   ARG_TRY(cfg->n_sd >= 2 && cfg->n_sd < INT32_MAX && cfg->n_cell >= 1 && cfg->n_attr >= 1);
   ARG_TRY(st->idx && st->tmp_idx && st->multiplicity && st->attributes && st->cell_id &&
@@ -1208,6 +1251,7 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   A.list_count = S.list_count;
   A.block_min = S.block_min;
   A.n_block_min = (int)grid_for((N + 1) / 2);
+  A.slots = C == 1 ? ctx->cnt_slots : nullptr;
 
   uint64_t off = st->rng_offset, off_b = st->rng_offset_breakup;
   uint64_t draw_off = off, draw_off_b = off_b;  // stream positions of the current draw
@@ -1470,6 +1514,10 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
       if (rc) return rc;
     }
   }
+  if (A.slots && fold_counters) {
+    hipLaunchKernelGGL(k_fold_counters, one, dim3(SDM_CNT_SLOTS), 0, s, A);
+    LAUNCH_CHECK();
+  }
   res->n_substeps = n_sub;
   res->idx_swapped = swaps & 1;
   res->rng_offset = off;
@@ -1500,6 +1548,11 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   return SDM_OK;
 }
 
+extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st,
+                                  sdm_step_result *res, int flags) {
+  return collision_step(ctx, cfg, st, res, flags, true);
+}
+
 // n_steps consecutive time steps in one call (no host-side work between them): what
 // `Particulator.run(n_steps)` amounts to when the collision dynamic is the only dynamic and nothing
 // observes the intermediate states (PySDM/particulator.py:50-56).  state->idx / tmp_idx are
@@ -1518,8 +1571,8 @@ extern "C" int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step
     sdm_step_result one;
     const bool last = step == n_steps - 1;
     // read the control block back only after the last step
-    const int rc = sdm_collision_step(ctx, cfg, st, &one, (last ? (flags & 1) : 0) |
-                                                          (step == 0 ? (flags & 2) : 0));
+    const int rc = collision_step(ctx, cfg, st, &one, (last ? (flags & 1) : 0) |
+                                                      (step == 0 ? (flags & 2) : 0), last);
     if (rc) return rc;
     if (one.idx_swapped) {
       int64_t *t = st->idx;
