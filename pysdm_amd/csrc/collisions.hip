@@ -295,22 +295,22 @@ k_compute_gamma(const double *prob, const double *__restrict__ rand,
                 int64_t *__restrict__ collision_rate, const uint8_t *__restrict__ flag,
                 double *out) {
   const int64_t i = TID();
-  if (i >= length / 2) return;
-  double g = ceil(prob[i] - rand[i]);
-  int64_t j, k;
-  if (!pair_indices(i, idx, flag, g, j, k)) {
+  const bool in_range = i < length / 2;
+  double g = in_range ? ceil(prob[i] - rand[i]) : 0.0;
+  int64_t j, k, cid = 0, done = 0, deficit = 0;
+  if (in_range && !pair_indices(i, idx, flag, g, j, k)) {
     const int64_t nk = multiplicity[k];
     const int64_t prop = multiplicity[j] / nk;
     const int64_t gi = (int64_t)g;
     const int64_t gc = gi < prop ? gi : prop;
-    const int64_t cid = cell_id[j];
-    if (gc != 0) atomicAdd((unsigned long long *)&collision_rate[cid],
-                           (unsigned long long)(gc * nk));
-    if (gi != gc) atomicAdd((unsigned long long *)&collision_rate_deficit[cid],
-                            (unsigned long long)((gi - gc) * nk));
+    cid = cell_id[j];
+    done = gc * nk;
+    deficit = (gi - gc) * nk;
     g = (double)gc;
   }
-  out[i] = g;
+  wave_counter_add(collision_rate, cid, done, true);
+  wave_counter_add(collision_rate_deficit, cid, deficit, true);
+  if (in_range) out[i] = g;
 }
 
 extern "C" int sdm_compute_gamma(sdm_ctx *ctx, const double *prob, const double *rand,
@@ -381,13 +381,12 @@ k_collision_coalescence(int64_t *__restrict__ multiplicity, const int64_t *__res
                         int64_t *__restrict__ coalescence_rate,
                         const uint8_t *__restrict__ flag) {
   const int64_t i = TID();
-  if (i >= length / 2) return;
-  const double g = gamma[i];
+  const double g = i < length / 2 ? gamma[i] : 0.0;
   int64_t j, k;
-  if (pair_indices(i, idx, flag, g, j, k)) return;
-  const int64_t nk = multiplicity[k];
-  atomicAdd((unsigned long long *)&coalescence_rate[cell_id[j]],
-            (unsigned long long)(int64_t)(g * (double)nk));
+  const bool skip = i >= length / 2 || pair_indices(i, idx, flag, g, j, k);
+  const int64_t nk = skip ? 0 : multiplicity[k];
+  wave_counter_add(coalescence_rate, skip ? 0 : cell_id[j], (int64_t)(g * (double)nk), !skip);
+  if (skip) return;
   coalesce_pair(j, k, g, multiplicity, attributes, n_attr, n_sd);
   if (multiplicity[k] == 0 || multiplicity[j] == 0) healthy[0] = 0;
 }

@@ -166,6 +166,23 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
   return v;
 }
 
+// counter[cid] += v for the lanes with `active`: one atomic per wave when they all share cid
+// (same-address atomics serialise in L2).  Wave-collective: every lane of the wave calls it.
+__device__ __forceinline__ void wave_counter_add(int64_t *__restrict__ counter, int64_t cid,
+                                                 int64_t v, bool active) {
+  active = active && v != 0;
+  const unsigned long long am = __ballot(active);
+  if (am == 0) return;
+  const int first = __ffsll((long long)am) - 1;
+  const int64_t cid0 = __shfl((long long)cid, first, 64);
+  if (__all(!active || cid == cid0)) {
+    const int64_t s = wave_sum_i64(active ? v : 0);
+    if (lane_id() == first) atomicAdd((unsigned long long *)&counter[cid0], (unsigned long long)s);
+  } else if (active) {
+    atomicAdd((unsigned long long *)&counter[cid], (unsigned long long)v);
+  }
+}
+
 // atomic min on non-negative doubles through their (order-preserving) bit pattern
 __device__ __forceinline__ void atomic_min_pos_f64(double *addr, double v) {
   atomicMin((unsigned long long *)addr, (unsigned long long)__double_as_longlong(v));

@@ -6,6 +6,7 @@
 //      [+ per-cell min of optimal dt])
 //   -> k_cells (adaptive dt bookkeeping) -> k_pair_update (gamma + multiplicity/attribute update
 //      + counters + health flag) -> compaction if unhealthy -> [adaptive end / working length]
+#include <algorithm>
 #include "common.h"
 #include "index.h"
 #include "physics.h"
@@ -71,8 +72,13 @@ struct FusedArgs {
   // k_fold_counters adds the slots to the counters at the end of the call.  NULL: n_cell > 1
   int64_t *slots;
   // breakup: colliding pairs listed by the pair kernels, resolved by k_resolve_dense
+  // `list_nl` lists of capacity `list_cap` each (list l starts at list + l * list_cap, its fill
+  // count is list_count[l * SDM_CNT_STRIDE]); a workgroup appends to list (blockIdx % list_nl), so
+  // the appends of a launch do not all queue up on one counter word
   struct Collided *list;
   unsigned long long *list_count;
+  int list_nl;
+  int64_t list_cap;
 };
 
 enum { CNT_COLLISION = 0, CNT_COLLISION_DEFICIT, CNT_COALESCENCE, CNT_BREAKUP, CNT_BREAKUP_DEFICIT,
@@ -100,14 +106,7 @@ __device__ __forceinline__ void counter_add(const FusedArgs &A, int which, int64
                                                which], (unsigned long long)s);
     return;
   }
-  int64_t *__restrict__ counter = counter_of(A, which);
-  const int64_t cid0 = __shfl((long long)cid, first, 64);
-  if (__all(!active || cid == cid0)) {
-    const int64_t s = wave_sum_i64(active ? v : 0);
-    if (lane_id() == first) atomicAdd((unsigned long long *)&counter[cid0], (unsigned long long)s);
-  } else if (active) {
-    atomicAdd((unsigned long long *)&counter[cid], (unsigned long long)v);
-  }
+  wave_counter_add(counter_of(A, which), cid, v, active);
 }
 
 // adds the slots to the (single) cell's counters and clears them; one workgroup of SDM_CNT_SLOTS
@@ -657,13 +656,14 @@ __device__ __forceinline__ int pair_update_body(const sdm_step_cfg &cfg, const F
     if (m != 0) {
       const int lane = lane_id(), leader = __ffsll((long long)m) - 1;
       unsigned long long base = 0;
-      if (lane == leader) base = atomicAdd((unsigned long long *)A.list_count,
+      const int64_t l = blockIdx.x % (unsigned)A.list_nl;
+      if (lane == leader) base = atomicAdd(A.list_count + l * SDM_CNT_STRIDE,
                                            (unsigned long long)__popcll(m));
       base = __shfl((long long)base, leader, 64);
       if (collide) {
         Collided c;
         c.j = j; c.k = k; c.cid = cid; c.pos = pos; c.g = g; c.u_b = u_b;
-        A.list[base + __popcll(m & ((1ull << lane) - 1))] = c;
+        A.list[l * A.list_cap + base + __popcll(m & ((1ull << lane) - 1))] = c;
       }
     }
     return 0;
@@ -1033,13 +1033,14 @@ k_max_cell(const int64_t *__restrict__ cell_start, int64_t n_cell, int64_t *ctl)
 
 // ---- breakup: dense resolution of the listed colliding pairs ----------------------------------
 __global__ void __launch_bounds__(SDM_BLOCK) k_resolve_dense(sdm_step_cfg cfg, FusedArgs A) {
-  const int64_t n = (int64_t)*A.list_count;
-  if ((int64_t)blockIdx.x * SDM_BLOCK >= n) return;
-  const int64_t t = TID();
+  const int64_t l = blockIdx.x % (unsigned)A.list_nl, chunk = blockIdx.x / (unsigned)A.list_nl;
+  const int64_t n = (int64_t)A.list_count[l * SDM_CNT_STRIDE];
+  if (chunk * SDM_BLOCK >= n) return;
+  const int64_t t = chunk * SDM_BLOCK + threadIdx.x;
   const bool active = t < n;
   Collided c;
   c.j = c.k = c.cid = c.pos = 0; c.g = 0; c.u_b = 0;
-  if (active) c = A.list[t];
+  if (active) c = A.list[l * A.list_cap + t];
   const int died = resolve_collision<true>(cfg, A, active, c.j, c.k, c.cid, c.g, c.u_b);
   if (died) flag_dead(cfg, A.idx, c.pos, died);
 }
@@ -1092,10 +1093,12 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_fill_f64(double *p, double v, int
 }
 
 // ---------------------------------------------------------------------------------------------
+#define LIST_NL 64
 struct FusedScratch {
   double *prob, *dt_todo, *cell_min, *block_min;
   Collided *list;
   unsigned long long *list_count;
+  int64_t flat_list_cap;  // capacity of each of the LIST_NL lists of the flat pair kernels
   uint8_t *pair_off;
   int32_t *pair_cid;
   int64_t *sorted_buf, *cs_tmp, *gate_len, *cctl, *end2;
@@ -1110,8 +1113,11 @@ static FusedScratch layout(char *base, const sdm_step_cfg *cfg) {
   const bool split = cfg->adaptive != 0;  // prob etc. cross a kernel boundary only then
   S.prob = cv.take<double>(split ? P : 1);
   S.dt_todo = cv.take<double>(C);
-  S.list = cv.take<Collided>(cfg->enable_breakup ? P : 1);
-  S.list_count = cv.take<unsigned long long>(2);
+  // flat pair kernels: workgroups of SDM_BLOCK pair slots, list l fed by every LIST_NL-th of them
+  S.flat_list_cap = (grid_for((N + 1) / 2) + LIST_NL - 1) / LIST_NL * SDM_BLOCK;
+  S.list = cv.take<Collided>(cfg->enable_breakup ? std::max<int64_t>(P, LIST_NL * S.flat_list_cap)
+                                                 : 1);
+  S.list_count = cv.take<unsigned long long>(LIST_NL * SDM_CNT_STRIDE);
   S.cell_min = cv.take<double>(C);
   S.block_min = cv.take<double>(grid_for((cfg->n_sd + 1) / 2) + 1);
   S.pair_off = cv.take<uint8_t>(split ? P : 1);
@@ -1249,6 +1255,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   A.cell_min = S.cell_min;
   A.list = S.list;
   A.list_count = S.list_count;
+  A.list_nl = 1;  // the per-cell kernel: one list (a cell's workgroup may hold up to P pairs)
+  A.list_cap = P;
   A.block_min = S.block_min;
   A.n_block_min = (int)grid_for((N + 1) / 2);
   A.slots = C == 1 ? ctx->cnt_slots : nullptr;
@@ -1417,8 +1425,12 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       if (rc) return rc;
     }
     A.idx = cur;
-    if (cfg->enable_breakup && !cell_path)
-      HIP_TRY(hipMemsetAsync(S.list_count, 0, sizeof(unsigned long long), s));
+    if (cfg->enable_breakup && !cell_path) {
+      A.list_nl = LIST_NL;
+      A.list_cap = S.flat_list_cap;
+      HIP_TRY(hipMemsetAsync(S.list_count, 0,
+                             sizeof(unsigned long long) * LIST_NL * SDM_CNT_STRIDE, s));
+    }
     // (e)+(f) probabilities, gamma, update
     if (cell_path) {
       // done by k_cell_step above
@@ -1453,7 +1465,9 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     }
     if (cfg->enable_breakup) {
       PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
-      hipLaunchKernelGGL(k_resolve_dense, dim3(grid_for(P)), blk, 0, s, *cfg, A);
+      const int64_t chunks = (A.list_cap + SDM_BLOCK - 1) / SDM_BLOCK;
+      hipLaunchKernelGGL(k_resolve_dense, dim3((unsigned)(A.list_nl * chunks)), blk, 0, s, *cfg,
+                         A);
       LAUNCH_CHECK();
     }
     // (g) sanitize (particle_attributes.py:67-73), decided on the device by the healthy word

@@ -702,9 +702,11 @@ __device__ __forceinline__ bool sd_dead(const int64_t *__restrict__ multiplicity
 #define FCTL_SORTED 2
 #define FCTL_HEALTHY 3
 
-// ---- one launch: exits at once while healthy; otherwise four phases (dead count per tile, scan
-// of the counts, holes / fillers, apply) separated by a software grid barrier.  A tile is one
-// wavefront's worth of positions (ballots only, no LDS); the grid is COMPACT_GRID workgroups of
+// ---- one launch: exits at once while healthy; otherwise three phases (dead count per wavefront
+// chunk; holes / fillers; apply) separated by a software grid barrier.  A wavefront owns a
+// contiguous chunk of positions and walks it in tiles of SDM_WAVE (ballots only); after the first
+// barrier every workgroup scans the COMPACT_WAVES chunk totals for itself (8 KB from L2 - cheaper
+// than a fourth barrier around a scan by one workgroup).  The grid is COMPACT_GRID workgroups of
 // COMPACT_THREADS (always co-resident).  A grid barrier is one same-address atomic per workgroup
 // plus polling: measured 13.5 us with 256 workgroups, 5.1 us with 128, 3.0 us with 64 - hence
 // few, large ones (128 x 1024 threads measured best end to end).
@@ -735,27 +737,61 @@ __device__ __forceinline__ bool grid_barrier(unsigned int *bar, unsigned int tar
   return ok;
 }
 
+#define COMPACT_UNROLL 8
+// "dead" of lane's position in COMPACT_UNROLL consecutive tiles (false beyond tile_end / length);
+// val (optional): the idx values read
+template <bool FLAG_ONLY>
+__device__ __forceinline__ void compact_tiles(const int64_t *__restrict__ multiplicity,
+                                              const int64_t *__restrict__ idx, int64_t flag,
+                                              int64_t length, int tile, int tile_end, int lane,
+                                              bool *dead, int64_t *val) {
+  int64_t v[COMPACT_UNROLL], n[COMPACT_UNROLL];
+  bool in[COMPACT_UNROLL];
+#pragma unroll
+  for (int u = 0; u < COMPACT_UNROLL; ++u) {
+    const int64_t i = (int64_t)(tile + u) * SDM_WAVE + lane;
+    in[u] = tile + u < tile_end && i < length;
+    v[u] = in[u] ? idx[i] : flag;
+  }
+#pragma unroll
+  for (int u = 0; u < COMPACT_UNROLL; ++u)
+    n[u] = (FLAG_ONLY || v[u] == flag) ? 1 : multiplicity[v[u]];
+#pragma unroll
+  for (int u = 0; u < COMPACT_UNROLL; ++u) {
+    dead[u] = in[u] && (v[u] == flag || n[u] == 0);
+    if (val) val[u] = v[u];
+  }
+}
+
 // FLAG_ONLY: the caller guarantees that no live super-droplet has zero multiplicity (it entered
 // with a healthy state and only flags positions), so the random gather of multiplicities is skipped
 template <bool FLAG_ONLY>
 __global__ void __launch_bounds__(COMPACT_THREADS)
 k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restrict__ idx,
-                     int64_t flag, int64_t *__restrict__ fctl, int32_t *__restrict__ tile_dead,
+                     int64_t flag, int64_t *__restrict__ fctl, int32_t *__restrict__ wave_dead,
                      int n_tiles, int64_t *__restrict__ ctl, int32_t *__restrict__ holes,
                      int64_t *__restrict__ fillers, int64_t *__restrict__ cell_start_single,
                      unsigned int *__restrict__ bar) {
   if (fctl[FCTL_HEALTHY] != 0) return;
   const int64_t length = fctl[FCTL_VALID];
   __shared__ int sm[COMPACT_THREADS / SDM_WAVE];
+  __shared__ int excl[COMPACT_WAVES];
   const int lane = lane_id(), w = threadIdx.x / SDM_WAVE;
   const int wave = blockIdx.x * (COMPACT_THREADS / SDM_WAVE) + w;
-  // phase A: dead count of every tile of SDM_WAVE positions
-  for (int tile = wave; tile < n_tiles; tile += COMPACT_WAVES) {
-    const int64_t i = (int64_t)tile * SDM_WAVE + lane;
-    const bool dead =
-        i < length && (FLAG_ONLY ? idx[i] == flag : sd_dead(multiplicity, idx, i, flag));
-    const int c = __popcll(__ballot(dead));
-    if (lane == 0) tile_dead[tile] = c;
+  const int per_wave = (n_tiles + COMPACT_WAVES - 1) / COMPACT_WAVES;
+  const int tile0 = wave * per_wave, tile1 = min(n_tiles, tile0 + per_wave);
+  // phase A: dead count of every wavefront's chunk
+  // (COMPACT_UNROLL tiles per round: their loads are in flight together - a wavefront walking its
+  // chunk one dependent load at a time is latency-bound)
+  {
+    int count = 0;
+    for (int tile = tile0; tile < tile1; tile += COMPACT_UNROLL) {
+      bool dead[COMPACT_UNROLL];
+      compact_tiles<FLAG_ONLY>(multiplicity, idx, flag, length, tile, tile1, lane, dead, nullptr);
+#pragma unroll
+      for (int u = 0; u < COMPACT_UNROLL; ++u) count += __popcll(__ballot(dead[u]));
+    }
+    if (lane == 0) wave_dead[wave] = count;
   }
 #define BARRIER_OR_FAIL(k)                                   \
   if (!grid_barrier(bar, (k) * COMPACT_GRID)) {              \
@@ -763,15 +799,17 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
     return;                                                  \
   }
   BARRIER_OR_FAIL(1)
-  // phase B: workgroup 0 scans the tile counts (exclusive) and publishes the totals: every
-  // thread sums a contiguous chunk, the chunk sums are scanned across the workgroup, then each
-  // thread rewrites its chunk
-  if (blockIdx.x == 0) {
-    const int per = (n_tiles + COMPACT_THREADS - 1) / COMPACT_THREADS;
-    const int b0 = threadIdx.x * per;
-    int sum = 0;
-    for (int k = 0; k < per; ++k)
-      if (b0 + k < n_tiles) sum += ((volatile int32_t *)tile_dead)[b0 + k];
+  // exclusive scan of the chunk totals, by every workgroup for itself
+  int64_t total_dead;
+  {
+    constexpr int PER = (COMPACT_WAVES + COMPACT_THREADS - 1) / COMPACT_THREADS;
+    const int b0 = threadIdx.x * PER;
+    int v[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      v[k] = b0 + k < COMPACT_WAVES ? ((volatile int32_t *)wave_dead)[b0 + k] : 0;
+      sum += v[k];
+    }
     int incl = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -786,39 +824,42 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
       all += sm[k];
     }
     int run = base + incl - sum;
-    for (int k = 0; k < per; ++k)
-      if (b0 + k < n_tiles) {
-        const int v = ((volatile int32_t *)tile_dead)[b0 + k];
-        tile_dead[b0 + k] = run;
-        run += v;
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+      if (b0 + k < COMPACT_WAVES) {
+        excl[b0 + k] = run;
+        run += v[k];
       }
-    if (threadIdx.x == 0) {
-      ctl[3] = all;
-      ctl[1] = length - all;
-      ctl[2] = 0;
-    }
+    __syncthreads();
+    total_dead = all;
   }
-  BARRIER_OR_FAIL(2)
-  const int64_t total_dead = ((volatile int64_t *)ctl)[3], new_len = ((volatile int64_t *)ctl)[1];
+  const int64_t new_len = length - total_dead;
   // phase C: holes of the surviving prefix, live elements of the tail (from the end backwards)
-  if (total_dead != 0)
-    for (int tile = wave; tile < n_tiles; tile += COMPACT_WAVES) {
-      const int64_t i = (int64_t)tile * SDM_WAVE + lane;
-      const bool in = i < length;
-      const bool dead =
-          in && (FLAG_ONLY ? idx[i] == flag : sd_dead(multiplicity, idx, i, flag));
-      const unsigned long long m = __ballot(dead);
-      const int64_t dp = ((volatile int32_t *)tile_dead)[tile] + __popcll(m & ((1ull << lane) - 1));
-      if (in) {
-        if (i == new_len) ctl[2] = dp;
-        if (i < new_len) {
-          if (dead) holes[dp] = (int32_t)i;
-        } else if (!dead) {
-          fillers[(length - 1 - i) - (total_dead - dp)] = idx[i];
+  if (total_dead != 0) {
+    int64_t before = excl[wave];  // dead positions ahead of the current tile
+    for (int tile = tile0; tile < tile1; tile += COMPACT_UNROLL) {
+      bool dead[COMPACT_UNROLL];
+      int64_t val[COMPACT_UNROLL];
+      compact_tiles<FLAG_ONLY>(multiplicity, idx, flag, length, tile, tile1, lane, dead, val);
+#pragma unroll
+      for (int u = 0; u < COMPACT_UNROLL; ++u) {
+        const int64_t i = (int64_t)(tile + u) * SDM_WAVE + lane;
+        const bool in = tile + u < tile1 && i < length;
+        const unsigned long long m = __ballot(dead[u]);
+        const int64_t dp = before + __popcll(m & ((1ull << lane) - 1));
+        before += __popcll(m);
+        if (in) {
+          if (i == new_len) ctl[2] = dp;
+          if (i < new_len) {
+            if (dead[u]) holes[dp] = (int32_t)i;
+          } else if (!dead[u]) {
+            fillers[(length - 1 - i) - (total_dead - dp)] = val[u];
+          }
         }
       }
     }
-  BARRIER_OR_FAIL(3)
+  }
+  BARRIER_OR_FAIL(2)
   // phase D: apply
   if (total_dead != 0) {
     const int64_t n_holes = ((volatile int64_t *)ctl)[2];
@@ -828,7 +869,7 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
       if (t < n_holes) idx[((volatile int32_t *)holes)[t]] = ((volatile int64_t *)fillers)[t];
     }
   }
-  BARRIER_OR_FAIL(4)
+  BARRIER_OR_FAIL(3)
 #undef BARRIER_OR_FAIL
   // every workgroup is past the last barrier once it arrives here: the last one re-arms the
   // barrier words and commits the control words
@@ -856,25 +897,25 @@ int sdm_compact_fused_async(sdm_ctx *ctx, char *scratch, const int64_t *multipli
                             int64_t *ctl, int64_t *cell_start_single, bool flag_only) {
   Carver cv(scratch);
   const int n_tiles = (int)grid_for(length_bound, SDM_WAVE);
-  int32_t *tile_dead = cv.take<int32_t>(n_tiles + 1);
+  int32_t *wave_dead = cv.take<int32_t>(COMPACT_WAVES);
   int32_t *holes = cv.take<int32_t>(length_bound);
   int64_t *fillers = cv.take<int64_t>(length_bound);
   unsigned int *bar = (unsigned int *)(ctx->dscal + 12);
   if (flag_only)
     hipLaunchKernelGGL(k_compact_persistent<true>, dim3(COMPACT_GRID), dim3(COMPACT_THREADS), 0,
-                       ctx->stream, multiplicity, idx, flag, fctl, tile_dead, n_tiles, ctl, holes,
+                       ctx->stream, multiplicity, idx, flag, fctl, wave_dead, n_tiles, ctl, holes,
                        fillers, cell_start_single, bar);
   else
     hipLaunchKernelGGL(k_compact_persistent<false>, dim3(COMPACT_GRID), dim3(COMPACT_THREADS), 0,
-                       ctx->stream, multiplicity, idx, flag, fctl, tile_dead, n_tiles, ctl, holes,
+                       ctx->stream, multiplicity, idx, flag, fctl, wave_dead, n_tiles, ctl, holes,
                        fillers, cell_start_single, bar);
   LAUNCH_CHECK();
   return SDM_OK;
 }
 
 size_t sdm_compact_scratch(int64_t n) {
-  return carve_size(sizeof(int32_t) * (grid_for(n, SDM_WAVE) + 1)) +
-         carve_size(sizeof(int32_t) * n) + carve_size(sizeof(int64_t) * n);
+  return carve_size(sizeof(int32_t) * COMPACT_WAVES) + carve_size(sizeof(int32_t) * n) +
+         carve_size(sizeof(int64_t) * n);
 }
 
 extern "C" int sdm_remove_zero_n_or_flagged(sdm_ctx *ctx, const int64_t *multiplicity,
