@@ -82,13 +82,14 @@ struct FusedArgs {
 };
 
 enum { CNT_COLLISION = 0, CNT_COLLISION_DEFICIT, CNT_COALESCENCE, CNT_BREAKUP, CNT_BREAKUP_DEFICIT,
-       CNT_KINDS };
+       CNT_OVERFLOW, CNT_KINDS };
 
 __device__ __forceinline__ int64_t *counter_of(const FusedArgs &A, int which) {
   return which == CNT_COLLISION ? A.collision_rate
          : which == CNT_COLLISION_DEFICIT ? A.collision_rate_deficit
          : which == CNT_COALESCENCE ? A.coalescence_rate
-         : which == CNT_BREAKUP ? A.breakup_rate : A.breakup_rate_deficit;
+         : which == CNT_BREAKUP ? A.breakup_rate
+         : which == CNT_BREAKUP_DEFICIT ? A.breakup_rate_deficit : A.ctl + CTL_OVERFLOW;
 }
 
 // wave-aggregated int64 counter add: one atomic per wave when all contributing lanes share cid.
@@ -483,7 +484,8 @@ __device__ __forceinline__ int resolve_collision(const sdm_step_cfg &cfg, const 
   const int64_t j_in = j, k_in = k;
   const int64_t nk = collide ? A.multiplicity[k] : 0;
   bool coal = collide;
-  int64_t n_breakup = 0, n_breakup_deficit = 0;  // added to the counters once, at the end
+  // added to the counters once, at the end
+  int64_t n_breakup = 0, n_breakup_deficit = 0, n_overflow = 0;
   if (BREAKUP && collide) {
     const double eb = cfg.eb_const;
     double ec, fm;
@@ -543,12 +545,13 @@ __device__ __forceinline__ int resolve_collision(const sdm_step_cfg &cfg, const 
         const int64_t add = (int64_t)(gamma_deficit * (double)A.multiplicity[k]);
         n_breakup_deficit += add;
       }
-      if (ovf) atomicAdd((unsigned long long *)&A.ctl[CTL_OVERFLOW], 1ull);
+      n_overflow = ovf ? 1 : 0;
     }
   }
   if (BREAKUP) {
     counter_add(A, CNT_BREAKUP, cid, n_breakup, true);
     counter_add(A, CNT_BREAKUP_DEFICIT, cid, n_breakup_deficit, true);
+    counter_add(A, CNT_OVERFLOW, 0, n_overflow, true);
   }
   counter_add(A, CNT_COALESCENCE, cid, (int64_t)(g * (double)nk), coal);
   if (coal) coalesce_pair(j, k, g, A.multiplicity, A.attributes, cfg.n_attr, cfg.n_sd);
@@ -1079,9 +1082,27 @@ __global__ void k_single_cell_init(int64_t *ctl, int64_t *cell_start) {
 }
 
 // collision.py:185-187 for one cell: working length = whole cell while dt_left > 0
-__global__ void k_set_work_single(int64_t *ctl, const double *dt_left,
-                                  const int64_t *cell_start) {
-  ctl[CTL_WORK] = dt_left[0] != 0 ? cell_start[1] : 0;
+// launched with SDM_CNT_SLOTS threads.  `slots` (breakup only, else NULL): the overflow count
+// is part of the control block the host reads right after this kernel, so it is folded here rather
+// than at the end of the call
+__global__ void __launch_bounds__(SDM_CNT_SLOTS)
+k_set_work_single(int64_t *ctl, const double *dt_left, const int64_t *cell_start,
+                  int64_t *slots) {
+  if (slots) {
+    __shared__ int64_t part[SDM_CNT_SLOTS / SDM_WAVE];
+    int64_t *word = slots + threadIdx.x * SDM_CNT_STRIDE + CNT_OVERFLOW;
+    const int64_t v = *word;
+    if (v != 0) *word = 0;
+    const int64_t s = wave_sum_i64(v);
+    if (lane_id() == 0) part[threadIdx.x / SDM_WAVE] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int64_t all = 0;
+      for (int w = 0; w < SDM_CNT_SLOTS / SDM_WAVE; ++w) all += part[w];
+      if (all != 0) ctl[CTL_OVERFLOW] += all;
+    }
+  }
+  if (threadIdx.x == 0) ctl[CTL_WORK] = dt_left[0] != 0 ? cell_start[1] : 0;
 }
 
 __global__ void k_set_work(int64_t *ctl, const int64_t *end) { ctl[CTL_WORK] = end[0]; }
@@ -1487,8 +1508,9 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         {
           PhaseScope ph(ctx, SDM_PHASE_ADAPTIVE_END);
           if (C == 1) {
-            hipLaunchKernelGGL(k_set_work_single, one, one, 0, s, st->ctl, st->dt_left,
-                               st->cell_start);
+            hipLaunchKernelGGL(k_set_work_single, one, dim3(SDM_CNT_SLOTS), 0, s, st->ctl,
+                               st->dt_left, st->cell_start,
+                               cfg->enable_breakup ? A.slots : nullptr);
             LAUNCH_CHECK();
           } else {
             rc = sdm_adaptive_end_async(ctx, st->dt_left, C, st->cell_start, S.end2, S.end2 + 1);

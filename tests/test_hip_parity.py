@@ -144,6 +144,54 @@ def test_linear_kernel_routes_agree(hip_backend_class, oracle_backend_class):
             np.testing.assert_array_equal(value, ref, err_msg=key)
 
 
+def test_overflow_warnings_step_by_step(hip_backend_class, oracle_backend_class):
+    """breakups refused for multiplicity overflow (collisions_methods.py:113-118) raise the
+    reference's "overflow" warning in the very step they happen - on the fused route the count
+    travels through the control block - and leave the same state behind"""
+    import warnings  # pylint: disable=import-outside-toplevel
+
+    from pysdm_amd import Builder, Formulae  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.dynamics.collisions import (  # pylint: disable=import-outside-toplevel
+        AlwaysN, Collision, ConstEb, ConstEc, Golovin)
+    from pysdm_amd.environments import Box  # pylint: disable=import-outside-toplevel
+
+    rng = np.random.default_rng(3)
+    n_sd = 2048
+    volume = rng.exponential(1.2e-13, n_sd)
+    multiplicity = rng.integers(10**6, 10**7, n_sd)
+    outcomes = []
+    for backend_class, fused in ((hip_backend_class, None), (hip_backend_class, False),
+                                 (oracle_backend_class, None)):
+        builder = Builder(n_sd=n_sd, backend=backend_class(Formulae(seed=5,
+                          fragmentation_function="AlwaysN")), environment=Box(dt=1.0, dv=2e3))
+        builder.add_dynamic(Collision(
+            collision_kernel=Golovin(b=1.5e3), coalescence_efficiency=ConstEc(Ec=0.2),
+            breakup_efficiency=ConstEb(1.0), fragmentation_function=AlwaysN(n=3e6),
+            adaptive=True, warn_overflows=True, fused=fused))
+        particulator = builder.build({"volume": volume.copy(),
+                                      "multiplicity": multiplicity.copy()})
+        dynamic = particulator.dynamics["Collision"]
+        warned = []
+        for _ in range(12):
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                particulator.run(1)
+            warned.append(any("overflow" in str(w.message) for w in caught))
+        outcomes.append((warned, snapshot(particulator, dynamic)))
+    assert any(outcomes[2][0]) and not all(outcomes[2][0]), outcomes[2][0]
+    length = int(outcomes[0][1]["length"])
+    for warned, snap in outcomes[:2]:
+        assert warned == outcomes[2][0]
+        for key, value in snap.items():
+            ref = outcomes[2][1][key]
+            if key == "idx":
+                value, ref = value[:length], ref[:length]
+            if value.dtype.kind == "f":
+                np.testing.assert_allclose(value, ref, rtol=1e-12, atol=0, err_msg=key)
+            else:
+                np.testing.assert_array_equal(value, ref, err_msg=key)
+
+
 def test_degenerate_sizes_through_the_abi(kit):
     """empty and tiny inputs: zero-length arrays are accepted by every entry point that takes a
     length, two super-droplets form one pair, three leave one alone, a null context is refused"""
