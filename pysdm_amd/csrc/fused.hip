@@ -799,8 +799,12 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_update(sdm_step_cfg cfg, Fus
 // gathers (a sorted segment holds one cell: same key <=> same cell id); the per-cell minimum of the
 // optimal sub-step is a workgroup reduction, so probability, gamma and update are one kernel also
 // in adaptive mode.  Global random traffic left: one mirror record per droplet.
+#ifndef CELL_CAP
 #define CELL_CAP 6144
+#endif
+#ifndef CELL_THREADS
 #define CELL_THREADS 1024
+#endif
 #define CELL_MAXPOS (CELL_CAP / CELL_THREADS)
 #define CELL_MAXPAIR (CELL_CAP / 2 / CELL_THREADS)
 #define CELL_LDS_BYTES (5 * CELL_CAP * 4 + 2 * CELL_CAP * 2)
