@@ -336,9 +336,9 @@ typedef struct sdm_step_state {
    * (32-B stride): one random line per gather, derived attributes evaluated once per change.
    * (Re)initialised from the SoA columns when SDM_STEP_FRESH_CTL is passed.                   */
   void *nm;
-  /* library's bookkeeping between calls: live super-droplets as of the last read-back, so that
-   * a single-cell adaptive step need not ask the device again (-1 = unknown; set it to -1
-   * whenever SDM_STEP_FRESH_CTL is passed)                                                    */
+  /* library's bookkeeping between calls: live super-droplets as of the last read-back (also the
+   * one every adaptive sub-step ends with), so that a single-cell adaptive step need not ask the
+   * device again (-1 = unknown; set it to -1 whenever SDM_STEP_FRESH_CTL is passed)           */
   int64_t known_valid;
   uint64_t rng_offset;        /* doubles already drawn from the coll. stream (host-tracked) */
   uint64_t rng_offset_breakup;/* doubles already drawn from the proc/frag streams */

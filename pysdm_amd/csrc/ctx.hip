@@ -23,13 +23,35 @@ extern "C" int sdm_ctx_create(sdm_ctx **out, int device) {
   ctx->device = device;
   ctx->stream = nullptr;
   HIP_TRY(hipMalloc((void **)&ctx->pcg_tab, sizeof(u128) * 128));
-  HIP_TRY(hipHostMalloc((void **)&ctx->mailbox, sizeof(int64_t) * 16, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void **)&ctx->mailbox, sizeof(int64_t) * 32,
+                        hipHostMallocMapped | hipHostMallocCoherent));
+  memset(ctx->mailbox, 0, sizeof(int64_t) * 32);
+  HIP_TRY(hipHostGetDevicePointer((void **)&ctx->box_dev, ctx->mailbox + SDM_BOX, 0));
   HIP_TRY(hipMalloc((void **)&ctx->dscal, sizeof(int64_t) * 16));
   HIP_TRY(hipMemset(ctx->dscal, 0, sizeof(int64_t) * 16));
   HIP_TRY(hipMalloc((void **)&ctx->cnt_slots, sizeof(int64_t) * SDM_CNT_SLOTS * SDM_CNT_STRIDE));
   HIP_TRY(hipMemset(ctx->cnt_slots, 0, sizeof(int64_t) * SDM_CNT_SLOTS * SDM_CNT_STRIDE));
   *out = ctx;
   return SDM_OK;
+}
+
+// waits until a kernel published sequence number `seq` (publish_ctl); the stream is asked now and
+// then, so that a failed launch or a fault ends the wait with an error instead of a hang
+int sdm_wait_box(sdm_ctx *ctx, int64_t seq) {
+  const int64_t *flag = ctx->mailbox + SDM_BOX + 8;
+  for (uint64_t spins = 1;; ++spins) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return SDM_OK;
+    if ((spins & 0x3fff) == 0) {
+      const hipError_t e = hipStreamQuery(ctx->stream);
+      if (e == hipSuccess) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return SDM_OK;
+        sdm_set_error("control block was not published although the stream is idle");
+        return SDM_E_HIP;
+      }
+      if (e != hipErrorNotReady) HIP_TRY(e);
+    }
+    __builtin_ia32_pause();
+  }
 }
 
 extern "C" int sdm_ctx_destroy(sdm_ctx *ctx) {

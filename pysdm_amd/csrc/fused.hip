@@ -191,10 +191,13 @@ __device__ __forceinline__ void sd_refresh(const sdm_step_cfg &cfg, const FusedA
 }
 
 // ---- per-cell adaptive init (collisions_methods.py:355-356) -----------------------------------
-__global__ void __launch_bounds__(SDM_BLOCK) k_cells_pre(sdm_step_cfg cfg, FusedArgs A) {
+// fresh: first sub-step of a time step - dt_left[:] = dt (collision.py:180) happens here
+__global__ void __launch_bounds__(SDM_BLOCK) k_cells_pre(sdm_step_cfg cfg, FusedArgs A,
+                                                          int fresh) {
   const int64_t c = TID();
   if (c >= cfg.n_cell) return;
-  const double l = A.dt_left[c];
+  const double l = fresh ? cfg.dt : A.dt_left[c];
+  if (fresh) A.dt_left[c] = l;
   A.dt_todo[c] = cfg.dt_max < l ? cfg.dt_max : l;  // Python min(l, dt_max)
   A.cell_min[c] = INFINITY;
 }
@@ -1091,7 +1094,7 @@ __global__ void k_single_cell_init(int64_t *ctl, int64_t *cell_start) {
 // than at the end of the call
 __global__ void __launch_bounds__(SDM_CNT_SLOTS)
 k_set_work_single(int64_t *ctl, const double *dt_left, const int64_t *cell_start,
-                  int64_t *slots) {
+                  int64_t *slots, int64_t *box, int64_t seq) {
   if (slots) {
     __shared__ int64_t part[SDM_CNT_SLOTS / SDM_WAVE];
     int64_t *word = slots + threadIdx.x * SDM_CNT_STRIDE + CNT_OVERFLOW;
@@ -1106,10 +1109,16 @@ k_set_work_single(int64_t *ctl, const double *dt_left, const int64_t *cell_start
       if (all != 0) ctl[CTL_OVERFLOW] += all;
     }
   }
-  if (threadIdx.x == 0) ctl[CTL_WORK] = dt_left[0] != 0 ? cell_start[1] : 0;
+  if (threadIdx.x == 0) {
+    ctl[CTL_WORK] = dt_left[0] != 0 ? cell_start[1] : 0;
+    publish_ctl(ctl, box, seq);
+  }
 }
 
-__global__ void k_set_work(int64_t *ctl, const int64_t *end) { ctl[CTL_WORK] = end[0]; }
+__global__ void k_set_work(int64_t *ctl, const int64_t *end, int64_t *box, int64_t seq) {
+  ctl[CTL_WORK] = end[0];
+  publish_ctl(ctl, box, seq);
+}
 __global__ void k_reset_work(int64_t *ctl) { ctl[CTL_WORK] = ctl[CTL_VALID]; }
 
 __global__ void __launch_bounds__(SDM_BLOCK) k_fill_f64(double *p, double v, int64_t n) {
@@ -1307,7 +1316,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     hipLaunchKernelGGL(k_single_cell_init, one, one, 0, s, st->ctl, st->cell_start);
     LAUNCH_CHECK();
   }
-  if (cfg->adaptive) {  // collision.py:180: dt_left[:] = dt
+  // collision.py:180: dt_left[:] = dt.  One cell: nothing reads dt_left before the first
+  // sub-step's k_cells_pre, which then does it (one launch less per time step)
+  bool fill_pending = cfg->adaptive && C == 1;
+  if (cfg->adaptive && C > 1) {
     hipLaunchKernelGGL(k_fill_f64, dim3(grid_for(C)), blk, 0, s, st->dt_left, cfg->dt, C);
     LAUNCH_CHECK();
   }
@@ -1387,7 +1399,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         HIP_TRY(hipMemsetAsync(S.list_count, 0, sizeof(unsigned long long), s));
       if (cfg->adaptive) {
         PhaseScope ph(ctx, SDM_PHASE_CELLS_PRE);
-        hipLaunchKernelGGL(k_cells_pre, dim3(grid_for(C)), blk, 0, s, *cfg, A);
+        hipLaunchKernelGGL(k_cells_pre, dim3(grid_for(C)), blk, 0, s, *cfg, A, 0);
         LAUNCH_CHECK();
       }
       CellArgs X;
@@ -1466,8 +1478,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     } else {
       {
         PhaseScope ph(ctx, SDM_PHASE_CELLS_PRE);
-        hipLaunchKernelGGL(k_cells_pre, dim3(grid_for(C)), blk, 0, s, *cfg, A);
+        hipLaunchKernelGGL(k_cells_pre, dim3(grid_for(C)), blk, 0, s, *cfg, A,
+                           fill_pending ? 1 : 0);
         LAUNCH_CHECK();
+        fill_pending = false;
       }
       {
         PhaseScope ph(ctx, SDM_PHASE_PAIR_PROB);
@@ -1511,25 +1525,26 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       for (int attempt = 0; attempt < 2; ++attempt) {
         {
           PhaseScope ph(ctx, SDM_PHASE_ADAPTIVE_END);
+          // the control block comes back through the polled box (publish_ctl), not a copy
+          const int64_t seq = ++ctx->poll_seq;
           if (C == 1) {
             hipLaunchKernelGGL(k_set_work_single, one, dim3(SDM_CNT_SLOTS), 0, s, st->ctl,
                                st->dt_left, st->cell_start,
-                               cfg->enable_breakup ? A.slots : nullptr);
+                               cfg->enable_breakup ? A.slots : nullptr, ctx->box_dev, seq);
             LAUNCH_CHECK();
           } else {
             rc = sdm_adaptive_end_async(ctx, st->dt_left, C, st->cell_start, S.end2, S.end2 + 1);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_set_work, one, one, 0, s, st->ctl, S.end2 + 1);
+            hipLaunchKernelGGL(k_set_work, one, one, 0, s, st->ctl, S.end2 + 1, ctx->box_dev, seq);
             LAUNCH_CHECK();
           }
-          HIP_TRY(hipMemcpyAsync(ctx->mailbox + 8, st->ctl, sizeof(int64_t) * 8,
-                                 hipMemcpyDeviceToHost, s));
-          HIP_TRY(hipStreamSynchronize(s));
+          rc = sdm_wait_box(ctx, seq);
+          if (rc) return rc;
         }
-        memcpy(last_ctl, ctx->mailbox + 8, sizeof(last_ctl));
+        memcpy(last_ctl, ctx->mailbox + SDM_BOX, sizeof(last_ctl));
         have_ctl = true;
-        work_host = ctx->mailbox[8 + CTL_WORK];
-        if (C == 1 || ctx->mailbox[8 + CTL_SORTED] != 0) { sorted_host = C == 1 ? sorted_host : 1; break; }
+        work_host = last_ctl[CTL_WORK];
+        if (C == 1 || last_ctl[CTL_SORTED] != 0) { sorted_host = C == 1 ? sorted_host : 1; break; }
         // a compaction happened in this sub-step: sort by cell first (particle_attributes.py
         // cell_start getter), then the end of the working range is taken from the new cell_start
         sorted_host = 0;
@@ -1539,6 +1554,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         if (rc) return rc;
       }
     }
+  }
+  if (fill_pending) {  // no sub-step ran (nothing to work on): the fill still has to happen
+    hipLaunchKernelGGL(k_fill_f64, dim3(grid_for(C)), blk, 0, s, st->dt_left, cfg->dt, C);
+    LAUNCH_CHECK();
   }
   if (cfg->adaptive) {
     // collision.py:189-190 reset_working_length(); reset_cell_idx() (identity + sort)
@@ -1579,7 +1598,9 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     res->valid_n_sd = res->ctl[CTL_VALID];
     st->known_valid = res->valid_n_sd;
   } else {
-    st->known_valid = -1;
+    // one adaptive cell: the last sub-step's read-back told the valid length anyway - the next
+    // step of the same run need not ask the device again
+    st->known_valid = (C == 1 && cfg->adaptive && have_ctl) ? last_ctl[CTL_VALID] : -1;
   }
   // non-adaptive without read-back: the caller derives the pair count from its own length
   res->n_pairs = (cfg->adaptive || work_host >= 0) ? n_pairs : -1;
