@@ -13,6 +13,7 @@ typedef unsigned __int128 u128;
 #define SDM_MAX_EVENTS 8192
 #define SDM_WAVE 64
 
+#define SDM_CNT_OVERFLOW 5  // word of a counter slot that counts refused breakups (fused.hip)
 #define SDM_CNT_SLOTS 128
 #define SDM_CNT_STRIDE 16  // int64 per slot: one 128-B line each
 

@@ -83,6 +83,8 @@ struct FusedArgs {
 
 enum { CNT_COLLISION = 0, CNT_COLLISION_DEFICIT, CNT_COALESCENCE, CNT_BREAKUP, CNT_BREAKUP_DEFICIT,
        CNT_OVERFLOW, CNT_KINDS };
+static_assert(CNT_OVERFLOW == SDM_CNT_OVERFLOW && CTL_OVERFLOW == 4,
+              "index.hip:compact_epilogue folds this slot word into control word 4");
 
 __device__ __forceinline__ int64_t *counter_of(const FusedArgs &A, int which) {
   return which == CNT_COLLISION ? A.collision_rate
@@ -191,13 +193,10 @@ __device__ __forceinline__ void sd_refresh(const sdm_step_cfg &cfg, const FusedA
 }
 
 // ---- per-cell adaptive init (collisions_methods.py:355-356) -----------------------------------
-// fresh: first sub-step of a time step - dt_left[:] = dt (collision.py:180) happens here
-__global__ void __launch_bounds__(SDM_BLOCK) k_cells_pre(sdm_step_cfg cfg, FusedArgs A,
-                                                          int fresh) {
+__global__ void __launch_bounds__(SDM_BLOCK) k_cells_pre(sdm_step_cfg cfg, FusedArgs A) {
   const int64_t c = TID();
   if (c >= cfg.n_cell) return;
-  const double l = fresh ? cfg.dt : A.dt_left[c];
-  if (fresh) A.dt_left[c] = l;
+  const double l = A.dt_left[c];
   A.dt_todo[c] = cfg.dt_max < l ? cfg.dt_max : l;  // Python min(l, dt_max)
   A.cell_min[c] = INFINITY;
 }
@@ -745,7 +744,11 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_prob(sdm_step_cfg cfg, Fused
 }
 
 // ---- per-cell adaptive bookkeeping (collisions_methods.py:357-374) ---------------------------
-__global__ void __launch_bounds__(SDM_BLOCK) k_cells_adaptive(sdm_step_cfg cfg, FusedArgs A) {
+// pre: 0 = dt_todo / dt_left were prepared by k_cells_pre; 1 = do its part here (one cell: no
+// kernel in between needs them); 2 = likewise, and this is the first sub-step of the time step
+// (dt_left[:] = dt, collision.py:180)
+__global__ void __launch_bounds__(SDM_BLOCK) k_cells_adaptive(sdm_step_cfg cfg, FusedArgs A,
+                                                               int pre) {
   if (cfg.n_cell == 1) {  // fold the per-workgroup partial minima (one workgroup launched)
     __shared__ double wmin[SDM_BLOCK / SDM_WAVE];
     double m = INFINITY;
@@ -766,12 +769,13 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_cells_adaptive(sdm_step_cfg cfg, 
   if (c >= cfg.n_cell) return;
   if (A.ctl[CTL_WORK] == 0) return;
   const double m = ((volatile double *)A.cell_min)[c];
-  double t = A.dt_todo[c];
+  const double l = pre == 2 ? cfg.dt : A.dt_left[c];
+  double t = pre ? (cfg.dt_max < l ? cfg.dt_max : l) : A.dt_todo[c];  // Python min(l, dt_max)
   if (m < t) t = m;
   A.dt_todo[c] = t;
   const double s = A.stats_dt_min[c];
   A.stats_dt_min[c] = m < s ? m : s;  // Python min(s, m): NaN-sticky
-  A.dt_left[c] -= t;
+  A.dt_left[c] = l - t;
   if (t > 0) A.stats_n_substep[c] += 1;
 }
 
@@ -1089,32 +1093,6 @@ __global__ void k_single_cell_init(int64_t *ctl, int64_t *cell_start) {
 }
 
 // collision.py:185-187 for one cell: working length = whole cell while dt_left > 0
-// launched with SDM_CNT_SLOTS threads.  `slots` (breakup only, else NULL): the overflow count
-// is part of the control block the host reads right after this kernel, so it is folded here rather
-// than at the end of the call
-__global__ void __launch_bounds__(SDM_CNT_SLOTS)
-k_set_work_single(int64_t *ctl, const double *dt_left, const int64_t *cell_start,
-                  int64_t *slots, int64_t *box, int64_t seq) {
-  if (slots) {
-    __shared__ int64_t part[SDM_CNT_SLOTS / SDM_WAVE];
-    int64_t *word = slots + threadIdx.x * SDM_CNT_STRIDE + CNT_OVERFLOW;
-    const int64_t v = *word;
-    if (v != 0) *word = 0;
-    const int64_t s = wave_sum_i64(v);
-    if (lane_id() == 0) part[threadIdx.x / SDM_WAVE] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int64_t all = 0;
-      for (int w = 0; w < SDM_CNT_SLOTS / SDM_WAVE; ++w) all += part[w];
-      if (all != 0) ctl[CTL_OVERFLOW] += all;
-    }
-  }
-  if (threadIdx.x == 0) {
-    ctl[CTL_WORK] = dt_left[0] != 0 ? cell_start[1] : 0;
-    publish_ctl(ctl, box, seq);
-  }
-}
-
 __global__ void k_set_work(int64_t *ctl, const int64_t *end, int64_t *box, int64_t seq) {
   ctl[CTL_WORK] = end[0];
   publish_ctl(ctl, box, seq);
@@ -1317,13 +1295,14 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     LAUNCH_CHECK();
   }
   // collision.py:180: dt_left[:] = dt.  One cell: nothing reads dt_left before the first
-  // sub-step's k_cells_pre, which then does it (one launch less per time step)
+  // sub-step's k_cells_adaptive, which then does it (one launch less per time step)
   bool fill_pending = cfg->adaptive && C == 1;
   if (cfg->adaptive && C > 1) {
     hipLaunchKernelGGL(k_fill_f64, dim3(grid_for(C)), blk, 0, s, st->dt_left, cfg->dt, C);
     LAUNCH_CHECK();
   }
   int64_t work_host = -1;
+  int64_t box_seq = 0;   // sequence number of the control block publication being waited for
   int sorted_host = -1;  // host's knowledge of ctl[CTL_SORTED]
   int64_t max_cell = -1;  // upper bound of the cell sizes during this call (-1: unknown)
   if (flags & 2) st->known_valid = -1;
@@ -1399,7 +1378,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         HIP_TRY(hipMemsetAsync(S.list_count, 0, sizeof(unsigned long long), s));
       if (cfg->adaptive) {
         PhaseScope ph(ctx, SDM_PHASE_CELLS_PRE);
-        hipLaunchKernelGGL(k_cells_pre, dim3(grid_for(C)), blk, 0, s, *cfg, A, 0);
+        hipLaunchKernelGGL(k_cells_pre, dim3(grid_for(C)), blk, 0, s, *cfg, A);
         LAUNCH_CHECK();
       }
       CellArgs X;
@@ -1430,7 +1409,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       }
       if (cfg->adaptive) {
         PhaseScope ph(ctx, SDM_PHASE_CELLS_ADAPTIVE);
-        hipLaunchKernelGGL(k_cells_adaptive, dim3(grid_for(C)), blk, 0, s, *cfg, A);
+        hipLaunchKernelGGL(k_cells_adaptive, dim3(grid_for(C)), blk, 0, s, *cfg, A, 0);
         LAUNCH_CHECK();
       }
       { int64_t *t = cur; cur = alt; alt = t; }
@@ -1476,12 +1455,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       DISPATCH_PAIR(k_pair_all, dim3(grid_for((N + 1) / 2)));
       LAUNCH_CHECK();
     } else {
-      {
+      if (C > 1) {  // one cell: k_cells_adaptive does this part too
         PhaseScope ph(ctx, SDM_PHASE_CELLS_PRE);
-        hipLaunchKernelGGL(k_cells_pre, dim3(grid_for(C)), blk, 0, s, *cfg, A,
-                           fill_pending ? 1 : 0);
+        hipLaunchKernelGGL(k_cells_pre, dim3(grid_for(C)), blk, 0, s, *cfg, A);
         LAUNCH_CHECK();
-        fill_pending = false;
       }
       {
         PhaseScope ph(ctx, SDM_PHASE_PAIR_PROB);
@@ -1490,8 +1467,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       }
       {
         PhaseScope ph(ctx, SDM_PHASE_CELLS_ADAPTIVE);
-        hipLaunchKernelGGL(k_cells_adaptive, dim3(grid_for(C)), blk, 0, s, *cfg, A);
+        hipLaunchKernelGGL(k_cells_adaptive, dim3(grid_for(C)), blk, 0, s, *cfg, A,
+                           C > 1 ? 0 : (fill_pending ? 2 : 1));
         LAUNCH_CHECK();
+        fill_pending = false;
       }
       {
         PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
@@ -1512,8 +1491,18 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     // (g) sanitize (particle_attributes.py:67-73), decided on the device by the healthy word
     {
       PhaseScope ph(ctx, SDM_PHASE_SANITIZE);
+      // one adaptive cell: the kernel also ends the sub-step (collision.py:185-187: working
+      // length = whole cell while dt_left > 0) and publishes the control block for the host
+      CompactEpilogue epilogue = {nullptr, nullptr, nullptr, 0};
+      if (C == 1 && cfg->adaptive) {
+        box_seq = ++ctx->poll_seq;
+        epilogue.dt_left = st->dt_left;
+        epilogue.slots = cfg->enable_breakup ? A.slots : nullptr;  // refused-breakup count
+        epilogue.box = ctx->box_dev;
+        epilogue.seq = box_seq;
+      }
       rc = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl, S.cctl,
-                                   C == 1 ? st->cell_start : nullptr, true);
+                                   C == 1 ? st->cell_start : nullptr, true, &epilogue);
       if (rc) return rc;
       if (C > 1) sorted_host = -1;  // a compaction (decided on the device) un-sorts
     }
@@ -1526,19 +1515,15 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         {
           PhaseScope ph(ctx, SDM_PHASE_ADAPTIVE_END);
           // the control block comes back through the polled box (publish_ctl), not a copy
-          const int64_t seq = ++ctx->poll_seq;
-          if (C == 1) {
-            hipLaunchKernelGGL(k_set_work_single, one, dim3(SDM_CNT_SLOTS), 0, s, st->ctl,
-                               st->dt_left, st->cell_start,
-                               cfg->enable_breakup ? A.slots : nullptr, ctx->box_dev, seq);
-            LAUNCH_CHECK();
-          } else {
+          if (C > 1) {
+            box_seq = ++ctx->poll_seq;
             rc = sdm_adaptive_end_async(ctx, st->dt_left, C, st->cell_start, S.end2, S.end2 + 1);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_set_work, one, one, 0, s, st->ctl, S.end2 + 1, ctx->box_dev, seq);
+            hipLaunchKernelGGL(k_set_work, one, one, 0, s, st->ctl, S.end2 + 1, ctx->box_dev,
+                               box_seq);
             LAUNCH_CHECK();
           }
-          rc = sdm_wait_box(ctx, seq);
+          rc = sdm_wait_box(ctx, box_seq);
           if (rc) return rc;
         }
         memcpy(last_ctl, ctx->mailbox + SDM_BOX, sizeof(last_ctl));

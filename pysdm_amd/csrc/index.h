@@ -25,6 +25,17 @@ int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
                             const int64_t *cell_start, int64_t n_cell, const int64_t *p_length,
                             int64_t length_bound, const uint64_t *rng_state_inc,
                             uint64_t rng_offset, ShuffleViews *views);
+// What ends an adaptive sub-step of a single cell (collision.py:185-187), done by the compaction
+// kernel's last act instead of a launch of its own: refused-breakup count of the counter slots
+// into fctl[4] (slots may be NULL), working length = dt_left[0] != 0 ? valid length : 0, control
+// block published to the polled host box with sequence number `seq` (common.h:publish_ctl)
+struct CompactEpilogue {
+  const double *dt_left;  // NULL: no epilogue
+  int64_t *slots;
+  int64_t *box;
+  int64_t seq;
+};
 int sdm_compact_fused_async(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity,
                             int64_t *idx, int64_t length_bound, int64_t flag, int64_t *fctl,
-                            int64_t *ctl, int64_t *cell_start_single, bool flag_only = false);
+                            int64_t *ctl, int64_t *cell_start_single, bool flag_only = false,
+                            const CompactEpilogue *epilogue = nullptr);

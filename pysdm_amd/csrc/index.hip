@@ -763,6 +763,31 @@ __device__ __forceinline__ void compact_tiles(const int64_t *__restrict__ multip
   }
 }
 
+// called by every thread of one workgroup (>= SDM_CNT_SLOTS threads) once the control words are final
+__device__ __forceinline__ void compact_epilogue(const CompactEpilogue &E,
+                                                 int64_t *__restrict__ fctl) {
+  if (E.slots) {
+    __shared__ int64_t part[SDM_CNT_SLOTS / SDM_WAVE];
+    if (threadIdx.x < SDM_CNT_SLOTS) {
+      int64_t *word = E.slots + threadIdx.x * SDM_CNT_STRIDE + SDM_CNT_OVERFLOW;
+      const int64_t v = *word;
+      if (v != 0) *word = 0;
+      const int64_t s = wave_sum_i64(v);
+      if (lane_id() == 0) part[threadIdx.x / SDM_WAVE] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int64_t all = 0;
+      for (int w = 0; w < SDM_CNT_SLOTS / SDM_WAVE; ++w) all += part[w];
+      if (all != 0) fctl[4] += all;
+    }
+  }
+  if (threadIdx.x == 0) {
+    fctl[FCTL_WORK] = E.dt_left[0] != 0 ? fctl[FCTL_VALID] : 0;
+    publish_ctl(fctl, E.box, E.seq);
+  }
+}
+
 // FLAG_ONLY: the caller guarantees that no live super-droplet has zero multiplicity (it entered
 // with a healthy state and only flags positions), so the random gather of multiplicities is skipped
 template <bool FLAG_ONLY>
@@ -771,8 +796,11 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
                      int64_t flag, int64_t *__restrict__ fctl, int32_t *__restrict__ wave_dead,
                      int n_tiles, int64_t *__restrict__ ctl, int32_t *__restrict__ holes,
                      int64_t *__restrict__ fillers, int64_t *__restrict__ cell_start_single,
-                     unsigned int *__restrict__ bar) {
-  if (fctl[FCTL_HEALTHY] != 0) return;
+                     unsigned int *__restrict__ bar, CompactEpilogue E) {
+  if (fctl[FCTL_HEALTHY] != 0) {
+    if (E.dt_left && blockIdx.x == 0) compact_epilogue(E, fctl);
+    return;
+  }
   const int64_t length = fctl[FCTL_VALID];
   __shared__ int sm[COMPACT_THREADS / SDM_WAVE];
   __shared__ int excl[COMPACT_WAVES];
@@ -889,12 +917,16 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
       fctl[FCTL_SORTED] = 0;
     }
   }
+  if (last && E.dt_left) compact_epilogue(E, fctl);
 }
 
 // `bar`: 4 zero-initialised device words owned by the caller (persist across launches)
 int sdm_compact_fused_async(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity,
                             int64_t *idx, int64_t length_bound, int64_t flag, int64_t *fctl,
-                            int64_t *ctl, int64_t *cell_start_single, bool flag_only) {
+                            int64_t *ctl, int64_t *cell_start_single, bool flag_only,
+                            const CompactEpilogue *epilogue) {
+  CompactEpilogue E = {nullptr, nullptr, nullptr, 0};
+  if (epilogue) E = *epilogue;
   Carver cv(scratch);
   const int n_tiles = (int)grid_for(length_bound, SDM_WAVE);
   int32_t *wave_dead = cv.take<int32_t>(COMPACT_WAVES);
@@ -904,11 +936,11 @@ int sdm_compact_fused_async(sdm_ctx *ctx, char *scratch, const int64_t *multipli
   if (flag_only)
     hipLaunchKernelGGL(k_compact_persistent<true>, dim3(COMPACT_GRID), dim3(COMPACT_THREADS), 0,
                        ctx->stream, multiplicity, idx, flag, fctl, wave_dead, n_tiles, ctl, holes,
-                       fillers, cell_start_single, bar);
+                       fillers, cell_start_single, bar, E);
   else
     hipLaunchKernelGGL(k_compact_persistent<false>, dim3(COMPACT_GRID), dim3(COMPACT_THREADS), 0,
                        ctx->stream, multiplicity, idx, flag, fctl, wave_dead, n_tiles, ctl, holes,
-                       fillers, cell_start_single, bar);
+                       fillers, cell_start_single, bar, E);
   LAUNCH_CHECK();
   return SDM_OK;
 }
