@@ -55,10 +55,13 @@ int sdm_wait_box(sdm_ctx *ctx, int64_t seq);  // ctx.hip
 
 #ifdef __HIPCC__
 // last act of a one-thread epilogue: control block -> host-visible box, then the sequence number
-__device__ __forceinline__ void publish_ctl(const int64_t *ctl, int64_t *box, int64_t seq) {
+// (work: what the host is to see as working length, word 1)
+__device__ __forceinline__ void publish_ctl(const int64_t *ctl, int64_t *box, int64_t seq,
+                                            int64_t work) {
   if (!box) return;
   for (int w = 0; w < 8; ++w)
-    __hip_atomic_store(&box[w], ctl[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&box[w], w == 1 ? work : ctl[w], __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(&box[8], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 #endif

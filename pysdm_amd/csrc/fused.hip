@@ -77,10 +77,14 @@ struct FusedArgs {
   // the appends of a launch do not all queue up on one counter word
   struct Collided *list;
   unsigned long long *list_count;
+  // the fill counts are double-buffered by sub-step: k_resolve_dense clears the set the next
+  // sub-step will use (no memset launch per sub-step)
+  unsigned long long *list_count_next;
   int list_nl;
   int64_t list_cap;
 };
 
+#define LIST_NL 64  // lists of colliding pairs (flat pair kernels; the per-cell kernel uses one)
 enum { CNT_COLLISION = 0, CNT_COLLISION_DEFICIT, CNT_COALESCENCE, CNT_BREAKUP, CNT_BREAKUP_DEFICIT,
        CNT_OVERFLOW, CNT_KINDS };
 static_assert(CNT_OVERFLOW == SDM_CNT_OVERFLOW && CTL_OVERFLOW == 4,
@@ -1048,6 +1052,7 @@ k_max_cell(const int64_t *__restrict__ cell_start, int64_t n_cell, int64_t *ctl)
 // ---- breakup: dense resolution of the listed colliding pairs ----------------------------------
 __global__ void __launch_bounds__(SDM_BLOCK) k_resolve_dense(sdm_step_cfg cfg, FusedArgs A) {
   const int64_t l = blockIdx.x % (unsigned)A.list_nl, chunk = blockIdx.x / (unsigned)A.list_nl;
+  if (blockIdx.x == 0 && threadIdx.x < LIST_NL) A.list_count_next[threadIdx.x * SDM_CNT_STRIDE] = 0;
   const int64_t n = (int64_t)A.list_count[l * SDM_CNT_STRIDE];
   if (chunk * SDM_BLOCK >= n) return;
   const int64_t t = chunk * SDM_BLOCK + threadIdx.x;
@@ -1095,7 +1100,7 @@ __global__ void k_single_cell_init(int64_t *ctl, int64_t *cell_start) {
 // collision.py:185-187 for one cell: working length = whole cell while dt_left > 0
 __global__ void k_set_work(int64_t *ctl, const int64_t *end, int64_t *box, int64_t seq) {
   ctl[CTL_WORK] = end[0];
-  publish_ctl(ctl, box, seq);
+  publish_ctl(ctl, box, seq, end[0]);
 }
 __global__ void k_reset_work(int64_t *ctl) { ctl[CTL_WORK] = ctl[CTL_VALID]; }
 
@@ -1105,7 +1110,6 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_fill_f64(double *p, double v, int
 }
 
 // ---------------------------------------------------------------------------------------------
-#define LIST_NL 64
 struct FusedScratch {
   double *prob, *dt_todo, *cell_min, *block_min;
   Collided *list;
@@ -1129,7 +1133,7 @@ static FusedScratch layout(char *base, const sdm_step_cfg *cfg) {
   S.flat_list_cap = (grid_for((N + 1) / 2) + LIST_NL - 1) / LIST_NL * SDM_BLOCK;
   S.list = cv.take<Collided>(cfg->enable_breakup ? std::max<int64_t>(P, LIST_NL * S.flat_list_cap)
                                                  : 1);
-  S.list_count = cv.take<unsigned long long>(LIST_NL * SDM_CNT_STRIDE);
+  S.list_count = cv.take<unsigned long long>(2 * LIST_NL * SDM_CNT_STRIDE);
   S.cell_min = cv.take<double>(C);
   S.block_min = cv.take<double>(grid_for((cfg->n_sd + 1) / 2) + 1);
   S.pair_off = cv.take<uint8_t>(split ? P : 1);
@@ -1267,6 +1271,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   A.cell_min = S.cell_min;
   A.list = S.list;
   A.list_count = S.list_count;
+  A.list_count_next = S.list_count + LIST_NL * SDM_CNT_STRIDE;
+  if (cfg->enable_breakup)  // both sets once per call (the arena is shared with other calls)
+    HIP_TRY(hipMemsetAsync(S.list_count, 0,
+                           sizeof(unsigned long long) * 2 * LIST_NL * SDM_CNT_STRIDE, ctx->stream));
   A.list_nl = 1;  // the per-cell kernel: one list (a cell's workgroup may hold up to P pairs)
   A.list_cap = P;
   A.block_min = S.block_min;
@@ -1374,8 +1382,6 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     const bool split = C == 1 && cfg->croupier_local && sdm_shuffle_can_split(N, false);
     if (cell_path) {
       // one workgroup per cell does the whole sub-step of its cell (see k_cell_step)
-      if (cfg->enable_breakup)
-        HIP_TRY(hipMemsetAsync(S.list_count, 0, sizeof(unsigned long long), s));
       if (cfg->adaptive) {
         PhaseScope ph(ctx, SDM_PHASE_CELLS_PRE);
         hipLaunchKernelGGL(k_cells_pre, dim3(grid_for(C)), blk, 0, s, *cfg, A);
@@ -1444,8 +1450,6 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     if (cfg->enable_breakup && !cell_path) {
       A.list_nl = LIST_NL;
       A.list_cap = S.flat_list_cap;
-      HIP_TRY(hipMemsetAsync(S.list_count, 0,
-                             sizeof(unsigned long long) * LIST_NL * SDM_CNT_STRIDE, s));
     }
     // (e)+(f) probabilities, gamma, update
     if (cell_path) {
@@ -1487,6 +1491,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       hipLaunchKernelGGL(k_resolve_dense, dim3((unsigned)(A.list_nl * chunks)), blk, 0, s, *cfg,
                          A);
       LAUNCH_CHECK();
+      std::swap(A.list_count, A.list_count_next);  // it left the other set of counts cleared
     }
     // (g) sanitize (particle_attributes.py:67-73), decided on the device by the healthy word
     {
@@ -1546,8 +1551,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   }
   if (cfg->adaptive) {
     // collision.py:189-190 reset_working_length(); reset_cell_idx() (identity + sort)
-    hipLaunchKernelGGL(k_reset_work, one, one, 0, s, st->ctl);
-    LAUNCH_CHECK();
+    if (C > 1 || n_sub == 0) {  // (one cell: the compaction's epilogue left work = valid)
+      hipLaunchKernelGGL(k_reset_work, one, one, 0, s, st->ctl);
+      LAUNCH_CHECK();
+    }
     if (C > 1) {
       rc = sdm_identity_index(ctx, st->cell_idx, C);
       if (rc) return rc;

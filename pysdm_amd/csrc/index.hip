@@ -783,8 +783,10 @@ __device__ __forceinline__ void compact_epilogue(const CompactEpilogue &E,
     }
   }
   if (threadIdx.x == 0) {
-    fctl[FCTL_WORK] = E.dt_left[0] != 0 ? fctl[FCTL_VALID] : 0;
-    publish_ctl(fctl, E.box, E.seq);
+    // device side: the working length of one cell is the valid length whether the time step goes
+    // on or ends (reset_working_length, collision.py:189); only the host is told "0 = done"
+    fctl[FCTL_WORK] = fctl[FCTL_VALID];
+    publish_ctl(fctl, E.box, E.seq, E.dt_left[0] != 0 ? fctl[FCTL_VALID] : 0);
   }
 }
 
