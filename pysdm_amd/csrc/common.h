@@ -37,6 +37,15 @@ struct sdm_ctx {
   // (9.8 us against 15.4 us for hipMemcpyAsync + hipStreamSynchronize, measured)
   int64_t *box_dev;
   int64_t poll_seq;
+  // fused.hip: head of the next sub-step launched ahead of a read-back, carried over a step boundary
+  struct {
+    bool active;
+    const void *owner;  // the sdm_step_state it belongs to
+    uint64_t off_before, off_b_before;  // stream positions to return to if it is discarded
+    u128 s_rand, s_rand_b;
+    const void *rec, *ovf_head, *ovf_next;
+    int64_t *cur, *alt;  // permutation buffers as its kernels left them (cur: written)
+  } ahead;
   // device control words for fine-grained calls (int64[16])
   int64_t *dscal;
   // single-cell collision counters, spread over SDM_CNT_SLOTS cache lines (fused.hip)

@@ -1210,8 +1210,10 @@ static int cond_sort(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st, 
 // flags: bit 0 = read the control block back at the end; bit 1 = the control block was freshly
 // pushed by the host (single-cell bookkeeping has to be initialised)
 // fold_counters: false when further steps of the same call follow (sdm_collision_run)
+// more_follow: further steps of the same call follow (then the head of the next sub-step is
+// launched ahead of each read-back, see `launch_head`)
 static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st,
-                          sdm_step_result *res, int flags, bool fold_counters) {
+                          sdm_step_result *res, int flags, bool fold_counters, bool more_follow) {
   ARG_TRY(ctx && cfg && st && res);
   ARG_TRY(cfg->n_sd >= 2 && cfg->n_sd < INT32_MAX && cfg->n_cell >= 1 && cfg->n_attr >= 1);
   ARG_TRY(st->idx && st->tmp_idx && st->multiplicity && st->attributes && st->cell_id &&
@@ -1353,9 +1355,78 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       attr_done = true;
     }
   }
+  // One adaptive cell, plain random numbers: what a sub-step does before its first global
+  // dependency - draw, shuffle build, permutation + probabilities (k_pair_prob) - is the same
+  // whether it continues this time step or opens the next one (the generator stream simply goes
+  // on; dt_left enters only afterwards, in k_cells_adaptive).  So when more steps follow, that
+  // head is launched right after the compaction of the current sub-step, *before* the host waits
+  // for the control block: the GPU works through the ~12 us of the read-back instead of idling.
+  // The head touches nothing but scratch and the spare permutation buffer, so it can be dropped
+  // (stream positions restored) in the one case it was not needed: no super-droplet left.
+  const bool head_ok = C == 1 && cfg->adaptive && !cfg->optimized_random && cfg->croupier_local &&
+                       sdm_shuffle_can_split(N, false) && N >= 4096;
+  bool head_done = false;
+  uint64_t head_off_before = off, head_off_b_before = off_b;
+  auto launch_head = [&]() -> int {
+    head_off_before = off;
+    head_off_b_before = off_b;
+    draw_off = off;
+    draw_off_b = off_b;
+    off += (uint64_t)(N + shift + P);
+    if (cfg->enable_breakup) off_b += (uint64_t)P;
+    A.s_rand = sdm_pcg_advance_host(rng_state, rng_inc, draw_off + (uint64_t)(N + shift));
+    A.s_rand_b = sdm_pcg_advance_host(rng_state, rng_inc, draw_off_b);
+    ShuffleViews views;
+    const int r = sdm_shuffle_build_async(ctx, S.shuffle, cur, st->cell_start, C,
+                                          st->cell_start + C, N, cfg->rng_state_inc, draw_off,
+                                          &views);
+    if (r) return r;
+    A.rec = views.rec;
+    A.ovf_head = views.ovf_head;
+    A.ovf_next = views.ovf_next;
+    A.idx_prev = cur;
+    { int64_t *t = cur; cur = alt; alt = t; }
+    ++swaps;
+    A.idx = cur;
+    PhaseScope ph(ctx, SDM_PHASE_PAIR_PROB);
+    DISPATCH_PAIR(k_pair_prob, dim3(grid_for((N + 1) / 2)));
+    LAUNCH_CHECK();
+    return SDM_OK;
+  };
+  if (head_ok && cfg->enable_breakup) {
+    A.list_nl = LIST_NL;
+    A.list_cap = S.flat_list_cap;
+  }
+  if (ctx->ahead.active) {  // left by the previous step of this call
+    ctx->ahead.active = false;
+    if (head_ok && work_host != 0 && ctx->ahead.owner == (const void *)st &&
+        ctx->ahead.cur == st->tmp_idx && ctx->ahead.alt == st->idx) {
+      A.s_rand = ctx->ahead.s_rand;
+      A.s_rand_b = ctx->ahead.s_rand_b;
+      A.rec = (const PackRec *)ctx->ahead.rec;
+      A.ovf_head = (const int32_t *)ctx->ahead.ovf_head;
+      A.ovf_next = (const int32_t *)ctx->ahead.ovf_next;
+      cur = ctx->ahead.cur;
+      alt = ctx->ahead.alt;
+      A.idx_prev = alt;
+      A.idx = cur;
+      swaps = 1;
+      head_done = true;
+    } else {  // not needed after all: its draw goes back to the streams
+      off = ctx->ahead.off_before;
+      off_b = ctx->ahead.off_b_before;
+    }
+  }
   for (;;) {
     if (!cfg->adaptive && n_sub >= cfg->substeps) break;
     if (cfg->adaptive && work_host == 0) break;
+    if (head_ok) {
+      if (!head_done) {
+        rc = launch_head();
+        if (rc) return rc;
+      }
+      head_done = false;
+    } else {
     // (a) collision.py:183 cell_idx.sort_by_key(dt_left)
     if (cfg->adaptive && C > 1) {
       rc = sdm_sort_by_key_async(ctx, st->cell_idx, st->dt_left, C);
@@ -1451,6 +1522,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       A.list_nl = LIST_NL;
       A.list_cap = S.flat_list_cap;
     }
+    }  // !head_ok
     // (e)+(f) probabilities, gamma, update
     if (cell_path) {
       // done by k_cell_step above
@@ -1464,7 +1536,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         hipLaunchKernelGGL(k_cells_pre, dim3(grid_for(C)), blk, 0, s, *cfg, A);
         LAUNCH_CHECK();
       }
-      {
+      if (!head_ok) {
         PhaseScope ph(ctx, SDM_PHASE_PAIR_PROB);
         DISPATCH_PAIR(k_pair_prob, dim3(grid_for((N + 1) / 2)));
         LAUNCH_CHECK();
@@ -1516,6 +1588,11 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     if (cfg->adaptive) {
       // (h) collision.py:185-187 cut_working_length(adaptive_sdm_end(dt_left))
       n_pairs += work_host / 2;
+      if (head_ok && more_follow) {  // ahead of the read-back (see launch_head)
+        rc = launch_head();
+        if (rc) return rc;
+        head_done = true;
+      }
       for (int attempt = 0; attempt < 2; ++attempt) {
         {
           PhaseScope ph(ctx, SDM_PHASE_ADAPTIVE_END);
@@ -1544,6 +1621,20 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         if (rc) return rc;
       }
     }
+  }
+  if (head_done) {  // the head launched last opens the next step: hand it over
+    swaps -= 1;     // its buffer exchange counts there
+    ctx->ahead.active = true;
+    ctx->ahead.owner = st;
+    ctx->ahead.off_before = head_off_before;
+    ctx->ahead.off_b_before = head_off_b_before;
+    ctx->ahead.s_rand = A.s_rand;
+    ctx->ahead.s_rand_b = A.s_rand_b;
+    ctx->ahead.rec = A.rec;
+    ctx->ahead.ovf_head = A.ovf_head;
+    ctx->ahead.ovf_next = A.ovf_next;
+    ctx->ahead.cur = cur;
+    ctx->ahead.alt = alt;
   }
   if (fill_pending) {  // no sub-step ran (nothing to work on): the fill still has to happen
     hipLaunchKernelGGL(k_fill_f64, dim3(grid_for(C)), blk, 0, s, st->dt_left, cfg->dt, C);
@@ -1603,7 +1694,9 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
 
 extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st,
                                   sdm_step_result *res, int flags) {
-  return collision_step(ctx, cfg, st, res, flags, true);
+  ARG_TRY(ctx != nullptr);
+  ctx->ahead.active = false;
+  return collision_step(ctx, cfg, st, res, flags, true, false);
 }
 
 // n_steps consecutive time steps in one call (no host-side work between them): what
@@ -1613,7 +1706,8 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
 // the totals, idx_swapped the parity over the whole run.
 extern "C" int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st,
                                  sdm_step_result *res, int flags, int64_t n_steps) {
-  ARG_TRY(res && st && n_steps >= 0);
+  ARG_TRY(ctx && res && st && n_steps >= 0);
+  ctx->ahead.active = false;
   sdm_step_result total;
   memset(&total, 0, sizeof(total));
   total.valid_n_sd = -1;
@@ -1625,8 +1719,11 @@ extern "C" int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step
     const bool last = step == n_steps - 1;
     // read the control block back only after the last step
     const int rc = collision_step(ctx, cfg, st, &one, (last ? (flags & 1) : 0) |
-                                                      (step == 0 ? (flags & 2) : 0), last);
-    if (rc) return rc;
+                                                      (step == 0 ? (flags & 2) : 0), last, !last);
+    if (rc) {
+      ctx->ahead.active = false;
+      return rc;
+    }
     if (one.idx_swapped) {
       int64_t *t = st->idx;
       st->idx = st->tmp_idx;

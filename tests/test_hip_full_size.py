@@ -133,6 +133,40 @@ def test_many_steps_in_one_call_equal_oracle(n_sd, steps, thin, hip_backend_clas
         assert int(snaps[0]["length"]) < n_sd
 
 
+@pytest.mark.parametrize("name,n_sd,steps,dt,thin", [
+    ("shima", 2**16, 40, None, None),      # one sub-step per step
+    ("shima", 2**16, 25, 400.0, None),     # several sub-steps per step
+    ("shima", 2**16, 25, 200.0, 0.02),     # super-droplets die in every step
+    ("shima", 2**12, 60, 200.0, 0.02),     # below the look-ahead's size threshold
+    ("berry_breakup", 2**15, 40, None, None),
+    ("straub", 2**14, 12, None, None),
+])
+def test_adaptive_steps_in_one_call_equal_oracle(name, n_sd, steps, dt, thin, hip_backend_class,
+                                                 oracle_backend_class):
+    """`Particulator.run(n)` of an adaptive single-cell box in one `sdm_collision_run` call: the
+    head of each next sub-step (draw, shuffle build, probabilities) is launched ahead of the
+    read-back that decides whether it continues the time step or opens the next one; state,
+    counters and sub-step statistics equal the oracle's step-by-step run"""
+    snaps = []
+    for backend_class in (hip_backend_class, oracle_backend_class):
+        particulator, dynamic = make_box(backend_class, name, n_sd=n_sd, adaptive=True, dt=dt)
+        if thin:
+            mult = particulator.attributes["multiplicity"]
+            mult.upload((1 + np.arange(n_sd) % 3).astype(np.int64))
+            particulator.attributes.mark_updated("multiplicity")
+            particulator.environment.mesh.dv = thin * n_sd / 2**16
+        run(particulator, 1)
+        run(particulator, steps)
+        run(particulator, 3)
+        snaps.append(snapshot(particulator, dynamic))
+    assert_same(snaps[0], snaps[1], float_rtol=0.0 if name == "shima" else 1e-12)
+    assert snaps[0]["stats_n_substep"][0] >= steps + 4
+    if dt:
+        assert snaps[0]["stats_n_substep"][0] > steps + 4
+    if thin:
+        assert int(snaps[0]["length"]) < n_sd
+
+
 def test_shima_box_3600_steps_equal_oracle(hip_backend_class, oracle_backend_class):
     """the whole Shima-2009 experiment (3600 steps of 1 s) in one library call at 2^16
     super-droplets: permutation, multiplicities, masses and counters identical to the oracle's"""
