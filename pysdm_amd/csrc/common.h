@@ -37,6 +37,14 @@ struct sdm_ctx {
   // (9.8 us against 15.4 us for hipMemcpyAsync + hipStreamSynchronize, measured)
   int64_t *box_dev;
   int64_t poll_seq;
+  // fused.hip: what a multi-cell adaptive step knows at its end, for the next step of the same call
+  // (valid length, an upper bound of the cell sizes; the state is sorted) - saves that step's
+  // opening read-back
+  struct {
+    bool active;
+    const void *owner;
+    int64_t valid, max_cell;
+  } carry;
   // fused.hip: head of the next sub-step launched ahead of a read-back, carried over a step boundary
   struct {
     bool active;

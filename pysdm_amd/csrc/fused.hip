@@ -783,6 +783,80 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_cells_adaptive(sdm_step_cfg cfg, 
   if (t > 0) A.stats_n_substep[c] += 1;
 }
 
+// ---- multi-cell per-cell route: what opens and what ends a sub-step, one launch each ----------
+// k_cells_begin, one workgroup per cell i: cell_idx.sort_by_key(dt_left) (collision.py:183; rank
+// of dt_left[i] by counting, as index.hip:k_sort_by_key) and the per-cell adaptive init
+// (collisions_methods.py:355-356); workgroup 0 clears the words k_cells_end accumulates in
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_cells_begin(sdm_step_cfg cfg, FusedArgs A, int64_t *__restrict__ cell_idx,
+              int64_t *__restrict__ end2) {
+  __shared__ int sm[SDM_BLOCK / SDM_WAVE];
+  const int64_t i = blockIdx.x, n = cfg.n_cell;
+  const double ki = A.dt_left[i];
+  int rank = 0;
+  for (int64_t j = threadIdx.x; j < n; j += SDM_BLOCK) {
+    const double kj = A.dt_left[j];
+    rank += (kj < ki) || (kj == ki && j < i);
+  }
+  rank = wave_sum_i32(rank);
+  if (lane_id() == 0) sm[threadIdx.x / SDM_WAVE] = rank;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int total = 0;
+    for (int w = 0; w < SDM_BLOCK / SDM_WAVE; ++w) total += sm[w];
+    cell_idx[n - 1 - total] = i;
+    A.dt_todo[i] = cfg.dt_max < ki ? cfg.dt_max : ki;  // Python min(l, dt_max)
+    A.cell_min[i] = INFINITY;
+    if (i == 0) { end2[0] = 0; end2[2] = 0; }
+  }
+}
+
+// k_cells_end, one thread per cell, after the compaction: the per-cell adaptive bookkeeping
+// (collisions_methods.py:357-374, `bookkeeping`; k_cell_step left the cell minima), then
+// adaptive_sdm_end (collisions_methods.py:313-328): end2[0] = 1 + largest c with dt_left[c] != 0,
+// and by the workgroup that finishes last: working length = cell_start[that], control block
+// published for the host (end2[2]: finish ticket - a handful of workgroups)
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_cells_end(sdm_step_cfg cfg, FusedArgs A, int bookkeeping, int64_t *__restrict__ end2,
+            int64_t *box, int64_t seq) {
+  const int64_t c = TID();
+  bool nz = false;
+  if (c < cfg.n_cell) {
+    double left = A.dt_left[c];
+    if (bookkeeping) {
+      const double m = A.cell_min[c];
+      double t = A.dt_todo[c];
+      if (m < t) t = m;
+      A.dt_todo[c] = t;
+      const double smin = A.stats_dt_min[c];
+      A.stats_dt_min[c] = m < smin ? m : smin;  // Python min(s, m): NaN-sticky
+      left -= t;
+      A.dt_left[c] = left;
+      if (t > 0) A.stats_n_substep[c] += 1;
+    }
+    nz = left != 0;
+  }
+  const unsigned long long mask = __ballot(nz);
+  if (mask && lane_id() == 0)
+    atomicMax((long long *)&end2[0], (long long)((c - lane_id()) + (63 - __clzll(mask)) + 1));
+  __shared__ bool last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    last = atomicAdd((unsigned long long *)&end2[2], 1ull) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    __threadfence();
+    const int64_t top = __hip_atomic_load(&end2[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int64_t end = top == 0 ? 0 : A.cell_start[top];
+    end2[1] = end;
+    end2[2] = 0;
+    A.ctl[CTL_WORK] = end;
+    publish_ctl(A.ctl, box, seq, end);
+  }
+}
+
 template <bool BREAKUP>
 __global__ void __launch_bounds__(SDM_BLOCK) k_pair_update(sdm_step_cfg cfg, FusedArgs A) {
   __shared__ u128 lds[2];
@@ -1103,6 +1177,16 @@ __global__ void k_set_work(int64_t *ctl, const int64_t *end, int64_t *box, int64
   publish_ctl(ctl, box, seq, end[0]);
 }
 __global__ void k_reset_work(int64_t *ctl) { ctl[CTL_WORK] = ctl[CTL_VALID]; }
+// multi-cell: reset_working_length + reset_cell_idx (identity; un-sorts) in one launch
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_step_close(int64_t *ctl, int64_t *__restrict__ cell_idx, int64_t n_cell) {
+  const int64_t c = TID();
+  if (c < n_cell) cell_idx[c] = c;
+  if (c == 0) {
+    ctl[CTL_WORK] = ctl[CTL_VALID];
+    ctl[CTL_SORTED] = 0;
+  }
+}
 
 __global__ void __launch_bounds__(SDM_BLOCK) k_fill_f64(double *p, double v, int64_t n) {
   const int64_t i = TID();
@@ -1322,6 +1406,12 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     // one cell, nothing touched the state since the last read-back: no need to ask the device
     work_host = st->known_valid;
     sorted_host = 1;
+  } else if (C > 1 && cfg->adaptive && ctx->carry.active && ctx->carry.owner == (const void *)st &&
+             !(flags & 2)) {
+    // multi-cell, previous step of the same call: sorted, lengths and cell-size bound known
+    work_host = ctx->carry.valid;
+    sorted_host = 1;
+    max_cell = ctx->carry.max_cell;
   } else if (cfg->adaptive || read_back) {
     if (C > 1 && cfg->croupier_local) {
       // meaningful only if the state is sorted (checked below): cells can only shrink in a call
@@ -1338,6 +1428,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     if (C > 1 && cfg->croupier_local && sorted_host == 1 && !(flags & 2))
       max_cell = ctx->mailbox[8 + 6];
   }
+  ctx->carry.active = false;
   const bool cell_path = max_cell >= 0 && max_cell <= CELL_CAP;
   if (cell_path) {
     static bool attr_done = false;  // > 64 KiB of dynamic LDS must be opted into, per kernel
@@ -1428,7 +1519,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       head_done = false;
     } else {
     // (a) collision.py:183 cell_idx.sort_by_key(dt_left)
-    if (cfg->adaptive && C > 1) {
+    if (cfg->adaptive && C > 1 && !cell_path) {  // (per-cell route: k_cells_begin below)
       rc = sdm_sort_by_key_async(ctx, st->cell_idx, st->dt_left, C);
       if (rc) return rc;
     }
@@ -1455,7 +1546,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       // one workgroup per cell does the whole sub-step of its cell (see k_cell_step)
       if (cfg->adaptive) {
         PhaseScope ph(ctx, SDM_PHASE_CELLS_PRE);
-        hipLaunchKernelGGL(k_cells_pre, dim3(grid_for(C)), blk, 0, s, *cfg, A);
+        hipLaunchKernelGGL(k_cells_begin, dim3((unsigned)C), blk, 0, s, *cfg, A, st->cell_idx,
+                           S.end2);
         LAUNCH_CHECK();
       }
       CellArgs X;
@@ -1484,11 +1576,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
 #undef CELL_LAUNCH
         LAUNCH_CHECK();
       }
-      if (cfg->adaptive) {
-        PhaseScope ph(ctx, SDM_PHASE_CELLS_ADAPTIVE);
-        hipLaunchKernelGGL(k_cells_adaptive, dim3(grid_for(C)), blk, 0, s, *cfg, A, 0);
-        LAUNCH_CHECK();
-      }
+      // (the per-cell bookkeeping follows the compaction: k_cells_end)
       { int64_t *t = cur; cur = alt; alt = t; }
       ++swaps;
     } else if (split) {
@@ -1597,7 +1685,12 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         {
           PhaseScope ph(ctx, SDM_PHASE_ADAPTIVE_END);
           // the control block comes back through the polled box (publish_ctl), not a copy
-          if (C > 1) {
+          if (C > 1 && cell_path && attempt == 0) {
+            box_seq = ++ctx->poll_seq;
+            hipLaunchKernelGGL(k_cells_end, dim3(grid_for(C)), blk, 0, s, *cfg, A, 1, S.end2,
+                               ctx->box_dev, box_seq);
+            LAUNCH_CHECK();
+          } else if (C > 1) {
             box_seq = ++ctx->poll_seq;
             rc = sdm_adaptive_end_async(ctx, st->dt_left, C, st->cell_start, S.end2, S.end2 + 1);
             if (rc) return rc;
@@ -1642,19 +1735,24 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   }
   if (cfg->adaptive) {
     // collision.py:189-190 reset_working_length(); reset_cell_idx() (identity + sort)
-    if (C > 1 || n_sub == 0) {  // (one cell: the compaction's epilogue left work = valid)
+    if (C == 1 && n_sub == 0) {  // (else the compaction's epilogue left work = valid)
       hipLaunchKernelGGL(k_reset_work, one, one, 0, s, st->ctl);
       LAUNCH_CHECK();
     }
     if (C > 1) {
-      rc = sdm_identity_index(ctx, st->cell_idx, C);
-      if (rc) return rc;
-      hipLaunchKernelGGL(k_mark_unsorted, one, one, 0, s, st->ctl);
+      hipLaunchKernelGGL(k_step_close, dim3(grid_for(C)), blk, 0, s, st->ctl, st->cell_idx, C);
       LAUNCH_CHECK();
       sorted_host = 0;
       rc = cond_sort(ctx, cfg, st, cur, S, &sorted_host);
       if (rc) return rc;
     }
+  }
+  if (more_follow && cfg->adaptive && C > 1 && cfg->croupier_local && have_ctl &&
+      sorted_host == 1 && max_cell >= 0) {
+    ctx->carry.active = true;  // cells can only shrink within a call: max_cell stays a bound
+    ctx->carry.owner = st;
+    ctx->carry.valid = last_ctl[CTL_VALID];
+    ctx->carry.max_cell = max_cell;
   }
   if (A.slots && fold_counters) {
     hipLaunchKernelGGL(k_fold_counters, one, dim3(SDM_CNT_SLOTS), 0, s, A);
@@ -1696,6 +1794,7 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
                                   sdm_step_result *res, int flags) {
   ARG_TRY(ctx != nullptr);
   ctx->ahead.active = false;
+  ctx->carry.active = false;
   return collision_step(ctx, cfg, st, res, flags, true, false);
 }
 
@@ -1708,6 +1807,7 @@ extern "C" int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step
                                  sdm_step_result *res, int flags, int64_t n_steps) {
   ARG_TRY(ctx && res && st && n_steps >= 0);
   ctx->ahead.active = false;
+  ctx->carry.active = false;
   sdm_step_result total;
   memset(&total, 0, sizeof(total));
   total.valid_n_sd = -1;
@@ -1722,6 +1822,7 @@ extern "C" int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step
                                                       (step == 0 ? (flags & 2) : 0), last, !last);
     if (rc) {
       ctx->ahead.active = false;
+      ctx->carry.active = false;
       return rc;
     }
     if (one.idx_swapped) {
