@@ -20,6 +20,9 @@ int sdm_counting_sort_async(sdm_ctx *ctx, char *scratch, int64_t *new_idx, const
                             const int64_t *cell_id, const int64_t *cell_idx,
                             const int64_t *p_length, int64_t length_bound, int64_t *cell_start,
                             int64_t n_cell);
+// cell_start[0..n_cell] = exclusive scan of count[0..n_cell) (no-op while *p_gate == 0)
+int sdm_cell_start_from_counts_async(sdm_ctx *ctx, const int64_t *count, int64_t *cell_start,
+                                     int64_t n_cell, const int64_t *p_gate);
 bool sdm_shuffle_can_split(int64_t n, bool global);
 int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
                             const int64_t *cell_start, int64_t n_cell, const int64_t *p_length,
