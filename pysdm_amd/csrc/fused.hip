@@ -830,9 +830,15 @@ k_reseg_copy(int64_t *__restrict__ out, const int64_t *__restrict__ idx,
 // (collisions_methods.py:355-356); workgroup 0 clears the words k_cells_end accumulates in
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_cells_begin(sdm_step_cfg cfg, FusedArgs A, int64_t *__restrict__ cell_idx,
-              int64_t *__restrict__ end2, int fresh) {
+              int64_t *__restrict__ end2, int fresh, int gated) {
   __shared__ int sm[SDM_BLOCK / SDM_WAVE];
   const int64_t i = blockIdx.x, n = cfg.n_cell;
+  // gated: the sub-step was launched ahead of the read-back of the previous one; it runs only if
+  // that one left work to do and the state sorted (no compaction).  end2[3] tells the kernels
+  // that follow (nothing they do changes the two words before this kernel has finished)
+  const bool run = !gated || (A.ctl[CTL_WORK] != 0 && A.ctl[CTL_SORTED] != 0);
+  if (i == 0 && threadIdx.x == 0) end2[3] = run ? 1 : 0;
+  if (!run) return;
   // fresh: first sub-step of a time step, dt_left[:] = dt (collision.py:180) happens here
   const double ki = fresh ? cfg.dt : A.dt_left[i];
   int rank = 0;
@@ -863,10 +869,11 @@ __global__ void __launch_bounds__(SDM_BLOCK)
 k_cells_end(sdm_step_cfg cfg, FusedArgs A, int bookkeeping, int64_t *__restrict__ end2,
             int64_t *box, int64_t seq) {
   const int64_t c = TID();
+  const bool ran = !bookkeeping || end2[3] != 0;  // (see k_cells_begin: gated sub-steps)
   bool nz = false;
   if (c < cfg.n_cell) {
     double left = A.dt_left[c];
-    if (bookkeeping) {
+    if (bookkeeping && ran) {
       const double m = A.cell_min[c];
       double t = A.dt_todo[c];
       if (m < t) t = m;
@@ -895,8 +902,8 @@ k_cells_end(sdm_step_cfg cfg, FusedArgs A, int bookkeeping, int64_t *__restrict_
     const int64_t end = top == 0 ? 0 : A.cell_start[top];
     end2[1] = end;
     end2[2] = 0;
-    A.ctl[CTL_WORK] = end;
-    publish_ctl(A.ctl, box, seq, end);
+    if (ran) A.ctl[CTL_WORK] = end;
+    publish_ctl(A.ctl, box, seq, ran ? end : A.ctl[CTL_WORK]);
   }
 }
 
@@ -942,6 +949,7 @@ struct CellArgs {
   int64_t *idx_out;
   u128 s_u01;  // PCG64 state at draw 0 of the sub-step's u01 window
   int n_tail_blocks;
+  const int64_t *gate;  // NULL, or a word written by k_cells_begin: 0 = this sub-step does not run
 };
 
 #ifdef CELL_PROFILE
@@ -966,6 +974,7 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   __shared__ u128 s_rng[3];  // generator states at the cell's first position / first pair slot
   const int64_t C = cfg.n_cell, N = cfg.n_sd;
   const int tid = threadIdx.x;
+  if (X.gate && X.gate[0] == 0) return;
   if ((int64_t)blockIdx.x >= C) {  // dead tail [cell_start[C], N) is carried over unchanged
     const int64_t from = A.cell_start[C];
     for (int64_t i = from + ((int64_t)blockIdx.x - C) * CELL_THREADS + tid; i < N;
@@ -1563,6 +1572,136 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       off_b = ctx->ahead.off_b_before;
     }
   }
+  // Multi-cell per-cell route, adaptive: the same idea with a device-side gate.  Sub-step k + 1
+  // is launched before the host waits for the control block of sub-step k; its first kernel
+  // (k_cells_begin) looks at what k left - work to do and no compaction (state still sorted) - and
+  // if not, the whole sub-step falls through (end2[3]) and the host takes back what it had booked
+  // for it (stream positions, buffer exchange).  A compaction is followed, as before, by a
+  // counting sort and a fresh working length before the next sub-step.
+  if (cell_path && cfg->adaptive && work_host != 0) {
+    int64_t launched = 0;  // sub-steps launched in this time step (the draw window shifts by it)
+    auto launch_substep = [&](bool gated, int64_t *seq_out) -> int {
+      if (!cfg->optimized_random || launched == 0) {  // (c), as in the loop below
+        draw_off = off;
+        draw_off_b = off_b;
+        off += (uint64_t)(N + shift + P);
+        if (cfg->enable_breakup) off_b += (uint64_t)P;
+      }
+      A.s_rand = sdm_pcg_advance_host(rng_state, rng_inc, draw_off + (uint64_t)(N + shift));
+      A.s_rand_b = sdm_pcg_advance_host(rng_state, rng_inc, draw_off_b);
+      const uint64_t u01_off = draw_off + (uint64_t)(cfg->optimized_random ? launched : 0);
+      {
+        PhaseScope ph(ctx, SDM_PHASE_CELLS_PRE);
+        hipLaunchKernelGGL(k_cells_begin, dim3((unsigned)C), blk, 0, s, *cfg, A, st->cell_idx,
+                           S.end2, fill_pending ? 1 : 0, gated ? 1 : 0);
+        LAUNCH_CHECK();
+        fill_pending = false;
+      }
+      CellArgs X;
+      X.idx_in = cur;
+      X.idx_out = alt;
+      X.s_u01 = sdm_pcg_advance_host(rng_state, rng_inc, u01_off);
+      X.n_tail_blocks = 64;
+      X.gate = S.end2 + 3;
+      A.idx = alt;
+      {
+        PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
+        const dim3 grid((unsigned)(C + X.n_tail_blocks)), cblk(CELL_THREADS);
+        const bool brk = cfg->enable_breakup != 0;
+#define CELL_LAUNCH(K)                                                                        \
+  do {                                                                                        \
+    if (brk) hipLaunchKernelGGL((k_cell_step<K, true>), grid, cblk, CELL_LDS_BYTES, s, *cfg, A, X); \
+    else hipLaunchKernelGGL((k_cell_step<K, false>), grid, cblk, CELL_LDS_BYTES, s, *cfg, A, X);    \
+  } while (0)
+        switch (cfg->kernel) {
+          case SDM_KERNEL_GOLOVIN: CELL_LAUNCH(SDM_KERNEL_GOLOVIN); break;
+          case SDM_KERNEL_GEOMETRIC: CELL_LAUNCH(SDM_KERNEL_GEOMETRIC); break;
+          case SDM_KERNEL_PARAMETERIZED: CELL_LAUNCH(SDM_KERNEL_PARAMETERIZED); break;
+          case SDM_KERNEL_SIMPLE_GEOMETRIC: CELL_LAUNCH(SDM_KERNEL_SIMPLE_GEOMETRIC); break;
+          case SDM_KERNEL_LINEAR: CELL_LAUNCH(SDM_KERNEL_LINEAR); break;
+          default: CELL_LAUNCH(SDM_KERNEL_CONSTANT);
+        }
+#undef CELL_LAUNCH
+        LAUNCH_CHECK();
+      }
+      { int64_t *t = cur; cur = alt; alt = t; }
+      ++swaps;
+      if (cfg->enable_breakup) {
+        PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
+        const int64_t chunks = (A.list_cap + SDM_BLOCK - 1) / SDM_BLOCK;
+        hipLaunchKernelGGL(k_resolve_dense, dim3((unsigned)(A.list_nl * chunks)), blk, 0, s, *cfg,
+                           A);
+        LAUNCH_CHECK();
+        std::swap(A.list_count, A.list_count_next);
+      }
+      {
+        PhaseScope ph(ctx, SDM_PHASE_SANITIZE);
+        const int r = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl,
+                                              S.cctl, nullptr, true);
+        if (r) return r;
+      }
+      *seq_out = ++ctx->poll_seq;
+      hipLaunchKernelGGL(k_cells_end, dim3(grid_for(C)), blk, 0, s, *cfg, A, 1, S.end2,
+                         ctx->box_dev, *seq_out);
+      LAUNCH_CHECK();
+      ++launched;
+      return SDM_OK;
+    };
+    int64_t seq_k = 0;
+    rc = launch_substep(false, &seq_k);
+    if (rc) return rc;
+    for (;;) {
+      const uint64_t keep[4] = {off, off_b, draw_off, draw_off_b};
+      int64_t seq_next = 0;
+      rc = launch_substep(true, &seq_next);
+      if (rc) return rc;
+      auto take_back = [&]() {  // the sub-step launched ahead fell through on the device
+        off = keep[0]; off_b = keep[1]; draw_off = keep[2]; draw_off_b = keep[3];
+        { int64_t *t = cur; cur = alt; alt = t; }
+        --swaps;
+        --launched;
+      };
+      {
+        PhaseScope ph(ctx, SDM_PHASE_ADAPTIVE_END);
+        rc = sdm_wait_box(ctx, seq_k);
+        if (rc) return rc;
+      }
+      memcpy(last_ctl, ctx->mailbox + SDM_BOX, sizeof(last_ctl));
+      have_ctl = true;
+      ++n_sub;
+      n_pairs += work_host / 2;
+      if (last_ctl[CTL_SORTED] == 0) {
+        // a compaction happened in sub-step k: sort by cell, then the end of the working range
+        // from the new cell_start (particle_attributes.py cell_start getter)
+        take_back();
+        sorted_host = 0;
+        hipLaunchKernelGGL(k_reset_work, one, one, 0, s, st->ctl);  // sanitize left work = valid
+        LAUNCH_CHECK();
+        rc = cond_sort(ctx, cfg, st, cur, S, &sorted_host);
+        if (rc) return rc;
+        const int64_t seq = ++ctx->poll_seq;
+        rc = sdm_adaptive_end_async(ctx, st->dt_left, C, st->cell_start, S.end2, S.end2 + 1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_set_work, one, one, 0, s, st->ctl, S.end2 + 1, ctx->box_dev, seq);
+        LAUNCH_CHECK();
+        rc = sdm_wait_box(ctx, seq);
+        if (rc) return rc;
+        memcpy(last_ctl, ctx->mailbox + SDM_BOX, sizeof(last_ctl));
+        work_host = last_ctl[CTL_WORK];
+        if (work_host == 0) break;
+        rc = launch_substep(false, &seq_k);
+        if (rc) return rc;
+        continue;
+      }
+      sorted_host = 1;
+      work_host = last_ctl[CTL_WORK];
+      if (work_host == 0) {
+        take_back();
+        break;
+      }
+      seq_k = seq_next;
+    }
+  }
   for (;;) {
     if (!cfg->adaptive && n_sub >= cfg->substeps) break;
     if (cfg->adaptive && work_host == 0) break;
@@ -1602,7 +1741,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       if (cfg->adaptive) {
         PhaseScope ph(ctx, SDM_PHASE_CELLS_PRE);
         hipLaunchKernelGGL(k_cells_begin, dim3((unsigned)C), blk, 0, s, *cfg, A, st->cell_idx,
-                           S.end2, fill_pending ? 1 : 0);
+                           S.end2, fill_pending ? 1 : 0, 0);
         LAUNCH_CHECK();
         fill_pending = false;
       }
@@ -1611,6 +1750,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       X.idx_out = alt;
       X.s_u01 = sdm_pcg_advance_host(rng_state, rng_inc, u01_off);
       X.n_tail_blocks = 64;
+      X.gate = nullptr;
       A.idx = alt;
       {
         PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
