@@ -72,8 +72,24 @@ extern "C" int sdm_ctx_destroy(sdm_ctx *ctx) {
   return SDM_OK;
 }
 
+// elapsed times of the recorded (begin, end) pairs into phase_ms / phase_count; empties the pool
+static int resolve_events(sdm_ctx *ctx) {
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i + 1 < ctx->n_ev; i += 2) {
+    const int phase = ctx->ev_phase[i / 2];
+    if (phase < 0 || phase >= SDM_N_PHASES) continue;
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, ctx->ev[i], ctx->ev[i + 1]));
+    ctx->phase_ms[phase] += t;
+    ctx->phase_count[phase] += 1;
+  }
+  ctx->n_ev = 0;
+  return SDM_OK;
+}
+
 void sdm_phase_begin(sdm_ctx *ctx, int phase) {
-  if (ctx->n_ev + 2 > SDM_MAX_EVENTS) { ctx->ev_phase[SDM_MAX_EVENTS / 2 - 1] = -1; return; }
+  // pool full (a long run in one call): resolve what is there - timing mode is a diagnostic pass
+  if (ctx->n_ev + 2 > SDM_MAX_EVENTS && resolve_events(ctx) != SDM_OK) return;
   ctx->ev_phase[ctx->n_ev / 2] = phase;
   (void)hipEventRecord(ctx->ev[ctx->n_ev], ctx->stream);
   ctx->n_ev += 1;
@@ -98,16 +114,8 @@ extern "C" int sdm_ctx_set_timing(sdm_ctx *ctx, int enable) {
 
 extern "C" int sdm_ctx_read_timing(sdm_ctx *ctx, double *ms, int64_t *count) {
   ARG_TRY(ctx && ms && count);
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  for (int i = 0; i + 1 < ctx->n_ev; i += 2) {
-    const int phase = ctx->ev_phase[i / 2];
-    if (phase < 0 || phase >= SDM_N_PHASES) continue;
-    float t = 0;
-    HIP_TRY(hipEventElapsedTime(&t, ctx->ev[i], ctx->ev[i + 1]));
-    ctx->phase_ms[phase] += t;
-    ctx->phase_count[phase] += 1;
-  }
-  ctx->n_ev = 0;
+  const int rc = resolve_events(ctx);
+  if (rc) return rc;
   for (int p = 0; p < SDM_N_PHASES; ++p) {
     ms[p] = ctx->phase_ms[p];
     count[p] = ctx->phase_count[p];

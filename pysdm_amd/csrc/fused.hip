@@ -1714,8 +1714,12 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     for (;;) {
       const uint64_t keep[4] = {off, off_b, draw_off, draw_off_b};
       int64_t seq_next = 0;
-      rc = launch_substep(true, &seq_next);
-      if (rc) return rc;
+      // (not in timing mode: a sub-step that falls through would count as a launch)
+      const bool ahead = !ctx->timing;
+      if (ahead) {
+        rc = launch_substep(true, &seq_next);
+        if (rc) return rc;
+      }
       auto take_back = [&]() {  // the sub-step launched ahead fell through on the device
         off = keep[0]; off_b = keep[1]; draw_off = keep[2]; draw_off_b = keep[3];
         { int64_t *t = cur; cur = alt; alt = t; }
@@ -1734,7 +1738,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       if (last_ctl[CTL_SORTED] == 0) {
         // a compaction happened in sub-step k: sort by cell, then the end of the working range
         // from the new cell_start (particle_attributes.py cell_start getter)
-        take_back();
+        if (ahead) take_back();
         sorted_host = 0;
         hipLaunchKernelGGL(k_reset_work, one, one, 0, s, st->ctl);  // sanitize left work = valid
         LAUNCH_CHECK();
@@ -1757,10 +1761,15 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       sorted_host = 1;
       work_host = last_ctl[CTL_WORK];
       if (work_host == 0) {
-        take_back();
+        if (ahead) take_back();
         break;
       }
-      seq_k = seq_next;
+      if (ahead) {
+        seq_k = seq_next;
+      } else {
+        rc = launch_substep(false, &seq_k);
+        if (rc) return rc;
+      }
     }
   }
   for (;;) {
@@ -1798,14 +1807,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     const uint64_t u01_off = draw_off + (uint64_t)(cfg->optimized_random ? n_sub : 0);
     const bool split = C == 1 && cfg->croupier_local && sdm_shuffle_can_split(N, false);
     if (cell_path) {
-      // one workgroup per cell does the whole sub-step of its cell (see k_cell_step)
-      if (cfg->adaptive) {
-        PhaseScope ph(ctx, SDM_PHASE_CELLS_PRE);
-        hipLaunchKernelGGL(k_cells_begin, dim3((unsigned)C), blk, 0, s, *cfg, A, st->cell_idx,
-                           S.end2, fill_pending ? 1 : 0, 0);
-        LAUNCH_CHECK();
-        fill_pending = false;
-      }
+      // one workgroup per cell does the whole sub-step of its cell (see k_cell_step); adaptive
+      // steps took the loop above
       CellArgs X;
       X.idx_in = cur;
       X.idx_out = alt;
@@ -1833,7 +1836,6 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
 #undef CELL_LAUNCH
         LAUNCH_CHECK();
       }
-      // (the per-cell bookkeeping follows the compaction: k_cells_end)
       { int64_t *t = cur; cur = alt; alt = t; }
       ++swaps;
     } else if (split) {
@@ -1942,12 +1944,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         {
           PhaseScope ph(ctx, SDM_PHASE_ADAPTIVE_END);
           // the control block comes back through the polled box (publish_ctl), not a copy
-          if (C > 1 && cell_path && attempt == 0) {
-            box_seq = ++ctx->poll_seq;
-            hipLaunchKernelGGL(k_cells_end, dim3(grid_for(C)), blk, 0, s, *cfg, A, 1, S.end2,
-                               ctx->box_dev, box_seq);
-            LAUNCH_CHECK();
-          } else if (C > 1) {
+          if (C > 1) {
             box_seq = ++ctx->poll_seq;
             rc = sdm_adaptive_end_async(ctx, st->dt_left, C, st->cell_start, S.end2, S.end2 + 1);
             if (rc) return rc;
