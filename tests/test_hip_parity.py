@@ -192,6 +192,41 @@ def test_overflow_warnings_step_by_step(hip_backend_class, oracle_backend_class)
                 np.testing.assert_array_equal(value, ref, err_msg=key)
 
 
+@pytest.mark.parametrize("base,adaptive", [("straub", True), ("berry_breakup", True),
+                                            ("straub", False)])
+def test_multicell_breakup_equals_oracle(base, adaptive, hip_backend_class, oracle_backend_class):
+    """breakup on a 4 x 4 grid (the reference has no such golden): the per-cell kernel's listing of
+    colliding pairs + the dense resolution, sub-steps launched ahead of the read-back, per-cell
+    counters - against the oracle's method-by-method run"""
+    from pysdm_amd.examples import CONFIGS, make_box  # pylint: disable=import-outside-toplevel
+
+    name = "_grid_" + base
+    CONFIGS[name] = dict(CONFIGS[base], grid=(4, 4))
+    try:
+        snaps = []
+        for backend_class in (hip_backend_class, oracle_backend_class):
+            particulator, dynamic = make_box(backend_class, name, n_sd=2**13, adaptive=adaptive,
+                                             dt=5.0)
+            for steps in (1, 12, 3):
+                import warnings  # pylint: disable=import-outside-toplevel
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    particulator.run(steps)
+            snaps.append(snapshot(particulator, dynamic))
+    finally:
+        del CONFIGS[name]
+    length = int(snaps[0]["length"])
+    assert snaps[1]["breakup_rate"].sum() > 0
+    for key, value in snaps[0].items():
+        ref = snaps[1][key]
+        if key == "idx":
+            value, ref = value[:length], ref[:length]
+        if value.dtype.kind == "f":
+            np.testing.assert_allclose(value, ref, rtol=1e-12, atol=0, err_msg=key)
+        else:
+            np.testing.assert_array_equal(value, ref, err_msg=key)
+
+
 def test_degenerate_sizes_through_the_abi(kit):
     """empty and tiny inputs: zero-length arrays are accepted by every entry point that takes a
     length, two super-droplets form one pair, three leave one alone, a null context is refused"""
