@@ -1222,6 +1222,273 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
 #endif
 }
 
+// ---- the same sub-step with two workgroups per CU (coalescence only, one extensive attribute) ---
+// k_cell_step keeps a CU to one workgroup (147 KB of LDS), so its phases - LDS-bound shuffle,
+// chip-wide miss-rate-bound gathers, update - never overlap: two co-resident workgroups of 512
+// threads gave +23 % at 2048 super-droplets per cell.  To fit two (<= 80 KB each, <= 128 VGPRs):
+// 14 B of LDS per position - the two inline hit slots share one word (CAS on the pair), the
+// overflow heads are 16-bit (exchange through a CAS on the containing word), the permutation is
+// written over the hit words once every walk has finished (results held in registers across a
+// barrier) - and no member state is carried in registers into the update: the colliding pairs are
+// listed (slot, gamma) and resolved one per thread from the mirror, which is where the per-pair
+// counters are formed too.  Pairs are gathered and evaluated three at a time.
+#define CELL2_CAP 5632
+#define CELL2_THREADS 512
+#define CELL2_MAXPOS (CELL2_CAP / CELL2_THREADS)
+#define CELL2_MAXPAIR ((CELL2_CAP / 2 + CELL2_THREADS - 1) / CELL2_THREADS)
+#define CELL2_BATCH 3
+#define CELL2_LDS_BYTES (CELL2_CAP * 14)
+static_assert(CELL2_MAXPAIR % CELL2_BATCH == 0, "pairs are taken in whole batches");
+
+__device__ __forceinline__ int lds_exch16(uint32_t *words, int i, int v) {
+  uint32_t *w = words + (i >> 1);
+  const int sh = (i & 1) * 16;
+  uint32_t old = *(volatile uint32_t *)w;
+  for (;;) {
+    const uint32_t nw = (old & ~(0xFFFFu << sh)) | ((uint32_t)v << sh);
+    const uint32_t prev = atomicCAS(w, old, nw);
+    if (prev == old) break;
+    old = prev;
+  }
+  return (int)((old >> sh) & 0xFFFFu);
+}
+
+template <int KERNEL>
+__global__ void __launch_bounds__(CELL2_THREADS, 4)
+k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t *hits = (uint32_t *)smem;                 // [CAP] two 16-bit hit slots, 0xFFFF = free
+  int32_t *out = (int32_t *)smem;                    // ... later the permuted ids
+  int32_t *val = (int32_t *)(smem + CELL2_CAP * 4);  // [CAP] ids before the shuffle
+  double *list_g = (double *)val;                    // ... later gamma of the colliding pairs
+  uint16_t *head = (uint16_t *)(smem + CELL2_CAP * 8);   // [CAP] overflow list heads
+  int32_t *list_lp = (int32_t *)head;                    // ... later their pair slots
+  int16_t *jown = (int16_t *)(smem + CELL2_CAP * 10);    // [CAP] own target
+  uint16_t *next = (uint16_t *)(smem + CELL2_CAP * 12);  // [CAP] overflow links
+  __shared__ double red[CELL2_THREADS / SDM_WAVE];
+  __shared__ int64_t s_cid, s_base;
+  __shared__ u128 s_rng[2];
+  __shared__ int s_ncoll;
+  const int64_t C = cfg.n_cell, N = cfg.n_sd;
+  const int tid = threadIdx.x;
+  if (X.gate && X.gate[0] == 0) return;
+  if ((int64_t)blockIdx.x >= C) {  // dead tail [cell_start[C], N) is carried over unchanged
+    const int64_t from = A.cell_start[C];
+    for (int64_t i = from + ((int64_t)blockIdx.x - C) * CELL2_THREADS + tid; i < N;
+         i += (int64_t)X.n_tail_blocks * CELL2_THREADS)
+      X.idx_out[i] = X.idx_in[i];
+    return;
+  }
+  const int64_t lo = A.cell_start[blockIdx.x], hi = A.cell_start[blockIdx.x + 1];
+  const int n = (int)(hi - lo);
+  if (n == 0) return;
+  if (n > CELL2_CAP) {  // never taken: the host enables this path only below the cap
+    if (tid == 0) A.ctl[7] = 1;
+    for (int li = tid; li < n; li += CELL2_THREADS) X.idx_out[lo + li] = X.idx_in[lo + li];
+    return;
+  }
+  const int64_t W = A.ctl[CTL_WORK];
+  for (int li = tid; li < n; li += CELL2_THREADS) {
+    val[li] = (int32_t)X.idx_in[lo + li];
+    hits[li] = 0xFFFFFFFFu;
+    head[li] = 0xFFFFu;
+  }
+  if (tid == 0) s_ncoll = 0;
+  __syncthreads();
+  if (tid == 0) {
+    s_cid = A.cell_id[val[0]];
+    s_base = A.cell_start[A.cell_idx[s_cid]];
+  }
+  if (tid == 64) s_rng[0] = pcg_jump(X.s_u01, A.rng_tab, (uint64_t)lo);
+  if (tid == 128) s_rng[1] = pcg_jump(A.s_rand, A.rng_tab, (uint64_t)(lo >> 1));
+  __syncthreads();
+  // shuffle_local events of this cell (index_methods.py:35-41): consecutive positions per thread
+  {
+    const int chunk = (n + CELL2_THREADS - 1) / CELL2_THREADS;
+    const int li0 = tid * chunk;
+    if (li0 < n) {
+      u128 state = pcg_jump(s_rng[0], A.rng_tab, (uint64_t)li0);
+      const u128 mult = pcg_mult();
+      for (int e = 0; e < chunk && li0 + e < n; ++e) {
+        const int li = li0 + e;
+        state = state * mult + A.rng_inc;
+        const double u = pcg_output(state);
+        int jt = -1;
+        if (li > 0) {
+          const int64_t t = (int64_t)((double)lo + u * (double)(hi - lo)) - lo;
+          jt = (int)(t > n - 1 ? n - 1 : (t < 0 ? 0 : t));
+          uint32_t old = *(volatile uint32_t *)&hits[jt];
+          for (;;) {
+            uint32_t nw;
+            if ((old & 0xFFFFu) == 0xFFFFu) nw = (old & 0xFFFF0000u) | (uint32_t)li;
+            else if ((old >> 16) == 0xFFFFu) nw = (old & 0xFFFFu) | ((uint32_t)li << 16);
+            else { next[li] = (uint16_t)lds_exch16((uint32_t *)head, jt, li); break; }
+            const uint32_t prev = atomicCAS(&hits[jt], old, nw);
+            if (prev == old) break;
+            old = prev;
+          }
+        }
+        jown[li] = (int16_t)jt;
+      }
+    }
+  }
+  __syncthreads();
+  // backward walks (see index.hip), entirely in LDS; results stay in registers until every walk
+  // is through with the hit words
+  int32_t walked[CELL2_MAXPOS];
+#pragma unroll
+  for (int w = 0; w < CELL2_MAXPOS; ++w) {
+    const int li = tid + w * CELL2_THREADS;
+    walked[w] = 0;
+    if (li < n) {
+      int e = 0, q = li;
+      for (;;) {
+        int best = INT32_MAX;
+        const int jq = jown[q];
+        if (q > e && jq >= 0) best = q;
+        const uint32_t h = hits[q];
+        const int a = (int)(h & 0xFFFFu), b = (int)(h >> 16);
+        if (a != 0xFFFF && a > e && a < best) best = a;
+        if (b != 0xFFFF && b > e && b < best) best = b;
+        for (int t = head[q]; t != 0xFFFF; t = next[t])
+          if (t > e && t < best) best = t;
+        if (best == INT32_MAX) break;
+        q = (best == q) ? jq : best;
+        e = best;
+      }
+      walked[w] = val[q];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < CELL2_MAXPOS; ++w) {
+    const int li = tid + w * CELL2_THREADS;
+    if (li < n) out[li] = walked[w];
+  }
+  __syncthreads();
+  // pairs: positions p with (p - cell_start[cell_idx[cid]]) even and p + 1 in the same segment
+  const int64_t cid = s_cid;
+  const int lp0 = (int)((lo - s_base) & 1);
+  double pprob[CELL2_MAXPAIR];
+  double my_min = INFINITY;
+  const bool need_r = KERNEL == SDM_KERNEL_GEOMETRIC || KERNEL == SDM_KERNEL_PARAMETERIZED ||
+                      KERNEL == SDM_KERNEL_SIMPLE_GEOMETRIC;
+#pragma unroll
+  for (int b0 = 0; b0 < CELL2_MAXPAIR; b0 += CELL2_BATCH) {
+    int64_t pj[CELL2_BATCH], pk[CELL2_BATCH];
+    bool pvalid[CELL2_BATCH];
+    SD psj[CELL2_BATCH], psk[CELL2_BATCH];
+#pragma unroll
+    for (int r = 0; r < CELL2_BATCH; ++r) {
+      const int lp = lp0 + 2 * (tid * CELL2_MAXPAIR + b0 + r);  // consecutive pair slots per thread
+      pvalid[r] = lp + 1 < n && lo + lp < W - 1;
+      pj[r] = pk[r] = 0;
+      if (pvalid[r]) {
+        pj[r] = out[lp];
+        pk[r] = out[lp + 1];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < CELL2_BATCH; ++r) {
+      psj[r].n = psk[r].n = 1;
+      psj[r].m = psk[r].m = psj[r].r = psk[r].r = psj[r].u = psk[r].u = 0;
+      if (pvalid[r]) {
+        psj[r] = sd_load(cfg, A, pj[r], need_r);
+        psk[r] = sd_load(cfg, A, pk[r], need_r);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < CELL2_BATCH; ++r) {
+      const int lp = lp0 + 2 * (tid * CELL2_MAXPAIR + b0 + r);
+      const int64_t p = lo + lp;
+      pprob[b0 + r] = 0.0;
+      if (pvalid[r]) {
+        if (psj[r].n < psk[r].n) {  // sort_within_pair_by_attr
+          const SD ts = psj[r]; psj[r] = psk[r]; psk[r] = ts;
+          out[lp] = (int32_t)pk[r];
+          out[lp + 1] = (int32_t)pj[r];
+        }
+        const double prob = pair_prob_value<KERNEL>(cfg, A, p >> 1, psj[r], psk[r]);
+        pprob[b0 + r] = prob;
+        if (cfg.adaptive && prob != 0) {
+          const int64_t prop = psj[r].n / psk[r].n;
+          const double t = cfg.dt * (double)prop / prob;
+          const double dt_opt = cfg.dt_min > t ? cfg.dt_min : t;
+          my_min = dt_opt < my_min ? dt_opt : my_min;
+        }
+      }
+    }
+  }
+  double scale = 1.0 / (double)cfg.substeps;
+  if (cfg.adaptive) {  // workgroup minimum of the optimal sub-step (collisions_methods.py:357-368)
+    const double m = wave_min_f64(my_min);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    double bmin = red[0];
+    for (int w = 1; w < CELL2_THREADS / SDM_WAVE; ++w) bmin = red[w] < bmin ? red[w] : bmin;
+    if (tid == 0) A.cell_min[cid] = bmin;  // k_cells_end does the per-cell bookkeeping
+    const double l = A.dt_left[cid];
+    double todo = cfg.dt_max < l ? cfg.dt_max : l;
+    if (bmin < todo) todo = bmin;
+    scale = todo / cfg.dt;
+  }
+  // gamma (collisions_methods.py:560): the pairs that collide are listed, over val / head
+  {
+    u128 st = pcg_jump(s_rng[1], A.rng_tab,
+                       (uint64_t)(((lo + lp0 + 2 * (int64_t)(tid * CELL2_MAXPAIR)) >> 1) -
+                                  (lo >> 1)));
+#pragma unroll
+    for (int r = 0; r < CELL2_MAXPAIR; ++r) {
+      const int lp = lp0 + 2 * (tid * CELL2_MAXPAIR + r);
+      st = st * pcg_mult() + A.rng_inc;
+      const double u = pcg_output(st);
+      double p = pprob[r];
+      const bool valid = lp + 1 < n && lo + lp < W - 1;
+      if (valid && p != 0) { if (cfg.adaptive) p *= scale; else p /= (double)cfg.substeps; }
+      const double g = valid ? ceil(p - u) : 0.0;
+      if (g != 0) {
+        const int slot = atomicAdd(&s_ncoll, 1);
+        list_lp[slot] = lp;
+        list_g[slot] = g;
+      }
+    }
+  }
+  __syncthreads();
+  // update: one colliding pair per thread, state from the mirror (compute_gamma's clamp and
+  // counters :566-585, coalescence :44-59)
+  const int n_coll = s_ncoll;
+  for (int base = 0; base < n_coll; base += CELL2_THREADS) {
+    const int t = base + tid;
+    const bool act = t < n_coll;
+    int lp = 0;
+    double g = 0;
+    int64_t j = 0, k = 0, gi = 0, gc = 0;
+    SD sj, sk;
+    sj.n = sk.n = 1; sj.m = sk.m = sj.r = sk.r = sj.u = sk.u = 0;
+    if (act) {
+      lp = list_lp[t];
+      g = list_g[t];
+      j = out[lp];
+      k = out[lp + 1];
+      sj = sd_load(cfg, A, j, need_r);
+      sk = sd_load(cfg, A, k, need_r);
+      const int64_t prop = sj.n / sk.n;
+      gi = (int64_t)g;
+      gc = gi < prop ? gi : prop;
+      g = (double)gc;
+    }
+    counter_add(A, CNT_COLLISION, cid, gc * sk.n, act);
+    counter_add(A, CNT_COLLISION_DEFICIT, cid, (gi - gc) * sk.n, act);
+    const bool coal = act && g != 0;
+    counter_add(A, CNT_COALESCENCE, cid, (int64_t)(g * (double)sk.n), coal);
+    const int died = coal ? coalesce_known(cfg, A, j, k, g, sj, sk) : 0;
+    if (died & 1) out[lp] = (int32_t)N;  // the permutation is still in LDS here
+    if (died & 2) out[lp + 1] = (int32_t)N;
+  }
+  __syncthreads();
+  for (int li = tid; li < n; li += CELL2_THREADS) X.idx_out[lo + li] = out[li];
+}
+
 // largest cell of a sorted state -> ctl[6]
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_max_cell(const int64_t *__restrict__ cell_start, int64_t n_cell, int64_t *ctl) {
@@ -1550,6 +1817,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   }
   ctx->carry.active = false;
   const bool cell_path = max_cell >= 0 && max_cell <= CELL_CAP;
+  // two workgroups per CU where the kernel for it applies (see k_cell_step2)
+  const bool cell2 = cell_path && max_cell <= CELL2_CAP && !cfg->enable_breakup && cfg->n_attr == 1;
   if (fill_pending && C > 1 && !cell_path) {  // the per-cell route's k_cells_begin does it itself
     hipLaunchKernelGGL(k_fill_f64, dim3(grid_for(C)), blk, 0, s, st->dt_left, cfg->dt, C);
     LAUNCH_CHECK();
@@ -1568,6 +1837,12 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       CELL_ATTR(SDM_KERNEL_SIMPLE_GEOMETRIC, false); CELL_ATTR(SDM_KERNEL_SIMPLE_GEOMETRIC, true);
       CELL_ATTR(SDM_KERNEL_LINEAR, false); CELL_ATTR(SDM_KERNEL_LINEAR, true);
 #undef CELL_ATTR
+#define CELL2_ATTR(K) HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K>, \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, CELL2_LDS_BYTES))
+      CELL2_ATTR(SDM_KERNEL_GOLOVIN); CELL2_ATTR(SDM_KERNEL_GEOMETRIC);
+      CELL2_ATTR(SDM_KERNEL_CONSTANT); CELL2_ATTR(SDM_KERNEL_PARAMETERIZED);
+      CELL2_ATTR(SDM_KERNEL_SIMPLE_GEOMETRIC); CELL2_ATTR(SDM_KERNEL_LINEAR);
+#undef CELL2_ATTR
       attr_done = true;
     }
   }
@@ -1633,6 +1908,28 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       off_b = ctx->ahead.off_b_before;
     }
   }
+  auto launch_cell_kernel = [&](const CellArgs &X) -> int {
+    PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
+    const bool brk = cfg->enable_breakup != 0;
+    const dim3 grid((unsigned)(C + X.n_tail_blocks));
+#define CELL_LAUNCH(K)                                                                        \
+  do {                                                                                        \
+    if (cell2) hipLaunchKernelGGL((k_cell_step2<K>), grid, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
+    else if (brk) hipLaunchKernelGGL((k_cell_step<K, true>), grid, dim3(CELL_THREADS), CELL_LDS_BYTES, s, *cfg, A, X); \
+    else hipLaunchKernelGGL((k_cell_step<K, false>), grid, dim3(CELL_THREADS), CELL_LDS_BYTES, s, *cfg, A, X);    \
+  } while (0)
+    switch (cfg->kernel) {
+      case SDM_KERNEL_GOLOVIN: CELL_LAUNCH(SDM_KERNEL_GOLOVIN); break;
+      case SDM_KERNEL_GEOMETRIC: CELL_LAUNCH(SDM_KERNEL_GEOMETRIC); break;
+      case SDM_KERNEL_PARAMETERIZED: CELL_LAUNCH(SDM_KERNEL_PARAMETERIZED); break;
+      case SDM_KERNEL_SIMPLE_GEOMETRIC: CELL_LAUNCH(SDM_KERNEL_SIMPLE_GEOMETRIC); break;
+      case SDM_KERNEL_LINEAR: CELL_LAUNCH(SDM_KERNEL_LINEAR); break;
+      default: CELL_LAUNCH(SDM_KERNEL_CONSTANT);
+    }
+#undef CELL_LAUNCH
+    LAUNCH_CHECK();
+    return SDM_OK;
+  };
   // Multi-cell per-cell route, adaptive: the same idea with a device-side gate.  Sub-step k + 1
   // is launched before the host waits for the control block of sub-step k; its first kernel
   // (k_cells_begin) looks at what k left - work to do and no compaction (state still sorted) - and
@@ -1666,24 +1963,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       X.gate = S.end2 + 3;
       A.idx = alt;
       {
-        PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
-        const dim3 grid((unsigned)(C + X.n_tail_blocks)), cblk(CELL_THREADS);
-        const bool brk = cfg->enable_breakup != 0;
-#define CELL_LAUNCH(K)                                                                        \
-  do {                                                                                        \
-    if (brk) hipLaunchKernelGGL((k_cell_step<K, true>), grid, cblk, CELL_LDS_BYTES, s, *cfg, A, X); \
-    else hipLaunchKernelGGL((k_cell_step<K, false>), grid, cblk, CELL_LDS_BYTES, s, *cfg, A, X);    \
-  } while (0)
-        switch (cfg->kernel) {
-          case SDM_KERNEL_GOLOVIN: CELL_LAUNCH(SDM_KERNEL_GOLOVIN); break;
-          case SDM_KERNEL_GEOMETRIC: CELL_LAUNCH(SDM_KERNEL_GEOMETRIC); break;
-          case SDM_KERNEL_PARAMETERIZED: CELL_LAUNCH(SDM_KERNEL_PARAMETERIZED); break;
-          case SDM_KERNEL_SIMPLE_GEOMETRIC: CELL_LAUNCH(SDM_KERNEL_SIMPLE_GEOMETRIC); break;
-          case SDM_KERNEL_LINEAR: CELL_LAUNCH(SDM_KERNEL_LINEAR); break;
-          default: CELL_LAUNCH(SDM_KERNEL_CONSTANT);
-        }
-#undef CELL_LAUNCH
-        LAUNCH_CHECK();
+        const int r = launch_cell_kernel(X);
+        if (r) return r;
       }
       { int64_t *t = cur; cur = alt; alt = t; }
       ++swaps;
@@ -1817,24 +2098,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       X.gate = nullptr;
       A.idx = alt;
       {
-        PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
-        const dim3 grid((unsigned)(C + X.n_tail_blocks)), cblk(CELL_THREADS);
-        const bool brk = cfg->enable_breakup != 0;
-#define CELL_LAUNCH(K)                                                                        \
-  do {                                                                                        \
-    if (brk) hipLaunchKernelGGL((k_cell_step<K, true>), grid, cblk, CELL_LDS_BYTES, s, *cfg, A, X); \
-    else hipLaunchKernelGGL((k_cell_step<K, false>), grid, cblk, CELL_LDS_BYTES, s, *cfg, A, X);    \
-  } while (0)
-        switch (cfg->kernel) {
-          case SDM_KERNEL_GOLOVIN: CELL_LAUNCH(SDM_KERNEL_GOLOVIN); break;
-          case SDM_KERNEL_GEOMETRIC: CELL_LAUNCH(SDM_KERNEL_GEOMETRIC); break;
-          case SDM_KERNEL_PARAMETERIZED: CELL_LAUNCH(SDM_KERNEL_PARAMETERIZED); break;
-          case SDM_KERNEL_SIMPLE_GEOMETRIC: CELL_LAUNCH(SDM_KERNEL_SIMPLE_GEOMETRIC); break;
-          case SDM_KERNEL_LINEAR: CELL_LAUNCH(SDM_KERNEL_LINEAR); break;
-          default: CELL_LAUNCH(SDM_KERNEL_CONSTANT);
-        }
-#undef CELL_LAUNCH
-        LAUNCH_CHECK();
+        const int r = launch_cell_kernel(X);
+        if (r) return r;
       }
       { int64_t *t = cur; cur = alt; alt = t; }
       ++swaps;
