@@ -227,6 +227,35 @@ def test_multicell_breakup_equals_oracle(base, adaptive, hip_backend_class, orac
             np.testing.assert_array_equal(value, ref, err_msg=key)
 
 
+@pytest.mark.parametrize("n_sd,which", [(4 * 5850, "one workgroup per CU"),
+                                        (4 * 4000, "two workgroups per CU")])
+def test_both_per_cell_kernels_equal_oracle(n_sd, which, hip_backend_class, oracle_backend_class):
+    """2 x 2 cells of ~5850 super-droplets take k_cell_step (cells above k_cell_step2's 5632),
+    cells of ~4000 take k_cell_step2: adaptive geometric coalescence with optimized_random,
+    state and counters equal the oracle's"""
+    from pysdm_amd.examples import CONFIGS, make_box  # pylint: disable=import-outside-toplevel
+
+    CONFIGS["_grid_2x2"] = dict(CONFIGS["kinematic2d"], grid=(2, 2))
+    try:
+        snaps = []
+        for backend_class in (hip_backend_class, oracle_backend_class):
+            particulator, dynamic = make_box(backend_class, "_grid_2x2", n_sd=n_sd)
+            for steps in (1, 8, 2):
+                particulator.run(steps)
+            snaps.append(snapshot(particulator, dynamic))
+    finally:
+        del CONFIGS["_grid_2x2"]
+    sizes = np.diff(snaps[1]["cell_start"])
+    assert (sizes.max() > 5632) == (which == "one workgroup per CU") and sizes.max() <= 6144
+    length = int(snaps[0]["length"])
+    assert snaps[1]["collision_rate"].sum() > 0
+    for key, value in snaps[0].items():
+        ref = snaps[1][key]
+        if key == "idx":
+            value, ref = value[:length], ref[:length]
+        np.testing.assert_array_equal(value, ref, err_msg=key)
+
+
 def test_degenerate_sizes_through_the_abi(kit):
     """empty and tiny inputs: zero-length arrays are accepted by every entry point that takes a
     length, two super-droplets form one pair, three leave one alone, a null context is refused"""
