@@ -52,6 +52,7 @@ struct sdm_ctx {
     uint64_t off_before, off_b_before;  // stream positions to return to if it is discarded
     u128 s_rand, s_rand_b;
     const void *rec, *ovf_head, *ovf_next;
+    int rec_fmt;
     int64_t *cur, *alt;  // permutation buffers as its kernels left them (cur: written)
   } ahead;
   // device control words for fine-grained calls (int64[16])

@@ -59,7 +59,8 @@ struct FusedArgs {
   int n_block_min;
   // single-cell fast path: the pair kernels do the shuffle's backward walk themselves (two
   // positions per thread) and write the permuted, pair-sorted idx once; NULL otherwise
-  const PackRec *rec;
+  const void *rec;  // records of layout rec_fmt (shuffle_device.h: SDM_REC_*)
+  int rec_fmt;
   const int32_t *ovf_head, *ovf_next;
   const int64_t *idx_prev;  // previous permutation (source of the dead tail)
   // {multiplicity, mass} of each super-droplet side by side (one random line per gather instead
@@ -422,12 +423,26 @@ __device__ __forceinline__ PairInfo pair_prob_body(const sdm_step_cfg &cfg, cons
     if (2 * d + 1 < W) { R.have = true; i = 2 * d; }
     if (A.rec) {  // permutation resolved here (shuffle_local of the single cell [0, W))
       if (R.have) {
-        walk_packed2(A.rec, A.ovf_head, A.ovf_next, (int32_t)(2 * d), (int32_t)(2 * d + 1), 0, tj,
-                     tk);
+        if (A.rec_fmt == SDM_REC_P21) {
+          PackRec21 fj, fk;
+          walk_packed2((const PackRec21 *)A.rec, A.ovf_head, A.ovf_next, (int32_t)(2 * d),
+                       (int32_t)(2 * d + 1), 0, fj, fk);
+          tj = rec_id(fj); tk = rec_id(fk);
+        } else {
+          PackRec fj, fk;
+          walk_packed2((const PackRec *)A.rec, A.ovf_head, A.ovf_next, (int32_t)(2 * d),
+                       (int32_t)(2 * d + 1), 0, fj, fk);
+          tj = rec_id(fj); tk = rec_id(fk);
+        }
       } else {
         for (int o = 0; o < 2; ++o) {  // unpaired last position / dead tail
           const int64_t p = 2 * d + o;
-          if (p < W) A.idx[p] = walk_packed(A.rec, A.ovf_head, A.ovf_next, (int32_t)p, 0);
+          if (p < W)
+            A.idx[p] = A.rec_fmt == SDM_REC_P21
+                           ? rec_id(walk_packed((const PackRec21 *)A.rec, A.ovf_head, A.ovf_next,
+                                                (int32_t)p, 0))
+                           : rec_id(walk_packed((const PackRec *)A.rec, A.ovf_head, A.ovf_next,
+                                                (int32_t)p, 0));
           else if (p < cfg.n_sd) A.idx[p] = A.idx_prev[p];
         }
       }
@@ -1870,9 +1885,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     ShuffleViews views;
     const int r = sdm_shuffle_build_async(ctx, S.shuffle, cur, st->cell_start, C,
                                           st->cell_start + C, N, cfg->rng_state_inc, draw_off,
-                                          &views);
+                                          &views, N);
     if (r) return r;
     A.rec = views.rec;
+    A.rec_fmt = views.fmt;
     A.ovf_head = views.ovf_head;
     A.ovf_next = views.ovf_next;
     A.idx_prev = cur;
@@ -1894,7 +1910,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         ctx->ahead.cur == st->tmp_idx && ctx->ahead.alt == st->idx) {
       A.s_rand = ctx->ahead.s_rand;
       A.s_rand_b = ctx->ahead.s_rand_b;
-      A.rec = (const PackRec *)ctx->ahead.rec;
+      A.rec = ctx->ahead.rec;
+      A.rec_fmt = ctx->ahead.rec_fmt;
       A.ovf_head = (const int32_t *)ctx->ahead.ovf_head;
       A.ovf_next = (const int32_t *)ctx->ahead.ovf_next;
       cur = ctx->ahead.cur;
@@ -2107,9 +2124,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       // single cell: event records only; the pair kernels walk them (2 positions per thread)
       ShuffleViews views;
       rc = sdm_shuffle_build_async(ctx, S.shuffle, cur, st->cell_start, C, p_shuffle_len, N,
-                                   cfg->rng_state_inc, u01_off, &views);
+                                   cfg->rng_state_inc, u01_off, &views, N);
       if (rc) return rc;
       A.rec = views.rec;
+      A.rec_fmt = views.fmt;
       A.ovf_head = views.ovf_head;
       A.ovf_next = views.ovf_next;
       A.idx_prev = cur;
@@ -2243,6 +2261,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     ctx->ahead.s_rand = A.s_rand;
     ctx->ahead.s_rand_b = A.s_rand_b;
     ctx->ahead.rec = A.rec;
+    ctx->ahead.rec_fmt = A.rec_fmt;
     ctx->ahead.ovf_head = A.ovf_head;
     ctx->ahead.ovf_next = A.ovf_next;
     ctx->ahead.cur = cur;

@@ -166,7 +166,7 @@ static bool binned_ok(int64_t n, bool global);
 static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *idx0,
                                 const double *u01, const int64_t *cell_start, int64_t n_cell,
                                 const int64_t *p_length, int64_t length_bound, int64_t n_total,
-                                u128 s_off, u128 inc, ShuffleViews *views);
+                                u128 s_off, u128 inc, ShuffleViews *views, int64_t id_bound = -1);
 
 // out-of-place core: out[0:length) = shuffled idx0[0:length), out[length:n_total) = idx0[...].
 // u01 == nullptr: draws generated in the kernel from (rng_state_inc, rng_offset).
@@ -453,43 +453,56 @@ k_bin_scatter(int2 *__restrict__ events, const int32_t *__restrict__ pre,
   for (int t = threadIdx.x; t < n_ev; t += BIN_THREADS) events[gdst[t]] = ev_buf[t];
 }
 
-// K4: one workgroup per bin (BIN_POS positions): assemble and write its records
+// K4: one workgroup per bin (BIN_POS positions): assemble and write its records.
+// P21: 21-bit fields with four inline hits (shuffle_device.h)
+template <bool P21>
 __global__ void __launch_bounds__(BIN_THREADS)
-k_bin_build(PackRec *__restrict__ rec, int32_t *__restrict__ ovf_head,
+k_bin_build(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
             int32_t *__restrict__ ovf_next, const int2 *__restrict__ events,
             const int32_t *__restrict__ total, const int32_t *__restrict__ jarr, int n_bins,
             const int64_t *__restrict__ idx0, const int64_t *__restrict__ p_length,
             int64_t length_arg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int32_t *start = (int32_t *)smem;                // n_bins + 1
-  int32_t *s0 = start + ((n_bins + 1 + 3) & ~3);   // BIN_POS each below
-  int32_t *s1 = s0 + BIN_POS, *head = s1 + BIN_POS;
+  constexpr int SLOTS = P21 ? 4 : 2;
+  int32_t *start = (int32_t *)smem;                 // n_bins + 1
+  int32_t *slot = start + ((n_bins + 1 + 3) & ~3);  // SLOTS x BIN_POS, then BIN_POS list heads
+  int32_t *head = slot + SLOTS * BIN_POS;
   const int64_t length = p_length ? *p_length : length_arg;
   const int64_t base = (int64_t)blockIdx.x * BIN_POS;
   if (base >= length) return;
   bin_starts(total, n_bins, start);
-  for (int q = threadIdx.x; q < BIN_POS; q += BIN_THREADS) { s0[q] = -1; s1[q] = -1; head[q] = -1; }
+  for (int q = threadIdx.x; q < (SLOTS + 1) * BIN_POS; q += BIN_THREADS) slot[q] = -1;
   __syncthreads();
-  // hits on this bin's positions: first two inline (claimed by compare-and-swap), rest listed
+  // hits on this bin's positions: the first SLOTS inline (claimed by compare-and-swap), rest listed
   const int ev_first = start[blockIdx.x], ev_last = start[blockIdx.x + 1];
   for (int t = ev_first + threadIdx.x; t < ev_last; t += BIN_THREADS) {
     const int2 ev = events[t];
     const int q = ev.y - (int)base;
-    if (atomicCAS(&s0[q], -1, ev.x) != -1)
-      if (atomicCAS(&s1[q], -1, ev.x) != -1)
-        ovf_next[ev.x] = atomicExch(&head[q], ev.x);  // -1 terminated, built entirely here
+    bool placed = false;
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k)
+      if (!placed) placed = atomicCAS(&slot[k * BIN_POS + q], -1, ev.x) == -1;
+    if (!placed) ovf_next[ev.x] = atomicExch(&head[q], ev.x);  // -1 terminated, built entirely here
   }
   __syncthreads();
   for (int q = threadIdx.x; q < BIN_POS; q += BIN_THREADS) {
     const int64_t p = base + q;
     if (p >= length) break;
     const int32_t h = head[q];
-    PackRec r;
-    r.j = jarr[p];
-    r.s0 = s0[q];
-    r.s1 = s1[q];
-    r.val = (int32_t)idx0[p] | (h >= 0 ? (int32_t)0x80000000 : 0);
-    rec[p] = r;
+    const int32_t id = (int32_t)idx0[p];
+    if (P21) {
+      PackRec21 r;
+      p21_pack(r.lo, r.hi, jarr[p], slot[q], slot[BIN_POS + q], slot[2 * BIN_POS + q],
+               slot[3 * BIN_POS + q], id, h >= 0);
+      ((PackRec21 *)rec_out)[p] = r;
+    } else {
+      PackRec r;
+      r.j = jarr[p];
+      r.s0 = slot[q];
+      r.s1 = slot[BIN_POS + q];
+      r.val = id | (h >= 0 ? (int32_t)0x80000000 : 0);
+      ((PackRec *)rec_out)[p] = r;
+    }
     if (h >= 0) ovf_head[p] = h;
   }
 }
@@ -508,7 +521,7 @@ k_trace_packed(int64_t *__restrict__ out, const int64_t *__restrict__ idx0,
     return;
   }
   const int64_t c = n_cell == 1 ? 0 : find_cell(cell_start, n_cell, p);
-  out[p] = walk_packed(rec, ovf_head, ovf_next, (int32_t)p, (int32_t)cell_start[c]);
+  out[p] = rec_id(walk_packed(rec, ovf_head, ovf_next, (int32_t)p, (int32_t)cell_start[c]));
 }
 
 static int bin_count(int64_t n) { return (int)((n + BIN_POS - 1) / BIN_POS); }
@@ -528,7 +541,9 @@ static bool binned_ok(int64_t n, bool global) { return !global && n >= 2 && bin_
 static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *idx0,
                                 const double *u01, const int64_t *cell_start, int64_t n_cell,
                                 const int64_t *p_length, int64_t length_bound, int64_t n_total,
-                                u128 s_off, u128 inc, ShuffleViews *views) {
+                                u128 s_off, u128 inc, ShuffleViews *views, int64_t id_bound) {
+  // id_bound: the ids in idx0 are below it (-1: unknown); decides the record layout
+  const bool p21 = id_bound >= 0 && id_bound <= P21_MAX && length_bound <= P21_MAX;
   Carver cv(scratch);
   const int nb = bin_count(length_bound), nt = ev_tile_count(length_bound);
   PackRec *rec = cv.take<PackRec>(length_bound);
@@ -542,12 +557,14 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
   const size_t lds_hist = sizeof(int32_t) * (size_t)(nb + 1);
   const size_t lds_scatter = sizeof(int32_t) * (size_t)(2 * (nb + 1) + ((nb + 1) & ~1)) +
                              (sizeof(int2) + sizeof(int32_t)) * EV_TILE;
-  const size_t lds_build = sizeof(int32_t) * (size_t)(((nb + 1 + 3) & ~3) + 3 * BIN_POS);
+  const size_t lds_build =
+      sizeof(int32_t) * (size_t)(((nb + 1 + 3) & ~3) + (p21 ? 5 : 3) * BIN_POS);
   if (lds_scatter > 65536)  // gfx950 has 160 KiB of LDS per CU; > 64 KiB dynamic needs opting in
     HIP_TRY(hipFuncSetAttribute((const void *)k_bin_scatter,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scatter));
   if (lds_build > 65536)
-    HIP_TRY(hipFuncSetAttribute((const void *)k_bin_build,
+    HIP_TRY(hipFuncSetAttribute(p21 ? (const void *)k_bin_build<true>
+                                    : (const void *)k_bin_build<false>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
   {
     PhaseScope ph(ctx, SDM_PHASE_SHUFFLE_BUILD);
@@ -562,12 +579,17 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
     hipLaunchKernelGGL(k_bin_colscan, dim3(nb), block, 0, ctx->stream, cnt, total, nb, nt);
     hipLaunchKernelGGL(k_bin_scatter, dim3(nt), block, lds_scatter, ctx->stream, events, cnt,
                        total, jarr, nb, p_length, length_bound);
-    hipLaunchKernelGGL(k_bin_build, dim3(nb), block, lds_build, ctx->stream, rec, ovf_head,
-                       ovf_next, events, total, jarr, nb, idx0, p_length, length_bound);
+    if (p21)
+      hipLaunchKernelGGL(k_bin_build<true>, dim3(nb), block, lds_build, ctx->stream, (void *)rec,
+                         ovf_head, ovf_next, events, total, jarr, nb, idx0, p_length, length_bound);
+    else
+      hipLaunchKernelGGL(k_bin_build<false>, dim3(nb), block, lds_build, ctx->stream, (void *)rec,
+                         ovf_head, ovf_next, events, total, jarr, nb, idx0, p_length, length_bound);
     LAUNCH_CHECK();
   }
   if (views) {  // build only: the caller's kernels do the walk
     views->rec = rec;
+    views->fmt = p21 ? SDM_REC_P21 : SDM_REC_PLAIN;
     views->ovf_head = ovf_head;
     views->ovf_next = ovf_next;
     return SDM_OK;
@@ -589,14 +611,14 @@ bool sdm_shuffle_can_split(int64_t n, bool global) { return binned_ok(n, global)
 int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
                             const int64_t *cell_start, int64_t n_cell, const int64_t *p_length,
                             int64_t length_bound, const uint64_t *rng_state_inc,
-                            uint64_t rng_offset, ShuffleViews *views) {
+                            uint64_t rng_offset, ShuffleViews *views, int64_t id_bound) {
   int rc = sdm_pcg_prepare(ctx, rng_state_inc);
   if (rc) return rc;
   const u128 st = (((u128)rng_state_inc[0]) << 64) | rng_state_inc[1];
   const u128 inc = (((u128)rng_state_inc[2]) << 64) | rng_state_inc[3];
   const u128 s_off = sdm_pcg_advance_host(st, inc, rng_offset);
   return shuffle_binned_async(ctx, scratch, nullptr, idx0, nullptr, cell_start, n_cell, p_length,
-                              length_bound, 0, s_off, inc, views);
+                              length_bound, 0, s_off, inc, views, id_bound);
 }
 
 size_t sdm_shuffle_scratch(int64_t n) {

@@ -2,79 +2,124 @@
 #pragma once
 #include "common.h"
 
-// own target j (-1: none), first / second hitting event (-1: none), initial content of the
-// position (int32) with bit 31 = "further hits in the overflow list"
+// Record of one position: own target j (-1: none), the first hitting events inline (-1: none),
+// initial content of the position (its super-droplet id) and a flag "further hits in the
+// overflow list".  Four layouts:
+//   PackRec     16 B: j, 2 inline hits, id | flag in bit 31                      (any size)
+//   PackRec21   16 B: 21-bit fields - j, 4 inline hits, id, flag    (positions and ids < 2^21 - 1)
+// A position is hit by Poisson(1) events: 8 % of them overflow two inline slots, 0.4 % four.  An
+// overflow costs a walk two or more *dependent* loads (list head, links) on top of the record's,
+// and a wavefront walks 128 positions per round - with two slots nearly every round of every
+// wavefront waited for such a chain (k_pair_all 74 us, 53 us with the lists ignored); hence the
+// packed layout wherever it fits.
 struct __align__(16) PackRec { int32_t j, s0, s1, val; };
+struct __align__(16) PackRec21 { uint64_t lo, hi; };
+#define P21_NONE 0x1FFFFFu
+#define P21_MAX 0x1FFFFE  // largest count of positions / ids the packed layout holds
+
+#define SDM_REC_PLAIN 0
+#define SDM_REC_P21 1
 
 struct ShuffleViews {
-  const PackRec *rec;
+  const void *rec;  // array of the record type `fmt` names
+  int fmt;
   const int32_t *ovf_head, *ovf_next;
 };
 
 #ifdef __HIPCC__
-// content of position p after the whole swap chain of its cell (cell starts at position `lo`):
-// walk the swap history backwards (see index.hip)
-__device__ __forceinline__ int64_t walk_packed(const PackRec *__restrict__ rec,
-                                               const int32_t *__restrict__ ovf_head,
-                                               const int32_t *__restrict__ ovf_next, int32_t p,
-                                               int32_t lo) {
+// lo: j [0,21) s0 [21,42) s1 [42,63) flag [63]; hi: s2 [0,21) s3 [21,42) id [42,63)
+__device__ __forceinline__ void p21_pack(uint64_t &lo, uint64_t &hi, int32_t j, int32_t s0,
+                                         int32_t s1, int32_t s2, int32_t s3, int32_t id,
+                                         bool more) {
+  lo = ((uint64_t)((uint32_t)j & P21_NONE)) | ((uint64_t)((uint32_t)s0 & P21_NONE) << 21) |
+       ((uint64_t)((uint32_t)s1 & P21_NONE) << 42) | ((uint64_t)(more ? 1 : 0) << 63);
+  hi = ((uint64_t)((uint32_t)s2 & P21_NONE)) | ((uint64_t)((uint32_t)s3 & P21_NONE) << 21) |
+       ((uint64_t)(uint32_t)id << 42);
+}
+__device__ __forceinline__ int32_t p21_field(uint64_t w, int shift) {
+  const uint32_t f = (uint32_t)(w >> shift) & P21_NONE;
+  return f == P21_NONE ? -1 : (int32_t)f;
+}
+
+// uniform view of a record for the walk: own target, up to four inline hits, overflow flag, id
+struct RecView { int32_t j, h0, h1, h2, h3; bool more; };
+__device__ __forceinline__ RecView rec_view(const PackRec &r) {
+  return {r.j, r.s0, r.s1, -1, -1, r.val < 0};
+}
+__device__ __forceinline__ RecView rec_view(const PackRec21 &r) {
+  return {p21_field(r.lo, 0), p21_field(r.lo, 21), p21_field(r.lo, 42), p21_field(r.hi, 0),
+          p21_field(r.hi, 21), (r.lo >> 63) != 0};
+}
+__device__ __forceinline__ int64_t rec_id(const PackRec &r) { return r.val & 0x7fffffff; }
+__device__ __forceinline__ int64_t rec_id(const PackRec21 &r) { return (int64_t)(r.hi >> 42); }
+
+// the event that moved the content of position q last before event e (index.hip): smallest
+// event index > e among q's own event and the events that hit q; INT32_MAX if none
+__device__ __forceinline__ int32_t walk_next(const RecView &v, int32_t q, int32_t e,
+                                             const int32_t *__restrict__ ovf_head,
+                                             const int32_t *__restrict__ ovf_next) {
+  int32_t best = INT32_MAX;
+  if (q > e && v.j >= 0) best = q;
+  if (v.h0 > e && v.h0 < best) best = v.h0;
+  if (v.h1 > e && v.h1 < best) best = v.h1;
+  if (v.h2 > e && v.h2 < best) best = v.h2;
+  if (v.h3 > e && v.h3 < best) best = v.h3;
+  if (v.more)
+    for (int32_t t = ovf_head[q]; t >= 0; t = ovf_next[t])
+      if (t > e && t < best) best = t;
+  return best;
+}
+
+// the record at which the walk from position p ends: it names the content of p after the whole
+// swap chain of its cell (cell starts at position `lo`)
+template <class REC>
+__device__ __forceinline__ REC walk_packed(const REC *__restrict__ rec,
+                                           const int32_t *__restrict__ ovf_head,
+                                           const int32_t *__restrict__ ovf_next, int32_t p,
+                                           int32_t lo) {
   int32_t e = lo, q = p;  // only events with index > e are still "in the past" of the walk
-  PackRec r;
+  REC r;
   for (;;) {
     r = rec[q];
-    int32_t best = INT32_MAX;
-    if (q > e && r.j >= 0) best = q;
-    if (r.s0 > e && r.s0 < best) best = r.s0;
-    if (r.s1 > e && r.s1 < best) best = r.s1;
-    if (r.val < 0)
-      for (int32_t t = ovf_head[q]; t >= 0; t = ovf_next[t])
-        if (t > e && t < best) best = t;
+    const RecView v = rec_view(r);
+    const int32_t best = walk_next(v, q, e, ovf_head, ovf_next);
     if (best == INT32_MAX) break;
     // event `best` exchanged positions (best, j_best); q is one end, continue at the other
-    q = (best == q) ? r.j : best;
+    q = (best == q) ? v.j : best;
     e = best;
   }
-  return (int64_t)(r.val & 0x7fffffff);
+  return r;
 }
 
 // two walks advanced in lockstep: both record loads of a round are in flight together
-__device__ __forceinline__ void walk_packed2(const PackRec *__restrict__ rec,
+template <class REC>
+__device__ __forceinline__ void walk_packed2(const REC *__restrict__ rec,
                                              const int32_t *__restrict__ ovf_head,
                                              const int32_t *__restrict__ ovf_next, int32_t p0,
-                                             int32_t p1, int32_t lo, int64_t &v0, int64_t &v1) {
+                                             int32_t p1, int32_t lo, REC &f0, REC &f1) {
   int32_t e0 = lo, q0 = p0, e1 = lo, q1 = p1;
   bool done0 = false, done1 = false;
-  PackRec r0 = rec[q0], r1 = rec[q1];
+  REC r0 = rec[q0], r1 = rec[q1];
   for (;;) {
     if (!done0) {
-      int32_t best = INT32_MAX;
-      if (q0 > e0 && r0.j >= 0) best = q0;
-      if (r0.s0 > e0 && r0.s0 < best) best = r0.s0;
-      if (r0.s1 > e0 && r0.s1 < best) best = r0.s1;
-      if (r0.val < 0)
-        for (int32_t t = ovf_head[q0]; t >= 0; t = ovf_next[t])
-          if (t > e0 && t < best) best = t;
-      if (best == INT32_MAX) { done0 = true; } else { q0 = (best == q0) ? r0.j : best; e0 = best; }
+      const RecView v = rec_view(r0);
+      const int32_t best = walk_next(v, q0, e0, ovf_head, ovf_next);
+      if (best == INT32_MAX) { done0 = true; } else { q0 = (best == q0) ? v.j : best; e0 = best; }
     }
     if (!done1) {
-      int32_t best = INT32_MAX;
-      if (q1 > e1 && r1.j >= 0) best = q1;
-      if (r1.s0 > e1 && r1.s0 < best) best = r1.s0;
-      if (r1.s1 > e1 && r1.s1 < best) best = r1.s1;
-      if (r1.val < 0)
-        for (int32_t t = ovf_head[q1]; t >= 0; t = ovf_next[t])
-          if (t > e1 && t < best) best = t;
-      if (best == INT32_MAX) { done1 = true; } else { q1 = (best == q1) ? r1.j : best; e1 = best; }
+      const RecView v = rec_view(r1);
+      const int32_t best = walk_next(v, q1, e1, ovf_head, ovf_next);
+      if (best == INT32_MAX) { done1 = true; } else { q1 = (best == q1) ? v.j : best; e1 = best; }
     }
     if (done0 && done1) break;
     // next round: both loads issued back to back
-    PackRec n0 = r0, n1 = r1;
+    REC n0 = r0, n1 = r1;
     if (!done0) n0 = rec[q0];
     if (!done1) n1 = rec[q1];
     r0 = n0;
     r1 = n1;
   }
-  v0 = (int64_t)(r0.val & 0x7fffffff);
-  v1 = (int64_t)(r1.val & 0x7fffffff);
+  f0 = r0;
+  f1 = r1;
 }
 #endif
