@@ -423,26 +423,12 @@ __device__ __forceinline__ PairInfo pair_prob_body(const sdm_step_cfg &cfg, cons
     if (2 * d + 1 < W) { R.have = true; i = 2 * d; }
     if (A.rec) {  // permutation resolved here (shuffle_local of the single cell [0, W))
       if (R.have) {
-        if (A.rec_fmt == SDM_REC_P21) {
-          PackRec21 fj, fk;
-          walk_packed2((const PackRec21 *)A.rec, A.ovf_head, A.ovf_next, (int32_t)(2 * d),
-                       (int32_t)(2 * d + 1), 0, fj, fk);
-          tj = rec_id(fj); tk = rec_id(fk);
-        } else {
-          PackRec fj, fk;
-          walk_packed2((const PackRec *)A.rec, A.ovf_head, A.ovf_next, (int32_t)(2 * d),
-                       (int32_t)(2 * d + 1), 0, fj, fk);
-          tj = rec_id(fj); tk = rec_id(fk);
-        }
+        walk_ids2(A.rec, A.rec_fmt, A.ovf_head, A.ovf_next, (int32_t)(2 * d),
+                  (int32_t)(2 * d + 1), 0, tj, tk);
       } else {
         for (int o = 0; o < 2; ++o) {  // unpaired last position / dead tail
           const int64_t p = 2 * d + o;
-          if (p < W)
-            A.idx[p] = A.rec_fmt == SDM_REC_P21
-                           ? rec_id(walk_packed((const PackRec21 *)A.rec, A.ovf_head, A.ovf_next,
-                                                (int32_t)p, 0))
-                           : rec_id(walk_packed((const PackRec *)A.rec, A.ovf_head, A.ovf_next,
-                                                (int32_t)p, 0));
+          if (p < W) A.idx[p] = walk_id(A.rec, A.rec_fmt, A.ovf_head, A.ovf_next, (int32_t)p, 0);
           else if (p < cfg.n_sd) A.idx[p] = A.idx_prev[p];
         }
       }

@@ -454,8 +454,8 @@ k_bin_scatter(int2 *__restrict__ events, const int32_t *__restrict__ pre,
 }
 
 // K4: one workgroup per bin (BIN_POS positions): assemble and write its records.
-// P21: 21-bit fields with four inline hits (shuffle_device.h)
-template <bool P21>
+// FMT: record layout (shuffle_device.h: 2, 4 or 3 inline hits)
+template <int FMT>
 __global__ void __launch_bounds__(BIN_THREADS)
 k_bin_build(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
             int32_t *__restrict__ ovf_next, const int2 *__restrict__ events,
@@ -463,7 +463,7 @@ k_bin_build(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
             const int64_t *__restrict__ idx0, const int64_t *__restrict__ p_length,
             int64_t length_arg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int SLOTS = P21 ? 4 : 2;
+  constexpr int SLOTS = FMT == SDM_REC_P21 ? 4 : (FMT == SDM_REC_P24 ? 3 : 2);
   int32_t *start = (int32_t *)smem;                 // n_bins + 1
   int32_t *slot = start + ((n_bins + 1 + 3) & ~3);  // SLOTS x BIN_POS, then BIN_POS list heads
   int32_t *head = slot + SLOTS * BIN_POS;
@@ -490,11 +490,15 @@ k_bin_build(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
     if (p >= length) break;
     const int32_t h = head[q];
     const int32_t id = (int32_t)idx0[p];
-    if (P21) {
+    if (FMT == SDM_REC_P21) {
       PackRec21 r;
       p21_pack(r.lo, r.hi, jarr[p], slot[q], slot[BIN_POS + q], slot[2 * BIN_POS + q],
-               slot[3 * BIN_POS + q], id, h >= 0);
+               slot[(SLOTS - 1) * BIN_POS + q], id, h >= 0);
       ((PackRec21 *)rec_out)[p] = r;
+    } else if (FMT == SDM_REC_P24) {
+      PackRec24 r;
+      p24_pack(r.lo, r.hi, jarr[p], slot[q], slot[BIN_POS + q], slot[2 * BIN_POS + q], id, h >= 0);
+      ((PackRec24 *)rec_out)[p] = r;
     } else {
       PackRec r;
       r.j = jarr[p];
@@ -543,7 +547,10 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
                                 const int64_t *p_length, int64_t length_bound, int64_t n_total,
                                 u128 s_off, u128 inc, ShuffleViews *views, int64_t id_bound) {
   // id_bound: the ids in idx0 are below it (-1: unknown); decides the record layout
-  const bool p21 = id_bound >= 0 && id_bound <= P21_MAX && length_bound <= P21_MAX;
+  const int64_t both = id_bound > length_bound ? id_bound : length_bound;
+  const int fmt = id_bound < 0 ? SDM_REC_PLAIN
+                  : both <= P21_MAX ? SDM_REC_P21 : (both <= P24_MAX ? SDM_REC_P24 : SDM_REC_PLAIN);
+  const int slots = fmt == SDM_REC_P21 ? 4 : (fmt == SDM_REC_P24 ? 3 : 2);
   Carver cv(scratch);
   const int nb = bin_count(length_bound), nt = ev_tile_count(length_bound);
   PackRec *rec = cv.take<PackRec>(length_bound);
@@ -558,13 +565,14 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
   const size_t lds_scatter = sizeof(int32_t) * (size_t)(2 * (nb + 1) + ((nb + 1) & ~1)) +
                              (sizeof(int2) + sizeof(int32_t)) * EV_TILE;
   const size_t lds_build =
-      sizeof(int32_t) * (size_t)(((nb + 1 + 3) & ~3) + (p21 ? 5 : 3) * BIN_POS);
+      sizeof(int32_t) * (size_t)(((nb + 1 + 3) & ~3) + (slots + 1) * BIN_POS);
   if (lds_scatter > 65536)  // gfx950 has 160 KiB of LDS per CU; > 64 KiB dynamic needs opting in
     HIP_TRY(hipFuncSetAttribute((const void *)k_bin_scatter,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scatter));
   if (lds_build > 65536)
-    HIP_TRY(hipFuncSetAttribute(p21 ? (const void *)k_bin_build<true>
-                                    : (const void *)k_bin_build<false>,
+    HIP_TRY(hipFuncSetAttribute(fmt == SDM_REC_P21   ? (const void *)k_bin_build<SDM_REC_P21>
+                                : fmt == SDM_REC_P24 ? (const void *)k_bin_build<SDM_REC_P24>
+                                                     : (const void *)k_bin_build<SDM_REC_PLAIN>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
   {
     PhaseScope ph(ctx, SDM_PHASE_SHUFFLE_BUILD);
@@ -579,17 +587,18 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
     hipLaunchKernelGGL(k_bin_colscan, dim3(nb), block, 0, ctx->stream, cnt, total, nb, nt);
     hipLaunchKernelGGL(k_bin_scatter, dim3(nt), block, lds_scatter, ctx->stream, events, cnt,
                        total, jarr, nb, p_length, length_bound);
-    if (p21)
-      hipLaunchKernelGGL(k_bin_build<true>, dim3(nb), block, lds_build, ctx->stream, (void *)rec,
-                         ovf_head, ovf_next, events, total, jarr, nb, idx0, p_length, length_bound);
-    else
-      hipLaunchKernelGGL(k_bin_build<false>, dim3(nb), block, lds_build, ctx->stream, (void *)rec,
-                         ovf_head, ovf_next, events, total, jarr, nb, idx0, p_length, length_bound);
+#define BUILD_LAUNCH(F)                                                                        \
+  hipLaunchKernelGGL(k_bin_build<F>, dim3(nb), block, lds_build, ctx->stream, (void *)rec, ovf_head, \
+                     ovf_next, events, total, jarr, nb, idx0, p_length, length_bound)
+    if (fmt == SDM_REC_P21) BUILD_LAUNCH(SDM_REC_P21);
+    else if (fmt == SDM_REC_P24) BUILD_LAUNCH(SDM_REC_P24);
+    else BUILD_LAUNCH(SDM_REC_PLAIN);
+#undef BUILD_LAUNCH
     LAUNCH_CHECK();
   }
   if (views) {  // build only: the caller's kernels do the walk
     views->rec = rec;
-    views->fmt = p21 ? SDM_REC_P21 : SDM_REC_PLAIN;
+    views->fmt = fmt;
     views->ovf_head = ovf_head;
     views->ovf_next = ovf_next;
     return SDM_OK;

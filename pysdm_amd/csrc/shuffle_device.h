@@ -7,18 +7,24 @@
 // overflow list".  Four layouts:
 //   PackRec     16 B: j, 2 inline hits, id | flag in bit 31                      (any size)
 //   PackRec21   16 B: 21-bit fields - j, 4 inline hits, id, flag    (positions and ids < 2^21 - 1)
-// A position is hit by Poisson(1) events: 8 % of them overflow two inline slots, 0.4 % four.  An
+//   PackRec24   16 B: 24-bit fields - j, 3 inline hits, id, flag    (positions and ids < 2^24 - 1)
+// A position is hit by Poisson(1) events: 8 % of them overflow two inline slots, 1.9 % three,
+// 0.4 % four.  An
 // overflow costs a walk two or more *dependent* loads (list head, links) on top of the record's,
 // and a wavefront walks 128 positions per round - with two slots nearly every round of every
 // wavefront waited for such a chain (k_pair_all 74 us, 53 us with the lists ignored); hence the
 // packed layout wherever it fits.
 struct __align__(16) PackRec { int32_t j, s0, s1, val; };
 struct __align__(16) PackRec21 { uint64_t lo, hi; };
+struct __align__(16) PackRec24 { uint64_t lo, hi; };
 #define P21_NONE 0x1FFFFFu
 #define P21_MAX 0x1FFFFE  // largest count of positions / ids the packed layout holds
 
+#define P24_NONE 0xFFFFFFu
+#define P24_MAX 0xFFFFFE
 #define SDM_REC_PLAIN 0
 #define SDM_REC_P21 1
+#define SDM_REC_P24 2
 
 struct ShuffleViews {
   const void *rec;  // array of the record type `fmt` names
@@ -41,6 +47,19 @@ __device__ __forceinline__ int32_t p21_field(uint64_t w, int shift) {
   return f == P21_NONE ? -1 : (int32_t)f;
 }
 
+// lo: j [0,24) s0 [24,48) id bits 0-14 [48,63) flag [63]; hi: s1 [0,24) s2 [24,48) id bits 15-23 [48,57)
+__device__ __forceinline__ void p24_pack(uint64_t &lo, uint64_t &hi, int32_t j, int32_t s0,
+                                         int32_t s1, int32_t s2, int32_t id, bool more) {
+  lo = ((uint64_t)((uint32_t)j & P24_NONE)) | ((uint64_t)((uint32_t)s0 & P24_NONE) << 24) |
+       ((uint64_t)((uint32_t)id & 0x7FFFu) << 48) | ((uint64_t)(more ? 1 : 0) << 63);
+  hi = ((uint64_t)((uint32_t)s1 & P24_NONE)) | ((uint64_t)((uint32_t)s2 & P24_NONE) << 24) |
+       ((uint64_t)((uint32_t)id >> 15) << 48);
+}
+__device__ __forceinline__ int32_t p24_field(uint64_t w, int shift) {
+  const uint32_t f = (uint32_t)(w >> shift) & P24_NONE;
+  return f == P24_NONE ? -1 : (int32_t)f;
+}
+
 // uniform view of a record for the walk: own target, up to four inline hits, overflow flag, id
 struct RecView { int32_t j, h0, h1, h2, h3; bool more; };
 __device__ __forceinline__ RecView rec_view(const PackRec &r) {
@@ -49,6 +68,13 @@ __device__ __forceinline__ RecView rec_view(const PackRec &r) {
 __device__ __forceinline__ RecView rec_view(const PackRec21 &r) {
   return {p21_field(r.lo, 0), p21_field(r.lo, 21), p21_field(r.lo, 42), p21_field(r.hi, 0),
           p21_field(r.hi, 21), (r.lo >> 63) != 0};
+}
+__device__ __forceinline__ RecView rec_view(const PackRec24 &r) {
+  return {p24_field(r.lo, 0), p24_field(r.lo, 24), p24_field(r.hi, 0), p24_field(r.hi, 24), -1,
+          (r.lo >> 63) != 0};
+}
+__device__ __forceinline__ int64_t rec_id(const PackRec24 &r) {
+  return (int64_t)((r.lo >> 48) & 0x7FFFu) | (int64_t)(((r.hi >> 48) & 0x1FFu) << 15);
 }
 __device__ __forceinline__ int64_t rec_id(const PackRec &r) { return r.val & 0x7fffffff; }
 __device__ __forceinline__ int64_t rec_id(const PackRec21 &r) { return (int64_t)(r.hi >> 42); }
@@ -121,5 +147,31 @@ __device__ __forceinline__ void walk_packed2(const REC *__restrict__ rec,
   }
   f0 = r0;
   f1 = r1;
+}
+// the walks' results as super-droplet ids, for records of layout `fmt`
+__device__ __forceinline__ void walk_ids2(const void *rec, int fmt, const int32_t *ovf_head,
+                                          const int32_t *ovf_next, int32_t p0, int32_t p1,
+                                          int32_t lo, int64_t &id0, int64_t &id1) {
+  if (fmt == SDM_REC_P21) {
+    PackRec21 f0, f1;
+    walk_packed2((const PackRec21 *)rec, ovf_head, ovf_next, p0, p1, lo, f0, f1);
+    id0 = rec_id(f0); id1 = rec_id(f1);
+  } else if (fmt == SDM_REC_P24) {
+    PackRec24 f0, f1;
+    walk_packed2((const PackRec24 *)rec, ovf_head, ovf_next, p0, p1, lo, f0, f1);
+    id0 = rec_id(f0); id1 = rec_id(f1);
+  } else {
+    PackRec f0, f1;
+    walk_packed2((const PackRec *)rec, ovf_head, ovf_next, p0, p1, lo, f0, f1);
+    id0 = rec_id(f0); id1 = rec_id(f1);
+  }
+}
+__device__ __forceinline__ int64_t walk_id(const void *rec, int fmt, const int32_t *ovf_head,
+                                           const int32_t *ovf_next, int32_t p, int32_t lo) {
+  if (fmt == SDM_REC_P21)
+    return rec_id(walk_packed((const PackRec21 *)rec, ovf_head, ovf_next, p, lo));
+  if (fmt == SDM_REC_P24)
+    return rec_id(walk_packed((const PackRec24 *)rec, ovf_head, ovf_next, p, lo));
+  return rec_id(walk_packed((const PackRec *)rec, ovf_head, ovf_next, p, lo));
 }
 #endif
