@@ -1525,7 +1525,7 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_resolve_dense(sdm_step_cfg cfg, F
 // gate_len[1]: "the sort runs" (k_sort_commit then copies the result in and marks the state sorted)
 __global__ void k_sort_gate(int64_t *ctl, int64_t *gate_len) {
   gate_len[0] = ctl[CTL_SORTED] ? 0 : ctl[CTL_WORK];
-  gate_len[1] = ctl[CTL_SORTED] ? 0 : 1;
+  gate_len[1] = (ctl[CTL_SORTED] || ctl[CTL_WORK] == 0) ? 0 : 1;  // (nothing to sort: no commit)
 }
 
 __global__ void __launch_bounds__(SDM_BLOCK)
@@ -1801,8 +1801,23 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     sorted_host = 1;
     max_cell = ctx->carry.max_cell;
   } else if (cfg->adaptive || read_back) {
+    bool sorted_now = false;
     if (C > 1 && cfg->croupier_local) {
-      // meaningful only if the state is sorted (checked below): cells can only shrink in a call
+      // The route depends on the largest cell, which is known only for a sorted state - and a
+      // state that comes from the host (after a displacement, say) is not sorted.  So what the
+      // first sub-step would do first anyway is done here: dt_left[:] = dt and
+      // cell_idx.sort_by_key(dt_left) (collision.py:180-183; adaptive), then the cell_start
+      // getter's counting sort, gated on the device by the sorted flag
+      if (cfg->adaptive) {
+        hipLaunchKernelGGL(k_fill_f64, dim3(grid_for(C)), blk, 0, s, st->dt_left, cfg->dt, C);
+        LAUNCH_CHECK();
+        fill_pending = false;
+        rc = sdm_sort_by_key_async(ctx, st->cell_idx, st->dt_left, C);
+        if (rc) return rc;
+      }
+      rc = cond_sort(ctx, cfg, st, cur, S, &sorted_host);
+      if (rc) return rc;
+      sorted_now = true;
       HIP_TRY(hipMemsetAsync(st->ctl + 6, 0, sizeof(int64_t), s));
       hipLaunchKernelGGL(k_max_cell, dim3(grid_for(C)), blk, 0, s, st->cell_start, C, st->ctl);
       LAUNCH_CHECK();
@@ -1813,8 +1828,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     work_host = ctx->mailbox[8 + CTL_WORK];
     sorted_host = (int)ctx->mailbox[8 + CTL_SORTED];
     if (C == 1 && (flags & 2)) sorted_host = 1;
-    if (C > 1 && cfg->croupier_local && sorted_host == 1 && !(flags & 2))
-      max_cell = ctx->mailbox[8 + 6];
+    if (sorted_now && sorted_host == 1) max_cell = ctx->mailbox[8 + 6];
   }
   ctx->carry.active = false;
   const bool cell_path = max_cell >= 0 && max_cell <= CELL_CAP;
