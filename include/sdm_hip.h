@@ -354,9 +354,13 @@ typedef struct sdm_step_result {
 } sdm_step_result;
 
 /* flags: bit 0 = read the control block back (fills result->valid_n_sd; synchronises);
- *        bit 1 = state->ctl was freshly written by the host (first call / after host-side edits) */
+ *        bit 1 = state->ctl was freshly written by the host (first call / after host-side edits);
+ *        bit 2 = with bit 1: multiplicities and attributes are untouched since the last fused call
+ *                (only the permutation / cell ids changed, e.g. by a displacement), so the mirror
+ *                state->nm is still current and is not rebuilt                                 */
 #define SDM_STEP_READ_BACK 1
 #define SDM_STEP_FRESH_CTL 2
+#define SDM_STEP_MIRROR_VALID 4
 int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *state,
                        sdm_step_result *result, int flags);
 /* n_steps time steps back to back (`Particulator.run(n_steps)` with the collision dynamic alone,

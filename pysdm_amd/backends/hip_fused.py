@@ -76,6 +76,7 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
         self.nm = torch.empty(4 * part.n_sd, dtype=torch.int64, device=self.idx.data.device)
         self._ctl_initialised = False
         self._stamps = None
+        self._mirror_built = False
         self._state_cache = None
         self.result = StepResult()
 
@@ -130,12 +131,17 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
         flags = int(self.read_back)
         # anything else that touched multiplicities / attributes since the last fused call
         # (method-by-method calls, uploads) invalidates the device-side bookkeeping
-        if self._stamps != self._timestamps():
+        stamps = self._timestamps()
+        mirror_valid = self._stamps is not None and self._stamps[0] == stamps[0]
+        if self._stamps != stamps:
             self._ctl_initialised = False
             self._state_cache = None
         if not self._ctl_initialised:
             self._push_host_state()
             flags |= 2
+            if mirror_valid and self._mirror_built:  # only the permutation / cell ids changed
+                flags |= 4
+        self._mirror_built = True
         state = self._state()
         ctx = _Context.get()
         if n_steps == 1:
@@ -162,9 +168,11 @@ class FusedStep:  # pylint: disable=too-many-instance-attributes
         self._stamps = self._timestamps()
 
     def _timestamps(self):
+        """(stamps of what the mirror holds, stamp of the cell ids)"""
         attrs = self.particulator.attributes
-        names = ["multiplicity", "cell id"] + list(attrs.get_extensive_attribute_keys())
-        return tuple(state_access.attribute_object(attrs, name).timestamp for name in names)
+        names = ["multiplicity"] + list(attrs.get_extensive_attribute_keys())
+        stamp = lambda name: state_access.attribute_object(attrs, name).timestamp  # noqa: E731
+        return tuple(stamp(name) for name in names), stamp("cell id")
 
     def _commit(self, words):
         state_access.commit(self.particulator.attributes, valid_n_sd=int(words[0]),

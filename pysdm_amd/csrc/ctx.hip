@@ -356,12 +356,20 @@ k_reduce_f64(int kind, const double *__restrict__ a, int64_t n, double *__restri
   }
 }
 
-__global__ void k_reduce_final(int kind, const double *partial, int np, const int *has_nan,
-                               double *out) {
+// one workgroup of 1024: min / max of the (at most 1024) partials (order does not matter)
+__global__ void __launch_bounds__(1024)
+k_reduce_final(int kind, const double *partial, int np, const int *has_nan, double *out) {
+  __shared__ double sm[1024 / SDM_WAVE];
   double v = kind == 0 ? INFINITY : -INFINITY;
-  for (int i = 0; i < np; ++i)
-    v = kind == 0 ? (partial[i] < v ? partial[i] : v) : (partial[i] > v ? partial[i] : v);
-  out[0] = *has_nan ? NAN : v;
+  if ((int)threadIdx.x < np) v = partial[threadIdx.x];
+  v = kind == 0 ? wave_min_f64(v) : wave_max_f64(v);
+  if (lane_id() == 0) sm[threadIdx.x / SDM_WAVE] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 1024 / SDM_WAVE; ++w)
+      v = kind == 0 ? (sm[w] < v ? sm[w] : v) : (sm[w] > v ? sm[w] : v);
+    out[0] = *has_nan ? NAN : v;
+  }
 }
 
 extern "C" int sdm_reduce_f64(sdm_ctx *ctx, int kind, const double *a, int64_t n,
@@ -378,7 +386,7 @@ extern "C" int sdm_reduce_f64(sdm_ctx *ctx, int kind, const double *a, int64_t n
   hipLaunchKernelGGL(k_reduce_f64, dim3(nb), dim3(SDM_BLOCK), 0, ctx->stream, kind, a, n,
                      partial, has_nan);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1), 0, ctx->stream, kind, partial, nb,
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, ctx->stream, kind, partial, nb,
                      has_nan, out);
   LAUNCH_CHECK();
   HIP_TRY(hipMemcpyAsync(ctx->mailbox, out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

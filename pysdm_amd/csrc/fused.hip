@@ -1772,7 +1772,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
               (cfg->enable_breakup &&
                (cfg->ec != SDM_EC_CONST || cfg->frag == SDM_FRAG_STRAUB2010 ||
                 cfg->frag == SDM_FRAG_LOWLIST1982));
-  if (st->nm && (flags & 2)) {
+  if (st->nm && (flags & 2) && !(flags & 4)) {
     hipLaunchKernelGGL(k_nm_init, dim3(grid_for(N)), blk, 0, s, *cfg, A);
     LAUNCH_CHECK();
   }
