@@ -1,11 +1,16 @@
 // fused.hip -- the per-time-step fused path: one C call = one `Collision.__call__`
 // (PySDM/dynamics/collisions/collision.py:174-234), all sub-steps, with the control state
-// (lengths, sorted / healthy flags) resident on the device.  Per sub-step:
-//   [cell_idx sort by dt_left] -> [counting sort if unsorted] -> PCG64 draws -> shuffle
-//   -> k_pair_prob (pairing + sort-within-pair + kernel + probability [+ Ec, fragment mass]
-//      [+ per-cell min of optimal dt])
-//   -> k_cells (adaptive dt bookkeeping) -> k_pair_update (gamma + multiplicity/attribute update
-//      + counters + health flag) -> compaction if unhealthy -> [adaptive end / working length]
+// (lengths, sorted / healthy flags) resident on the device.  Three routes per sub-step:
+//   one cell, non-adaptive:  shuffle record build (index.hip) -> k_pair_all (walks, pairing,
+//      sort-within-pair, kernel, probability, gamma, update, counters) -> gated compaction
+//   one cell, adaptive:  build -> k_pair_prob -> k_cells_adaptive (the per-cell minimum of the
+//      optimal sub-step is the one global dependency) -> k_pair_update [-> k_resolve_dense with
+//      breakup] -> compaction, whose epilogue closes the sub-step and publishes the control block;
+//      the head of the next sub-step (build + k_pair_prob) is launched ahead of the read-back
+//   many cells of at most 6144 super-droplets:  k_cells_begin -> k_cell_step2 / k_cell_step (one
+//      workgroup per cell: shuffle in LDS, pairs, probabilities, update) -> compaction ->
+//      k_cells_end; the next sub-step is launched ahead, gated on the device
+//   larger cells / global croupier:  generic kernels (per-position cell look-ups, counting sort)
 #include <algorithm>
 #include "common.h"
 #include "index.h"
