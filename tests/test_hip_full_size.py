@@ -167,6 +167,19 @@ def test_adaptive_steps_in_one_call_equal_oracle(name, n_sd, steps, dt, thin, hi
         assert int(snaps[0]["length"]) < n_sd
 
 
+@pytest.mark.parametrize("n_sd", [2**21 - 2, 2**21 - 1, 2**20 - 3])
+def test_record_layouts_at_their_size_limits(n_sd, hip_backend_class, oracle_backend_class):
+    """the shuffle records switch layout with the size (21-bit fields with four inline hits up to
+    2^21 - 2 positions, 24-bit fields with three above): same permutation and state either side
+    of the limit, and for an odd count (an unpaired last position)"""
+    snaps = []
+    for backend_class in (hip_backend_class, oracle_backend_class):
+        particulator, dynamic = make_box(backend_class, "shima", n_sd=n_sd, adaptive=False)
+        run(particulator, 3)
+        snaps.append(snapshot(particulator, dynamic))
+    assert_same(snaps[0], snaps[1])
+
+
 def test_shima_box_3600_steps_equal_oracle(hip_backend_class, oracle_backend_class):
     """the whole Shima-2009 experiment (3600 steps of 1 s) in one library call at 2^16
     super-droplets: permutation, multiplicities, masses and counters identical to the oracle's"""
