@@ -1228,7 +1228,7 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
 #endif
 }
 
-// ---- the same sub-step with two workgroups per CU (coalescence only, one extensive attribute) ---
+// ---- the same sub-step with two workgroups per CU (one extensive attribute) --------------------
 // k_cell_step keeps a CU to one workgroup (147 KB of LDS), so its phases - LDS-bound shuffle,
 // chip-wide miss-rate-bound gathers, update - never overlap: two co-resident workgroups of 512
 // threads gave +23 % at 2048 super-droplets per cell.  To fit two (<= 80 KB each, <= 128 VGPRs):
@@ -1259,7 +1259,7 @@ __device__ __forceinline__ int lds_exch16(uint32_t *words, int i, int v) {
   return (int)((old >> sh) & 0xFFFFu);
 }
 
-template <int KERNEL>
+template <int KERNEL, bool BREAKUP>
 __global__ void __launch_bounds__(CELL2_THREADS, 4)
 k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1271,9 +1271,10 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   int32_t *list_lp = (int32_t *)head;                    // ... later their pair slots
   int16_t *jown = (int16_t *)(smem + CELL2_CAP * 10);    // [CAP] own target
   uint16_t *next = (uint16_t *)(smem + CELL2_CAP * 12);  // [CAP] overflow links
+  double *list_ub = (double *)jown;                      // ... later (breakup) their second draws
   __shared__ double red[CELL2_THREADS / SDM_WAVE];
   __shared__ int64_t s_cid, s_base;
-  __shared__ u128 s_rng[2];
+  __shared__ u128 s_rng[3];
   __shared__ int s_ncoll;
   const int64_t C = cfg.n_cell, N = cfg.n_sd;
   const int tid = threadIdx.x;
@@ -1307,6 +1308,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   }
   if (tid == 64) s_rng[0] = pcg_jump(X.s_u01, A.rng_tab, (uint64_t)lo);
   if (tid == 128) s_rng[1] = pcg_jump(A.s_rand, A.rng_tab, (uint64_t)(lo >> 1));
+  if (BREAKUP && tid == 192) s_rng[2] = pcg_jump(A.s_rand_b, A.rng_tab, (uint64_t)(lo >> 1));
   __syncthreads();
   // shuffle_local events of this cell (index_methods.py:35-41): consecutive positions per thread
   {
@@ -1440,14 +1442,20 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   }
   // gamma (collisions_methods.py:560): the pairs that collide are listed, over val / head
   {
-    u128 st = pcg_jump(s_rng[1], A.rng_tab,
-                       (uint64_t)(((lo + lp0 + 2 * (int64_t)(tid * CELL2_MAXPAIR)) >> 1) -
-                                  (lo >> 1)));
+    const uint64_t dd0 = (uint64_t)(((lo + lp0 + 2 * (int64_t)(tid * CELL2_MAXPAIR)) >> 1) -
+                                    (lo >> 1));
+    u128 st = pcg_jump(s_rng[1], A.rng_tab, dd0), sb = 0;
+    if (BREAKUP) sb = pcg_jump(s_rng[2], A.rng_tab, dd0);
 #pragma unroll
     for (int r = 0; r < CELL2_MAXPAIR; ++r) {
       const int lp = lp0 + 2 * (tid * CELL2_MAXPAIR + r);
       st = st * pcg_mult() + A.rng_inc;
       const double u = pcg_output(st);
+      double u_b = 0.0;
+      if (BREAKUP) {
+        sb = sb * pcg_mult() + A.rng_inc;
+        u_b = pcg_output(sb);
+      }
       double p = pprob[r];
       const bool valid = lp + 1 < n && lo + lp < W - 1;
       if (valid && p != 0) { if (cfg.adaptive) p *= scale; else p /= (double)cfg.substeps; }
@@ -1456,6 +1464,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
         const int slot = atomicAdd(&s_ncoll, 1);
         list_lp[slot] = lp;
         list_g[slot] = g;
+        if (BREAKUP) list_ub[slot] = u_b;
       }
     }
   }
@@ -1486,6 +1495,24 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     counter_add(A, CNT_COLLISION, cid, gc * sk.n, act);
     counter_add(A, CNT_COLLISION_DEFICIT, cid, (gi - gc) * sk.n, act);
     const bool coal = act && g != 0;
+    if (BREAKUP) {
+      // bounce / coalescence / breakup is decided and applied by k_resolve_dense: list the pair
+      const unsigned long long m = __ballot(coal);
+      if (m != 0) {
+        const int lane = lane_id(), leader = __ffsll((long long)m) - 1;
+        const int64_t l = blockIdx.x % (unsigned)A.list_nl;
+        unsigned long long at = 0;
+        if (lane == leader) at = atomicAdd(A.list_count + l * SDM_CNT_STRIDE,
+                                           (unsigned long long)__popcll(m));
+        at = __shfl((long long)at, leader, 64);
+        if (coal) {
+          Collided c;
+          c.j = j; c.k = k; c.cid = cid; c.pos = lo + lp; c.g = g; c.u_b = list_ub[t];
+          A.list[l * A.list_cap + at + __popcll(m & ((1ull << lane) - 1))] = c;
+        }
+      }
+      continue;
+    }
     counter_add(A, CNT_COALESCENCE, cid, (int64_t)(g * (double)sk.n), coal);
     const int died = coal ? coalesce_known(cfg, A, j, k, g, sj, sk) : 0;
     if (died & 1) out[lp] = (int32_t)N;  // the permutation is still in LDS here
@@ -1838,7 +1865,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   ctx->carry.active = false;
   const bool cell_path = max_cell >= 0 && max_cell <= CELL_CAP;
   // two workgroups per CU where the kernel for it applies (see k_cell_step2)
-  const bool cell2 = cell_path && max_cell <= CELL2_CAP && !cfg->enable_breakup && cfg->n_attr == 1;
+  const bool cell2 = cell_path && max_cell <= CELL2_CAP && cfg->n_attr == 1;
   if (fill_pending && C > 1 && !cell_path) {  // the per-cell route's k_cells_begin does it itself
     hipLaunchKernelGGL(k_fill_f64, dim3(grid_for(C)), blk, 0, s, st->dt_left, cfg->dt, C);
     LAUNCH_CHECK();
@@ -1857,8 +1884,11 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       CELL_ATTR(SDM_KERNEL_SIMPLE_GEOMETRIC, false); CELL_ATTR(SDM_KERNEL_SIMPLE_GEOMETRIC, true);
       CELL_ATTR(SDM_KERNEL_LINEAR, false); CELL_ATTR(SDM_KERNEL_LINEAR, true);
 #undef CELL_ATTR
-#define CELL2_ATTR(K) HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K>, \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, CELL2_LDS_BYTES))
+#define CELL2_ATTR(K)                                                                           \
+  HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K, false>,                             \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, CELL2_LDS_BYTES));    \
+  HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K, true>,                              \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, CELL2_LDS_BYTES))
       CELL2_ATTR(SDM_KERNEL_GOLOVIN); CELL2_ATTR(SDM_KERNEL_GEOMETRIC);
       CELL2_ATTR(SDM_KERNEL_CONSTANT); CELL2_ATTR(SDM_KERNEL_PARAMETERIZED);
       CELL2_ATTR(SDM_KERNEL_SIMPLE_GEOMETRIC); CELL2_ATTR(SDM_KERNEL_LINEAR);
@@ -1936,7 +1966,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     const dim3 grid((unsigned)(C + X.n_tail_blocks));
 #define CELL_LAUNCH(K)                                                                        \
   do {                                                                                        \
-    if (cell2) hipLaunchKernelGGL((k_cell_step2<K>), grid, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
+    if (cell2 && brk) hipLaunchKernelGGL((k_cell_step2<K, true>), grid, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
+    else if (cell2) hipLaunchKernelGGL((k_cell_step2<K, false>), grid, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
     else if (brk) hipLaunchKernelGGL((k_cell_step<K, true>), grid, dim3(CELL_THREADS), CELL_LDS_BYTES, s, *cfg, A, X); \
     else hipLaunchKernelGGL((k_cell_step<K, false>), grid, dim3(CELL_THREADS), CELL_LDS_BYTES, s, *cfg, A, X);    \
   } while (0)

@@ -192,22 +192,26 @@ def test_overflow_warnings_step_by_step(hip_backend_class, oracle_backend_class)
                 np.testing.assert_array_equal(value, ref, err_msg=key)
 
 
-@pytest.mark.parametrize("base,adaptive", [("straub", True), ("berry_breakup", True),
-                                            ("straub", False)])
-def test_multicell_breakup_equals_oracle(base, adaptive, hip_backend_class, oracle_backend_class):
-    """breakup on a 4 x 4 grid (the reference has no such golden): the per-cell kernel's listing of
+@pytest.mark.parametrize("base,adaptive,grid,n_sd", [
+    ("straub", True, (4, 4), 2**13), ("berry_breakup", True, (4, 4), 2**13),
+    ("straub", False, (4, 4), 2**13),
+    ("straub", True, (2, 2), 4 * 5850),  # cells above k_cell_step2's cap: k_cell_step<.., true>
+])
+def test_multicell_breakup_equals_oracle(base, adaptive, grid, n_sd, hip_backend_class,
+                                         oracle_backend_class):
+    """breakup on a grid (the reference has no such golden): the per-cell kernels' listing of
     colliding pairs + the dense resolution, sub-steps launched ahead of the read-back, per-cell
     counters - against the oracle's method-by-method run"""
     from pysdm_amd.examples import CONFIGS, make_box  # pylint: disable=import-outside-toplevel
 
     name = "_grid_" + base
-    CONFIGS[name] = dict(CONFIGS[base], grid=(4, 4))
+    CONFIGS[name] = dict(CONFIGS[base], grid=grid)
     try:
         snaps = []
         for backend_class in (hip_backend_class, oracle_backend_class):
-            particulator, dynamic = make_box(backend_class, name, n_sd=2**13, adaptive=adaptive,
+            particulator, dynamic = make_box(backend_class, name, n_sd=n_sd, adaptive=adaptive,
                                              dt=5.0)
-            for steps in (1, 12, 3):
+            for steps in ((1, 12, 3) if n_sd == 2**13 else (1, 3, 1)):
                 import warnings  # pylint: disable=import-outside-toplevel
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")
