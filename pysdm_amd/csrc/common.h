@@ -31,12 +31,15 @@ struct sdm_ctx {
   u128 tab_inc;
   bool tab_valid;
   // pinned host mailbox for scalar read-backs
-  int64_t *mailbox;  // 32 x int64, hipHostMalloc (mapped, coherent)
-  // words 16..24 of the mailbox as the device sees them: a kernel publishes the 8 control words
-  // there and then the sequence number `poll_seq` in word 24; the host polls that word
-  // (9.8 us against 15.4 us for hipMemcpyAsync + hipStreamSynchronize, measured)
+  int64_t *mailbox;  // SDM_MAILBOX_WORDS x int64, hipHostMalloc (mapped, coherent)
+  // the two box slots (SDM_BOX) as the device sees them: a kernel publishes the 8 control words
+  // into slot poll_seq & 1 and then the sequence number in the slot's word 8; the host polls that
+  // word (9.8 us against 15.4 us for hipMemcpyAsync + hipStreamSynchronize, measured)
   int64_t *box_dev;
   int64_t poll_seq;
+  bool cell_attr_done;     // fused.hip: large-LDS attribute of the per-cell kernels set on this device
+  int compact_grid;        // index.hip: workgroups of k_compact_persistent that are co-resident here
+  int debug_box_delay_us;  // SDM_DEBUG_BOX_DELAY_US (tests): the host sleeps before each wait
   // fused.hip: what a multi-cell adaptive step knows at its end, for the next step of the same call
   // (valid length, an upper bound of the cell sizes; the state is sorted) - saves that step's
   // opening read-back
@@ -68,8 +71,17 @@ struct sdm_ctx {
   int64_t phase_count[SDM_N_PHASES];
 };
 
-#define SDM_BOX 16  // first mailbox word of the polled copy of the control block
+// The polled copy of the control block is double-buffered: publication number `seq` goes to slot
+// seq & 1 (16 words apart; words 0-7 the block, word 8 the sequence number).  One sub-step at most
+// is launched ahead of the host's wait, so the publication the host waits for and the one that
+// follows it never share a slot.
+#define SDM_BOX 16         // first mailbox word of slot 0
+#define SDM_BOX_STRIDE 16  // words between the two slots
+#define SDM_MAILBOX_WORDS 64
 int sdm_wait_box(sdm_ctx *ctx, int64_t seq);  // ctx.hip
+// waits for publication `seq` and copies its eight words; fails if the slot was overwritten while
+// it was read (cannot happen with one publication in flight ahead: checked, not assumed)
+int sdm_read_box(sdm_ctx *ctx, int64_t seq, int64_t out[8]);
 
 #ifdef __HIPCC__
 // last act of a one-thread epilogue: control block -> host-visible box, then the sequence number
@@ -77,6 +89,7 @@ int sdm_wait_box(sdm_ctx *ctx, int64_t seq);  // ctx.hip
 __device__ __forceinline__ void publish_ctl(const int64_t *ctl, int64_t *box, int64_t seq,
                                             int64_t work) {
   if (!box) return;
+  box += (seq & 1) * SDM_BOX_STRIDE;
   for (int w = 0; w < 8; ++w)
     __hip_atomic_store(&box[w], w == 1 ? work : ctl[w], __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_SYSTEM);

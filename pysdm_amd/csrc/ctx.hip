@@ -1,5 +1,7 @@
 // ctx.hip -- context, error reporting, PCG64 stream fill, Storage element-wise ops, reductions
 #include <stdarg.h>
+#include <stdlib.h>
+#include <unistd.h>
 
 #include "common.h"
 
@@ -15,6 +17,20 @@ void sdm_set_error(const char *fmt, ...) {
 extern "C" const char *sdm_last_error(void) { return g_err; }
 extern "C" int sdm_abi_version(void) { return 1; }
 
+static int ctx_allocate(sdm_ctx *ctx) {
+  HIP_TRY(hipMalloc((void **)&ctx->pcg_tab, sizeof(u128) * 128));
+  HIP_TRY(hipHostMalloc((void **)&ctx->mailbox, sizeof(int64_t) * SDM_MAILBOX_WORDS,
+                        hipHostMallocMapped | hipHostMallocCoherent));
+  memset(ctx->mailbox, 0, sizeof(int64_t) * SDM_MAILBOX_WORDS);
+  if (const char *delay = getenv("SDM_DEBUG_BOX_DELAY_US")) ctx->debug_box_delay_us = atoi(delay);
+  HIP_TRY(hipHostGetDevicePointer((void **)&ctx->box_dev, ctx->mailbox + SDM_BOX, 0));
+  HIP_TRY(hipMalloc((void **)&ctx->dscal, sizeof(int64_t) * 16));
+  HIP_TRY(hipMemset(ctx->dscal, 0, sizeof(int64_t) * 16));
+  HIP_TRY(hipMalloc((void **)&ctx->cnt_slots, sizeof(int64_t) * SDM_CNT_SLOTS * SDM_CNT_STRIDE));
+  HIP_TRY(hipMemset(ctx->cnt_slots, 0, sizeof(int64_t) * SDM_CNT_SLOTS * SDM_CNT_STRIDE));
+  return SDM_OK;
+}
+
 extern "C" int sdm_ctx_create(sdm_ctx **out, int device) {
   ARG_TRY(out != nullptr);
   HIP_TRY(hipSetDevice(device));
@@ -22,15 +38,11 @@ extern "C" int sdm_ctx_create(sdm_ctx **out, int device) {
   memset(ctx, 0, sizeof(*ctx));
   ctx->device = device;
   ctx->stream = nullptr;
-  HIP_TRY(hipMalloc((void **)&ctx->pcg_tab, sizeof(u128) * 128));
-  HIP_TRY(hipHostMalloc((void **)&ctx->mailbox, sizeof(int64_t) * 32,
-                        hipHostMallocMapped | hipHostMallocCoherent));
-  memset(ctx->mailbox, 0, sizeof(int64_t) * 32);
-  HIP_TRY(hipHostGetDevicePointer((void **)&ctx->box_dev, ctx->mailbox + SDM_BOX, 0));
-  HIP_TRY(hipMalloc((void **)&ctx->dscal, sizeof(int64_t) * 16));
-  HIP_TRY(hipMemset(ctx->dscal, 0, sizeof(int64_t) * 16));
-  HIP_TRY(hipMalloc((void **)&ctx->cnt_slots, sizeof(int64_t) * SDM_CNT_SLOTS * SDM_CNT_STRIDE));
-  HIP_TRY(hipMemset(ctx->cnt_slots, 0, sizeof(int64_t) * SDM_CNT_SLOTS * SDM_CNT_STRIDE));
+  const int rc = ctx_allocate(ctx);
+  if (rc != SDM_OK) {  // release whatever was allocated before the failing call
+    (void)sdm_ctx_destroy(ctx);
+    return rc;
+  }
   *out = ctx;
   return SDM_OK;
 }
@@ -38,7 +50,10 @@ extern "C" int sdm_ctx_create(sdm_ctx **out, int device) {
 // waits until a kernel published sequence number `seq` (publish_ctl); the stream is asked now and
 // then, so that a failed launch or a fault ends the wait with an error instead of a hang
 int sdm_wait_box(sdm_ctx *ctx, int64_t seq) {
-  const int64_t *flag = ctx->mailbox + SDM_BOX + 8;
+  const int64_t *flag = ctx->mailbox + SDM_BOX + (seq & 1) * SDM_BOX_STRIDE + 8;
+  // test knob: a host that is slower than the device by about a sub-step (the situation in which
+  // a single-slot box would be overwritten by the sub-step launched ahead)
+  if (ctx->debug_box_delay_us > 0) usleep((useconds_t)ctx->debug_box_delay_us);
   for (uint64_t spins = 1;; ++spins) {
     if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return SDM_OK;
     if ((spins & 0x3fff) == 0) {
@@ -52,6 +67,19 @@ int sdm_wait_box(sdm_ctx *ctx, int64_t seq) {
     }
     __builtin_ia32_pause();
   }
+}
+
+int sdm_read_box(sdm_ctx *ctx, int64_t seq, int64_t out[8]) {
+  const int rc = sdm_wait_box(ctx, seq);
+  if (rc) return rc;
+  const int64_t *slot = ctx->mailbox + SDM_BOX + (seq & 1) * SDM_BOX_STRIDE;
+  for (int w = 0; w < 8; ++w) out[w] = __atomic_load_n(slot + w, __ATOMIC_RELAXED);
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  if (__atomic_load_n(slot + 8, __ATOMIC_ACQUIRE) != seq) {
+    sdm_set_error("control block %lld was overwritten while it was read", (long long)seq);
+    return SDM_E_HIP;
+  }
+  return SDM_OK;
 }
 
 extern "C" int sdm_ctx_destroy(sdm_ctx *ctx) {

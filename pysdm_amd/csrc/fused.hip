@@ -1872,8 +1872,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     fill_pending = false;
   }
   if (cell_path) {
-    static bool attr_done = false;  // > 64 KiB of dynamic LDS must be opted into, per kernel
-    if (!attr_done) {
+    // > 64 KiB of dynamic LDS must be opted into, per kernel and per device (one ctx = one device)
+    if (!ctx->cell_attr_done) {
       const int lds = CELL_LDS_BYTES;
 #define CELL_ATTR(K, B) HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step<K, B>, \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds))
@@ -1893,7 +1893,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       CELL2_ATTR(SDM_KERNEL_CONSTANT); CELL2_ATTR(SDM_KERNEL_PARAMETERIZED);
       CELL2_ATTR(SDM_KERNEL_SIMPLE_GEOMETRIC); CELL2_ATTR(SDM_KERNEL_LINEAR);
 #undef CELL2_ATTR
-      attr_done = true;
+      ctx->cell_attr_done = true;
     }
   }
   // One adaptive cell, plain random numbers: what a sub-step does before its first global
@@ -2062,10 +2062,9 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       };
       {
         PhaseScope ph(ctx, SDM_PHASE_ADAPTIVE_END);
-        rc = sdm_wait_box(ctx, seq_k);
+        rc = sdm_read_box(ctx, seq_k, last_ctl);
         if (rc) return rc;
       }
-      memcpy(last_ctl, ctx->mailbox + SDM_BOX, sizeof(last_ctl));
       have_ctl = true;
       ++n_sub;
       n_pairs += work_host / 2;
@@ -2083,9 +2082,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         if (rc) return rc;
         hipLaunchKernelGGL(k_set_work, one, one, 0, s, st->ctl, S.end2 + 1, ctx->box_dev, seq);
         LAUNCH_CHECK();
-        rc = sdm_wait_box(ctx, seq);
+        rc = sdm_read_box(ctx, seq, last_ctl);
         if (rc) return rc;
-        memcpy(last_ctl, ctx->mailbox + SDM_BOX, sizeof(last_ctl));
         work_host = last_ctl[CTL_WORK];
         if (work_host == 0) break;
         rc = launch_substep(false, &seq_k);
@@ -2271,10 +2269,9 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
                                box_seq);
             LAUNCH_CHECK();
           }
-          rc = sdm_wait_box(ctx, box_seq);
+          rc = sdm_read_box(ctx, box_seq, last_ctl);
           if (rc) return rc;
         }
-        memcpy(last_ctl, ctx->mailbox + SDM_BOX, sizeof(last_ctl));
         have_ctl = true;
         work_host = last_ctl[CTL_WORK];
         if (C == 1 || last_ctl[CTL_SORTED] != 0) { sorted_host = C == 1 ? sorted_host : 1; break; }
@@ -2369,6 +2366,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     }
     res->valid_n_sd = res->ctl[CTL_VALID];
     st->known_valid = res->valid_n_sd;
+    if (res->ctl[7] == 2) (void)sdm_compact_rearm(ctx);  // the caller raises; the ctx stays usable
   } else {
     // one adaptive cell: the last sub-step's read-back told the valid length anyway - the next
     // step of the same run need not ask the device again

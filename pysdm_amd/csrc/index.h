@@ -15,6 +15,7 @@ int sdm_shuffle_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *
                       int64_t n_total, const uint64_t *rng_state_inc, uint64_t rng_offset);
 int sdm_sort_by_key_async(sdm_ctx *ctx, int64_t *idx, const double *keys, int64_t n);
 size_t sdm_compact_scratch(int64_t n);
+int sdm_compact_rearm(sdm_ctx *ctx);  // clears the grid-barrier words after a time-out
 size_t sdm_sort_scratch(int64_t length_bound, int64_t n_cell);
 int sdm_counting_sort_async(sdm_ctx *ctx, char *scratch, int64_t *new_idx, const int64_t *idx,
                             const int64_t *cell_id, const int64_t *cell_idx,

@@ -737,8 +737,9 @@ __device__ __forceinline__ bool sd_dead(const int64_t *__restrict__ multiplicity
 // chunk; holes / fillers; apply) separated by a software grid barrier.  A wavefront owns a
 // contiguous chunk of positions and walks it in tiles of SDM_WAVE (ballots only); after the first
 // barrier every workgroup scans the COMPACT_WAVES chunk totals for itself (8 KB from L2 - cheaper
-// than a fourth barrier around a scan by one workgroup).  The grid is COMPACT_GRID workgroups of
-// COMPACT_THREADS (always co-resident).  A grid barrier is one same-address atomic per workgroup
+// than a fourth barrier around a scan by one workgroup).  The grid is ctx->compact_grid workgroups
+// of COMPACT_THREADS: COMPACT_GRID, or as many as the occupancy query says are co-resident on this
+// device (a partitioned or CU-masked device has fewer CUs), fixed at the context's first use.  A grid barrier is one same-address atomic per workgroup
 // plus polling: measured 13.5 us with 256 workgroups, 5.1 us with 128, 3.0 us with 64 - hence
 // few, large ones (128 x 1024 threads measured best end to end).
 // Every spin is bounded (bar[2] is set on time-out).
@@ -839,7 +840,8 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
   __shared__ int excl[COMPACT_WAVES];
   const int lane = lane_id(), w = threadIdx.x / SDM_WAVE;
   const int wave = blockIdx.x * (COMPACT_THREADS / SDM_WAVE) + w;
-  const int per_wave = (n_tiles + COMPACT_WAVES - 1) / COMPACT_WAVES;
+  const int n_waves = (int)gridDim.x * (COMPACT_THREADS / SDM_WAVE);  // <= COMPACT_WAVES
+  const int per_wave = (n_tiles + n_waves - 1) / n_waves;
   const int tile0 = wave * per_wave, tile1 = min(n_tiles, tile0 + per_wave);
   // phase A: dead count of every wavefront's chunk
   // (COMPACT_UNROLL tiles per round: their loads are in flight together - a wavefront walking its
@@ -855,7 +857,7 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
     if (lane == 0) wave_dead[wave] = count;
   }
 #define BARRIER_OR_FAIL(k)                                   \
-  if (!grid_barrier(bar, (k) * COMPACT_GRID)) {              \
+  if (!grid_barrier(bar, (k) * gridDim.x)) {                 \
     if (threadIdx.x == 0) fctl[7] = 2; /* surfaced by the host as an error */ \
     return;                                                  \
   }
@@ -868,7 +870,7 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
     int v[PER], sum = 0;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      v[k] = b0 + k < COMPACT_WAVES ? ((volatile int32_t *)wave_dead)[b0 + k] : 0;
+      v[k] = b0 + k < n_waves ? ((volatile int32_t *)wave_dead)[b0 + k] : 0;
       sum += v[k];
     }
     int incl = sum;
@@ -887,7 +889,7 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
     int run = base + incl - sum;
 #pragma unroll
     for (int k = 0; k < PER; ++k)
-      if (b0 + k < COMPACT_WAVES) {
+      if (b0 + k < n_waves) {
         excl[b0 + k] = run;
         run += v[k];
       }
@@ -925,7 +927,7 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
   if (total_dead != 0) {
     const int64_t n_holes = ((volatile int64_t *)ctl)[2];
     for (int64_t t = (int64_t)blockIdx.x * COMPACT_THREADS + threadIdx.x; t < length - new_len;
-         t += (int64_t)COMPACT_GRID * COMPACT_THREADS) {
+         t += (int64_t)gridDim.x * COMPACT_THREADS) {
       idx[new_len + t] = flag;
       if (t < n_holes) idx[((volatile int32_t *)holes)[t]] = ((volatile int64_t *)fillers)[t];
     }
@@ -935,7 +937,7 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
   // every workgroup is past the last barrier once it arrives here: the last one re-arms the
   // barrier words and commits the control words
   __shared__ bool last;
-  if (threadIdx.x == 0) last = atomicAdd(&bar[1], 1u) == COMPACT_GRID - 1;
+  if (threadIdx.x == 0) last = atomicAdd(&bar[1], 1u) == gridDim.x - 1;
   __syncthreads();
   if (last && threadIdx.x == 0) {
     bar[0] = 0;
@@ -966,15 +968,37 @@ int sdm_compact_fused_async(sdm_ctx *ctx, char *scratch, const int64_t *multipli
   int32_t *holes = cv.take<int32_t>(length_bound);
   int64_t *fillers = cv.take<int64_t>(length_bound);
   unsigned int *bar = (unsigned int *)(ctx->dscal + 12);
+  if (ctx->compact_grid == 0) {
+    // the software grid barrier needs every workgroup resident at once
+    int per_cu = 0, cus = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_compact_persistent<false>,
+                                                         COMPACT_THREADS, 0));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    const int fit = per_cu * cus;
+    if (fit < 1) {
+      sdm_set_error("the compaction kernel does not fit this device (occupancy query: %d x %d)",
+                    per_cu, cus);
+      return SDM_E_HIP;
+    }
+    ctx->compact_grid = fit < COMPACT_GRID ? fit : COMPACT_GRID;
+  }
+  const unsigned grid = (unsigned)ctx->compact_grid;
   if (flag_only)
-    hipLaunchKernelGGL(k_compact_persistent<true>, dim3(COMPACT_GRID), dim3(COMPACT_THREADS), 0,
+    hipLaunchKernelGGL(k_compact_persistent<true>, dim3(grid), dim3(COMPACT_THREADS), 0,
                        ctx->stream, multiplicity, idx, flag, fctl, wave_dead, n_tiles, ctl, holes,
                        fillers, cell_start_single, bar, E);
   else
-    hipLaunchKernelGGL(k_compact_persistent<false>, dim3(COMPACT_GRID), dim3(COMPACT_THREADS), 0,
+    hipLaunchKernelGGL(k_compact_persistent<false>, dim3(grid), dim3(COMPACT_THREADS), 0,
                        ctx->stream, multiplicity, idx, flag, fctl, wave_dead, n_tiles, ctl, holes,
                        fillers, cell_start_single, bar, E);
   LAUNCH_CHECK();
+  return SDM_OK;
+}
+
+// after a timed-out grid barrier (error word 2) the workgroups returned without re-arming the
+// barrier words: clear them, so that the context stays usable
+int sdm_compact_rearm(sdm_ctx *ctx) {
+  HIP_TRY(hipMemsetAsync(ctx->dscal + 12, 0, sizeof(int64_t) * 4, ctx->stream));
   return SDM_OK;
 }
 
@@ -1003,6 +1027,7 @@ extern "C" int sdm_remove_zero_n_or_flagged(sdm_ctx *ctx, const int64_t *multipl
   HIP_TRY(hipMemcpyAsync(ctx->mailbox, fctl, sizeof(words), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (ctx->mailbox[7] != 0) {
+    (void)sdm_compact_rearm(ctx);
     sdm_set_error("remove_zero_n_or_flagged: grid barrier of the compaction kernel timed out");
     return SDM_E_HIP;
   }

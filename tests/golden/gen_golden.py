@@ -1024,7 +1024,183 @@ def gen_displacement():
         save(f"traj_{name}", **out)
 
 
+# ------------------------------------------------------------------------------------------
+# digests of full-size runs (too large to store as arrays).  The initial
+# state is a closed-form function of the case parameters (recomputed by the tests, pinned here by
+# its SHA-256), the expected state is stored as SHA-256 of the integer / float columns plus
+# fp64 moments and the (small) per-cell counters.
+# ------------------------------------------------------------------------------------------
+import hashlib
+import time
+
+
+def sha(array):
+    return hashlib.sha256(np.ascontiguousarray(array).tobytes()).hexdigest()
+
+
+def digest_of(snap, rho_w=1000.0):
+    """snap: dict as _snapshot returns.  Everything a test needs to pin a state it cannot store"""
+    length = int(snap["length"])
+    idx = snap["idx"][:length]
+    n = snap["multiplicity"]
+    mass = snap["attributes"][0]
+    live_n = n[idx].astype(np.float64)
+    vol = mass[idx] / rho_w
+    out = {
+        "length": np.asarray(length),
+        "sha_idx": np.asarray(sha(idx)),
+        "sha_multiplicity_raw": np.asarray(sha(n)),
+        "sha_multiplicity_live": np.asarray(sha(n[idx])),
+        "sha_mass_raw": np.asarray(sha(mass)),
+        "sha_mass_live": np.asarray(sha(mass[idx])),
+        "sha_cell_start": np.asarray(sha(snap["cell_start"])),
+        "moments": np.asarray([np.sum(live_n * vol**k) for k in range(4)]),
+        "total_mass": np.asarray(np.sum(live_n * mass[idx])),
+        "sum_multiplicity": np.asarray(int(np.sum(n[idx]))),
+    }
+    for key in ("collision_rate", "collision_rate_deficit", "coalescence_rate", "breakup_rate",
+                "breakup_rate_deficit", "stats_n_substep", "stats_dt_min"):
+        if key in snap:
+            out[key] = snap[key]
+    return out
+
+
+def run_digest(name, *, n_sd, seed, dt, dv, volume, multiplicity, make_dynamic, record_steps,
+               formulae_kwargs=None, grid=None, cell_id=None, breakup=False, extra=None):
+    t0 = time.time()
+    formulae = Formulae(seed=seed, **(formulae_kwargs or {}))
+    env = Box(dv=dv, dt=dt)
+    if grid is not None:
+        env.mesh = Mesh(grid, size=tuple(float(g) for g in grid))
+        env.mesh.dv = dv
+    builder = Builder(n_sd=n_sd, backend=CPU(formulae), environment=env)
+    builder.add_dynamic(make_dynamic())
+    attributes = {"volume": volume.copy(), "multiplicity": multiplicity.copy()}
+    if cell_id is not None:
+        attributes["cell id"] = cell_id.copy()
+    particulator = builder.build(attributes)
+    dyn = particulator.dynamics["Collision"]
+    out = {
+        "init/sha_volume": np.asarray(sha(volume)),
+        "init/sha_multiplicity": np.asarray(sha(
+            particulator.attributes["multiplicity"].to_ndarray(raw=True))),
+        "record_steps": np.asarray(record_steps),
+    }
+    if cell_id is not None:
+        out["init/sha_cell_id"] = np.asarray(sha(cell_id))
+    for key, value in (extra or {}).items():
+        out[key] = np.asarray(value)
+    for step in record_steps:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            particulator.run(step - particulator.n_steps)
+        for k, v in digest_of(_snapshot(particulator, dyn, breakup)).items():
+            out[f"step{step}/{k}"] = v
+        print(f"  {name}: step {step} done after {time.time() - t0:.0f} s", flush=True)
+    save(f"digest_{name}", **out)
+
+
+def kinematic_init(n_sd, n_cell, dv_cell):
+    """the initial state of pysdm_amd's kinematic2d case (cases.py): exponential spectrum of
+    config 3's concentration, randomly permuted, uniform-random cell ids"""
+    x0 = Formulae().trivia.volume(radius=15e-6)
+    spectrum = spectra.Exponential(norm_factor=239e6 * dv_cell * n_cell, scale=x0)
+    volume, mult = ConstantMultiplicity(spectrum).sample(n_sd)
+    rng = np.random.default_rng(7)
+    cell_id = rng.integers(0, n_cell, size=n_sd).astype(np.int64)
+    order = rng.permutation(n_sd)
+    return volume[order], mult[order], cell_id
+
+
+def rain_init(n_sd, dv):
+    """Marshall-Palmer spectrum at 54 mm/h sampled logarithmically in diameter
+    (deJong_Mackay_et_al_2023/simulation_ss.py:13-52, simulation_0D.py:37-43)"""
+    from PySDM.initialisation.sampling.spectral_sampling import Logarithmic
+
+    rain_rate = 54 * si.mm / si.h
+    mp_scale = 4.1e3 * (rain_rate / si.mm * si.h) ** (-0.21) / si.m
+    n_part = 8e6 / si.m**4 / mp_scale
+    spectrum = spectra.Exponential(norm_factor=n_part * dv, scale=1 / mp_scale)
+    diams, mult = Logarithmic(spectrum).sample(n_sd)
+    return Formulae().trivia.volume(radius=diams / 2), mult
+
+
+def gen_digests(which):
+    triv = Formulae().trivia
+    gk = {"terminal_velocity": "GunnKinzer1949"}
+    cases = []
+    # configs[0]/[1]: Shima 2009 box, Golovin (settings.py: adaptive=False; Coalescence default True)
+    for log2n, adaptive, steps in ((14, 0, (1, 10)), (14, 1, (1, 10)), (17, 0, (1, 10)),
+                                   (17, 1, (1, 10)), (20, 0, (1, 10)), (20, 1, (1, 3))):
+        n_sd = 2**log2n
+
+        def shima(n_sd=n_sd, adaptive=adaptive, steps=steps):
+            volume, mult = shima_init(n_sd)
+            run_digest(f"shima_n{n_sd}_a{adaptive}", n_sd=n_sd, seed=44, dt=1.0, dv=1e6,
+                       volume=volume, multiplicity=mult, record_steps=steps,
+                       make_dynamic=lambda: Coalescence(collision_kernel=Golovin(b=1.5e3),
+                                                        adaptive=bool(adaptive)))
+        cases.append((f"shima{log2n}a{adaptive}", shima))
+    # configs[2]: Berry 1967 box + breakup (geometric, Berry1967 Ec, exponential fragments)
+    for log2n, steps in ((14, (1, 10)), (17, (1, 10)), (20, (1, 3))):
+        n_sd = 2**log2n
+
+        def berry(n_sd=n_sd, steps=steps):
+            dv = 10.0 * n_sd / 2**13
+            spectrum = spectra.Exponential(norm_factor=239e6 * dv,
+                                           scale=triv.volume(radius=10e-6))
+            volume, mult = ConstantMultiplicity(spectrum).sample(n_sd)
+            run_digest(f"berry_breakup_n{n_sd}", n_sd=n_sd, seed=44, dt=1.0, dv=dv,
+                       volume=volume, multiplicity=mult, record_steps=steps, breakup=True,
+                       formulae_kwargs={"fragmentation_function": "Exponential", **gk},
+                       make_dynamic=lambda: Collision(
+                           collision_kernel=Geometric(), coalescence_efficiency=Berry1967(),
+                           breakup_efficiency=ConstEb(1.0),
+                           fragmentation_function=ExpFrag(scale=triv.volume(radius=100e-6)),
+                           adaptive=True, warn_overflows=False))
+        cases.append((f"berry{log2n}", berry))
+    # configs[3]: 32 x 32 cells, geometric, adaptive, optimized_random, dt = 5 s
+    for per_cell in (64, 4096):
+        def kin(per_cell=per_cell):
+            n_cell = 1024
+            n_sd = per_cell * n_cell
+            dv_cell = 2197.0 * per_cell / 4096
+            volume, mult, cell_id = kinematic_init(n_sd, n_cell, dv_cell)
+            run_digest(f"kinematic2d_{per_cell}percell", n_sd=n_sd, seed=44, dt=5.0, dv=dv_cell,
+                       volume=volume, multiplicity=mult, record_steps=(1, 3), grid=(32, 32),
+                       cell_id=cell_id, formulae_kwargs=gk,
+                       make_dynamic=lambda: Coalescence(
+                           collision_kernel=Geometric(collection_efficiency=1), adaptive=True,
+                           optimized_random=True))
+        cases.append((f"kin{per_cell}", kin))
+    # configs[4] stress variant: rain spectrum, Straub 2010 Ec + Nf; dt = 10 s so that the
+    # adaptive scheme really sub-steps (2.8 sub-steps per step, a third of the collisions break up)
+    for log2n, steps in ((12, (1, 10)), (14, (1, 10)), (17, (1, 5)), (20, (1, 2))):
+        n_sd = 2**log2n
+
+        def rain(n_sd=n_sd, steps=steps):
+            dv = 1e6 * n_sd / 2**12
+            volume, mult = rain_init(n_sd, dv)
+            run_digest(f"straub_rain_n{n_sd}", n_sd=n_sd, seed=44, dt=10.0, dv=dv,
+                       volume=volume, multiplicity=mult, record_steps=steps, breakup=True,
+                       formulae_kwargs={"fragmentation_function": "Straub2010Nf", **gk},
+                       make_dynamic=lambda: Collision(
+                           collision_kernel=Geometric(), coalescence_efficiency=Straub2010Ec(),
+                           breakup_efficiency=ConstEb(1.0),
+                           fragmentation_function=Straub2010Nf(
+                               vmin=(0.01 * si.mm) ** 3 * np.pi / 6, nfmax=10000),
+                           adaptive=True, warn_overflows=False))
+        cases.append((f"rain{log2n}", rain))
+    for key, fun in cases:
+        if not which or key in which or any(key.startswith(w) and w.isalpha() for w in which):
+            fun()
+
+
+
 if __name__ == "__main__":
+    if sys.argv[1:2] == ["digests"]:
+        gen_digests(sys.argv[2:])
+        sys.exit(0)
     what = sys.argv[1:] or ["micro", "frag", "traj", "breakup", "shards", "moments", "displacement",
                             "kernels", "breakup_more"]
     if "displacement" in what:
