@@ -1,0 +1,1031 @@
+/*
+ * sdm_oracle_abi.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * The CPU oracle behind the SAME C ABI as the product (include/sdm_hip.h), with host pointers in
+ * place of device pointers: every symbol the header declares is defined here by forwarding to the
+ * serial restatement in sdm_oracle.c (included below: one translation unit), and the fused entry
+ * points (`sdm_collision_step`, `sdm_collision_run`, `sdm_displacement_step`) are the reference's
+ * own driver loops restated in C as chains of those array passes:
+ *   PySDM/dynamics/collisions/collision.py:174-290 (`Collision.__call__`, `step`, ...),
+ *   PySDM/impl/particle_attributes.py:47-110 (lazy counting sort, sanitize, working length),
+ *   PySDM/dynamics/impl/random_generator_optimizer*.py (stream layout),
+ *   PySDM/dynamics/collisions/{collision_kernels,coalescence_efficiencies,breakup_efficiencies,
+ *   breakup_fragmentations}/ *.py (the chains of pair-wise Storage operations, in their order),
+ *   PySDM/attributes/physics/{volume,radius,area,terminal_velocity}.py (derived attributes),
+ *   PySDM/dynamics/displacement.py:100-153.
+ * Because both libraries implement one header, the tests drive product and checker through one
+ * binding and compare; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load
+ * this library.  With -fopenmp the loops the reference's Numba backend runs under `prange` are
+ * parallel (integer counters through atomics: results do not depend on the thread count).
+ */
+#include "sdm_oracle.c"
+
+#include <stdio.h>
+
+#include "../include/sdm_hip.h"
+
+#undef API
+#define API __attribute__((visibility("default")))
+
+struct sdm_ctx {
+  int dummy;
+};
+
+static __thread char g_err[256] = "";
+#define FAIL(code, msg)                         \
+  do {                                          \
+    snprintf(g_err, sizeof(g_err), "%s", msg);  \
+    return (code);                              \
+  } while (0)
+
+API int sdm_ctx_create(sdm_ctx **out, int device) {
+  (void)device;
+  if (!out) FAIL(SDM_E_ARG, "sdm_ctx_create: null out pointer");
+  *out = (sdm_ctx *)calloc(1, sizeof(sdm_ctx));
+  return *out ? SDM_OK : SDM_E_NOMEM;
+}
+API int sdm_ctx_destroy(sdm_ctx *ctx) { free(ctx); return SDM_OK; }
+API int sdm_ctx_set_stream(sdm_ctx *ctx, void *s) { (void)ctx; (void)s; return SDM_OK; }
+API int sdm_ctx_synchronize(sdm_ctx *ctx) { (void)ctx; return SDM_OK; }
+API const char *sdm_last_error(void) { return g_err; }
+API int sdm_abi_version(void) { return 1; }
+API int sdm_ctx_set_timing(sdm_ctx *ctx, int enable) { (void)ctx; (void)enable; return SDM_OK; }
+API int sdm_ctx_read_timing(sdm_ctx *ctx, double *ms, int64_t *count) {
+  (void)ctx;
+  for (int i = 0; i < SDM_N_PHASES; ++i) { ms[i] = 0; count[i] = 0; }
+  return SDM_OK;
+}
+API const char *sdm_phase_name(int phase) { (void)phase; return "oracle"; }
+
+/* ---- one symbol per backend method: forwarders ------------------------------------------- */
+API int sdm_pcg64_uniform(sdm_ctx *ctx, double *out, int64_t n, const uint64_t state_inc[4],
+                          uint64_t offset) {
+  (void)ctx;
+  uint64_t st[4] = {state_inc[0], state_inc[1], state_inc[2], state_inc[3]};
+  oracle_pcg64_advance(st, 0, offset);
+  oracle_pcg64_fill(st, out, n);
+  return SDM_OK;
+}
+API int sdm_identity_index(sdm_ctx *c, int64_t *idx, int64_t n) {
+  (void)c; oracle_identity_index(idx, n); return SDM_OK;
+}
+API int sdm_shuffle_global(sdm_ctx *c, int64_t *idx, int64_t length, const double *u01) {
+  (void)c; oracle_shuffle_global(idx, length, u01); return SDM_OK;
+}
+API int sdm_shuffle_local(sdm_ctx *c, int64_t *idx, const double *u01, const int64_t *cell_start,
+                          int64_t n_cell) {
+  (void)c; oracle_shuffle_local(idx, u01, cell_start, n_cell); return SDM_OK;
+}
+API int sdm_sort_by_key(sdm_ctx *c, int64_t *idx, const double *keys, int64_t n) {
+  (void)c; oracle_sort_by_key(idx, keys, n); return SDM_OK;
+}
+API int sdm_remove_zero_n_or_flagged(sdm_ctx *c, const int64_t *multiplicity, int64_t *idx,
+                                     int64_t length, int64_t idx_len, int64_t *new_length) {
+  (void)c;
+  *new_length = oracle_remove_zero_n_or_flagged(multiplicity, idx, length, idx_len);
+  return SDM_OK;
+}
+API int sdm_counting_sort_by_cell_id(sdm_ctx *c, int64_t *new_idx, const int64_t *idx,
+                                     const int64_t *cell_id, const int64_t *cell_idx,
+                                     int64_t length, int64_t *cell_start, int64_t n_cell) {
+  (void)c;
+  oracle_counting_sort_by_cell_id(new_idx, idx, cell_id, cell_idx, length, cell_start,
+                                  n_cell + 1);
+  return SDM_OK;
+}
+API int sdm_cell_id(sdm_ctx *c, int64_t *cell_id, const int64_t *cell_origin,
+                    const int64_t *strides, int64_t n_dim, int64_t n_sd) {
+  (void)c; oracle_cell_id(cell_id, cell_origin, strides, n_dim, n_sd); return SDM_OK;
+}
+API int sdm_find_pairs(sdm_ctx *c, const int64_t *cell_start, uint8_t *flag,
+                       const int64_t *cell_id, const int64_t *cell_idx, const int64_t *idx,
+                       int64_t length) {
+  (void)c; oracle_find_pairs(cell_start, flag, cell_id, cell_idx, idx, length); return SDM_OK;
+}
+API int sdm_sort_within_pair_by_attr(sdm_ctx *c, int64_t *idx, int64_t length,
+                                     const uint8_t *flag, const void *attr, int attr_is_int) {
+  (void)c;
+  if (attr_is_int) oracle_sort_within_pair_by_attr_i64(idx, length, flag, (const int64_t *)attr);
+  else oracle_sort_within_pair_by_attr_f64(idx, length, flag, (const double *)attr);
+  return SDM_OK;
+}
+API int sdm_pair_op(sdm_ctx *c, int op, double *out, int64_t n_out, const void *in,
+                    int in_is_int, const uint8_t *flag, const int64_t *idx, int64_t length) {
+  (void)c;
+  if (in_is_int) oracle_pair_op_i64(op, out, n_out, (const int64_t *)in, flag, idx, length);
+  else oracle_pair_op_f64(op, out, n_out, (const double *)in, flag, idx, length);
+  return SDM_OK;
+}
+API int sdm_sort_pair(sdm_ctx *c, double *out, int64_t n_out, const double *in,
+                      const uint8_t *flag, const int64_t *idx, int64_t length) {
+  (void)c; oracle_sort_pair_f64(out, n_out, in, flag, idx, length); return SDM_OK;
+}
+API int sdm_normalize(sdm_ctx *c, double *prob, int64_t n_prob, const int64_t *cell_id,
+                      const int64_t *cell_idx, const int64_t *cell_start, double *norm_factor,
+                      int64_t n_cell, double timestep, double dv) {
+  (void)c;
+  oracle_normalize(prob, n_prob, cell_id, cell_idx, cell_start, norm_factor, n_cell, timestep,
+                   dv);
+  return SDM_OK;
+}
+API int sdm_scale_prob_for_adaptive_sdm_gamma(sdm_ctx *c, double *prob, const int64_t *idx,
+                                              int64_t length, const int64_t *multiplicity,
+                                              const int64_t *cell_id, double *dt_left,
+                                              int64_t n_cell, double dt, double dt_min,
+                                              double dt_max, const uint8_t *flag,
+                                              int64_t *stats_n_substep, double *stats_dt_min) {
+  (void)c;
+  oracle_scale_prob_for_adaptive_sdm_gamma(prob, idx, length, multiplicity, cell_id, dt_left,
+                                           n_cell, dt, dt_min, dt_max, flag, stats_n_substep,
+                                           stats_dt_min);
+  return SDM_OK;
+}
+API int sdm_compute_gamma(sdm_ctx *c, const double *prob, const double *rand, const int64_t *idx,
+                          int64_t length, const int64_t *multiplicity, const int64_t *cell_id,
+                          int64_t *collision_rate_deficit, int64_t *collision_rate,
+                          const uint8_t *flag, double *out) {
+  (void)c;
+  oracle_compute_gamma(prob, rand, idx, length, multiplicity, cell_id, collision_rate_deficit,
+                       collision_rate, flag, out);
+  return SDM_OK;
+}
+API int sdm_adaptive_sdm_end(sdm_ctx *c, const double *dt_left, int64_t n_cell,
+                             const int64_t *cell_start, int64_t *end) {
+  (void)c; *end = oracle_adaptive_sdm_end(dt_left, n_cell, cell_start); return SDM_OK;
+}
+API int sdm_collision_coalescence(sdm_ctx *c, int64_t *multiplicity, const int64_t *idx,
+                                  int64_t length, double *attributes, int64_t n_attr,
+                                  int64_t n_sd, const double *gamma, int64_t *healthy,
+                                  const int64_t *cell_id, int64_t *coalescence_rate,
+                                  const uint8_t *flag) {
+  (void)c;
+  oracle_collision_coalescence(multiplicity, idx, length, attributes, n_attr, n_sd, gamma,
+                               healthy, cell_id, coalescence_rate, flag);
+  return SDM_OK;
+}
+API int sdm_collision_coalescence_breakup(
+    sdm_ctx *c, int64_t *multiplicity, const int64_t *idx, int64_t length, double *attributes,
+    int64_t n_attr, int64_t n_sd, const double *gamma, const double *rand, const double *Ec,
+    const double *Eb, const double *fragment_mass, int64_t *healthy, const int64_t *cell_id,
+    int64_t *coalescence_rate, int64_t *breakup_rate, int64_t *breakup_rate_deficit,
+    const uint8_t *flag, int64_t max_multiplicity, const double *particle_mass,
+    int handle_all_breakups, int64_t *n_overflow) {
+  (void)c;
+  const int64_t n = oracle_collision_coalescence_breakup(
+      multiplicity, idx, length, attributes, n_attr, n_sd, gamma, rand, Ec, Eb, fragment_mass,
+      healthy, cell_id, coalescence_rate, breakup_rate, breakup_rate_deficit, flag,
+      max_multiplicity, particle_mass, handle_all_breakups);
+  if (n_overflow) *n_overflow += n;
+  return SDM_OK;
+}
+API int sdm_linear_collection_efficiency(sdm_ctx *c, const double params[13], double *output,
+                                         int64_t n_out, const double *radii,
+                                         const uint8_t *flag, const int64_t *idx,
+                                         int64_t length, double unit) {
+  (void)c;
+  oracle_linear_collection_efficiency(params, output, n_out, radii, flag, idx, length, unit);
+  return SDM_OK;
+}
+API int sdm_interpolation(sdm_ctx *c, double *output, const double *radius, int64_t n,
+                          double factor, const double *b, const double *cc, int64_t table_len) {
+  (void)c; (void)table_len;
+  oracle_interpolation(output, radius, n, factor, b, cc);
+  return SDM_OK;
+}
+API int sdm_volume_of_water_mass(sdm_ctx *c, double *volume, const double *mass, int64_t n,
+                                 double rho_w) {
+  (void)c; oracle_volume_of_water_mass(volume, mass, n, rho_w); return SDM_OK;
+}
+API int sdm_mass_of_water_volume(sdm_ctx *c, double *mass, const double *volume, int64_t n,
+                                 double rho_w) {
+  (void)c; oracle_mass_of_water_volume(mass, volume, n, rho_w); return SDM_OK;
+}
+API int sdm_exp_fragmentation(sdm_ctx *c, double *n_fragment, double scale, double *frag_volume,
+                              const double *x_plus_y, const double *rand, int64_t n, double vmin,
+                              double nfmax, double tol) {
+  (void)c;
+  oracle_exp_fragmentation(scale, frag_volume, rand, n, tol);
+  oracle_fragmentation_limiters(n_fragment, frag_volume, n, vmin, nfmax, x_plus_y);
+  return SDM_OK;
+}
+API int sdm_straub_fragmentation(sdm_ctx *c, double *n_fragment, const double *CW,
+                                 const double *gam, const double *ds, double *frag_volume,
+                                 const double *v_max, const double *x_plus_y, const double *rand,
+                                 int64_t n, double vmin, double nfmax, double *Nr1, double *Nr2,
+                                 double *Nr3, double *Nr4, double *Nrt, double *d34,
+                                 const double consts[6]) {
+  (void)c;
+  oracle_straub_fragmentation(CW, gam, ds, v_max, frag_volume, rand, Nr1, Nr2, Nr3, Nr4, Nrt,
+                              d34, n, consts);
+  oracle_fragmentation_limiters(n_fragment, frag_volume, n, vmin, nfmax, x_plus_y);
+  return SDM_OK;
+}
+API int sdm_gauss_fragmentation(sdm_ctx *c, double *n_fragment, double mu, double sigma,
+                                double *frag_volume, const double *x_plus_y, const double *rand,
+                                int64_t n, double vmin, double nfmax, const double consts[2]) {
+  (void)c;
+  oracle_gauss_fragmentation(mu, sigma, frag_volume, rand, n, consts);
+  oracle_fragmentation_limiters(n_fragment, frag_volume, n, vmin, nfmax, x_plus_y);
+  return SDM_OK;
+}
+API int sdm_feingold1988_fragmentation(sdm_ctx *c, double *n_fragment, double scale,
+                                       double *frag_volume, const double *x_plus_y,
+                                       const double *rand, int64_t n, double fragtol,
+                                       double vmin, double nfmax) {
+  (void)c;
+  oracle_feingold1988_fragmentation(scale, frag_volume, x_plus_y, rand, n, fragtol);
+  oracle_fragmentation_limiters(n_fragment, frag_volume, n, vmin, nfmax, x_plus_y);
+  return SDM_OK;
+}
+API int sdm_slams_fragmentation(sdm_ctx *c, double *n_fragment, double *frag_volume,
+                                const double *x_plus_y, double *probs, const double *rand,
+                                int64_t n, double vmin, double nfmax) {
+  (void)c;
+  oracle_slams_fragmentation(n_fragment, frag_volume, x_plus_y, probs, rand, n);
+  oracle_fragmentation_limiters(n_fragment, frag_volume, n, vmin, nfmax, x_plus_y);
+  return SDM_OK;
+}
+API int sdm_ll82_fragmentation(sdm_ctx *c, double *n_fragment, const double *CKE,
+                               const double *W, const double *W2, const double *St,
+                               const double *ds, const double *dl, const double *dcoal,
+                               double *frag_volume, const double *x_plus_y, double *rand,
+                               int64_t n, double vmin, double nfmax, double *Rf, double *Rs,
+                               double *Rd, double tol, const double consts[4]) {
+  (void)c;
+  oracle_ll82_fragmentation(CKE, W, W2, St, ds, dl, dcoal, frag_volume, rand, Rf, Rs, Rd, n, tol,
+                            consts);
+  oracle_fragmentation_limiters(n_fragment, frag_volume, n, vmin, nfmax, x_plus_y);
+  return SDM_OK;
+}
+API int sdm_ll82_coalescence_check(sdm_ctx *c, double *Ec, const double *dl, int64_t n) {
+  (void)c; oracle_ll82_coalescence_check(Ec, dl, n); return SDM_OK;
+}
+API int sdm_terminal_velocity(sdm_ctx *c, double *values, const double *radius, int64_t n,
+                              const double consts[5]) {
+  (void)c; oracle_terminal_velocity(values, radius, n, consts); return SDM_OK;
+}
+API int sdm_power_series(sdm_ctx *c, double *values, const double *radius, int64_t n,
+                         int num_terms, const double *prefactors, const double *powers) {
+  (void)c; oracle_power_series(values, radius, n, num_terms, prefactors, powers); return SDM_OK;
+}
+API int sdm_calculate_displacement(sdm_ctx *c, int dim, int n_dims, int scheme,
+                                   double *displacement, const double *courant,
+                                   const int64_t *courant_shape, const int64_t *cell_origin,
+                                   const double *position_in_cell, int64_t n_sd,
+                                   double n_substeps) {
+  (void)c;
+  oracle_calculate_displacement(dim, n_dims, scheme, displacement, courant, courant_shape,
+                                cell_origin, position_in_cell, n_sd, n_substeps);
+  return SDM_OK;
+}
+API int sdm_flag_precipitated(sdm_ctx *c, const int64_t *cell_origin,
+                              const double *position_in_cell, const double *water_mass,
+                              const int64_t *multiplicity, int64_t *idx, int64_t length,
+                              int64_t n_sd, int n_dims, int64_t *healthy, double level,
+                              const double *displacement, double *rainfall_mass) {
+  (void)c;
+  *rainfall_mass = oracle_flag_precipitated(cell_origin, position_in_cell, water_mass,
+                                            multiplicity, idx, length, n_sd, n_dims, healthy,
+                                            level, displacement);
+  return SDM_OK;
+}
+API int sdm_flag_out_of_column(sdm_ctx *c, const int64_t *cell_origin,
+                               const double *position_in_cell, int64_t *idx, int64_t length,
+                               int64_t n_sd, int n_dims, int64_t *healthy, double top) {
+  (void)c;
+  oracle_flag_out_of_column(cell_origin, position_in_cell, idx, length, n_sd, n_dims, healthy,
+                            top);
+  return SDM_OK;
+}
+API int sdm_moments(sdm_ctx *c, double *moment_0, double *moments, const int64_t *multiplicity,
+                    const double *attr_data, const int64_t *cell_id, const int64_t *idx,
+                    int64_t length, const double *ranks, int64_t n_ranks, int64_t n_cell,
+                    double min_x, double max_x, const double *x_attr,
+                    const double *weighting_attribute, double weighting_rank,
+                    int skip_division_by_m0) {
+  (void)c;
+  oracle_moments(moment_0, moments, multiplicity, attr_data, cell_id, idx, length, ranks, n_ranks,
+                 n_cell, min_x, max_x, x_attr, weighting_attribute, weighting_rank,
+                 skip_division_by_m0);
+  return SDM_OK;
+}
+API int sdm_spectrum_moments(sdm_ctx *c, double *moment_0, double *moments,
+                             const int64_t *multiplicity, const double *attr_data,
+                             const int64_t *cell_id, const int64_t *idx, int64_t length,
+                             double rank, const double *x_bins, int64_t n_bins, int64_t n_cell,
+                             const double *x_attr, const double *weighting_attribute,
+                             double weighting_rank) {
+  (void)c;
+  oracle_spectrum_moments(moment_0, moments, multiplicity, attr_data, cell_id, idx, length, rank,
+                          x_bins, n_bins, n_cell, x_attr, weighting_attribute, weighting_rank);
+  return SDM_OK;
+}
+
+/* ---- Storage element-wise operations, PySDM/backends/impl_numba/storage_impl.py ------------
+ * each operation rounds once per element, exactly as the separate numpy / njit passes do */
+static inline double sign_of(double x) { return (double)((x > 0) - (x < 0)); }
+static inline double signed_power(double x, double p) { /* :75-78 */
+  if (x != x) return x;
+  return sign_of(x) * (p == 2.0 ? x * x : pow(fabs(x), p));
+}
+static inline double py_mod(double a, double b) { /* numpy's float % (npy_divmod) */
+  double m = fmod(a, b);
+  if (m != 0.0) {
+    if ((b < 0) != (m < 0)) m += b;
+  } else {
+    m = copysign(0.0, b);
+  }
+  return m;
+}
+
+API int sdm_elementwise_f64(sdm_ctx *c, int op, double *out, const double *a, const double *b,
+                            double s, int64_t n) {
+  (void)c;
+  if (op < 0 || op > SDM_EW_MOD) FAIL(SDM_E_ARG, "sdm_elementwise_f64: unknown op");
+  for (int64_t i = 0; i < n; ++i) {
+    const double x = a ? a[i] : 0.0, y = b ? b[i] : s;
+    double r;
+    switch (op) {
+      case SDM_EW_ADD: r = x + y; break;
+      case SDM_EW_SUB: r = x - y; break;
+      case SDM_EW_MUL: r = x * y; break;
+      case SDM_EW_DIV: r = x / y; break;
+      case SDM_EW_POW: r = signed_power(x, s); break;
+      case SDM_EW_DIV_IF_NOT_ZERO: r = (y != 0.0) ? x / y : x; break;
+      case SDM_EW_FLOOR: r = floor(x); break;
+      case SDM_EW_EXP: r = exp(x); break;
+      case SDM_EW_ABS: r = fabs(x); break;
+      case SDM_EW_FILL: r = y; break;
+      case SDM_EW_ADD_MUL: r = x + s * b[i]; break;
+      default: r = py_mod(x, y);
+    }
+    out[i] = r;
+  }
+  return SDM_OK;
+}
+API int sdm_elementwise_i64(sdm_ctx *c, int op, int64_t *out, const int64_t *a, const int64_t *b,
+                            int64_t s, int64_t n) {
+  (void)c;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t x = a ? a[i] : 0, y = b ? b[i] : s;
+    int64_t r;
+    switch (op) {
+      case SDM_EW_ADD: r = x + y; break;
+      case SDM_EW_SUB: r = x - y; break;
+      case SDM_EW_MUL: r = x * y; break;
+      case SDM_EW_ABS: r = x < 0 ? -x : x; break;
+      case SDM_EW_FILL: r = y; break;
+      case SDM_EW_MOD: {
+        r = x % y;
+        if (r != 0 && ((r < 0) != (y < 0))) r += y;
+        break;
+      }
+      default: FAIL(SDM_E_ARG, "sdm_elementwise_i64: unsupported op");
+    }
+    out[i] = r;
+  }
+  return SDM_OK;
+}
+API int sdm_reduce_f64(sdm_ctx *c, int kind, const double *a, int64_t n, double *result) {
+  (void)c;
+  if (n <= 0) FAIL(SDM_E_ARG, "sdm_reduce_f64: empty array");
+  double r = a[0];  /* numpy amin / amax: a NaN anywhere gives NaN */
+  for (int64_t i = 1; i < n; ++i) {
+    if (r != r) break;
+    if (a[i] != a[i] || (kind == 0 ? a[i] < r : a[i] > r)) r = a[i];
+  }
+  *result = r;
+  return SDM_OK;
+}
+API int sdm_floor_to_i64(sdm_ctx *c, int64_t *out, const double *a, int64_t n) {
+  (void)c;
+  for (int64_t i = 0; i < n; ++i) out[i] = (int64_t)floor(a[i]);
+  return SDM_OK;
+}
+API int sdm_subtract_i64(sdm_ctx *c, double *out, const int64_t *b, int64_t n) {
+  (void)c;
+  for (int64_t i = 0; i < n; ++i) out[i] = out[i] - (double)b[i];
+  return SDM_OK;
+}
+
+/* =============================================================================================
+ * The fused entry points: the reference's driver loops as chains of the array passes above.
+ * ============================================================================================= */
+typedef struct {
+  const sdm_step_cfg *cfg;
+  sdm_step_state *st;
+  int64_t N, P, C;
+  int64_t *idx, *tmp_idx;         /* current / spare permutation buffer (exchanged by the sort) */
+  int64_t swaps;
+  int64_t valid, work;            /* ParticleAttributes.__valid_n_sd, len(idx) */
+  int sorted;
+  int64_t healthy;                /* healthy_memory[0] */
+  /* scratch */
+  uint8_t *flag;
+  double *pairs_rand, *rand, *proc_rand, *rand_frag;
+  double *kernel_temp, *prob, *norm, *tmp, *tmp2;
+  double *Ec, *Eb, *nfrag, *fmass;
+  double *pw[12];                 /* further pair-wise temporaries of the long chains */
+  double *volume, *radius, *velocity, *area;
+  int have_volume, have_radius, have_velocity, have_area;
+  uint64_t off, off_b;            /* doubles drawn so far from the collision / breakup streams */
+  int64_t substep;                /* RandomGeneratorOptimizer.substep */
+  int64_t n_sub, n_pairs, n_overflow;
+} Box;
+
+static void box_sort_by_cell(Box *B) { /* particle_attributes.py:106-110 __sort_by_cell_id */
+  oracle_counting_sort_by_cell_id(B->tmp_idx, B->idx, B->st->cell_id, B->st->cell_idx, B->work,
+                                  B->st->cell_start, B->C + 1);
+  int64_t *t = B->idx; B->idx = B->tmp_idx; B->tmp_idx = t;
+  ++B->swaps;
+  B->sorted = 1;
+}
+static const int64_t *box_cell_start(Box *B) { /* :51-55 the lazy `cell_start` property */
+  if (!B->sorted) box_sort_by_cell(B);
+  return B->st->cell_start;
+}
+static void box_sanitize(Box *B) { /* :67-73 */
+  if (B->healthy) return;
+  B->work = B->valid;
+  B->work = oracle_remove_zero_n_or_flagged(B->st->multiplicity, B->idx, B->work, B->N);
+  B->valid = B->work;
+  B->healthy = 1;
+  B->sorted = 0;
+}
+
+/* derived attributes, recomputed over all raw slots whenever the state changed (the reference's
+ * timestamp logic, attributes/impl/derived_attribute.py:15-23, recomputes them on first use after
+ * every update; the values are pure functions of the water mass) */
+static const double *box_mass(Box *B) { return B->st->attributes + B->cfg->mass_attr * B->N; }
+static const double *box_volume(Box *B) {
+  if (!B->have_volume) {
+    oracle_volume_of_water_mass(B->volume, box_mass(B), B->N, B->cfg->rho_w);
+    B->have_volume = 1;
+  }
+  return B->volume;
+}
+static const double *box_radius(Box *B) { /* attributes/physics/radius.py:15-17 */
+  if (!B->have_radius) {
+    const double *v = box_volume(B);
+    const double inv = 1 / (3.141592653589793 * 4 / 3);
+    for (int64_t i = 0; i < B->N; ++i) B->radius[i] = v[i] * inv;
+    for (int64_t i = 0; i < B->N; ++i) B->radius[i] = signed_power(B->radius[i], 1.0 / 3);
+    B->have_radius = 1;
+  }
+  return B->radius;
+}
+static const double *box_area(Box *B) { /* attributes/physics/area.py */
+  if (!B->have_area) {
+    const double *v = box_volume(B);
+    const double pi43 = 3.141592653589793 * 4 / 3, inv = 1 / pi43;
+    for (int64_t i = 0; i < B->N; ++i) B->area[i] = v[i] * inv;
+    for (int64_t i = 0; i < B->N; ++i) B->area[i] = signed_power(B->area[i], 2.0 / 3);
+    for (int64_t i = 0; i < B->N; ++i) B->area[i] = B->area[i] * (pi43 * 3);
+    B->have_area = 1;
+  }
+  return B->area;
+}
+static const double *box_velocity(Box *B) { /* terminal_velocity.py + gunn_and_kinzer.py:127-137 */
+  if (!B->have_velocity) {
+    oracle_interpolation(B->velocity, box_radius(B), B->N, B->cfg->gk_factor, B->st->gk_a,
+                         B->st->gk_b);
+    B->have_velocity = 1;
+  }
+  return B->velocity;
+}
+
+/* pair-wise Storage helpers on P-long arrays */
+static void pw_op(Box *B, int op, double *out, const double *attr) {
+  oracle_pair_op_f64(op, out, B->P, attr, B->flag, B->idx, B->work);
+}
+static void pw_scale(Box *B, double *a, double s) { for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] * s; }
+static void pw_shift(Box *B, double *a, double s) { for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] + s; }
+static void pw_div_s(Box *B, double *a, double s) { for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] / s; }
+static void pw_pow(Box *B, double *a, double p) { for (int64_t i = 0; i < B->P; ++i) a[i] = signed_power(a[i], p); }
+static void pw_mul(Box *B, double *a, const double *b) { for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] * b[i]; }
+static void pw_add(Box *B, double *a, const double *b) { for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] + b[i]; }
+static void pw_sub(Box *B, double *a, const double *b) { for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] - b[i]; }
+static void pw_div(Box *B, double *a, const double *b) { for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] / b[i]; }
+static void pw_div_nz(Box *B, double *a, const double *b) { /* divide_if_not_zero */
+  for (int64_t i = 0; i < B->P; ++i) if (b[i] != 0.0) a[i] = a[i] / b[i];
+}
+static void pw_exp(Box *B, double *a) { for (int64_t i = 0; i < B->P; ++i) a[i] = exp(a[i]); }
+static void pw_fill(Box *B, double *a, double s) { for (int64_t i = 0; i < B->P; ++i) a[i] = s; }
+static void pw_copy(Box *B, double *a, const double *b) { memcpy(a, b, sizeof(double) * B->P); }
+
+#define PI_ 3.141592653589793
+
+/* collision kernels: collision_kernels/{golovin.py:14-16, geometric.py:15-22, constantK.py,
+ * impl/parameterized.py:8-30, simple_geometric.py, linear.py} */
+static int box_kernel(Box *B, double *out) {
+  const sdm_step_cfg *c = B->cfg;
+  double *tmp = B->tmp;
+  switch (c->kernel) {
+    case SDM_KERNEL_GOLOVIN:
+      pw_op(B, SDM_PAIR_SUM, out, box_volume(B));
+      pw_scale(B, out, c->kernel_param[0]);
+      return 0;
+    case SDM_KERNEL_GEOMETRIC:
+      pw_op(B, SDM_PAIR_SUM, out, box_radius(B));
+      pw_pow(B, out, 2);
+      pw_scale(B, out, c->kernel_param[0]);
+      pw_op(B, SDM_PAIR_DISTANCE, tmp, box_velocity(B));
+      pw_mul(B, out, tmp);
+      return 0;
+    case SDM_KERNEL_CONSTANT:
+      pw_fill(B, out, c->kernel_param[0]);
+      return 0;
+    case SDM_KERNEL_PARAMETERIZED:
+      oracle_linear_collection_efficiency(c->kernel_berry_params, out, B->P, box_radius(B),
+                                          B->flag, B->idx, B->work, c->kernel_berry_unit);
+      pw_pow(B, out, 2);
+      pw_scale(B, out, PI_);
+      pw_op(B, SDM_PAIR_MAX, tmp, box_radius(B));
+      pw_pow(B, tmp, 2);
+      pw_mul(B, out, tmp);
+      pw_op(B, SDM_PAIR_DISTANCE, tmp, box_velocity(B));
+      pw_mul(B, out, tmp);
+      return 0;
+    case SDM_KERNEL_SIMPLE_GEOMETRIC:
+      pw_fill(B, out, c->kernel_param[0]);
+      pw_op(B, SDM_PAIR_SUM, tmp, box_radius(B));
+      pw_pow(B, tmp, 2);
+      pw_mul(B, out, tmp);
+      pw_op(B, SDM_PAIR_DISTANCE, tmp, box_area(B));
+      pw_mul(B, out, tmp);
+      return 0;
+    case SDM_KERNEL_LINEAR:
+      pw_op(B, SDM_PAIR_SUM, out, box_volume(B));
+      pw_scale(B, out, c->kernel_param[1]);
+      pw_shift(B, out, c->kernel_param[0]);
+      return 0;
+    default:
+      return 1;
+  }
+}
+
+/* Sc, St and CKE as both Low & List classes form them (coalescence_efficiencies/lowlist1982.py:
+ * 46-80, breakup_fragmentations/lowlist82.py:53-78); `ext` = water mass (Ec) or volume (Nf) */
+static void ll82_surface_and_kinetic(Box *B, double *Sc, double *St, double *tmp, double *tmp2,
+                                     double *CKE, const double *ext, double factor) {
+  const sdm_step_cfg *c = B->cfg;
+  pw_op(B, SDM_PAIR_SUM, Sc, ext);
+  pw_pow(B, Sc, 2.0 / 3);
+  pw_scale(B, Sc, factor);
+  pw_op(B, SDM_PAIR_MIN, St, box_radius(B));
+  pw_scale(B, St, 2);
+  pw_pow(B, St, 2);
+  pw_op(B, SDM_PAIR_MAX, tmp, box_radius(B));
+  pw_scale(B, tmp, 2);
+  pw_pow(B, tmp, 2);
+  pw_add(B, St, tmp);
+  pw_scale(B, St, PI_ * c->sgm_w);
+  pw_op(B, SDM_PAIR_SUM, tmp, ext);
+  pw_op(B, SDM_PAIR_DISTANCE, tmp2, box_velocity(B));
+  pw_pow(B, tmp2, 2);
+  pw_op(B, SDM_PAIR_MULTIPLY, CKE, ext);
+  pw_div_nz(B, CKE, tmp);
+  pw_mul(B, CKE, tmp2);
+  pw_scale(B, CKE, c->rho_w / 2);
+}
+
+/* coalescence efficiencies: constEc.py:12-13, _parameterized.py:17-25, straub2010.py:27-50,
+ * lowlist1982.py:30-103 */
+static int box_ec(Box *B, double *out) {
+  const sdm_step_cfg *c = B->cfg;
+  double **w = B->pw;
+  switch (c->ec) {
+    case SDM_EC_CONST:
+      pw_fill(B, out, c->ec_param[0]);
+      return 0;
+    case SDM_EC_BERRY1967:
+      oracle_linear_collection_efficiency(c->berry_params, out, B->P, box_radius(B), B->flag,
+                                          B->idx, B->work, c->berry_unit);
+      pw_pow(B, out, 2);
+      return 0;
+    case SDM_EC_STRAUB2010: {
+      double *Sc = w[0], *tmp = w[1], *tmp2 = w[2], *We = w[3];
+      pw_op(B, SDM_PAIR_SUM, tmp, box_volume(B));
+      pw_copy(B, Sc, tmp);
+      pw_scale(B, Sc, 6 / PI_);
+      pw_scale(B, tmp, 2);
+      pw_op(B, SDM_PAIR_DISTANCE, tmp2, box_velocity(B));
+      pw_pow(B, tmp2, 2);
+      pw_op(B, SDM_PAIR_MULTIPLY, We, box_volume(B));
+      pw_div_nz(B, We, tmp);
+      pw_mul(B, We, tmp2);
+      pw_scale(B, We, c->rho_w);
+      pw_pow(B, Sc, 2.0 / 3);
+      pw_scale(B, Sc, PI_ * c->sgm_w);
+      pw_div_nz(B, We, Sc);
+      pw_scale(B, We, -1.15);
+      pw_exp(B, We);
+      pw_copy(B, out, We);
+      return 0;
+    }
+    case SDM_EC_LOWLIST1982: {
+      double *Sc = w[0], *St = w[1], *dS = w[2], *tmp = w[3], *tmp2 = w[4], *CKE = w[5],
+             *Et = w[6], *ds = w[7], *dl = w[8];
+      pw_op(B, SDM_PAIR_MIN, ds, box_radius(B));
+      pw_scale(B, ds, 2);
+      pw_op(B, SDM_PAIR_MAX, dl, box_radius(B));
+      pw_scale(B, dl, 2);
+      ll82_surface_and_kinetic(B, Sc, St, tmp, tmp2, CKE, box_mass(B), c->ec_param[1]);
+      pw_copy(B, dS, St);
+      pw_sub(B, dS, Sc);
+      pw_copy(B, Et, CKE);
+      pw_add(B, Et, dS);
+      pw_copy(B, tmp2, Et);
+      pw_pow(B, tmp2, 2);
+      pw_scale(B, tmp2, -1.0 * 2.61e6 * c->sgm_w);
+      pw_div(B, tmp2, Sc);
+      pw_copy(B, out, ds);
+      pw_div(B, out, dl);
+      pw_shift(B, out, 1.0);
+      pw_pow(B, out, -2.0);
+      pw_scale(B, out, 0.778);
+      pw_exp(B, tmp2);
+      pw_mul(B, out, tmp2);
+      oracle_ll82_coalescence_check(out, dl, B->P);
+      return 0;
+    }
+    default:
+      return 1;
+  }
+}
+
+/* fragmentation functions: always_n.py:11-14, constant_mass.py, impl/volume_based.py:10-17 with
+ * exponential.py:23-37, gaussian.py, feingold1988.py, slams.py, straub2010.py:42-101,
+ * lowlist82.py:37-117 */
+static int box_fragments(Box *B, double *nf, double *fm, double *u01) {
+  const sdm_step_cfg *c = B->cfg;
+  double **w = B->pw;
+  const double vmin = c->frag_vmin, nfmax = c->frag_nfmax;
+  double *sum_v = B->tmp2;
+  switch (c->frag) {
+    case SDM_FRAG_ALWAYS_N:
+      pw_fill(B, nf, c->frag_param[0]);
+      pw_op(B, SDM_PAIR_SUM, fm, box_mass(B));
+      pw_div_s(B, fm, c->frag_param[0]);
+      return 0;
+    case SDM_FRAG_CONSTANT_MASS:
+      pw_fill(B, fm, c->frag_param[0]);
+      pw_op(B, SDM_PAIR_SUM, nf, box_mass(B));
+      pw_div_s(B, nf, c->frag_param[0]);
+      return 0;
+    case SDM_FRAG_EXPONENTIAL:
+      pw_op(B, SDM_PAIR_SUM, sum_v, box_volume(B));
+      oracle_exp_fragmentation(c->frag_param[0], fm, u01, B->P, 1e-5);
+      oracle_fragmentation_limiters(nf, fm, B->P, vmin, nfmax, sum_v);
+      break;
+    case SDM_FRAG_GAUSSIAN: {
+      const double k[2] = {c->straub_consts[3], c->straub_consts[4]};
+      pw_op(B, SDM_PAIR_SUM, sum_v, box_volume(B));
+      oracle_gauss_fragmentation(c->frag_param[0], c->frag_param[1], fm, u01, B->P, k);
+      oracle_fragmentation_limiters(nf, fm, B->P, vmin, nfmax, sum_v);
+      break;
+    }
+    case SDM_FRAG_FEINGOLD1988:
+      pw_op(B, SDM_PAIR_SUM, sum_v, box_volume(B));
+      oracle_feingold1988_fragmentation(c->frag_param[0], fm, sum_v, u01, B->P,
+                                        c->frag_param[1]);
+      oracle_fragmentation_limiters(nf, fm, B->P, vmin, nfmax, sum_v);
+      break;
+    case SDM_FRAG_SLAMS:
+      pw_op(B, SDM_PAIR_SUM, sum_v, box_volume(B));
+      oracle_slams_fragmentation(nf, fm, sum_v, w[0], u01, B->P);
+      oracle_fragmentation_limiters(nf, fm, B->P, vmin, nfmax, sum_v);
+      break;
+    case SDM_FRAG_STRAUB2010: {
+      double *Sc = w[0], *tmp = w[1], *tmp2 = w[2], *CKE = w[3], *We = w[4], *gam = w[5],
+             *CW = w[6], *ds = w[7], *vmax = w[8];
+      double *Nr = w[9];  /* 6 x P: Nr1..Nr4, Nrt, d34 */
+      pw_op(B, SDM_PAIR_MAX, vmax, box_volume(B));
+      pw_op(B, SDM_PAIR_SUM, sum_v, box_volume(B));
+      pw_op(B, SDM_PAIR_MIN, ds, box_radius(B));
+      pw_scale(B, ds, 2);
+      pw_op(B, SDM_PAIR_SUM, tmp, box_volume(B));
+      pw_copy(B, Sc, tmp);
+      pw_pow(B, Sc, 2.0 / 3);
+      pw_scale(B, Sc, c->frag_param[1]);
+      pw_op(B, SDM_PAIR_DISTANCE, tmp2, box_velocity(B));
+      pw_pow(B, tmp2, 2);
+      pw_op(B, SDM_PAIR_MULTIPLY, CKE, box_volume(B));
+      pw_div_nz(B, CKE, tmp);
+      pw_mul(B, CKE, tmp2);
+      pw_scale(B, CKE, c->rho_w / 2);
+      pw_copy(B, We, CKE);
+      pw_div_nz(B, We, Sc);
+      pw_copy(B, CW, We);
+      pw_mul(B, CW, CKE);
+      pw_div_s(B, CW, 1e-6);
+      pw_op(B, SDM_PAIR_MAX, gam, box_radius(B));
+      pw_op(B, SDM_PAIR_MIN, tmp, box_radius(B));
+      pw_div_nz(B, gam, tmp);
+      memset(Nr, 0, sizeof(double) * 5 * B->P);
+      oracle_straub_fragmentation(CW, gam, ds, vmax, fm, u01, Nr, Nr + B->P, Nr + 2 * B->P,
+                                  Nr + 3 * B->P, Nr + 4 * B->P, Nr + 5 * B->P, B->P,
+                                  c->straub_consts);
+      oracle_fragmentation_limiters(nf, fm, B->P, vmin, nfmax, sum_v);
+      break;
+    }
+    case SDM_FRAG_LOWLIST1982: {
+      double *Sc = w[0], *St = w[1], *tmp = w[2], *tmp2 = w[3], *CKE = w[4], *We = w[5],
+             *W2 = w[6], *ds = w[7], *dl = w[8];
+      double *R = w[9];  /* dcoal, Rf, Rs, Rd */
+      double *dcoal = R, *Rf = R + B->P, *Rs = R + 2 * B->P, *Rd = R + 3 * B->P;
+      const double k[4] = {c->straub_consts[0], c->straub_consts[5], c->straub_consts[3],
+                           c->straub_consts[4]};
+      pw_op(B, SDM_PAIR_MIN, ds, box_radius(B));
+      pw_scale(B, ds, 2);
+      pw_op(B, SDM_PAIR_MAX, dl, box_radius(B));
+      pw_scale(B, dl, 2);
+      pw_op(B, SDM_PAIR_SUM, dcoal, box_volume(B));
+      pw_div_s(B, dcoal, PI_ / 6);
+      pw_pow(B, dcoal, 1.0 / 3);
+      ll82_surface_and_kinetic(B, Sc, St, tmp, tmp2, CKE, box_volume(B), c->frag_param[0]);
+      pw_copy(B, We, CKE);
+      pw_copy(B, W2, CKE);
+      pw_div_nz(B, We, Sc);
+      pw_div_nz(B, W2, St);
+      for (int64_t i = 0; i < 3 * B->P; ++i) Rf[i] = Rf[i] * 0.0;
+      pw_op(B, SDM_PAIR_SUM, sum_v, box_volume(B));
+      oracle_ll82_fragmentation(CKE, We, W2, St, ds, dl, dcoal, fm, u01, Rf, Rs, Rd, B->P, 1e-8,
+                                k);
+      oracle_fragmentation_limiters(nf, fm, B->P, vmin, nfmax, sum_v);
+      break;
+    }
+    default:
+      return 1;
+  }
+  oracle_mass_of_water_volume(fm, fm, B->P, c->rho_w);  /* volume_based.py:16 */
+  return 0;
+}
+
+static void draw(const sdm_step_cfg *cfg, uint64_t offset, double *out, int64_t n) {
+  uint64_t st[4] = {cfg->rng_state_inc[0], cfg->rng_state_inc[1], cfg->rng_state_inc[2],
+                    cfg->rng_state_inc[3]};
+  oracle_pcg64_advance(st, 0, offset);
+  oracle_pcg64_fill(st, out, n);
+}
+
+/* collision.py:196-234 `step` */
+static int box_step(Box *B, int64_t shift_len) {
+  const sdm_step_cfg *c = B->cfg;
+  sdm_step_state *st = B->st;
+  /* random_generator_optimizer.py:37-48 */
+  if (!c->optimized_random || B->substep == 0) {
+    draw(c, B->off, B->pairs_rand, B->N + shift_len);
+    B->off += (uint64_t)(B->N + shift_len);
+    draw(c, B->off, B->rand, B->P);
+    B->off += (uint64_t)B->P;
+    if (c->enable_breakup) {  /* two more generators with the same seed: identical streams */
+      draw(c, B->off_b, B->proc_rand, B->P);
+      memcpy(B->rand_frag, B->proc_rand, sizeof(double) * B->P);
+      B->off_b += (uint64_t)B->P;
+    }
+  }
+  const double *u01 = B->pairs_rand + (c->optimized_random ? B->substep : 0);
+  B->substep += 1;
+  /* toss pairs: permutation (particle_attributes.py:98-105), find_pairs, sort within pair */
+  if (c->croupier_local) {
+    const int64_t *cs = box_cell_start(B);
+    oracle_shuffle_local(B->idx, u01, cs, B->C);
+  } else {
+    oracle_shuffle_global(B->idx, B->work, u01);
+    B->sorted = 0;
+  }
+  {
+    const int64_t *cs = box_cell_start(B);
+    oracle_find_pairs(cs, B->flag, st->cell_id, st->cell_idx, B->idx, B->work);
+  }
+  oracle_sort_within_pair_by_attr_i64(B->idx, B->work, B->flag, st->multiplicity);
+  B->n_pairs += B->work / 2;
+  /* probabilities (eq. 20 of Shima et al. 2009): collision.py:265-271 */
+  double *prob = B->prob;
+  if (box_kernel(B, B->kernel_temp)) return SDM_E_ARG;
+  oracle_pair_op_i64(SDM_PAIR_MAX, prob, B->P, st->multiplicity, B->flag, B->idx, B->work);
+  pw_mul(B, prob, B->kernel_temp);
+  oracle_normalize(prob, B->P, st->cell_id, st->cell_idx, box_cell_start(B), B->norm, B->C,
+                   c->dt, c->dv);
+  if (c->enable_breakup) {
+    if (box_ec(B, B->Ec)) return SDM_E_ARG;
+    pw_fill(B, B->Eb, c->eb_const);
+    if (box_fragments(B, B->nfrag, B->fmass, B->rand_frag)) return SDM_E_ARG;
+  }
+  /* collision.py:273-290 compute_gamma */
+  if (c->adaptive) {
+    oracle_scale_prob_for_adaptive_sdm_gamma(prob, B->idx, B->work, st->multiplicity,
+                                             st->cell_id, st->dt_left, B->C, c->dt, c->dt_min,
+                                             c->dt_max, B->flag, st->stats_n_substep,
+                                             st->stats_dt_min);
+  } else {
+    pw_div_s(B, prob, (double)c->substeps);
+  }
+  oracle_compute_gamma(prob, B->rand, B->idx, B->work, st->multiplicity, st->cell_id,
+                       st->collision_rate_deficit, st->collision_rate, B->flag, prob);
+  /* particulator.py:157-213 collision_coalescence_breakup + sanitize */
+  if (c->enable_breakup) {
+    B->n_overflow += oracle_collision_coalescence_breakup(
+        st->multiplicity, B->idx, B->work, st->attributes, c->n_attr, B->N, prob, B->proc_rand,
+        B->Ec, B->Eb, B->fmass, &B->healthy, st->cell_id, st->coalescence_rate, st->breakup_rate,
+        st->breakup_rate_deficit, B->flag, c->max_multiplicity, box_mass(B),
+        c->handle_all_breakups);
+  } else {
+    oracle_collision_coalescence(st->multiplicity, B->idx, B->work, st->attributes, c->n_attr,
+                                 B->N, prob, &B->healthy, st->cell_id, st->coalescence_rate,
+                                 B->flag);
+  }
+  box_sanitize(B);
+  B->have_volume = B->have_radius = B->have_velocity = B->have_area = 0;
+  ++B->n_sub;
+  return SDM_OK;
+}
+
+static void *take(char **cursor, size_t bytes) {
+  void *p = *cursor;
+  *cursor += (bytes + 63) & ~(size_t)63;
+  return p;
+}
+
+/* one `Collision.__call__` (collision.py:174-194) */
+static int box_time_step(const sdm_step_cfg *cfg, sdm_step_state *st, sdm_step_result *res) {
+  if (!cfg || !st || !res) FAIL(SDM_E_ARG, "sdm_collision_step: null argument");
+  Box B;
+  memset(&B, 0, sizeof(B));
+  B.cfg = cfg;
+  B.st = st;
+  B.N = cfg->n_sd;
+  B.P = cfg->n_sd / 2;
+  B.C = cfg->n_cell;
+  B.idx = st->idx;
+  B.tmp_idx = st->tmp_idx;
+  B.valid = st->ctl[0];
+  B.work = st->ctl[1];
+  B.sorted = (int)st->ctl[2];
+  B.healthy = st->ctl[3];
+  B.off = st->rng_offset;
+  B.off_b = st->rng_offset_breakup;
+  const int64_t shift_len =
+      cfg->optimized_random ? (int64_t)ceil(cfg->dt / cfg->dt_min) : 0;
+  const size_t pw_bytes = sizeof(double) * (size_t)(B.P + 8);
+  const size_t total = (size_t)(B.N + 64) + sizeof(double) * (size_t)(B.N + shift_len + 8) +
+                       (12 + 9) * (pw_bytes + 64) + 6 * (pw_bytes + 64) +
+                       4 * (sizeof(double) * (size_t)B.N + 64) + 4096;
+  char *arena = (char *)malloc(total);
+  if (!arena) FAIL(SDM_E_NOMEM, "oracle scratch allocation failed");
+  char *cur = arena;
+  B.flag = (uint8_t *)take(&cur, (size_t)B.N + 1);
+  memset(B.flag, 0, (size_t)B.N + 1);
+  B.pairs_rand = (double *)take(&cur, sizeof(double) * (size_t)(B.N + shift_len));
+  double **pairwise[] = {&B.rand, &B.proc_rand, &B.rand_frag, &B.kernel_temp, &B.prob, &B.tmp,
+                         &B.tmp2, &B.Ec, &B.Eb, &B.nfrag, &B.fmass};
+  for (size_t k = 0; k < sizeof(pairwise) / sizeof(pairwise[0]); ++k)
+    *pairwise[k] = (double *)take(&cur, pw_bytes);
+  for (int k = 0; k < 9; ++k) B.pw[k] = (double *)take(&cur, pw_bytes);
+  B.pw[9] = (double *)take(&cur, 6 * pw_bytes);
+  B.norm = (double *)take(&cur, sizeof(double) * (size_t)(B.C + 1));
+  B.volume = (double *)take(&cur, sizeof(double) * (size_t)B.N);
+  B.radius = (double *)take(&cur, sizeof(double) * (size_t)B.N);
+  B.velocity = (double *)take(&cur, sizeof(double) * (size_t)B.N);
+  B.area = (double *)take(&cur, sizeof(double) * (size_t)B.N);
+  if ((size_t)(cur - arena) > total) {
+    free(arena);
+    FAIL(SDM_E_NOMEM, "oracle scratch under-sized");
+  }
+  int rc = SDM_OK;
+  box_sanitize(&B);  /* a state handed over unhealthy is compacted first */
+  if (!cfg->adaptive) {
+    for (int s = 0; s < cfg->substeps && rc == SDM_OK; ++s) rc = box_step(&B, shift_len);
+  } else {
+    for (int64_t c = 0; c < B.C; ++c) st->dt_left[c] = cfg->dt;
+    while (B.work != 0 && rc == SDM_OK) {
+      oracle_sort_by_key(st->cell_idx, st->dt_left, B.C);
+      rc = box_step(&B, shift_len);
+      if (rc) break;
+      const int64_t end = oracle_adaptive_sdm_end(st->dt_left, B.C, box_cell_start(&B));
+      B.work = end;  /* cut_working_length */
+    }
+    B.work = B.valid;                      /* reset_working_length */
+    oracle_identity_index(st->cell_idx, B.C);  /* reset_cell_idx */
+    box_sort_by_cell(&B);
+  }
+  free(arena);
+  if (rc) FAIL(rc, "oracle: unsupported kernel / efficiency / fragmentation code");
+  st->ctl[0] = B.valid;
+  st->ctl[1] = B.work;
+  st->ctl[2] = B.sorted;
+  st->ctl[3] = B.healthy;
+  st->ctl[4] += B.n_overflow;
+  st->rng_offset = B.off;
+  st->rng_offset_breakup = B.off_b;
+  st->known_valid = B.valid;
+  res->n_substeps = B.n_sub;
+  res->n_pairs = B.n_pairs;
+  res->valid_n_sd = B.valid;
+  res->idx_swapped = B.swaps & 1;
+  res->rng_offset = B.off;
+  res->rng_offset_breakup = B.off_b;
+  memcpy(res->ctl, st->ctl, sizeof(res->ctl));
+  return SDM_OK;
+}
+
+API int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st,
+                           sdm_step_result *res, int flags) {
+  (void)ctx; (void)flags;
+  return box_time_step(cfg, st, res);
+}
+
+API int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st,
+                          sdm_step_result *res, int flags, int64_t n_steps) {
+  (void)ctx; (void)flags;
+  sdm_step_result total;
+  memset(&total, 0, sizeof(total));
+  total.valid_n_sd = -1;
+  total.rng_offset = st->rng_offset;
+  total.rng_offset_breakup = st->rng_offset_breakup;
+  for (int64_t s = 0; s < n_steps; ++s) {
+    sdm_step_result one;
+    const int rc = box_time_step(cfg, st, &one);
+    if (rc) return rc;
+    if (one.idx_swapped) {
+      int64_t *t = st->idx; st->idx = st->tmp_idx; st->tmp_idx = t;
+      total.idx_swapped ^= 1;
+    }
+    total.n_substeps += one.n_substeps;
+    total.n_pairs += one.n_pairs;
+    total.valid_n_sd = one.valid_n_sd;
+    total.rng_offset = one.rng_offset;
+    total.rng_offset_breakup = one.rng_offset_breakup;
+    memcpy(total.ctl, one.ctl, sizeof(total.ctl));
+  }
+  *res = total;
+  return SDM_OK;
+}
+
+/* one `Displacement.__call__`, dynamics/displacement.py:100-153 */
+API int sdm_displacement_step(sdm_ctx *ctx, const sdm_disp_cfg *cfg, const sdm_disp_state *st,
+                              double *rainfall_mass, int64_t *valid_n_sd) {
+  (void)ctx;
+  if (!cfg || !st || !rainfall_mass || !valid_n_sd) FAIL(SDM_E_ARG, "null argument");
+  const int64_t N = cfg->n_sd;
+  const int D = cfg->n_dims;
+  int64_t length = st->ctl[0];
+  int64_t healthy = 1;
+  int64_t *whole = (int64_t *)malloc(sizeof(int64_t) * (size_t)(D * N));
+  if (!whole) FAIL(SDM_E_NOMEM, "oracle scratch allocation failed");
+  double rain = 0.0;
+  for (int s = 0; s < cfg->n_substeps; ++s) {
+    for (int d = 0; d < D; ++d) {
+      int64_t shape[3] = {cfg->grid[0], cfg->grid[1], cfg->grid[2]};
+      shape[d] += 1;
+      oracle_calculate_displacement(d, D, cfg->scheme, st->displacement, st->courant[d], shape,
+                                    st->cell_origin, st->position_in_cell, N,
+                                    (double)cfg->n_substeps);
+    }
+    if (cfg->enable_sedimentation) { /* :125-135 */
+      double *v = st->displacement + (int64_t)(D - 1) * N;
+      const double k = cfg->dt_over_dz;
+      for (int64_t i = 0; i < N; ++i) v[i] = v[i] * (1 / k);
+      for (int64_t i = 0; i < N; ++i) v[i] = v[i] - st->fall_velocity[i];
+      for (int64_t i = 0; i < N; ++i) v[i] = v[i] * k;
+    }
+    for (int64_t i = 0; i < D * N; ++i)
+      st->position_in_cell[i] = st->position_in_cell[i] + st->displacement[i];
+    if (cfg->enable_sedimentation) {
+      rain += oracle_flag_precipitated(st->cell_origin, st->position_in_cell, st->water_mass,
+                                       st->multiplicity, st->idx, length, N, D, &healthy,
+                                       cfg->level, st->displacement);
+      if (!healthy) {
+        length = oracle_remove_zero_n_or_flagged(st->multiplicity, st->idx, length, N);
+        healthy = 1;
+      }
+    }
+    oracle_flag_out_of_column(st->cell_origin, st->position_in_cell, st->idx, length, N, D,
+                              &healthy, (double)cfg->grid[D - 1]);
+    if (!healthy) {
+      length = oracle_remove_zero_n_or_flagged(st->multiplicity, st->idx, length, N);
+      healthy = 1;
+    }
+    for (int64_t i = 0; i < D * N; ++i) whole[i] = (int64_t)floor(st->position_in_cell[i]);
+    for (int64_t i = 0; i < D * N; ++i) st->cell_origin[i] = st->cell_origin[i] + whole[i];
+    for (int64_t i = 0; i < D * N; ++i)
+      st->position_in_cell[i] = st->position_in_cell[i] - (double)whole[i];
+    for (int d = 0; d < D; ++d)
+      for (int64_t i = 0; i < N; ++i) {
+        int64_t *o = st->cell_origin + (int64_t)d * N + i;
+        int64_t r = *o % cfg->grid[d];
+        if (r != 0 && ((r < 0) != (cfg->grid[d] < 0))) r += cfg->grid[d];
+        *o = r;
+      }
+    oracle_cell_id(st->cell_id, st->cell_origin, cfg->strides, D, N);
+  }
+  free(whole);
+  st->ctl[0] = length;
+  st->ctl[1] = length;
+  st->ctl[2] = 0;
+  st->ctl[3] = 1;
+  *rainfall_mass = rain;
+  *valid_n_sd = length;
+  return SDM_OK;
+}
