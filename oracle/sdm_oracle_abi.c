@@ -27,9 +27,22 @@
 #undef API
 #define API __attribute__((visibility("default")))
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 struct sdm_ctx {
   int dummy;
 };
+
+/* thread count of the OpenMP build (the serial build ignores it) */
+API void oracle_set_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 
 static __thread char g_err[256] = "";
 #define FAIL(code, msg)                         \
@@ -871,7 +884,8 @@ static int box_time_step(const sdm_step_cfg *cfg, sdm_step_state *st, sdm_step_r
   const size_t pw_bytes = sizeof(double) * (size_t)(B.P + 8);
   const size_t total = (size_t)(B.N + 64) + sizeof(double) * (size_t)(B.N + shift_len + 8) +
                        (12 + 9) * (pw_bytes + 64) + 6 * (pw_bytes + 64) +
-                       4 * (sizeof(double) * (size_t)B.N + 64) + 4096;
+                       4 * (sizeof(double) * (size_t)B.N + 64) +
+                       sizeof(double) * (size_t)(B.C + 8) + 4096;
   char *arena = (char *)malloc(total);
   if (!arena) FAIL(SDM_E_NOMEM, "oracle scratch allocation failed");
   char *cur = arena;
@@ -884,6 +898,8 @@ static int box_time_step(const sdm_step_cfg *cfg, sdm_step_state *st, sdm_step_r
     *pairwise[k] = (double *)take(&cur, pw_bytes);
   for (int k = 0; k < 9; ++k) B.pw[k] = (double *)take(&cur, pw_bytes);
   B.pw[9] = (double *)take(&cur, 6 * pw_bytes);
+  memset(B.pw[9], 0, 6 * pw_bytes);
+  memset(B.pw[0], 0, pw_bytes);
   B.norm = (double *)take(&cur, sizeof(double) * (size_t)(B.C + 1));
   B.volume = (double *)take(&cur, sizeof(double) * (size_t)B.N);
   B.radius = (double *)take(&cur, sizeof(double) * (size_t)B.N);

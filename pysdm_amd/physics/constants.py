@@ -57,3 +57,12 @@ ROGERS_YAU_TERM_VEL_MEDIUM_K = 8e3 / si.s
 ROGERS_YAU_TERM_VEL_LARGE_K = 2.01e3 * si.cm**0.5 / si.s
 ROGERS_YAU_TERM_VEL_SMALL_R_LIMIT = 35 * si.um
 ROGERS_YAU_TERM_VEL_MEDIUM_R_LIMIT = 600 * si.um
+
+
+def namespace(overrides=None):
+    """the numeric constants of this module as one namespace, optionally with overrides"""
+    values = {name: value for name, value in globals().items()
+              if not name.startswith("_") and isinstance(value, (int, float))
+              and not isinstance(value, bool)}
+    values.update(overrides or {})
+    return SimpleNamespace(**values)

@@ -1,71 +1,71 @@
 """Re-runs the displacement goldens (tests/golden/traj_disp*.npz, produced by the reference's
-Displacement dynamic, gen_golden.py:gen_displacement) with a given backend: advection by a random
-Courant field in 1/2/3-D, sedimentation with precipitation removal, and displacement ahead of the
-collision step in a 2-D box.  Integers (cell origin, cell id, idx, multiplicity, length) must be
-identical; positions, masses and the precipitated mass within 1e-12."""
+Displacement dynamic, gen_golden.py:gen_displacement) on a given engine and route: advection by a
+random Courant field in 1/2/3-D, sedimentation with precipitation removal, and displacement ahead
+of the collision step in a 2-D box.  Integers (cell origin, cell id, idx, multiplicity, length)
+must be identical; positions, masses and the precipitated mass within 1e-12."""
 import os
 import warnings
 
 import numpy as np
 
-from pysdm_amd import Builder, Formulae
-from pysdm_amd.dynamics.collisions import Coalescence, Geometric
-from pysdm_amd.dynamics.displacement import Displacement
-from pysdm_amd.environments import Box, Mesh
+from pysdm_amd import recipe as R
+from pysdm_amd.collisions import CollisionRunner
+from pysdm_amd.displacement import DisplacementRunner
+from pysdm_amd.population import Population, locate
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ("disp1d_implicit_sed", "disp2d_implicit_sed", "disp2d_explicit", "disp3d_implicit",
          "disp2d_collide")
 
 
-def run_case(name, backend_class, fused=None):
+def run_case(name, engine, route="fused"):
     gold = np.load(os.path.join(GOLDEN, f"traj_{name}.npz"))
     n_sd, dt, explicit, sed, adaptive, collide, steps = gold["cfg"]
-    n_sd, steps = int(n_sd), int(steps)
+    steps = int(steps)
     grid = tuple(int(g) for g in gold["grid"])
-    formulae = Formulae(
-        seed=44, particle_advection="ExplicitInSpace" if explicit else "ImplicitInSpace")
-    env = Box(dt=float(dt), dv=None)
-    env.mesh = Mesh(grid, tuple(float(v) for v in gold["size"]))
-    builder = Builder(n_sd=n_sd, backend=backend_class(formulae), environment=env)
-    builder.add_dynamic(Displacement(enable_sedimentation=bool(sed), adaptive=bool(adaptive),
-                                     precipitation_counting_level_index=0, fused=fused))
+    size = tuple(float(v) for v in gold["size"])
+    cell_id, cell_origin, position_in_cell = locate(gold["init/positions"], grid)
+    population = Population(engine, multiplicity=gold["init/multiplicity"],
+                            volume=gold["init/volume"], cell_id=cell_id, grid=grid,
+                            cell_origin=cell_origin, position_in_cell=position_in_cell)
+    assert population.n_sd == int(n_sd)
+    displacement = DisplacementRunner(
+        population, dt=float(dt), size=size, enable_sedimentation=bool(sed),
+        adaptive=bool(adaptive), precipitation_counting_level_index=0,
+        scheme="ExplicitInSpace" if explicit else "ImplicitInSpace", route=route)
+    collisions = None
     if collide:
-        builder.add_dynamic(Coalescence(collision_kernel=Geometric(), adaptive=True, fused=fused))
-    cell_id, cell_origin, position_in_cell = env.mesh.cellular_attributes(gold["init/positions"])
-    particulator = builder.build({
-        "volume": gold["init/volume"], "multiplicity": gold["init/multiplicity"],
-        "cell id": cell_id, "cell origin": cell_origin, "position in cell": position_in_cell,
-    })
-    disp = particulator.dynamics["Displacement"]
-    disp.upload_courant_field(tuple(gold[f"courant/{d}"] for d in range(len(grid))))
-    assert disp._n_substeps == int(gold["n_substeps"])  # pylint: disable=protected-access
+        dv = float(np.prod(np.asarray(size) / np.asarray(grid)))
+        collisions = CollisionRunner(
+            population, R.CollisionSetup.coalescence(R.Geometric(), adaptive=True, seed=44),
+            dt=float(dt), dv=dv, route=route)
+    displacement.set_courant(tuple(gold[f"courant/{d}"] for d in range(len(grid))))
+    assert displacement.n_substeps == int(gold["n_substeps"])
+    down = engine.download
     for step in range(1, steps + 1):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            particulator.run(1)
-        attrs = particulator.attributes
-        attrs.sanitize()
+            displacement.run()
+            if collisions is not None:
+                collisions.run(1)
+        population.compact()
         tag = f"{name} step {step}"
-        length = attrs.super_droplet_count
+        length = population.live
         assert length == int(gold[f"step{step}/length"]), tag
-        idx = attrs._fused_view()["idx"].to_ndarray()  # pylint: disable=protected-access
-        live = idx[:length]
+        live = down(population.perm)[:length]
         np.testing.assert_array_equal(live, gold[f"step{step}/idx"][:length], err_msg=tag)
-        np.testing.assert_allclose(disp.precipitation_mass_in_last_step,
+        np.testing.assert_allclose(displacement.precipitation_mass_in_last_step,
                                    float(gold[f"step{step}/precipitation"]), rtol=1e-12,
                                    err_msg=tag)
-        for key, short, exact in (("cell origin", "cell_origin", True),
-                                  ("cell id", "cell_id", True),
-                                  ("multiplicity", "multiplicity", True),
-                                  ("position in cell", "position", False),
-                                  ("water mass", "mass", False)):
-            actual = attrs[key].to_ndarray(raw=True)
-            expected = gold[f"step{step}/{short}"]
+        for column, short, exact in ((population.cell_origin, "cell_origin", True),
+                                     (population.cell_id, "cell_id", True),
+                                     (population.multiplicity, "multiplicity", True),
+                                     (population.position_in_cell, "position", False),
+                                     (population.mass, "mass", False)):
             # super-droplets that left the domain keep whatever they held: compare the live ones
-            actual, expected = actual[..., live], expected[..., live]
+            actual, expected = down(column)[..., live], gold[f"step{step}/{short}"][..., live]
             if exact:
-                np.testing.assert_array_equal(actual, expected, err_msg=f"{tag} {key}")
+                np.testing.assert_array_equal(actual, expected, err_msg=f"{tag} {short}")
             else:
                 np.testing.assert_allclose(actual, expected, rtol=1e-12, atol=1e-13,
-                                           err_msg=f"{tag} {key}")
+                                           err_msg=f"{tag} {short}")
