@@ -1,24 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the SDM collision hot path on MI355X.
 
-A "step" is one `Collision.__call__` (one time step of the Shima-2009 box: PCG64 draws, pair
-permutation, Golovin probabilities, gamma, multiplicity/attribute update, compaction) over the
-whole super-droplet population, state resident in HBM.  Metric (BASELINE.json): candidate
-super-droplet pairs per second; with --gpus N every rank runs an independent realisation of the
-box (the 0-D box has a single cell: "replicas only", no data-path collective) and rank 0 reports
-the aggregate.
+A "step" is one collision time step (the reference's `Collision.__call__`: PCG64 draws, pair
+permutation, kernel probabilities, gamma, multiplicity / attribute update, compaction) over the
+whole super-droplet population, state resident in HBM, fused route (`sdm_collision_run`).
+Metric (BASELINE.json): candidate super-droplet pairs per second.  With --gpus N a 0-D box runs N
+independent realisations ("replicas only": one cell, no data-path collective) and rank 0 reports
+the aggregate; the 32 x 32 configuration shards its cells over the ranks (pysdm_amd.sharding).
 
     python bench.py --gpus 1 --steps 200 --warmup 20
 
-One JSON line on stdout (rank 0).  `roofline` prices the dominant kernel of the step against the
-HBM peak with the algorithmic bytes of SURVEY.md section 8(d) (136 B per candidate pair for the
-coalescence-only box), timed live with HIP events on the library's stream; `cpu_baseline` times
-the oracle (serial C restatement of the reference algorithm) on the host for a bounded sample.
+One JSON line on stdout (rank 0).  The timed region (exactly `--steps` steps between barriers) is
+repeated `--reps` times and the median repetition is reported.  `roofline` prices the dominant
+kernel of the step against the HBM peak with the algorithmic bytes of SURVEY.md 8(d) (136 B per
+candidate pair, 152 B with breakup), timed live with HIP events on the library's stream;
+`cpu_baseline` times the oracle (C restatement of the reference's Numba-backend algorithm, OpenMP
+where Numba uses `prange`) on the host for a bounded sample, at 1 thread and at all cores.
 """
 import argparse
 import ctypes
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -30,6 +34,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_PAIR = 136   # 24 u01 + 32 idx + 32 multiplicity + 16 cell id + 32*A, A=1
+BYTES_PER_PAIR_BREAKUP = 152  # + proc_rand, rand_frag
 
 
 WORKLOADS = {
@@ -37,65 +42,81 @@ WORKLOADS = {
              "(BASELINE.json configs[1]); replicas only for N>1",
     "berry_breakup": "Berry 1967 0D box, geometric kernel + Berry1967 Ec + exponential "
                      "fragmentation, n_sd=2^20 per GPU (configs[2]); replicas only for N>1",
-    "straub": "Straub 2010 Ec + fragmentation, geometric kernel, n_sd=2^22 per GPU (configs[4]); "
-              "replicas only for N>1",
+    "straub": "Straub 2010 Ec + fragmentation on the cloud spectrum, geometric kernel, n_sd=2^22 "
+              "per GPU (configs[4] as written); replicas only for N>1",
+    "straub_rain": "Straub 2010 Ec + fragmentation on the Marshall-Palmer rain spectrum, dt=10 s, "
+                   "n_sd=2^22 per GPU (configs[4] adaptive-substep stress variant); replicas only",
     "kinematic2d": "32x32 cells, 2^22 super-droplets, geometric kernel, adaptive, "
                    "optimized_random, dt=5 s (configs[3]); cells sharded over the ranks",
 }
 
 
-def build_workload(name, backend_class, rank, world, n_sd=None, adaptive=None):
-    from pysdm_amd import sharding
-    from pysdm_amd.examples import CONFIGS, make_box
+def build_workload(name, engine, rank, world, n_sd=None, adaptive=None, read_back=True):
+    from pysdm_amd import cases, sharding
 
-    if name == "kinematic2d":
-        n_cell = int(np.prod(CONFIGS[name]["grid"]))
-        block = sharding.cell_block(n_cell, rank, world) if world > 1 else None
-        return make_box(backend_class, name, n_sd=n_sd, adaptive=adaptive, cell_block=block)
+    if name == "kinematic2d" and world > 1:
+        return sharding.make_sharded_box(engine, name, rank=rank, world=world, n_sd=n_sd,
+                                         adaptive=adaptive)
     # 0-D boxes: every rank an independent realisation (seed 44 + rank)
-    return make_box(backend_class, name, n_sd=n_sd, adaptive=adaptive, seed=44 + rank)
+    return cases.make_box(engine, name, n_sd=n_sd, adaptive=adaptive, seed=44 + rank,
+                          read_back=read_back)
 
 
-def cpu_baseline(workload, n_sd, adaptive, seconds_budget=12.0):
-    """the oracle (kind "port": serial C restatement of the reference's Numba-backend algorithm,
-    driven method by method like the reference) on one host core, same box, bounded sample"""
-    from oracle.backend import OracleBackend
+def cpu_model():
+    try:
+        for line in subprocess.check_output(["lscpu"], text=True).splitlines():
+            if line.startswith("Model name"):
+                return line.split(":", 1)[1].strip()
+    except (OSError, subprocess.CalledProcessError):
+        pass
+    return "unknown"
 
-    particulator, dynamic = build_workload(workload, OracleBackend, 0, 1, n_sd, adaptive)
-    particulator.run(1)  # warm-up (first-touch, lazy attribute allocation)
-    steps, t0 = 0, time.perf_counter()
-    substeps0 = int(dynamic.stats_n_substep.to_ndarray().sum())
-    while True:
-        particulator.run(1)
-        steps += 1
-        elapsed = time.perf_counter() - t0
-        if elapsed > seconds_budget or steps >= 2000:
-            break
-    if dynamic.adaptive:  # candidate pairs = sum over sub-steps (all cells still full-length)
-        n_cell = particulator.mesh.n_cell
-        substeps = int(dynamic.stats_n_substep.to_ndarray().sum()) - substeps0
-        pairs = substeps * (particulator.n_sd // n_cell // 2)
-    else:
-        pairs = steps * (particulator.n_sd // 2)
+
+def cpu_baseline(workload, n_sd, adaptive, seconds_budget=8.0):
+    """the oracle (kind "port": C restatement of the reference's Numba-backend algorithm; serial
+    where Numba is serial, `omp parallel for` where Numba uses `prange`) on the host cores, same
+    box, bounded sample: once with 1 thread, once with all cores"""
+    from oracle.engine import OracleEngine
+
+    n_threads = os.cpu_count() or 1
+    results = {}
+    for threads in sorted({1, n_threads}):
+        engine = OracleEngine.get(threads=threads)
+        runner = build_workload(workload, engine, 0, 1, n_sd, adaptive)
+        runner.run(1)  # warm-up (first touch)
+        steps, pairs0, t0 = 0, runner.pairs_done, time.perf_counter()
+        while True:
+            runner.run(1)
+            steps += 1
+            elapsed = time.perf_counter() - t0
+            if elapsed > seconds_budget or steps >= 2000:
+                break
+        results[threads] = ((runner.pairs_done - pairs0) / elapsed, steps, elapsed,
+                            runner.population.n_sd)
+    best = max(results, key=lambda k: results[k][0])
+    value, steps, elapsed, n = results[best]
     return {
-        "value": pairs / elapsed,
+        "value": value,
         "unit": "candidate SD-pairs/s",
-        "cores": 1,
+        "cores": best,
         "kind": "port",
-        "sample": f"{steps} time steps of the same workload ({workload}, n_sd={particulator.n_sd}; "
-                  f"{elapsed:.1f} s of CPU work, oracle/sdm_oracle.c via oracle/backend.py)",
+        "cpu": cpu_model(),
+        "value_1_thread": results[1][0],
+        f"value_{n_threads}_threads": results[n_threads][0],
+        "sample": f"{steps} time steps of the same workload ({workload}, n_sd={n}; "
+                  f"{elapsed:.1f} s of CPU work per thread count, oracle/sdm_oracle*.c, "
+                  f"sdm_collision_step of the oracle library)",
     }
 
 
-def phase_timing(lib, handle):
-    from pysdm_amd._lib import check
-
+def phase_timing(engine):
     n = 12
     ms = (ctypes.c_double * n)()
     count = (ctypes.c_int64 * n)()
-    check(lib.sdm_ctx_read_timing(handle, ms, count))
-    lib.sdm_phase_name.restype = ctypes.c_char_p
-    return {lib.sdm_phase_name(i).decode(): (ms[i], count[i]) for i in range(n) if count[i] > 0}
+    engine.call("sdm_ctx_read_timing", ms, count)
+    name = engine.library.cdll.sdm_phase_name
+    name.restype = ctypes.c_char_p
+    return {name(i).decode(): (ms[i], count[i]) for i in range(n) if count[i] > 0}
 
 
 def main():
@@ -103,6 +124,7 @@ def main():
     parser.add_argument("--gpus", type=int, default=1)
     parser.add_argument("--steps", type=int, default=200)
     parser.add_argument("--warmup", type=int, default=20)
+    parser.add_argument("--reps", type=int, default=3)
     parser.add_argument("--workload", default="shima", choices=sorted(WORKLOADS))
     parser.add_argument("--n-sd", type=int, default=None)
     parser.add_argument("--adaptive", type=int, default=None)
@@ -129,17 +151,16 @@ def main():
             dist.init_process_group(dist_backend)
     reduce_device = "cuda" if dist_backend == "nccl" else "cpu"
 
-    from pysdm_amd.backends import HIP
-    from pysdm_amd.backends.hip import _Context
+    from pysdm_amd.engine import HipEngine
 
+    engine = HipEngine.get(local_rank)
     adaptive = None if args.adaptive is None else bool(args.adaptive)
-    particulator, dynamic = build_workload(args.workload, HIP, rank, world, args.n_sd, adaptive)
-    n_sd = particulator.n_sd
-    particulator.run(1)  # builds the fused step, allocates scratch
-    fused = dynamic._fused_state  # pylint: disable=protected-access
-    assert fused not in (None, False), "the fused HIP route must be the one benchmarked"
+    runner = build_workload(args.workload, engine, rank, world, args.n_sd, adaptive)
+    pop, setup = runner.population, runner.setup
+    n_sd = pop.n_sd
+    runner.run(1)  # allocates scratch, builds the mirror
     # non-adaptive: no host read-back inside the timed loop
-    fused.read_back = bool(dynamic.adaptive)
+    runner.read_back = bool(setup.adaptive) or world > 1
 
     def barrier():
         torch.cuda.synchronize()
@@ -147,51 +168,54 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    particulator.run(args.warmup)
-    fused.total_pairs = 0
-    barrier()
-    pairs_before = int(fused.ctl[5].item())  # the library's own count (control word 5)
-    t0 = time.perf_counter()
-    particulator.run(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    fused.sync()
-    if dynamic.adaptive:
-        pairs = fused.total_pairs
-    elif particulator.mesh.n_cell == 1:
-        # counted by the pair kernel itself: super-droplets may have coalesced away meanwhile
-        pairs = int(fused.ctl[5].item()) - pairs_before
-        if particulator.attributes.super_droplet_count == n_sd:
-            assert pairs == args.steps * (n_sd // 2)
-    else:  # one sub-step per time step over the whole (still complete) population
-        assert particulator.attributes.super_droplet_count == n_sd, "droplets were removed"
-        pairs = args.steps * (n_sd // 2)
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
-    p = torch.tensor([float(pairs)], dtype=torch.float64, device=reduce_device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(p, op=dist.ReduceOp.SUM)
-    elapsed_max, pairs_total = float(t.item()), float(p.item())
+    runner.run(args.warmup)
+    reps = []
+    for _ in range(max(1, args.reps)):
+        barrier()
+        pairs_before = int(pop.ctl[5].item())  # the library's own count (control word 5)
+        host_pairs_before = runner.pairs_done
+        t0 = time.perf_counter()
+        runner.run(args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        runner.sync()
+        if setup.adaptive or pop.n_cell > 1:
+            pairs = runner.pairs_done - host_pairs_before
+        else:
+            # counted by the pair kernel itself: super-droplets may have coalesced away meanwhile
+            pairs = int(pop.ctl[5].item()) - pairs_before
+            if pop.live == n_sd:
+                assert pairs == args.steps * (n_sd // 2)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
+        p = torch.tensor([float(pairs)], dtype=torch.float64, device=reduce_device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if not getattr(runner, "counts_global_pairs", False):
+                dist.all_reduce(p, op=dist.ReduceOp.SUM)
+        reps.append((float(p.item()) / float(t.item()), float(t.item()), float(p.item())))
+    rates = [r[0] for r in reps]
+    median_rate = statistics.median(rates)
+    _, elapsed_max, pairs_total = min(reps, key=lambda r: abs(r[0] - median_rate))
 
     roofline = None
     baseline = None
     if rank == 0:
         # ---- per-kernel durations, HIP events on the library's own stream (separate pass)
-        ctx = _Context.get()
-        from pysdm_amd._lib import check
-
-        check(ctx.lib.sdm_ctx_set_timing(ctx.handle, 1))
-        fused.read_back = True  # events are resolved per call
-        particulator.run(args.roofline_steps)
-        phases = phase_timing(ctx.lib, ctx.handle)
-        check(ctx.lib.sdm_ctx_set_timing(ctx.handle, 0))
+        engine.call("sdm_ctx_set_timing", 1)
+        runner.read_back = True  # events are resolved per call
+        t0 = time.perf_counter()
+        runner.run(args.roofline_steps)
+        torch.cuda.synchronize()
+        timed_wall_ms = (time.perf_counter() - t0) * 1e3 / args.roofline_steps
+        phases = phase_timing(engine)
+        engine.call("sdm_ctx_set_timing", 0)
         per_launch = {k: v[0] / v[1] for k, v in phases.items()}
         per_step = {k: v[0] / args.roofline_steps for k, v in phases.items()}
         dominant = max(per_step, key=per_step.get)
         dom_ms = per_launch[dominant]
+        # one launch of the dominant kernel covers one sub-step over the working population
         launch_pairs = n_sd // 2
-        bytes_per_pair = BYTES_PER_PAIR + (16 if dynamic.enable_breakup else 0)
+        bytes_per_pair = BYTES_PER_PAIR_BREAKUP if setup.breakup else BYTES_PER_PAIR
         achieved = bytes_per_pair * launch_pairs / (dom_ms * 1e-3) / 1e9
         traffic = None
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
@@ -205,6 +229,8 @@ def main():
             "kernel": dominant, "kernel_ms": dom_ms,
             "algorithmic_bytes_per_launch": bytes_per_pair * launch_pairs,
             "phase_ms_per_step": {k: round(v, 5) for k, v in sorted(per_step.items())},
+            "phase_sum_ms_per_step": round(sum(per_step.values()), 5),
+            "timed_mode_ms_per_step": round(timed_wall_ms, 5),
         }
         if not args.no_cpu_baseline and world == 1:  # the CPU leg: rank 0 at N=1 only
             baseline = cpu_baseline(args.workload, args.n_sd, adaptive)
@@ -214,11 +240,13 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         value = pairs_total / elapsed_max
+        sharded = args.workload == "kinematic2d" and world > 1
         print(json.dumps({
             # BASELINE.json's metric; `value` is the aggregate over all ranks (bench contract)
             "metric": ("candidate SD-pairs/s per GPU; Shima-2009 box wall-clock at n_sd=2^20"
                        if args.workload == "shima" and n_sd == 2**20
-                       else f"candidate SD-pairs/s ({args.workload}, n_sd={n_sd} per rank)"),
+                       else f"candidate SD-pairs/s ({args.workload}, n_sd={n_sd}"
+                            f"{' in total' if sharded else ' per rank'})"),
             "value": value,
             "unit": "candidate SD-pairs/s",
             "n_gpus": world,
@@ -226,17 +254,19 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong" if args.workload == "kinematic2d" else "weak",
+            "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": WORKLOADS[args.workload] + "; "
-                            + ("adaptive" if dynamic.adaptive else "non-adaptive"),
+                            + ("adaptive" if setup.adaptive else "non-adaptive"),
                 "n_sd": n_sd,
                 "seed": 44,
-                "route": "fused sdm_collision_step",
+                "route": "fused sdm_collision_run",
             },
+            "repetitions": {"n": len(reps), "reported": "median",
+                            "values": [round(r, 1) for r in rates]},
             "shima_box_3600_steps_s": elapsed_max / args.steps * 3600,
             "roofline": roofline,
             "cpu_baseline": baseline,

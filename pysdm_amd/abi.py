@@ -139,6 +139,8 @@ def _pointer(value, param, symbol):
         return value
     if isinstance(value, int):
         return c_ptr(value)
+    if isinstance(value, (list, tuple)):  # a small host array (e.g. coefficients)
+        return (_SCALARS[param.base] * len(value))(*value)
     allowed = _ELEMENT.get(param.base)
     if isinstance(value, np.ndarray):
         if not value.flags["C_CONTIGUOUS"]:

@@ -1,0 +1,180 @@
+"""The set-ups of BASELINE.json's configurations as (Population, CollisionSetup) pairs.
+
+Parameters follow the reference's example settings (examples/PySDM_examples/):
+Shima_et_al_2009/settings.py:14-33; Berry_1967/settings.py:14-47 with the breakup set-up of
+deJong_Mackay_et_al_2023/settings_0D.py:21-52; the Straub case of
+tests/smoke_tests/box/dejong_and_mackay_et_al_2023/test_fig_8.py:20-31 and its stress variant on
+the rain spectrum of deJong_Mackay_et_al_2023/simulation_ss.py:13-52 (Marshall-Palmer at 54 mm/h
+sampled logarithmically in diameter, Straub2010Nf(vmin = volume of a 10-um drop, nfmax = 1e4),
+dt = 10 s so that the adaptive scheme sub-steps); a collisions-only slice of Arabas_et_al_2015
+(32 x 32 cells, 4096 super-droplets per cell, no advection) and the same grid with the
+single-eddy flow + sedimentation ahead of the collisions.  The initial states are closed-form
+(pysdm_amd.spectra) and pinned by tests/golden/digest_*.npz.
+"""
+import numpy as np
+
+from . import recipe as R
+from . import spectra
+from .collisions import CollisionRunner
+from .displacement import DisplacementRunner
+from .physics import constants as const
+from .physics.constants import si
+from .population import Population, locate
+
+
+def volume_of_radius(radius):
+    return const.PI_4_3 * np.power(radius, 3)
+
+
+RAIN_VMIN = (0.01 * si.mm) ** 3 * np.pi / 6
+
+
+def _shima(adaptive, **options):
+    return R.CollisionSetup.coalescence(R.Golovin(b=1.5e3), adaptive=adaptive, **options)
+
+
+def _berry_breakup(adaptive, **options):
+    return R.CollisionSetup.collision(
+        R.Geometric(), R.Berry1967(), R.ConstEb(1.0),
+        R.Exponential(scale=volume_of_radius(100e-6)), adaptive=adaptive, warn_overflows=False,
+        **options)
+
+
+def _kinematic2d(adaptive, **options):
+    return R.CollisionSetup.coalescence(R.Geometric(collection_efficiency=1), adaptive=adaptive,
+                                        optimized_random=True, **options)
+
+
+def _straub(adaptive, **options):
+    return R.CollisionSetup.collision(
+        R.Geometric(), R.Straub2010Ec(), R.ConstEb(1.0),
+        R.Straub2010Nf(vmin=volume_of_radius(30.531e-6) * 1e-3, nfmax=10), adaptive=adaptive,
+        warn_overflows=False, **options)
+
+
+def _straub_rain(adaptive, **options):
+    return R.CollisionSetup.collision(
+        R.Geometric(), R.Straub2010Ec(), R.ConstEb(1.0),
+        R.Straub2010Nf(vmin=RAIN_VMIN, nfmax=10000), adaptive=adaptive, warn_overflows=False,
+        **options)
+
+
+def _marshall_palmer(dv):
+    rain_rate = 54 * si.mm / si.h
+    slope = 4.1e3 * (rain_rate / si.mm * si.h) ** (-0.21) / si.m
+    n_part = 8e6 / si.m**4 / slope
+    return spectra.Exponential(norm_factor=n_part * dv, scale=1 / slope)
+
+
+CONFIGS = {
+    # configs[0] / configs[1]: Shima 2009 box, Golovin kernel
+    "shima": dict(n_sd=2**20, n_part=2**23, dv=1e6, radius=30.531e-6, adaptive=False,
+                  make=_shima),
+    # configs[2]: Berry 1967 box, geometric kernel + breakup
+    "berry_breakup": dict(n_sd=2**20, n_part=239e6, dv=10.0 * 2**20 / 2**13, radius=10e-6,
+                          adaptive=True, make=_berry_breakup),
+    # configs[3]: 32 x 32 cells, 2^22 super-droplets, geometric kernel, adaptive, optimized_random
+    "kinematic2d": dict(n_sd=2**22, n_part=239e6, dv=2197.0 * 1024, radius=15e-6, dt=5.0,
+                        grid=(32, 32), adaptive=True, make=_kinematic2d),
+    # configs[4] as written (cloud spectrum: hardly any breakup, one sub-step per step)
+    "straub": dict(n_sd=2**22, n_part=100e6, dv=1.0 * 2**22 / 2**10, radius=30.531e-6,
+                   adaptive=True, make=_straub),
+    # configs[4] stress variant: rain spectrum, a third of the collisions break up, ~3 sub-steps
+    # per time step
+    "straub_rain": dict(n_sd=2**22, dv=1e6 * 2**22 / 2**12, dt=10.0, adaptive=True,
+                        sampling="marshall_palmer", make=_straub_rain),
+}
+
+
+def initial_state(name, n_sd=None, dv=None):
+    """(volume, real-valued multiplicity, cell id or None, dv of the whole domain, grid or None)
+    of configuration `name`; with another `n_sd` the domain volume is rescaled so that the
+    multiplicities stay those of the configuration, unless `dv` is given"""
+    cfg = CONFIGS[name]
+    n_sd = n_sd or cfg["n_sd"]
+    dv = cfg["dv"] * n_sd / cfg["n_sd"] if dv is None else dv
+    if cfg.get("sampling") == "marshall_palmer":
+        diameter, multiplicity = spectra.sample_logarithmic(_marshall_palmer(dv), n_sd)
+        volume = volume_of_radius(diameter / 2)
+    else:
+        spectrum = spectra.Exponential(norm_factor=cfg["n_part"] * dv,
+                                       scale=volume_of_radius(cfg["radius"]))
+        volume, multiplicity = spectra.sample_constant_multiplicity(spectrum, n_sd)
+    cell_id, grid = None, cfg.get("grid")
+    if grid is not None:
+        n_cell = int(np.prod(grid))
+        rng = np.random.default_rng(7)
+        cell_id = rng.integers(0, n_cell, size=n_sd).astype(np.int64)
+        order = rng.permutation(n_sd)
+        volume, multiplicity = volume[order], multiplicity[order]
+    return volume, multiplicity, cell_id, dv, grid
+
+
+def make_box(engine, name, *, n_sd=None, adaptive=None, route="fused", seed=44, dt=None,
+             thin=None, grid=None, read_back=True, dv=None):
+    """a CollisionRunner for configuration `name`.  `thin` (a cell volume per 2^16
+    super-droplets) replaces the multiplicities by 1, 2, 3, 1, ... so that super-droplets die;
+    `grid` turns a box configuration into a multi-cell one with uniform-random cell ids"""
+    cfg = CONFIGS[name]
+    if grid is not None:
+        cfg = dict(cfg, grid=tuple(grid))
+        CONFIGS["_tmp"] = cfg
+        try:
+            volume, multiplicity, cell_id, dv, grid = initial_state("_tmp", n_sd, dv)
+        finally:
+            del CONFIGS["_tmp"]
+    else:
+        volume, multiplicity, cell_id, dv, grid = initial_state(name, n_sd, dv)
+    n_sd = len(volume)
+    adaptive = cfg["adaptive"] if adaptive is None else adaptive
+    if thin is not None:
+        multiplicity = (1 + np.arange(n_sd) % 3).astype(np.int64)
+        dv = thin * n_sd / 2**16
+    population = Population(engine, multiplicity=multiplicity, volume=volume, cell_id=cell_id,
+                            grid=grid)
+    dv_cell = dv / population.n_cell
+    return CollisionRunner(population, cfg["make"](adaptive, seed=seed),
+                           dt=dt or cfg.get("dt", 1.0), dv=dv_cell, route=route,
+                           read_back=read_back)
+
+
+def single_eddy_courant(grid, size, dt, w_max=0.6):
+    """Courant numbers of the non-divergent single-eddy flow of the 2-D kinematic set-up
+    (stream function psi = -w_max X/pi sin(pi z/Z) cos(2 pi x/X), as in
+    examples/PySDM_examples/Szumowski_et_al_1998/.., Arabas_et_al_2015) on the Arakawa-C faces:
+    differences of psi at the cell corners, so the discrete divergence vanishes"""
+    (n_x, n_z), (len_x, len_z) = grid, size
+    d_x, d_z = len_x / n_x, len_z / n_z
+    x = np.linspace(0, len_x, n_x + 1).reshape(-1, 1)
+    z = np.linspace(0, len_z, n_z + 1).reshape(1, -1)
+    psi = -w_max * len_x / np.pi * np.sin(np.pi * z / len_z) * np.cos(2 * np.pi * x / len_x)
+    courant_x = -(psi[:, 1:] - psi[:, :-1]) / d_z * dt / d_x  # (n_x + 1, n_z)
+    courant_z = (psi[1:, :] - psi[:-1, :]) / d_x * dt / d_z   # (n_x, n_z + 1)
+    return courant_x, courant_z
+
+
+def make_kinematic_flow(engine, *, n_sd=2**22, grid=(32, 32), size=(1500.0, 1500.0), dt=5.0,
+                        route="fused", seed=44, sedimentation=True):
+    """configs[3] with the step that precedes collisions in the 2-D kinematic set-up:
+    displacement (single-eddy flow + sedimentation) followed by adaptive Geometric coalescence.
+    Returns (displacement runner, collision runner) sharing one population"""
+    cfg = CONFIGS["kinematic2d"]
+    n_cell = int(np.prod(grid))
+    dv_cell = float(np.prod(np.asarray(size) / np.asarray(grid)))
+    spectrum = spectra.Exponential(
+        norm_factor=cfg["n_part"] * dv_cell * n_cell * n_sd / cfg["n_sd"],
+        scale=volume_of_radius(cfg["radius"]))
+    volume, multiplicity = spectra.sample_constant_multiplicity(spectrum, n_sd)
+    rng = np.random.default_rng(7)
+    order = rng.permutation(n_sd)
+    positions = rng.uniform(0, 1, (2, n_sd)) * np.asarray(grid).reshape(2, 1)
+    cell_id, cell_origin, position_in_cell = locate(positions, grid)
+    population = Population(engine, multiplicity=multiplicity[order], volume=volume[order],
+                            cell_id=cell_id, grid=grid, cell_origin=cell_origin,
+                            position_in_cell=position_in_cell)
+    displacement = DisplacementRunner(population, dt=dt, size=size,
+                                      enable_sedimentation=sedimentation, route=route)
+    displacement.set_courant(single_eddy_courant(grid, size, dt))
+    collisions = CollisionRunner(population, cfg["make"](True, seed=seed), dt=dt, dv=dv_cell,
+                                 route=route)
+    return displacement, collisions

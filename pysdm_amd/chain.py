@@ -165,7 +165,11 @@ class ChainedCollision:  # pylint: disable=too-many-instance-attributes
             self.execute(setup.breakup_efficiency.program(k), out=self.eb)
             self.execute(setup.fragmentation.program(k), nf=self.n_fragment,
                          fm=self.fragment_mass, u01=self.draws.fragment)
-        if setup.adaptive:
+        if run.gamma_hook is not None:
+            # test hook: stands in for the adaptive scaling + gamma stage (the scenarios of the
+            # reference's unit tests force gamma); gets (chain, probability array, rand array)
+            run.gamma_hook(self, self.prob, self.draws.gamma)
+        elif setup.adaptive:
             eng.call("sdm_scale_prob_for_adaptive_sdm_gamma", self.prob, pop.perm, pop.working,
                      pop.multiplicity, pop.cell_id, run.dt_left, pop.n_cell, run.dt,
                      run.dt_range[0], run.dt_range[1], self.flag, run.stats_n_substep,
@@ -177,9 +181,8 @@ class ChainedCollision:  # pylint: disable=too-many-instance-attributes
         else:
             eng.call("sdm_elementwise_f64", EW["div"], self.prob, self.prob, None,
                      float(setup.substeps), self.n_pairs)
-        eng.call("sdm_compute_gamma", self.prob, self.draws.gamma, pop.perm, pop.working,
-                 pop.multiplicity, pop.cell_id, run.collision_rate_deficit, run.collision_rate,
-                 self.flag, self.prob)
+        if run.gamma_hook is None:
+            self.compute_gamma()
         if setup.breakup:
             eng.fill(self.overflow, 0)
             eng.call("sdm_collision_coalescence_breakup", pop.multiplicity, pop.perm,
@@ -198,6 +201,12 @@ class ChainedCollision:  # pylint: disable=too-many-instance-attributes
         pop.compact()
         pop.touch_state()
         run.sub_steps_done += 1
+
+    def compute_gamma(self):
+        run, pop = self.runner, self.runner.population
+        run.engine.call("sdm_compute_gamma", self.prob, self.draws.gamma, pop.perm, pop.working,
+                        pop.multiplicity, pop.cell_id, run.collision_rate_deficit,
+                        run.collision_rate, self.flag, self.prob)
 
     # ---- one time step ------------------------------------------------------------------------------
     def time_step(self):

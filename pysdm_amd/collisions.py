@@ -56,6 +56,7 @@ class CollisionRunner:  # pylint: disable=too-many-instance-attributes
         self.pairs_done = 0
         self.steps_done = 0
         self.descriptor = setup.descriptor(self.constants)
+        self.gamma_hook = None  # chain route only, see pysdm_amd.chain
         self._law_name = terminal_velocity
         self._law = None
         self._chain = None

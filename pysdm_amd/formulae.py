@@ -1,4 +1,5 @@
-"""`Formulae`: the options + constants object a backend is constructed with.
+"""`Formulae`: the options + constants object a PySDM-shaped backend is constructed with (a
+stand-in for PySDM's own where PySDM is absent; under PySDM the real one is passed in).
 
 Collision-path subset of PySDM/formulae.py:27-67 (same keyword names: `seed`, `constants`,
 `terminal_velocity`, `fragmentation_function`, `handle_all_breakups`,
@@ -90,13 +91,6 @@ class Formulae:  # pylint: disable=too-few-public-methods,too-many-arguments
         if particle_advection not in schemes:
             raise NotImplementedError(particle_advection)
         self.particle_advection = schemes[particle_advection]()
-
-    @property
-    def terminal_velocity_class(self):
-        from .dynamics import terminal_velocity as tv  # pylint: disable=import-outside-toplevel
-
-        return {"GunnKinzer1949": tv.GunnKinzer1949, "RogersYau": tv.RogersYau,
-                "PowerSeries": tv.PowerSeries}[self.terminal_velocity]
 
     def __str__(self):
         return f"Formulae(seed={self.seed}, fragmentation_function={self.fragmentation_function})"

@@ -20,7 +20,7 @@ def _make_si():
                   "kelvin": 1.0, "pascal": 1.0, "litre": 1e-3, "liter": 1e-3, "newton": 1.0,
                   "watt": 1.0, "hertz": 1.0, "mole": 1.0}
     table = {"dimensionless": 1.0, "min": 60.0, "minute": 60.0, "minutes": 60.0,
-             "hour": 3600.0, "hours": 3600.0, "day": 86400.0}
+             "h": 3600.0, "hour": 3600.0, "hours": 3600.0, "day": 86400.0}
     for p_name, p_val in prefixes.items():
         for u_name, u_val in short_units.items():
             table.setdefault(p_name + u_name, p_val * u_val)

@@ -124,6 +124,33 @@ class Population:  # pylint: disable=too-many-instance-attributes
         if (multiplicity == 0).any():  # unused slots: compact them away before the first step
             self.compact(assume_unhealthy=True)
 
+    @classmethod
+    def adopt(cls, engine, *, perm, perm_spare, multiplicity, extensive, rows, cell_id,
+              cell_order, cell_start, live, ordered, healthy=None, rho_w=const.rho_w):
+        """a Population over columns that already live in the engine's memory and belong to
+        someone else (e.g. PySDM's ParticleAttributes, see pysdm_amd.pysdm_plugin); nothing is
+        copied"""
+        self = cls.__new__(cls)
+        self.engine, self.rho_w = engine, rho_w
+        self.n_sd = int(multiplicity.shape[0])
+        self.n_cell = int(cell_order.shape[0])
+        self.grid = None
+        self.rows = dict(rows)
+        self.perm, self.perm_spare = perm, perm_spare
+        self.multiplicity, self.extensive = multiplicity, extensive
+        self.cell_id, self.cell_order, self.cell_start = cell_id, cell_order, cell_start
+        self.healthy = healthy if healthy is not None else engine.full(1, INT, 1)
+        self.ctl = engine.zeros(8, INT)
+        self.mirror = engine.empty(4 * max(self.n_sd, 1), INT)
+        self.cell_origin = self.position_in_cell = None
+        self.live = self.working = int(live)
+        self.ordered = bool(ordered)
+        self.state_version = self.cells_version = 0
+        self._derived = {}
+        self.host_dirty = True
+        self.mirror_version = None
+        return self
+
     # ---- views ----------------------------------------------------------------------------------
     @property
     def mass(self):

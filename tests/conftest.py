@@ -17,18 +17,37 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session")
+def oracle_engine():
+    from oracle.engine import OracleEngine  # pylint: disable=import-outside-toplevel
+
+    return OracleEngine.get()
+
+
+@pytest.fixture(scope="session")
 def oracle_backend_class():
     from oracle.backend import OracleBackend  # pylint: disable=import-outside-toplevel
 
     return OracleBackend
 
 
-@pytest.fixture(scope="session")
-def hip_backend_class():
+def _need_gpu():
     import torch  # pylint: disable=import-outside-toplevel
 
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+
+
+@pytest.fixture(scope="session")
+def hip_engine():
+    _need_gpu()
+    from pysdm_amd.engine import HipEngine  # pylint: disable=import-outside-toplevel
+
+    return HipEngine.get()
+
+
+@pytest.fixture(scope="session")
+def hip_backend_class():
+    _need_gpu()
     from pysdm_amd.backends import HIP  # pylint: disable=import-outside-toplevel
 
     return HIP

@@ -1175,7 +1175,8 @@ def gen_digests(which):
         cases.append((f"kin{per_cell}", kin))
     # configs[4] stress variant: rain spectrum, Straub 2010 Ec + Nf; dt = 10 s so that the
     # adaptive scheme really sub-steps (2.8 sub-steps per step, a third of the collisions break up)
-    for log2n, steps in ((12, (1, 10)), (14, (1, 10)), (17, (1, 5)), (20, (1, 2))):
+    for log2n, steps in ((12, (1, 10)), (14, (1, 10)), (17, (1, 5)), (20, (1, 2)),
+                         (22, (1, 2))):
         n_sd = 2**log2n
 
         def rain(n_sd=n_sd, steps=steps):

@@ -12,7 +12,15 @@ import warnings
 
 import numpy as np
 
-from pysdm_amd.dynamics.collisions import DEFAULTS
+from pysdm_amd import diagnostics, spectra
+from pysdm_amd import recipe as C
+from pysdm_amd.chain import ChainedCollision
+from pysdm_amd.collisions import CollisionRunner
+from pysdm_amd.physics import constants as const
+from pysdm_amd.population import Population, locate
+
+MAX_MULTIPLICITY = C.MAX_MULTIPLICITY
+DT_COAL_MAX = 100.0  # upper end of the default dt_coal_range
 
 SCALE_PROB_CASES = (
     # gamma, idx, n, cell_id, dt_left, dt, dt_max, is_first_in_pair, expected_dt_left, n_substep
@@ -175,7 +183,7 @@ def check_single_breakup_known_answers(kit):
             cell_id=kit.IndexedStorage.from_ndarray(idx, np.zeros(2, dtype=np.int64)),
             coalescence_rate=counter(), breakup_rate=breakup_rate,
             breakup_rate_deficit=breakup_deficit, is_first_in_pair=flag, warn_overflows=False,
-            particle_mass=attrs[0, :], max_multiplicity=DEFAULTS.max_multiplicity)
+            particle_mass=attrs.row(0), max_multiplicity=MAX_MULTIPLICITY)
         case = f"gamma={gamma} n={n_init} v={v_init}"
         np.testing.assert_array_equal(mult.to_ndarray(raw=True), n_exp, err_msg=case)
         volumes = attrs.to_ndarray(raw=True)[0] / rho_w
@@ -187,155 +195,130 @@ def check_single_breakup_known_answers(kit):
             or gamma == 0
 
 
-def _two_drop_setup(kit, component, volume, fragmentation_function=None, water_mass=None):
-    """the arrangement shared by the reference's component tests: two droplets, one pair
-    (tests/unit_tests/dynamics/collisions/test_fragmentations.py:44-71 and siblings)"""
-    from pysdm_amd.environments import Box  # pylint: disable=import-outside-toplevel
-    from pysdm_amd.formulae import Formulae  # pylint: disable=import-outside-toplevel
-    from pysdm_amd.particulator import Builder  # pylint: disable=import-outside-toplevel
-
-    kwargs = {} if fragmentation_function is None else {
-        "fragmentation_function": fragmentation_function}
-    n_sd = len(volume if volume is not None else water_mass)
-    builder = Builder(n_sd, kit.backend.__class__(Formulae(**kwargs)),
-                      environment=Box(dv=None, dt=None))
-    component.register(builder)
-    attributes = {"multiplicity": np.ones(n_sd)}
-    if volume is not None:
-        attributes["volume"] = np.asarray(volume)
-    else:
-        attributes["water mass"] = np.asarray(water_mass)
-    particulator = builder.build(attributes=attributes)
-    flag = particulator.PairIndicator(length=n_sd)
-    flag.indicator = particulator.Storage.from_ndarray(np.asarray([True, False]))
-    return particulator, flag
-
-
 UM3 = 1e-18  # si.um**3
 RHO_W = 1000.0
 
 
-def _fragmentation_classes():
-    from pysdm_amd.dynamics import collisions as C  # pylint: disable=import-outside-toplevel
-
-    return C
+def volume_of_radius(radius):
+    return const.PI_4_3 * np.power(radius, 3)
 
 
-def _run_fragmentation(kit, make, volume, u01=0.5, vmin=None):
-    sut = make()
-    if vmin is not None:
-        sut.vmin = vmin
-    particulator, flag = _two_drop_setup(kit, sut, volume, sut.__class__.__name__)
-    nf = particulator.PairwiseStorage.from_ndarray(np.zeros(1))
-    frag_mass = particulator.PairwiseStorage.from_ndarray(np.zeros(1))
-    rand = particulator.PairwiseStorage.from_ndarray(np.asarray([u01], dtype=float))
-    sut(nf, frag_mass, rand, flag)
-    return nf.to_ndarray(), frag_mass.to_ndarray()
+def _pair_of_drops(kit, *, volume=None, water_mass=None):
+    """the arrangement shared by the reference's component tests
+    (tests/unit_tests/dynamics/collisions/test_fragmentations.py:44-71 and siblings): two
+    droplets forming one pair; returns a chain interpreter whose programs see that pair"""
+    n_sd = len(volume if volume is not None else water_mass)
+    pop = Population(kit.engine, multiplicity=np.ones(n_sd, dtype=np.int64), volume=volume,
+                     mass=water_mass)
+    runner = CollisionRunner(pop, C.CollisionSetup.coalescence(C.Golovin(b=1.0), seed=44),
+                             dt=1.0, dv=1.0, route="chain")
+    chain = ChainedCollision(runner)
+    kit.engine.assign(chain.flag, kit.engine.upload(np.asarray([True, False] + [False] * (n_sd - 2))))
+    return chain
+
+
+def _evaluate(kit, part, **drops):
+    chain = _pair_of_drops(kit, **drops)
+    out = kit.engine.upload(np.asarray([-1.0]))
+    chain.execute(part.program(chain.runner.constants), out=out)
+    return kit.engine.download(out)
+
+
+def _run_fragmentation(kit, part, volume=None, u01=0.5, water_mass=None):
+    chain = _pair_of_drops(kit, volume=volume, water_mass=water_mass)
+    eng = kit.engine
+    nf, fm = eng.zeros(1, np.float64), eng.zeros(1, np.float64)
+    chain.execute(part.program(chain.runner.constants), nf=nf, fm=fm,
+                  u01=eng.upload(np.asarray([u01], dtype=float)))
+    return eng.download(nf), eng.download(fm)
 
 
 def check_reference_fragmentation_tests(kit):
     """test_fragmentations.py:30-262 re-typed: call, vmin / vmax / nfmax limiters, and the
-    100-point sweep over u01 for two rain-size drops"""
-    C = _fragmentation_classes()
+    sweep over u01 for two rain-size drops"""
     volume = np.asarray([440.0 * UM3, 6660.0 * UM3])
     total = np.sum(volume) * RHO_W
+    one = 1 * UM3
     # :30-84 call
-    for make in (lambda: C.AlwaysN(n=2), lambda: C.Exponential(scale=1e6 * UM3),
-                 lambda: C.Feingold1988(scale=1e6 * UM3),
-                 lambda: C.Gaussian(mu=2e6 * UM3, sigma=1e6 * UM3), C.SLAMS, C.Straub2010Nf,
-                 C.LowList1982Nf):
-        nf, frag_mass = _run_fragmentation(kit, make, volume, vmin=1 * UM3)
+    for part in (C.AlwaysN(n=2), C.Exponential(scale=1e6 * UM3, vmin=one),
+                 C.Feingold1988(scale=1e6 * UM3, vmin=one),
+                 C.Gaussian(mu=2e6 * UM3, sigma=1e6 * UM3, vmin=one), C.SLAMS(vmin=one),
+                 C.Straub2010Nf(vmin=one), C.LowList1982Nf(vmin=one)):
+        nf, frag_mass = _run_fragmentation(kit, part, volume)
         assert (nf > 0.99).all() and (frag_mass > 0).all()
         np.testing.assert_approx_equal(nf[0] * frag_mass[0], total)
     # :86-146 vmin limiter: one fragment holding all the mass
-    for make in (lambda: C.Exponential(scale=1 * UM3, vmin=6660.0 * UM3),
-                 lambda: C.Feingold1988(scale=1 * UM3, vmin=6660.0 * UM3),
-                 lambda: C.Gaussian(mu=2 * UM3, sigma=1 * UM3, vmin=6660.0 * UM3),
-                 lambda: C.SLAMS(vmin=6660.0 * UM3), lambda: C.Straub2010Nf(vmin=6660.0 * UM3)):
-        nf, frag_mass = _run_fragmentation(kit, make, volume)
+    big = 6660.0 * UM3
+    for part in (C.Exponential(scale=one, vmin=big), C.Feingold1988(scale=one, vmin=big),
+                 C.Gaussian(mu=2 * UM3, sigma=one, vmin=big), C.SLAMS(vmin=big),
+                 C.Straub2010Nf(vmin=big)):
+        nf, frag_mass = _run_fragmentation(kit, part, volume)
         np.testing.assert_array_equal([1.0], nf)
         np.testing.assert_array_equal([(6660.0 + 440.0) * UM3 * RHO_W], frag_mass)
     # :148-204 vmax limiter
-    for make in (lambda: C.Exponential(scale=1.0 * 1e-6), lambda: C.Feingold1988(scale=1.0 * 1e-6),
-                 lambda: C.Gaussian(mu=1.0 * 1e-6, sigma=1e6 * UM3), C.SLAMS, C.Straub2010Nf):
-        nf, frag_mass = _run_fragmentation(kit, make, volume, vmin=1 * UM3)
+    for part in (C.Exponential(scale=1.0 * 1e-6, vmin=one),
+                 C.Feingold1988(scale=1.0 * 1e-6, vmin=one),
+                 C.Gaussian(mu=1.0 * 1e-6, sigma=1e6 * UM3, vmin=one), C.SLAMS(vmin=one),
+                 C.Straub2010Nf(vmin=one)):
+        nf, frag_mass = _run_fragmentation(kit, part, volume)
         assert (nf > 0.999).all()
         assert (frag_mass < (6661.0 + 440.0) * UM3 * RHO_W).all()
         np.testing.assert_approx_equal(nf[0] * frag_mass[0], total)
     # :206-262 nfmax limiter
-    for make in (lambda: C.Exponential(scale=1.0 * UM3, nfmax=2),
-                 lambda: C.Feingold1988(scale=1.0 * UM3, nfmax=2),
-                 lambda: C.Gaussian(mu=1.0 * UM3, sigma=1e6 * UM3, nfmax=2),
-                 lambda: C.SLAMS(nfmax=2), lambda: C.Straub2010Nf(nfmax=2)):
-        nf, frag_mass = _run_fragmentation(kit, make, volume, vmin=1 * UM3)
+    for part in (C.Exponential(scale=one, vmin=one, nfmax=2),
+                 C.Feingold1988(scale=one, vmin=one, nfmax=2),
+                 C.Gaussian(mu=one, sigma=1e6 * UM3, vmin=one, nfmax=2),
+                 C.SLAMS(vmin=one, nfmax=2), C.Straub2010Nf(vmin=one, nfmax=2)):
+        nf, frag_mass = _run_fragmentation(kit, part, volume)
         assert (nf < 2.0 + 1e-6).all()
         assert (frag_mass > ((6660.0 + 440.0) / 2 - 1) * UM3).all()
         np.testing.assert_approx_equal(nf[0] * frag_mass[0], total)
     # :264-340 distribution sweep (4 mm and 2 mm drops)
     rain = np.asarray([(4 / 3) * np.pi * (0.2e-2 / 2) ** 3, (4 / 3) * np.pi * (0.4e-2 / 2) ** 3])
-    for make in (lambda: C.Exponential(scale=1e6 * UM3), lambda: C.Gaussian(mu=2e6 * UM3,
-                                                                            sigma=1e6 * UM3),
-                 C.SLAMS, C.Straub2010Nf, C.LowList1982Nf):
+    for part in (C.Exponential(scale=1e6 * UM3, vmin=one),
+                 C.Gaussian(mu=2e6 * UM3, sigma=1e6 * UM3, vmin=one), C.SLAMS(vmin=one),
+                 C.Straub2010Nf(vmin=one), C.LowList1982Nf(vmin=one)):
         for rn in np.linspace(1e-6, 1 - 1e-6, 25):
-            nf, frag_mass = _run_fragmentation(kit, make, rain, u01=rn, vmin=1 * UM3)
-            assert (nf > 0.99).all() and (frag_mass > 0).all(), (make().__class__.__name__, rn)
+            nf, frag_mass = _run_fragmentation(kit, part, rain, u01=rn)
+            assert (nf > 0.99).all() and (frag_mass > 0).all(), (type(part).__name__, rn)
             np.testing.assert_approx_equal(nf[0] * frag_mass[0], np.sum(rain) * RHO_W)
     # :342-400 nf and fragment mass of ConstantMass / AlwaysN
-    for make in (lambda: C.ConstantMass(c=4 * UM3), lambda: C.AlwaysN(n=250)):
-        sut = make()
+    for part in (C.ConstantMass(c=4 * UM3), C.AlwaysN(n=250)):
         water_mass = np.asarray([400.0 * UM3, 600.0 * UM3])
-        particulator, flag = _two_drop_setup(kit, sut, None, water_mass=water_mass)
-        nf = particulator.PairwiseStorage.from_ndarray(np.zeros(1))
-        frag_mass = particulator.PairwiseStorage.from_ndarray(np.zeros(1))
-        rand = particulator.PairwiseStorage.from_ndarray(np.asarray([0.5]))
-        sut(nf, frag_mass, rand, flag)
-        np.testing.assert_array_equal(nf.to_ndarray(), [250])
-        np.testing.assert_array_almost_equal(frag_mass.to_ndarray(), [np.sum(water_mass) / 250])
+        nf, frag_mass = _run_fragmentation(kit, part, water_mass=water_mass)
+        np.testing.assert_array_equal(nf, [250])
+        np.testing.assert_array_almost_equal(frag_mass, [np.sum(water_mass) / 250])
 
 
 def check_reference_efficiency_and_kernel_tests(kit):
     """test_efficiencies.py:21-56 (values in [0, 1]) and test_kernels.py:32-89 (SimpleGeometric
     zero for C = 0 and for equal sizes, positive otherwise)"""
-    C = _fragmentation_classes()
     volume = np.asarray([440.0 * UM3, 6660.0 * UM3])
-    for sut in (C.Berry1967(), C.ConstEc(Ec=0.5), C.SpecifiedEff(A=0.8, B=0.6), C.Straub2010Ec(),
-                C.LowList1982Ec(), C.ConstEb(Eb=0.3)):
-        particulator, flag = _two_drop_setup(kit, sut, volume)
-        eff = particulator.PairwiseStorage.from_ndarray(np.asarray([-1.0]))
-        sut(eff, flag)
-        values = eff.to_ndarray()
-        assert np.min(values) >= 0 and np.max(values) <= 1, sut.__class__.__name__
-    sut = C.Linear(a=2.0, b=3.0)  # no reference run exists (stub there): analytic answer
-    particulator, flag = _two_drop_setup(kit, sut, np.asarray([44.0, 666.0]))
-    output = particulator.PairwiseStorage.from_ndarray(np.zeros(1))
-    sut(output, flag)
-    np.testing.assert_allclose(output.to_ndarray(), [2.0 + 3.0 * 710.0], rtol=1e-14)
+    custom = list(C.BERRY_HYDRODYNAMIC)
+    custom[0], custom[1] = 0.8, 0.6
+    for part in (C.Berry1967(), C.ConstEc(Ec=0.5), C.SpecifiedEff(params=tuple(custom)),
+                 C.Straub2010Ec(), C.LowList1982Ec(), C.ConstEb(Eb=0.3)):
+        values = _evaluate(kit, part, volume=volume)
+        assert np.min(values) >= 0 and np.max(values) <= 1, type(part).__name__
+    # Linear: no reference run exists (a stub there): analytic answer
+    np.testing.assert_allclose(_evaluate(kit, C.Linear(a=2.0, b=3.0),
+                                         volume=np.asarray([44.0, 666.0])),
+                               [2.0 + 3.0 * 710.0], rtol=1e-14)
     for c_value, vol, positive in ((0.0, [44.0, 666.0], False), (1.0, [44.0, 666.0], True),
                                    (1.0, [1.0, 2.0], True), (1.0, [1.0, 1.0], False)):
-        sut = C.SimpleGeometric(C=c_value)
-        particulator, flag = _two_drop_setup(kit, sut, np.asarray(vol))
-        output = particulator.PairwiseStorage.from_ndarray(np.zeros(1))
-        sut(output, is_first_in_pair=flag)
+        # (volumes of cubic metres are far beyond the Gunn-Kinzer table, which this kernel
+        # does not use)
+        value = _evaluate(kit, C.SimpleGeometric(C=c_value), volume=np.asarray(vol))
         if positive:
-            assert (output.to_ndarray() > 0).all()
+            assert (value > 0).all()
         else:
-            np.testing.assert_array_equal(output.to_ndarray(), [0.0])
+            np.testing.assert_array_equal(value, [0.0])
 
 
-class _StubKernel:  # tests/unit_tests/dynamics/collisions/conftest.py:12-21
-    def __init__(self, value=0):
-        self.value = value
-
-    def register(self, builder):
-        pass
-
-    def __call__(self, output, is_first_in_pair):
-        _fill(output, self.value)
-
-
-def _fill(array, value, odd_zeros=False):
-    """conftest.py:24-37: upload a constant (or every other entry, zeros in between)"""
-    shape = array.shape[0]
+def _fill(engine, array, value, odd_zeros=False):
+    """tests/unit_tests/dynamics/collisions/conftest.py:24-37: a constant in every pair slot (or in
+    every other one, zeros in between)"""
+    shape = int(array.shape[0])
     if odd_zeros:
         if isinstance(value, np.ndarray):
             full = np.stack((value[::2], np.zeros_like(value[::2]))).flatten(order="F")
@@ -347,44 +330,44 @@ def _fill(array, value, odd_zeros=False):
                 full = np.concatenate((full, np.zeros(1)))
     else:
         full = np.full(shape, value).astype(np.float64)
-    array.upload(full)
+    engine.assign(array, engine.upload(full))
 
 
-def _box_with_coalescence(kit, attributes, *, seed=None, environment=None, substeps=1,
-                          optimized_random=False):
-    """conftest.py:46-60: Box(dv=1, dt=dt_coal_range[1]), stub kernel, non-adaptive, the
-    method-by-method route (the scenarios patch `compute_gamma` on the dynamic)"""
-    from pysdm_amd.dynamics.collisions import Coalescence  # pylint: disable=import-outside-toplevel
-    from pysdm_amd.environments import Box  # pylint: disable=import-outside-toplevel
-    from pysdm_amd.formulae import Formulae  # pylint: disable=import-outside-toplevel
-    from pysdm_amd.particulator import Builder  # pylint: disable=import-outside-toplevel
+def _box_with_stub_kernel(kit, *, multiplicity, volume, cell_id=None, grid=None, substeps=1,
+                          optimized_random=False, adaptive=False):
+    """conftest.py:46-60: dv = 1, dt = upper end of dt_coal_range, a kernel that is never looked
+    at (the scenarios force gamma), non-adaptive, stage by stage"""
+    pop = Population(kit.engine, multiplicity=np.asarray(multiplicity), volume=np.asarray(volume),
+                     cell_id=cell_id, grid=grid)
+    setup = C.CollisionSetup.coalescence(C.ConstantK(a=0.0), adaptive=adaptive,
+                                         substeps=substeps, optimized_random=optimized_random,
+                                         seed=44)
+    return CollisionRunner(pop, setup, dt=DT_COAL_MAX, dv=1.0, route="chain")
 
-    env = environment or Box(dv=1, dt=DEFAULTS.dt_coal_range[1])
-    n_sd = len(attributes["multiplicity"])
-    kwargs = {} if seed is None else {"seed": seed}
-    builder = Builder(n_sd, kit.backend.__class__(Formulae(**kwargs)), environment=env)
-    builder.add_dynamic(Coalescence(collision_kernel=_StubKernel(), adaptive=False, fused=False,
-                                    substeps=substeps, optimized_random=optimized_random))
-    particulator = builder.build(attributes={k: np.asarray(v) for k, v in attributes.items()})
-    return particulator, particulator.dynamics["Collision"]
+
+def _live(runner, column):
+    pop = runner.population
+    return kit_download(runner, column)[pop.live_ids()]
+
+
+def kit_download(runner, column):
+    return runner.engine.download(column)
 
 
 def check_reference_single_cell_scenarios(kit):
     """test_sdm_single_cell.py:16-214 re-typed (without the "heat"/"temperature" attributes, which
     are off the path): forced gamma, multi-collision limits, odd droplets left alone, 32 steps"""
-    from pysdm_amd.dynamics.collisions import Coalescence  # pylint: disable=import-outside-toplevel
-
-    rho_w = kit.backend.formulae.constants.rho_w
+    eng = kit.engine
+    rho_w = const.rho_w
     pairs_v = (np.array([1.0, 1.0]), np.array([4.0, 2.0]))
     pairs_n = (np.array([1, 1]), np.array([5, 1]), np.array([5, 3]))
     # :16-79 single collision with gamma forced to one
     for v_2 in pairs_v:
         for n_2 in pairs_n:
-            particulator, sut = _box_with_coalescence(kit, {"multiplicity": n_2, "volume": v_2})
-            sut.compute_gamma = lambda prob, rand, is_first_in_pair, out: _fill(out, 1)
-            sut()
-            state = particulator.attributes
-            mult, vol = state["multiplicity"].to_ndarray(), state["volume"].to_ndarray()
+            sut = _box_with_stub_kernel(kit, multiplicity=n_2, volume=v_2)
+            sut.gamma_hook = lambda chain, prob, rand: _fill(eng, prob, 1)
+            sut.run(1)
+            mult, vol = _live(sut, sut.population.multiplicity), _live(sut, sut.population.volume())
             np.testing.assert_approx_equal(np.sum(mult * vol), np.sum(n_2 * v_2))
             assert np.sum(mult) == np.sum(n_2) - np.amin(n_2)
             np.testing.assert_approx_equal(np.amax(vol), np.sum(v_2))
@@ -393,21 +376,20 @@ def check_reference_single_cell_scenarios(kit):
     for p_value in (2, 4, 5, 7):
         for v_2 in pairs_v:
             for n_2 in pairs_n:
-                particulator, sut = _box_with_coalescence(kit, {"multiplicity": n_2,
-                                                                "volume": v_2})
+                sut = _box_with_stub_kernel(kit, multiplicity=n_2, volume=v_2)
 
-                def compute_gamma(prob, rand, is_first_in_pair, out, sut=sut, p_value=p_value):
-                    _fill(prob, p_value)
-                    Coalescence.compute_gamma(sut, prob, rand, is_first_in_pair, out=out)
+                def forced(chain, prob, rand, p_value=p_value):  # pylint: disable=unused-argument
+                    _fill(eng, prob, p_value)
+                    chain.compute_gamma()
 
-                sut.compute_gamma = compute_gamma
-                sut()
-                state = particulator.attributes
-                mult, vol = state["multiplicity"].to_ndarray(), state["volume"].to_ndarray()
+                sut.gamma_hook = forced
+                sut.run(1)
+                pop = sut.population
+                mult, vol = _live(sut, pop.multiplicity), _live(sut, pop.volume())
                 gamma = min(p_value, max(n_2[0] // n_2[1], n_2[1] // n_2[1]))
                 assert np.amin(mult) >= 0
-                np.testing.assert_approx_equal(
-                    np.sum(mult * state["water mass"].to_ndarray()), np.sum(n_2 * v_2 * rho_w))
+                np.testing.assert_approx_equal(np.sum(mult * _live(sut, pop.mass)),
+                                               np.sum(n_2 * v_2 * rho_w))
                 np.testing.assert_approx_equal(np.sum(mult * vol), np.sum(n_2 * v_2))
                 assert np.sum(mult) == np.sum(n_2) - gamma * np.amin(n_2)
                 np.testing.assert_approx_equal(
@@ -417,63 +399,60 @@ def check_reference_single_cell_scenarios(kit):
     for v, n, p_value in ((np.array([1.0, 1, 1]), np.array([1, 1, 1]), 2),
                           (np.array([1.0, 1, 1, 1, 1]), np.array([5, 1, 2, 1, 1]), 1),
                           (np.array([1.0, 1, 1, 1, 1]), np.array([5, 1, 2, 1, 1]), 6)):
-        particulator, sut = _box_with_coalescence(kit, {"multiplicity": n, "volume": v})
+        sut = _box_with_stub_kernel(kit, multiplicity=n, volume=v)
 
-        def compute_gamma(prob, rand, is_first_in_pair, out, sut=sut, p_value=p_value):
-            _fill(prob, p_value, odd_zeros=True)
-            Coalescence.compute_gamma(sut, prob, rand, is_first_in_pair, out=out)
+        def forced_odd(chain, prob, rand, p_value=p_value):  # pylint: disable=unused-argument
+            _fill(eng, prob, p_value, odd_zeros=True)
+            chain.compute_gamma()
 
-        sut.compute_gamma = compute_gamma
-        sut()
-        state = particulator.attributes
-        assert np.amin(state["multiplicity"].to_ndarray()) >= 0
-        np.testing.assert_allclose(
-            np.sum(state["multiplicity"].to_ndarray() * state["volume"].to_ndarray()),
-            np.sum(n * v), rtol=1e-14)
+        sut.gamma_hook = forced_odd
+        sut.run(1)
+        pop = sut.population
+        assert np.amin(_live(sut, pop.multiplicity)) >= 0
+        np.testing.assert_allclose(np.sum(_live(sut, pop.multiplicity) * _live(sut, pop.volume())),
+                                   np.sum(n * v), rtol=1e-14)
     # :187-214 32 steps with gamma = (rand > 0.5) on every other pair
     rng = np.random.default_rng(5)
     n_sd = 256
     n, v = rng.integers(1, 64, size=n_sd), rng.uniform(size=n_sd)
-    particulator, sut = _box_with_coalescence(kit, {"multiplicity": n, "volume": v})
-    sut.compute_gamma = lambda prob, rand, is_first_in_pair, out: _fill(
-        out, rand.to_ndarray() > 0.5, odd_zeros=True)
-    for _ in range(32):
-        sut()
-        particulator.attributes.sanitize()
-    state = particulator.attributes
-    assert np.amin(state["multiplicity"].to_ndarray()) >= 0
+    sut = _box_with_stub_kernel(kit, multiplicity=n, volume=v)
+    sut.gamma_hook = lambda chain, prob, rand: _fill(eng, prob, eng.download(rand) > 0.5,
+                                                    odd_zeros=True)
+    sut.run(32)
+    pop = sut.population
+    assert np.amin(_live(sut, pop.multiplicity)) >= 0
     np.testing.assert_approx_equal(
-        np.sum(state["multiplicity"].to_ndarray() * state["volume"].to_ndarray()), np.sum(n * v),
+        np.sum(_live(sut, pop.multiplicity) * _live(sut, pop.volume())), np.sum(n * v),
         significant=8)
 
 
 def check_reference_random_reuse_and_multi_cell_call(kit):
     """test_sdm_single_cell.py:260-307 (how often the generator is called) and
     test_sdm_multi_cell.py:15-49 (a call on a 25 x 25 grid leaves the cell ids alone)"""
-    from pysdm_amd.environments import Box, Mesh  # pylint: disable=import-outside-toplevel
-
     rng = np.random.default_rng(6)
     n_sd, n_substeps = 256, 5
     for optimized_random in (True, False):
         for adaptive in (True, False):
-            attributes = {"multiplicity": rng.integers(1, 64, size=n_sd),
-                          "volume": rng.uniform(size=n_sd)}
-            _, sut = _box_with_coalescence(kit, attributes, substeps=n_substeps,
-                                           optimized_random=optimized_random)
+            sut = _box_with_stub_kernel(
+                kit, multiplicity=rng.integers(1, 64, size=n_sd), volume=rng.uniform(size=n_sd),
+                substeps=1 if adaptive else n_substeps, optimized_random=optimized_random,
+                adaptive=adaptive)
+            sut.run(0)
+            from pysdm_amd import chain as chain_module  # pylint: disable=import-outside-toplevel
+
             calls = []
-            generator = sut.rnd_opt_coll.rnd
-            original = generator.__class__.__call__
+            original = chain_module.Draws._fill  # pylint: disable=protected-access
 
-            class Counting(generator.__class__):  # pylint: disable=too-few-public-methods
-                def __call__(self, storage):
-                    calls.append(1)
-                    original(self, storage)
+            def counting(self, array, offset, original=original, calls=calls):
+                calls.append(1)
+                return original(self, array, offset)
 
-            sut.rnd_opt_coll.rnd = Counting(n_sd, seed=44)
-            sut.stats_n_substep[:] = n_substeps
-            sut.adaptive = adaptive
-            sut()
-            if sut.rnd_opt_coll.optimized_random:
+            chain_module.Draws._fill = counting  # pylint: disable=protected-access
+            try:
+                sut.run(1)
+            finally:
+                chain_module.Draws._fill = original  # pylint: disable=protected-access
+            if optimized_random:
                 assert len(calls) == 2
             elif adaptive:
                 assert 2 <= len(calls) <= 2 * n_substeps
@@ -482,62 +461,59 @@ def check_reference_random_reuse_and_multi_cell_call(kit):
     for n_sd in (2, 3, 8000):
         for adaptive in (False, True):
             grid = (25, 25)
-            env = Box(dv=1, dt=DEFAULTS.dt_coal_range[1])
-            env.mesh = Mesh(grid, size=grid)
             positions = rng.uniform(0, 1, (2, n_sd)) * np.asarray(grid).reshape(2, 1)
-            cell_id, _, _ = env.mesh.cellular_attributes(positions)
-            particulator, sut = _box_with_coalescence(
-                kit, {"multiplicity": np.ones(n_sd), "volume": np.ones(n_sd), "cell id": cell_id},
-                environment=env)
-            sut.adaptive = adaptive
-            sut()
-            np.testing.assert_array_equal(
-                cell_id, particulator.attributes["cell id"].to_ndarray(raw=True))
+            cell_id, _, _ = locate(positions, grid)
+            sut = _box_with_stub_kernel(kit, multiplicity=np.ones(n_sd), volume=np.ones(n_sd),
+                                        cell_id=cell_id, grid=grid, adaptive=adaptive)
+            sut.run(1)
+            np.testing.assert_array_equal(cell_id, kit.engine.download(sut.population.cell_id))
 
 
 def _one_breakup_call(kit, *, n_init, v_init, gamma, frag_volume, rand=1.0, Eb=1.0,
                       is_first_in_pair=None, n_calls=1, warn_overflows=False,
                       handle_all_breakups=False):
-    """the arrangement shared by test_sdm_breakup.py:97-230,460-940: a NaN box, one backend call
-    `collision_coalescence_breakup` through the Particulator wrapper; returns
-    (multiplicities, volumes, breakup_rate, breakup_rate_deficit)"""
-    from pysdm_amd.environments import Box  # pylint: disable=import-outside-toplevel
+    """the arrangement shared by test_sdm_breakup.py:97-230,460-940: one backend call
+    `collision_coalescence_breakup` on a handful of droplets; returns (multiplicities, volumes,
+    breakup_rate, breakup_rate_deficit)"""
     from pysdm_amd.formulae import Formulae  # pylint: disable=import-outside-toplevel
-    from pysdm_amd.particulator import Builder  # pylint: disable=import-outside-toplevel
 
     n_sd = len(n_init)
     n_pairs = n_sd // 2
-    backend = kit.backend.__class__(Formulae(handle_all_breakups=handle_all_breakups))
-    builder = Builder(n_sd, backend, environment=Box(dv=np.nan, dt=np.nan))
-    particulator = builder.build(attributes={
-        "multiplicity": np.asarray(n_init), "volume": np.asarray(v_init, dtype=float)})
+    backend = type(kit.backend)(Formulae(handle_all_breakups=handle_all_breakups))
+    Storage = backend.Storage
+    idx = kit.Index.identity_index(n_sd)
+    mult = kit.IndexedStorage.from_ndarray(idx, np.asarray(n_init, dtype=np.int64))
+    attrs = kit.IndexedStorage.from_ndarray(
+        idx, (RHO_W * np.asarray(v_init, dtype=float)).reshape(1, n_sd))
 
     def pairwise(values):
         values = np.asarray(values, dtype=float)
         if values.ndim == 0:
             values = np.full(n_pairs, float(values))
-        return particulator.PairwiseStorage.from_ndarray(values)
+        return kit.PairwiseStorage.from_ndarray(values)
 
-    flag = particulator.PairIndicator(n_sd)
-    flag.indicator[:] = particulator.Storage.from_ndarray(np.asarray(
+    flag = kit.PairIndicator(n_sd)
+    flag.indicator.upload(np.asarray(
         is_first_in_pair if is_first_in_pair is not None else [True, False] * n_pairs
         + [False] * (n_sd % 2), dtype=bool))
-    breakup_rate = particulator.Storage.from_ndarray(np.array([0]))
-    deficit = particulator.Storage.from_ndarray(np.array([0]))
-    coalescence_rate = particulator.Storage.from_ndarray(np.array([0] * n_sd))
+    breakup_rate = Storage.from_ndarray(np.array([0]))
+    deficit = Storage.from_ndarray(np.array([0]))
+    coalescence_rate = Storage.from_ndarray(np.array([0] * n_sd))
     gamma_s, rand_s, eb_s = pairwise(gamma), pairwise(rand), pairwise(Eb)
     frag_mass = pairwise(np.asarray(frag_volume, dtype=float) * RHO_W)
     zeros = pairwise(0.0)
     for _ in range(n_calls):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            particulator.collision_coalescence_breakup(
-                enable_breakup=True, gamma=gamma_s, rand=rand_s, Ec=zeros, Eb=eb_s,
-                fragment_mass=frag_mass, coalescence_rate=coalescence_rate,
-                breakup_rate=breakup_rate, breakup_rate_deficit=deficit, is_first_in_pair=flag,
-                warn_overflows=warn_overflows, max_multiplicity=DEFAULTS.max_multiplicity)
-    attrs = particulator.attributes
-    return (attrs["multiplicity"].to_ndarray(), attrs["volume"].to_ndarray(),
+            backend.collision_coalescence_breakup(
+                multiplicity=mult, idx=idx, attributes=attrs, gamma=gamma_s, rand=rand_s, Ec=zeros,
+                Eb=eb_s, fragment_mass=frag_mass, healthy=Storage.from_ndarray(np.full((1,), 1)),
+                cell_id=kit.IndexedStorage.from_ndarray(idx, np.zeros(n_sd, dtype=np.int64)),
+                coalescence_rate=coalescence_rate, breakup_rate=breakup_rate,
+                breakup_rate_deficit=deficit, is_first_in_pair=flag,
+                warn_overflows=warn_overflows, particle_mass=attrs.row(0),
+                max_multiplicity=MAX_MULTIPLICITY)
+    return (mult.to_ndarray(raw=True), attrs.to_ndarray(raw=True)[0] / RHO_W,
             breakup_rate.to_ndarray(), deficit.to_ndarray())
 
 
@@ -615,41 +591,27 @@ def check_reference_breakup_scenarios(kit):
 def check_reference_breakup_dynamic_tests(kit):
     """test_sdm_breakup.py:34-83 (pure breakup with a constant kernel doubles two droplets ten
     times whatever dt) and :788-822 (multiplicities stay positive over 100 steps of
-    Geometric + ConstEc(0.01) + exponential fragmentation)"""
-    from pysdm_amd.dynamics import collisions as C  # pylint: disable=import-outside-toplevel
-    from pysdm_amd.environments import Box  # pylint: disable=import-outside-toplevel
-    from pysdm_amd.formulae import Formulae  # pylint: disable=import-outside-toplevel
-    from pysdm_amd.initialisation import ConstantMultiplicity  # pylint: disable=import-outside-toplevel
-    from pysdm_amd.initialisation import Exponential as Spectrum  # pylint: disable=import-outside-toplevel
-    from pysdm_amd.particulator import Builder  # pylint: disable=import-outside-toplevel
-
+    Geometric + ConstEc(0.01) + exponential fragmentation), on both routes"""
     um3, cm3 = 1e-18, 1e-6
-    for dt in (1.0, 10.0):
-        attributes = {"multiplicity": np.asarray([1, 1]),
-                      "volume": np.asarray([100 * um3, 100 * um3])}
-        builder = Builder(2, kit.backend.__class__(Formulae(fragmentation_function="AlwaysN")),
-                          environment=Box(dv=1 * cm3, dt=dt))
-        builder.add_dynamic(C.Breakup(collision_kernel=C.ConstantK(1 * cm3),
-                                      fragmentation_function=C.AlwaysN(4), adaptive=False,
-                                      warn_overflows=False))
-        particulator = builder.build(attributes=attributes)
-        particulator.run(10)
-        np.testing.assert_array_equal(particulator.attributes["multiplicity"].to_ndarray(),
-                                      [1024, 1024])
-    n_sd = 2**5
-    formulae = Formulae(fragmentation_function="Exponential")
-    builder = Builder(n_sd=n_sd, backend=kit.backend.__class__(formulae),
-                      environment=Box(dv=1.0, dt=1.0))
-    spectrum = Spectrum(norm_factor=100 / cm3, scale=formulae.trivia.volume(radius=30.531e-6))
-    volume, multiplicity = ConstantMultiplicity(spectrum).sample(n_sd)
-    builder.add_dynamic(C.Collision(
-        collision_kernel=C.Geometric(), breakup_efficiency=C.ConstEb(Eb=1.0),
-        coalescence_efficiency=C.ConstEc(Ec=0.01),
-        fragmentation_function=C.Exponential(scale=formulae.trivia.volume(radius=100e-6)),
-        warn_overflows=False))
-    particulator = builder.build({"volume": volume, "multiplicity": multiplicity})
-    particulator.run(100)
-    assert (particulator.attributes["multiplicity"].to_ndarray() > 0).all()
+    for route in ("fused", "chain"):
+        for dt in (1.0, 10.0):
+            pop = Population(kit.engine, multiplicity=np.asarray([1, 1]),
+                             volume=np.asarray([100 * um3, 100 * um3]))
+            setup = C.CollisionSetup.breakup_only(C.ConstantK(1 * cm3), C.AlwaysN(4),
+                                                  adaptive=False, warn_overflows=False, seed=44)
+            runner = CollisionRunner(pop, setup, dt=dt, dv=1 * cm3, route=route)
+            runner.run(10)
+            np.testing.assert_array_equal(kit.engine.download(pop.multiplicity), [1024, 1024])
+        n_sd = 2**5
+        spectrum = spectra.Exponential(norm_factor=100 / cm3, scale=volume_of_radius(30.531e-6))
+        volume, multiplicity = spectra.sample_constant_multiplicity(spectrum, n_sd)
+        pop = Population(kit.engine, multiplicity=multiplicity, volume=volume)
+        setup = C.CollisionSetup.collision(
+            C.Geometric(), C.ConstEc(Ec=0.01), C.ConstEb(Eb=1.0),
+            C.Exponential(scale=volume_of_radius(100e-6)), warn_overflows=False, seed=44)
+        runner = CollisionRunner(pop, setup, dt=1.0, dv=1.0, route=route)
+        runner.run(100)
+        assert (kit.engine.download(pop.multiplicity)[pop.live_ids()] > 0).all()
 
 
 def check_reference_small_backend_tests(kit):
@@ -692,7 +654,8 @@ def check_reference_small_backend_tests(kit):
     # cell caretaker: the flagged entry (4 == n_sd) is compacted out first, then sorted
     cell_start = Storage.from_ndarray(np.asarray([-1, -1]))
     idx = kit.Index.from_ndarray(np.asarray([0, 3, 2, 4], dtype=np.int64))
-    idx.remove_zero_n_or_flagged(kit.IndexedStorage.from_ndarray(idx, np.asarray([1, 1, 1, 1])))
+    idx.length = backend.remove_zero_n_or_flagged(
+        Storage.from_ndarray(np.asarray([1, 1, 1, 1])).data, idx.data, idx.length)
     caretaker = backend.make_cell_caretaker(idx.shape, idx.dtype, len(cell_start),
                                             scheme="default")
     caretaker(kit.IndexedStorage.from_ndarray(idx, np.asarray([0, 0, 0, 0])),
@@ -719,7 +682,8 @@ def check_reference_small_backend_tests(kit):
     idx = kit.Index.identity_index(n_sd)
     data = np.ones(n_sd).astype(np.int64)
     data[0], data[n_sd // 2], data[-1] = 0, 0, 0
-    idx.remove_zero_n_or_flagged(kit.IndexedStorage.from_ndarray(idx, data))
+    idx.length = backend.remove_zero_n_or_flagged(Storage.from_ndarray(data).data, idx.data,
+                                                  idx.length)
     assert len(idx) == n_sd - 3
     assert (data[idx.to_ndarray()[: len(idx)]] > 0).all()
     # mass <-> volume
@@ -733,20 +697,18 @@ def check_reference_small_backend_tests(kit):
     np.testing.assert_array_equal(mass_out.to_ndarray(), values * rho_w)
 
 
-def _exponential_box(kit, *, seed, n_sd, n_part, dv, radius, dt, dynamic):
-    from pysdm_amd.environments import Box  # pylint: disable=import-outside-toplevel
-    from pysdm_amd.formulae import Formulae  # pylint: disable=import-outside-toplevel
-    from pysdm_amd.initialisation import ConstantMultiplicity  # pylint: disable=import-outside-toplevel
-    from pysdm_amd.initialisation import Exponential as Spectrum  # pylint: disable=import-outside-toplevel
-    from pysdm_amd.particulator import Builder  # pylint: disable=import-outside-toplevel
+def _exponential_box(kit, *, seed, n_sd, n_part, dv, radius, dt, kernel, route="fused", **options):
+    spectrum = spectra.Exponential(norm_factor=n_part * dv, scale=volume_of_radius(radius))
+    volume, multiplicity = spectra.sample_constant_multiplicity(spectrum, n_sd)
+    pop = Population(kit.engine, multiplicity=multiplicity, volume=volume)
+    setup = C.CollisionSetup.coalescence(kernel, seed=seed, **options)
+    return CollisionRunner(pop, setup, dt=dt, dv=dv, route=route)
 
-    formulae = Formulae(seed=seed)
-    builder = Builder(n_sd=n_sd, backend=kit.backend.__class__(formulae),
-                      environment=Box(dt=dt, dv=dv))
-    spectrum = Spectrum(norm_factor=n_part * dv, scale=formulae.trivia.volume(radius=radius))
-    volume, multiplicity = ConstantMultiplicity(spectrum).sample(n_sd)
-    builder.add_dynamic(dynamic)
-    return builder.build({"volume": volume, "multiplicity": multiplicity})
+
+def _live_state(runner):
+    pop, down = runner.population, runner.engine.download
+    ids = pop.live_ids()
+    return down(pop.multiplicity)[ids], down(pop.volume())[ids]
 
 
 def check_reference_box_smoke_tests(kit):
@@ -754,22 +716,18 @@ def check_reference_box_smoke_tests(kit):
     1 g/m3 over 200 steps, the largest droplet keeps growing; local / global croupier, adaptive or
     not) and berry_1967/test_coalescence.py (Geometric / Electric / Hydrodynamic kernels over 800
     steps at 2^13 super-droplets: the largest droplet grows; plus the 2-droplet Golovin case)"""
-    from pysdm_amd.dynamics import collisions as C  # pylint: disable=import-outside-toplevel
-
     for croupier in ("local", "global"):
         for adaptive in (True, False):
             n_sd, n_part, dv = 2**14, 2**23, 1e6
-            particulator = _exponential_box(
-                kit, seed=256, n_sd=n_sd, n_part=n_part, dv=dv, radius=30.531e-6, dt=1.0,
-                dynamic=C.Coalescence(collision_kernel=C.Golovin(b=1.5e3), croupier=croupier,
-                                      adaptive=adaptive))
+            runner = _exponential_box(kit, seed=256, n_sd=n_sd, n_part=n_part, dv=dv,
+                                      radius=30.531e-6, dt=1.0, kernel=C.Golovin(b=1.5e3),
+                                      croupier=croupier, adaptive=adaptive)
             x_max = 0
             for step in (0, 100, 200):
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")
-                    particulator.run(step - particulator.n_steps)
-                mult = particulator.attributes["multiplicity"].to_ndarray()
-                vol = particulator.attributes["volume"].to_ndarray()
+                    runner.run(step - runner.steps_done)
+                mult, vol = _live_state(runner)
                 if step == 0:
                     np.testing.assert_approx_equal(np.amin(mult), np.amax(mult), 1)
                     np.testing.assert_approx_equal(mult[0], n_part * dv / n_sd, 1)
@@ -779,30 +737,28 @@ def check_reference_box_smoke_tests(kit):
     for make_kernel in (C.Geometric, C.Electric, C.Hydrodynamic):
         for croupier in ("local", "global"):
             for adaptive in (True, False):
-                particulator = _exponential_box(
-                    kit, seed=0, n_sd=2**13, n_part=239e6, dv=10.0, radius=10e-6, dt=1.0,
-                    dynamic=C.Coalescence(collision_kernel=make_kernel(), croupier=croupier,
-                                          adaptive=adaptive))
+                runner = _exponential_box(kit, seed=0, n_sd=2**13, n_part=239e6, dv=10.0,
+                                          radius=10e-6, dt=1.0, kernel=make_kernel(),
+                                          croupier=croupier, adaptive=adaptive)
                 x_max = 0
                 for step in (0, 800):
                     with warnings.catch_warnings():
                         warnings.simplefilter("ignore")
-                        particulator.run(step - particulator.n_steps)
-                    largest = np.amax(particulator.attributes["volume"].to_ndarray())
+                        runner.run(step - runner.steps_done)
+                    largest = np.amax(_live_state(runner)[1])
                     assert x_max < largest
                     x_max = largest
-    particulator = _exponential_box(
-        kit, seed=0, n_sd=2, n_part=239e6, dv=10.0, radius=10e-6, dt=1.0,
-        dynamic=C.Coalescence(collision_kernel=C.Golovin(b=1.5e12), adaptive=False))
+    runner = _exponential_box(kit, seed=0, n_sd=2, n_part=239e6, dv=10.0, radius=10e-6, dt=1.0,
+                              kernel=C.Golovin(b=1.5e12), adaptive=False)
     x_max = 0
     for step in (0, 200):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            particulator.run(step - particulator.n_steps)
-        largest = np.amax(particulator.attributes["volume"].to_ndarray())
+            runner.run(step - runner.steps_done)
+        largest = np.amax(_live_state(runner)[1])
         assert x_max < largest
         x_max = largest
-    assert particulator.attributes.super_droplet_count == 1
+    assert runner.population.live == 1
 
 
 def check_convergence_to_golovin_solution(kit):
@@ -812,36 +768,30 @@ def check_convergence_to_golovin_solution(kit):
     reference's ParticleVolumeVersusRadiusLogarithmSpectrum product does - approaches Golovin's
     analytic solution as the number of super-droplets grows (error measure of
     PySDM_examples/Shima_et_al_2009/error_measure.py)"""
-    from pysdm_amd.dynamics import collisions as C  # pylint: disable=import-outside-toplevel
-
     kernel = C.Golovin(b=1.5e3)
-    x_0 = kit.backend.formulae.trivia.volume(radius=30.531e-6)
+    x_0 = volume_of_radius(30.531e-6)
     for x in (5e-10, np.full(10, 5e-10)):
         assert np.all(np.isfinite(kernel.analytic_solution(x=x, t=1200, x_0=x_0, N_0=2**23)))
     n_part, dv, rho, t_end = 2**23, 1e6, 1000.0, 3600
     radius_edges = np.logspace(np.log10(10e-6), np.log10(5e3 * 1e-6), num=128, endpoint=True)
-    volume_edges = kit.backend.formulae.trivia.volume(radius=radius_edges)
+    volume_edges = volume_of_radius(radius_edges)
     d_m, d_r = np.diff(volume_edges), np.diff(radius_edges)
     mid_x, mid_r = volume_edges[:-1] + d_m / 2, radius_edges[:-1] + d_r / 2
     pdf_r = n_part * dv * kernel.analytic_solution(x=mid_x, t=t_end, x_0=x_0, N_0=n_part) \
         * d_m / d_r * mid_r
-    y_true = pdf_r * kit.backend.formulae.trivia.volume(radius=mid_r) * rho / dv * 1e3  # g/m3
+    y_true = pdf_r * volume_of_radius(mid_r) * rho / dv * 1e3  # g/m3
     errors = []
     for ln2_n_sd in (11, 14, 17):
-        particulator = _exponential_box(
-            kit, seed=44, n_sd=2**ln2_n_sd, n_part=n_part, dv=dv, radius=30.531e-6, dt=100.0,
-            dynamic=C.Coalescence(collision_kernel=C.Golovin(b=1.5e3), adaptive=True))
+        runner = _exponential_box(kit, seed=44, n_sd=2**ln2_n_sd, n_part=n_part, dv=dv,
+                                  radius=30.531e-6, dt=100.0, kernel=C.Golovin(b=1.5e3),
+                                  adaptive=True)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            particulator.run(t_end // 100)
-        moment_0 = kit.Storage.empty((len(radius_edges) - 1, 1), dtype=float)
-        moments = kit.Storage.empty((len(radius_edges) - 1, 1), dtype=float)
-        particulator.spectrum_moments(
-            moment_0=moment_0, moments=moments, attr="volume", rank=1,
-            attr_bins=kit.Storage.from_ndarray(volume_edges), attr_name="volume",
+            runner.run(t_end // 100)
+        moment_0, moments = diagnostics.spectrum_moments(
+            runner.population, volume_edges, attr="volume", rank=1, bin_attr="volume",
             weighting_attribute="volume", weighting_rank=0)
-        spectrum = (moments.to_ndarray()[:, 0] * moment_0.to_ndarray()[:, 0]
-                    / np.diff(np.log(radius_edges)) / dv * rho * 1e3)
+        spectrum = moments[:, 0] * moment_0[:, 0] / np.diff(np.log(radius_edges)) / dv * rho * 1e3
         deviation = y_true - spectrum
         errors.append(np.sum(np.abs((deviation[:-1] + deviation[1:]) * np.diff(mid_r * 1e6) / 2)))
     assert errors[0] > errors[1] > errors[2], errors

@@ -4,15 +4,15 @@ import os
 
 import numpy as np
 
-from pysdm_amd import Formulae
-from pysdm_amd.backends.impl_common import (
-    make_Index,
-    make_IndexedStorage,
-    make_PairIndicator,
-    make_PairwiseStorage,
-)
-from pysdm_amd.dynamics import collisions as C
-from pysdm_amd.dynamics.terminal_velocity import GunnKinzer1949
+from pysdm_amd import recipe as C
+from pysdm_amd.chain import ChainedCollision
+from pysdm_amd.collisions import CollisionRunner
+from pysdm_amd.formulae import Formulae
+from pysdm_amd.population import Population
+from pysdm_amd.terminal_velocity import (GunnKinzerTable, PowerSeries, RogersYau,
+                                         gunn_kinzer_table)
+
+from . import pysdm_ducks
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MICRO = np.load(os.path.join(GOLDEN, "micro.npz"))
@@ -23,11 +23,10 @@ MOMENTS = np.load(os.path.join(GOLDEN, "moments.npz"))
 class Kit:  # pylint: disable=too-few-public-methods
     def __init__(self, backend_class, **formulae_kwargs):
         self.backend = backend_class(Formulae(**formulae_kwargs))
+        self.engine = self.backend.engine
         self.Storage = self.backend.Storage
-        self.Index = make_Index(self.backend)
-        self.IndexedStorage = make_IndexedStorage(self.backend)
-        self.PairIndicator = make_PairIndicator(self.backend)
-        self.PairwiseStorage = make_PairwiseStorage(self.backend)
+        (self.Index, self.IndexedStorage, self.PairIndicator,
+         self.PairwiseStorage) = pysdm_ducks.make(self.backend)
 
 
 def check_pcg64(kit):
@@ -54,12 +53,12 @@ def check_shuffle(kit):
         u01 = kit.Storage.from_ndarray(MICRO[key + "/u01"])
         cell_start = kit.Storage.from_ndarray(MICRO[key + "/cell_start"])
         idx = kit.Index.from_ndarray(MICRO[key + "/idx0"].copy())
-        idx.shuffle(u01, parts=cell_start)
+        kit.backend.shuffle_local(idx=idx.data, u01=u01.data, cell_start=cell_start.data)
         np.testing.assert_array_equal(idx.to_ndarray(), MICRO[key + "/local"], err_msg=key)
         for length in (n_sd, n_sd - 3):
             idx = kit.Index.from_ndarray(MICRO[key + "/idx0"].copy())
-            idx.length = kit.Storage.INT(length)
-            idx.shuffle(u01)
+            idx.length = length
+            kit.backend.shuffle_global(idx=idx.data, length=length, u01=u01.data)
             np.testing.assert_array_equal(idx.to_ndarray(), MICRO[key + f"/global_{length}"],
                                           err_msg=f"{key} global {length}")
 
@@ -68,10 +67,11 @@ def check_shuffle_known_answers(kit):
     """tests/unit_tests/impl/test_particle_attributes.py:149-201 of the reference"""
     u01 = kit.Storage.from_ndarray(np.array([0.1, 0.4, 0.2, 0.5, 0.9, 0.1, 0.6, 0.3]))
     idx = kit.Index.identity_index(8)
-    idx.shuffle(u01)
+    kit.backend.shuffle_global(idx=idx.data, length=8, u01=u01.data)
     np.testing.assert_array_equal(idx.to_ndarray(), [1, 3, 5, 7, 6, 0, 4, 2])
     idx = kit.Index.identity_index(8)
-    idx.shuffle(u01, parts=kit.Storage.from_ndarray(np.array([0, 0, 2, 5, 7, 8])))
+    kit.backend.shuffle_local(idx=idx.data, u01=u01.data, cell_start=kit.Storage.from_ndarray(
+        np.array([0, 0, 2, 5, 7, 8])).data)
     np.testing.assert_array_equal(idx.to_ndarray(), [1, 0, 2, 3, 4, 5, 6, 7])
 
 
@@ -80,7 +80,7 @@ def check_counting_sort(kit):
         key = f"sort/{n_sd}_{n_cell}"
         length = int(MICRO[key + "/length"])
         idx = kit.Index.from_ndarray(MICRO[key + "/idx0"].copy())
-        idx.length = kit.Storage.INT(length)
+        idx.length = int(length)
         cell_start = kit.Storage.from_ndarray(np.zeros(n_cell + 1, dtype=np.int64))
         caretaker = kit.backend.make_cell_caretaker(idx.shape, idx.dtype, n_cell + 1)
         caretaker(kit.Storage.from_ndarray(MICRO[key + "/cell_id"]),
@@ -105,7 +105,7 @@ def check_sort_by_key_and_adaptive_end(kit):
     for i in range(3):
         keys = MICRO[f"sort_by_key/{i}/keys"]
         cidx = kit.Index.identity_index(len(keys))
-        cidx.sort_by_key(kit.Storage.from_ndarray(keys))
+        kit.backend.sort_by_key(cidx, kit.Storage.from_ndarray(keys))
         np.testing.assert_array_equal(cidx.to_ndarray(), MICRO[f"sort_by_key/{i}/out"])
         end = kit.backend.adaptive_sdm_end(
             kit.Storage.from_ndarray(MICRO[f"adaptive_sdm_end/{i}/dt_left"]),
@@ -124,9 +124,9 @@ def check_sort_by_key_and_adaptive_end(kit):
 def check_remove_zero(kit):
     for i in range(int(MICRO["remove/n"])):
         idx = kit.Index.from_ndarray(MICRO[f"remove/{i}/idx0"].copy())
-        idx.length = kit.Storage.INT(int(MICRO[f"remove/{i}/length0"]))
+        idx.length = int(int(MICRO[f"remove/{i}/length0"]))
         mult = kit.IndexedStorage.from_ndarray(idx, MICRO[f"remove/{i}/mult"])
-        idx.remove_zero_n_or_flagged(mult)
+        idx.length = kit.backend.remove_zero_n_or_flagged(mult.data, idx.data, idx.length)
         assert len(idx) == int(MICRO[f"remove/{i}/length"])
         np.testing.assert_array_equal(idx.to_ndarray(), MICRO[f"remove/{i}/idx"], f"case {i}")
 
@@ -137,7 +137,7 @@ def check_pair_chain(kit):  # pylint: disable=too-many-locals,too-many-statement
         g = lambda name, key=key: MICRO[f"{key}/{name}"]  # noqa: E731
         length = int(g("length"))
         idx = kit.Index.from_ndarray(g("idx_sorted").copy())
-        idx.length = kit.Storage.INT(length)
+        idx.length = int(length)
         cell_idx = kit.Index.identity_index(n_cell)
         cell_start = kit.Storage.from_ndarray(g("cell_start"))
         cell_id = kit.IndexedStorage.from_ndarray(idx, g("cell_id"))
@@ -145,19 +145,19 @@ def check_pair_chain(kit):  # pylint: disable=too-many-locals,too-many-statement
         mass = kit.IndexedStorage.from_ndarray(idx, g("mass"))
         flag = kit.PairIndicator(n_sd)
         flag.indicator[:] = False
-        flag.update(cell_start, cell_idx, cell_id)
+        kit.backend.find_pairs(cell_start, flag, cell_id, cell_idx, idx)
         np.testing.assert_array_equal(flag.indicator.to_ndarray(), g("flag"), key)
         kit.backend.sort_within_pair_by_attr(idx, flag, mult)
         np.testing.assert_array_equal(idx.to_ndarray(), g("idx_pairsorted"), key)
         for op in ("sum", "max", "min", "distance", "multiply"):
             pw = kit.PairwiseStorage.empty(n_sd // 2, dtype=float)
-            getattr(pw, op)(mass, flag)
+            getattr(kit.backend, op + "_pair")(pw, mass, flag, idx)
             np.testing.assert_array_equal(pw.to_ndarray(), g(op + "_pair"), f"{key} {op}")
         prob = kit.PairwiseStorage.empty(n_sd // 2, dtype=float)
-        prob.max(mult, flag)
+        kit.backend.max_pair(prob, mult, flag, idx)
         np.testing.assert_array_equal(prob.to_ndarray(), g("max_mult"), key)
         ksum = kit.PairwiseStorage.empty(n_sd // 2, dtype=float)
-        ksum.sum(mass, flag)
+        kit.backend.sum_pair(ksum, mass, flag, idx)
         ksum *= 3.0e8
         prob *= ksum
         norm_factor = kit.Storage.empty(n_cell, dtype=float)
@@ -202,33 +202,23 @@ def check_pair_chain(kit):  # pylint: disable=too-many-locals,too-many-statement
         np.testing.assert_array_equal(coal.to_ndarray(), g("coalescence_rate"), key)
 
 
-def check_physics(kit, exact, rtol):  # pylint: disable=too-many-locals
-    """derived attributes, Gunn-Kinzer table, kernels, efficiencies, fragmentations.
+def check_physics(kit, exact, rtol):  # pylint: disable=too-many-locals,too-many-statements
+    """derived attributes, Gunn-Kinzer table, kernels, efficiencies, fragmentations (the pair
+    programs of pysdm_amd.recipe run by the chain interpreter).
     `exact`: entries that must be bit-identical; the transcendental-heavy rest within rtol"""
     g = PHYSICS
-
-    class Part:  # pylint: disable=too-few-public-methods
-        pass
-
-    part = Part()
-    part.backend, part.formulae, part.n_sd = kit.backend, kit.backend.formulae, 512
-    part.PairwiseStorage = kit.PairwiseStorage
-    gk = GunnKinzer1949(part)
-    np.testing.assert_allclose(gk.table_a, g["gk/a"], rtol=1e-13, atol=0)
-    np.testing.assert_allclose(gk.table_b, g["gk/b"], rtol=1e-10, atol=1e-9)
-    # use the golden table for everything downstream so that only device arithmetic is compared
-    gk.a = kit.Storage.from_ndarray(g["gk/a"])
-    gk.b = kit.Storage.from_ndarray(g["gk/b"])
+    eng = kit.engine
+    table_a, table_b = gunn_kinzer_table()
+    np.testing.assert_allclose(table_a, g["gk/a"], rtol=1e-13, atol=0)
+    np.testing.assert_allclose(table_b, g["gk/b"], rtol=1e-10, atol=1e-9)
     n_sd = 512
-    idx = kit.Index.identity_index(n_sd)
-    mass = kit.IndexedStorage.from_ndarray(idx, g["derived/mass"])
-    vol = kit.IndexedStorage.empty(idx, (n_sd,), float)
-    kit.backend.volume_of_water_mass(vol, mass)
-    rad = kit.IndexedStorage.empty(idx, (n_sd,), float)
-    rad.product(vol, 1 / kit.backend.formulae.constants.PI_4_3)
-    rad **= 1 / 3
-    vel = kit.IndexedStorage.empty(idx, (n_sd,), float)
-    gk(vel, rad)
+    pop = Population(eng, multiplicity=np.ones(n_sd, dtype=np.int64), mass=g["derived/mass"])
+    runner = CollisionRunner(pop, C.CollisionSetup.coalescence(C.Golovin(b=1.0), seed=44),
+                             dt=1.0, dv=1.0, route="chain")
+    # use the golden table for everything downstream so that only device arithmetic is compared
+    law = runner.law
+    law.a, law.b = eng.upload(g["gk/a"]), eng.upload(g["gk/b"])
+    down = eng.download
 
     def cmp(name, actual, expected):
         if name in exact:
@@ -239,55 +229,41 @@ def check_physics(kit, exact, rtol):  # pylint: disable=too-many-locals
             tol = max(rtol, 1e-12) if "lowlist" in name else rtol
             np.testing.assert_allclose(actual, expected, rtol=tol, atol=0, err_msg=name)
 
-    cmp("volume", vol.to_ndarray(raw=True), g["derived/volume"])
-    cmp("radius", rad.to_ndarray(raw=True), g["derived/radius"])
-    cmp("velocity", vel.to_ndarray(raw=True), g["derived/velocity"])
-    from pysdm_amd.dynamics.terminal_velocity import PowerSeries, RogersYau  # pylint: disable=import-outside-toplevel
+    cmp("volume", down(pop.volume()), g["derived/volume"])
+    cmp("radius", down(pop.radius()), g["derived/radius"])
+    cmp("velocity", down(pop.fall_velocity(law)), g["derived/velocity"])
+    cmp("area", down(pop.area()), g["derived/area"])
+    alt = eng.empty(n_sd, np.float64)
+    plain = eng.upload(g["derived/radius"])
+    RogersYau().evaluate(eng, alt, plain, n_sd)
+    cmp("velocity_rogers_yau", down(alt), g["derived/velocity_rogers_yau"])
+    PowerSeries().evaluate(eng, alt, plain, n_sd)
+    cmp("velocity_power_series", down(alt), g["derived/velocity_power_series"])
+    PowerSeries(prefactors=[0.3, 1.1], powers=[1 / 6, 1 / 3]).evaluate(eng, alt, plain, n_sd)
+    cmp("velocity_power_series_2", down(alt), g["derived/velocity_power_series_2"])
 
-    alt = kit.Storage.empty(n_sd, dtype=float)
-    plain = kit.Storage.from_ndarray(g["derived/radius"])
-    RogersYau(part)(alt, plain)
-    cmp("velocity_rogers_yau", alt.to_ndarray(), g["derived/velocity_rogers_yau"])
-    PowerSeries(part)(alt, plain)
-    cmp("velocity_power_series", alt.to_ndarray(), g["derived/velocity_power_series"])
-    PowerSeries(part, prefactors=[0.3, 1.1], powers=[1 / 6, 1 / 3])(alt, plain)
-    cmp("velocity_power_series_2", alt.to_ndarray(), g["derived/velocity_power_series_2"])
-    flag = kit.PairIndicator(n_sd)
-    flag.indicator.upload(g["derived/flag"])
-    part.attributes = {"volume": vol, "radius": rad, "relative fall velocity": vel,
-                       "water mass": mass}
-
-    class Builder:  # pylint: disable=too-few-public-methods
-        particulator = part
-
-        @staticmethod
-        def request_attribute(_):
-            pass
-
-    area = kit.IndexedStorage.empty(idx, (n_sd,), float)
-    area.product(vol, 1 / kit.backend.formulae.constants.PI_4_3)
-    area **= 2 / 3
-    area *= kit.backend.formulae.constants.PI_4_3 * 3
-    cmp("area", area.to_ndarray(raw=True), g["derived/area"])
-    part.attributes["area"] = area
-    pw = kit.PairwiseStorage.empty(n_sd // 2, dtype=float)
+    chain = ChainedCollision(runner)
+    eng.assign(chain.flag, eng.upload(g["derived/flag"].astype(bool)))
+    k = runner.constants
+    out = eng.empty(n_sd // 2, np.float64)
     for name, kern in (("golovin", C.Golovin(b=1.5e3)),
                        ("geometric", C.Geometric(collection_efficiency=1.0)),
                        ("electric", C.Electric()), ("hydrodynamic", C.Hydrodynamic()),
                        ("simple_geometric", C.SimpleGeometric(C=2.5))):
-        kern.register(Builder)
-        kern(pw, flag)
-        cmp(name, pw.to_ndarray(), g["kernel/" + name])
+        chain.execute(kern.program(k), out=out)
+        cmp(name, down(out), g["kernel/" + name])
+    specified = list(C.BERRY_HYDRODYNAMIC)
+    specified[0], specified[1], specified[2] = 0.8, 0.9, -20
     for name, eff in (("berry1967", C.Berry1967()), ("straub2010", C.Straub2010Ec()),
-                      ("specified", C.SpecifiedEff(A=0.8, B=0.9, D1=-20)),
+                      ("specified", C.SpecifiedEff(params=tuple(specified))),
                       ("lowlist1982", C.LowList1982Ec())):
-        eff.register(Builder)
-        eff(pw, flag)
-        cmp(name, pw.to_ndarray(), g["ec/" + name])
-    u01 = kit.Storage.from_ndarray(g["frag/u01"])
-    nf = kit.PairwiseStorage.empty(n_sd // 2, dtype=float)
-    fm = kit.PairwiseStorage.empty(n_sd // 2, dtype=float)
-    tv = kit.backend.formulae.trivia.volume
+        chain.execute(eff.program(k), out=out)
+        cmp(name, down(out), g["ec/" + name])
+    nf, fm = eng.empty(n_sd // 2, np.float64), eng.empty(n_sd // 2, np.float64)
+
+    def tv(radius):
+        return k.PI_4_3 * np.power(radius, 3)
+
     um = 1e-6  # the goldens were made with `N * si.um`, which is not the literal `Ne-6`
     cases = {
         "always_n_4": C.AlwaysN(n=4),
@@ -306,13 +282,13 @@ def check_physics(kit, exact, rtol):  # pylint: disable=too-many-locals
         "lowlist_lim": C.LowList1982Nf(vmin=tv(5 * um), nfmax=50),
     }
     for name, frag in cases.items():
-        frag.register(Builder)
-        frag(nf, fm, kit.Storage.from_ndarray(g["frag/u01"]), flag)  # Low & List rescales u01
-        cmp("frag_" + name, nf.to_ndarray(), g[f"frag/{name}/nf"])
-        cmp("frag_" + name, fm.to_ndarray(), g[f"frag/{name}/mass"])
+        u01 = eng.upload(g["frag/u01"])  # Low & List rescales u01 in place
+        chain.execute(frag.program(k), nf=nf, fm=fm, u01=u01)
+        cmp("frag_" + name, down(nf), g[f"frag/{name}/nf"])
+        cmp("frag_" + name, down(fm), g[f"frag/{name}/mass"])
         if name.startswith("lowlist"):
             for key in ("Rf", "Rs", "Rd"):
-                cmp("frag_" + name, frag.ll82_tmp[key].to_ndarray(), g[f"frag/{name}/{key}"])
+                cmp("frag_" + name, down(chain.registers[key]), g[f"frag/{name}/{key}"])
 
 
 def check_moments(kit):
@@ -321,7 +297,7 @@ def check_moments(kit):
     rng = np.random.default_rng(3)
     n_sd, n_cell = 1000, 7
     idx = kit.Index.from_ndarray(rng.permutation(n_sd).astype(np.int64))
-    idx.length = kit.Storage.INT(900)
+    idx.length = int(900)
     mult = rng.integers(1, 1000, n_sd).astype(np.int64)
     vol = rng.uniform(1e-15, 1e-12, n_sd)
     cell = rng.integers(0, n_cell, n_sd).astype(np.int64)
@@ -358,7 +334,7 @@ def check_moments_goldens(kit):
     g = MOMENTS
     _, n_cell, length = (int(v) for v in g["dims"])
     idx = kit.Index.from_ndarray(g["perm"])
-    idx.length = kit.Storage.INT(length)
+    idx.length = int(length)
     common = {
         "multiplicity": kit.IndexedStorage.from_ndarray(idx, g["mult"]),
         "cell_id": kit.IndexedStorage.from_ndarray(idx, g["cell"]),

@@ -1,29 +1,33 @@
 """The C-ABI library loads and exports every symbol include/sdm_hip.h declares (no compute calls:
-runs without a GPU); struct layouts of the ctypes mirror match the C header."""
+runs without a GPU); struct layouts of the ctypes mirror match the C header; the header-driven
+binding understands every prototype; the oracle implements the same header."""
 import ctypes
 import os
 import subprocess
 import tempfile
 
-from pysdm_amd import _lib
+import numpy as np
+import pytest
+
+from pysdm_amd import abi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol():
-    lib = _lib.load()
-    names = _lib.declared_symbols()
-    assert len(names) >= 38
+    library = abi.hip_library()
+    names = abi.declared_symbols()
+    assert len(names) >= 50
     for name in names:
-        assert hasattr(lib, name), name
-    assert lib.sdm_abi_version() == 1
+        assert hasattr(library.cdll, name), name
+    assert library.cdll.sdm_abi_version() == 1
 
 
 def test_struct_layouts_match_the_header():
     source = (
         '#include "include/sdm_hip.h"\n#include <stdio.h>\n'
-        'int main(){printf("%zu %zu %zu\\n", sizeof(sdm_step_cfg), sizeof(sdm_step_state),'
-        " sizeof(sdm_step_result));return 0;}\n"
+        'int main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(sdm_step_cfg), sizeof(sdm_step_state),'
+        " sizeof(sdm_step_result), sizeof(sdm_disp_cfg), sizeof(sdm_disp_state));return 0;}\n"
     )
     with tempfile.TemporaryDirectory() as tmp:
         src, exe = os.path.join(tmp, "sz.c"), os.path.join(tmp, "sz")
@@ -31,39 +35,49 @@ def test_struct_layouts_match_the_header():
             handle.write(source)
         subprocess.check_call(["gcc", "-I", ROOT, src, "-o", exe], cwd=ROOT)
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
-    assert sizes == [ctypes.sizeof(_lib.StepCfg), ctypes.sizeof(_lib.StepState),
-                     ctypes.sizeof(_lib.StepResult)]
+    assert sizes == [ctypes.sizeof(t) for t in (abi.StepCfg, abi.StepState, abi.StepResult,
+                                                abi.DispCfg, abi.DispState)]
 
 
 def test_error_reporting_without_a_gpu_call():
-    lib = _lib.load()
+    cdll = abi.hip_library().cdll
     # a NULL ctx is rejected before anything touches the device
-    assert lib.sdm_ctx_set_stream(None, None) == -1
-    assert b"bad argument" in lib.sdm_last_error()
+    assert cdll.sdm_ctx_set_stream(None, None) == -1
+    assert "bad argument" in abi.hip_library().last_error()
 
 
-def test_hip_backend_and_oracle_backend_are_interface_twins(oracle_backend_class):
-    """every backend method the front-end may call exists on both with the same parameters:
-    what the oracle passes under the unmodified reference front-end (test_reference_plugin.py)
-    carries over to HIP"""
+def test_every_prototype_is_understood_by_the_binding():
+    table = abi.parse_header()
+    kinds = {param.kind for _, params in table.values() for param in params}
+    assert kinds == {"ctx", "scalar", "pointer", "host_array"}
+    first = {name: params[0].kind for name, (_, params) in table.items() if params}
+    not_ctx_first = {n for n, kind in first.items() if kind != "ctx"}
+    assert not_ctx_first == {"sdm_ctx_create", "sdm_phase_name"}
+    cfg = dict((p.name, p) for p in table["sdm_collision_step"][1])
+    assert cfg["cfg"].base == "sdm_step_cfg" and cfg["flags"].kind == "scalar"
+
+
+def test_the_oracle_implements_the_same_header(oracle_engine):
+    """one header, two libraries: product (device pointers) and checker (host pointers)"""
+    for name in abi.declared_symbols():
+        assert hasattr(oracle_engine.library.cdll, name), name
+    with pytest.raises(TypeError):  # operand checks of the binding, before any call
+        oracle_engine.call("sdm_identity_index", np.zeros(4), 4)
+    with pytest.raises(ValueError):
+        oracle_engine.call("sdm_identity_index", np.zeros((4, 2), dtype=np.int64)[:, 0], 4)
+
+
+def test_pysdm_shaped_backends_are_one_class(oracle_backend_class):
+    """`HIP` and the oracle's backend come from the same factory: every method PySDM may call
+    exists on both with the same parameters, by construction"""
     import inspect  # pylint: disable=import-outside-toplevel
 
-    from pysdm_amd.backends.hip import HIP, Storage  # pylint: disable=import-outside-toplevel
-    from pysdm_amd.backends.storage_base import StorageBase  # pylint: disable=import-outside-toplevel
+    from pysdm_amd.backends.hip import HIP  # pylint: disable=import-outside-toplevel
 
     def public(cls):
-        return {name: member for name, member in inspect.getmembers(cls, callable)
-                if not name.startswith("_")}
+        return {name: inspect.signature(member) for name, member
+                in inspect.getmembers(cls, inspect.isfunction) if not name.startswith("_")}
 
-    hip, oracle = public(HIP), public(oracle_backend_class)
-    device_only = {"make_collision_step", "collision_step", "straub_consts", "synchronize",
-                   "displacement_step"}
-    assert set(hip) - device_only == set(oracle) - device_only
-    for name in set(hip) - device_only:
-        if inspect.isclass(hip[name]):
-            continue
-        params = [[p for p in inspect.signature(side[name]).parameters if p != "self"]
-                  for side in (hip, oracle)]
-        assert params[0] == params[1], name
-    assert issubclass(Storage, StorageBase) and issubclass(oracle_backend_class.Storage,
-                                                           StorageBase)
+    assert public(HIP) == public(oracle_backend_class)
+    assert {"shuffle_local", "find_pairs", "compute_gamma", "collision_coalescence_breakup",
+            "moments", "calculate_displacement"} <= set(public(HIP))

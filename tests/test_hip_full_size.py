@@ -1,27 +1,28 @@
-"""GPU parity at BASELINE.json's full sizes.  The oracle still finishes in seconds per step at
-n_sd = 2^20 (serial C), so the first steps are compared directly; on top of that size-independent
-properties are checked (idx is a permutation of the live droplets, mass conservation, droplet
-count only decreases by coalescence, the two HIP routes agree)."""
+"""GPU parity at BASELINE.json's full sizes.  (i) HIP against the digests of runs of the
+REFERENCE itself (tests/golden/digest_*.npz: 2^14 .. 2^22 boxes, 32 x 32 cells); (ii) HIP against
+the oracle on the same seeded inputs where no digest exists (the oracle - serial C - still finishes
+in seconds per step at n_sd = 2^20, and is itself pinned by the digests); (iii) size-independent
+properties (idx is a permutation of the live droplets, mass conservation, the two HIP routes
+agree)."""
+import os
+import subprocess
+import sys
 import warnings
 
 import numpy as np
 import pytest
 
-from pysdm_amd.examples import CONFIGS, make_box, make_kinematic_flow
+from pysdm_amd.cases import CONFIGS, make_box, make_kinematic_flow
 
-from .trajectory import snapshot
+from . import digests
 
 pytestmark = pytest.mark.gpu
 
 
-def box(backend_class, name, adaptive, fused):
-    return make_box(backend_class, name, adaptive=adaptive, fused=fused)
-
-
-def run(particulator, steps):
+def run(runner, steps):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        particulator.run(steps)
+        runner.run(steps)
 
 
 def assert_same(a, b, float_rtol=0.0):
@@ -45,54 +46,64 @@ def invariants(snap, n_sd, total_mass0, rtol):
     np.testing.assert_allclose(np.sum(n[live].astype(float) * m[live]), total_mass0, rtol=rtol)
 
 
+@pytest.mark.parametrize("name", digests.available())
+def test_hip_equals_the_reference_digests(name, hip_engine):
+    """HIP == the reference's own run: permutation, multiplicities, cell_start and counters by
+    SHA-256 / exactly, masses by SHA-256 on the coalescence paths, moments at 1e-12 with breakup"""
+    digests.check(name, hip_engine)
+
+
 @pytest.mark.parametrize("name,adaptive,steps", [
     ("shima", False, 3), ("shima", True, 2), ("berry_breakup", True, 2),
-    ("straub", True, 1), ("kinematic2d", True, 2),
+    ("straub", True, 1), ("straub_rain", True, 2), ("kinematic2d", True, 2),
 ])
-def test_full_size_fused_equals_oracle(name, adaptive, steps, hip_backend_class,
-                                       oracle_backend_class):
+def test_full_size_fused_equals_oracle(name, adaptive, steps, hip_engine, oracle_engine):
     snaps = []
-    for backend_class in (hip_backend_class, oracle_backend_class):
-        particulator, dynamic = box(backend_class, name, adaptive, None)
-        # (taken for both backends: reading cell_start sorts by cell, which must happen at the
-        # same point of both histories -- before the first sort_by_key of an adaptive step)
-        first = snapshot(particulator, dynamic)
+    for engine in (hip_engine, oracle_engine):
+        runner = make_box(engine, name, adaptive=adaptive)
+        # (taken for both engines: reading cell_start sorts by cell, which must happen at the
+        # same point of both histories - before the first sort_by_key of an adaptive step)
+        first = runner.snapshot()
         live = first["idx"][: int(first["length"])]
         mass0 = np.sum(first["multiplicity"][live].astype(float) * first["attributes"][0][live])
-        run(particulator, steps)
-        snaps.append(snapshot(particulator, dynamic))
+        run(runner, steps)
+        snaps.append(runner.snapshot())
     breakup = "breakup" in name or "straub" in name
     assert_same(snaps[0], snaps[1], float_rtol=1e-12 if breakup else 0.0)
     invariants(snaps[0], CONFIGS[name]["n_sd"], mass0, rtol=1e-9 if breakup else 1e-12)
+    if name == "straub_rain":  # the stress variant really is one: breakups and sub-stepping
+        assert snaps[0]["breakup_rate"].sum() > 0
+        assert snaps[0]["stats_n_substep"][0] > steps
 
 
 @pytest.mark.parametrize("name,adaptive,steps", [("shima", True, 20), ("kinematic2d", True, 2)])
-def test_full_size_routes_agree(name, adaptive, steps, hip_backend_class):
+def test_full_size_routes_agree(name, adaptive, steps, hip_engine):
     snaps = []
-    for fused in (None, False):
-        particulator, dynamic = box(hip_backend_class, name, adaptive, fused)
-        run(particulator, steps)
-        snaps.append(snapshot(particulator, dynamic))
+    for route in ("fused", "chain"):
+        runner = make_box(hip_engine, name, adaptive=adaptive, route=route)
+        run(runner, steps)
+        snaps.append(runner.snapshot())
     assert_same(snaps[0], snaps[1])
 
 
-def test_full_size_displacement_then_collisions(hip_backend_class, oracle_backend_class):
+def test_full_size_displacement_then_collisions(hip_engine, oracle_engine):
     """configs[3] with its preceding step: 2^22 super-droplets advected by the single-eddy flow
     and sedimenting through a 32 x 32 grid (precipitation leaves through the bottom), then the
-    adaptive Geometric collision step on the unsorted state; HIP (fused collision route) against
-    the oracle"""
+    adaptive Geometric collision step on the unsorted state; HIP (fused routes) against the
+    oracle"""
     results = []
-    for backend_class in (hip_backend_class, oracle_backend_class):
-        particulator, displacement, collision = make_kinematic_flow(backend_class)
+    for engine in (hip_engine, oracle_engine):
+        displacement, collisions = make_kinematic_flow(engine)
         rain = []
         for _ in range(2):
-            run(particulator, 1)
-            rain.append(displacement.precipitation_mass_in_last_step)
-        attrs = particulator.attributes
-        snap = snapshot(particulator, collision)
-        snap["cell_origin"] = attrs["cell origin"].to_ndarray(raw=True)
-        snap["cell_id"] = attrs["cell id"].to_ndarray(raw=True)
-        results.append((snap, attrs["position in cell"].to_ndarray(raw=True), rain))
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                rain.append(displacement.run())
+                collisions.run(1)
+        pop, down = collisions.population, engine.download
+        snap = collisions.snapshot()
+        snap["cell_origin"], snap["cell_id"] = down(pop.cell_origin), down(pop.cell_id)
+        results.append((snap, down(pop.position_in_cell), rain))
     (hip, hip_pos, hip_rain), (ref, ref_pos, ref_rain) = results
     length = int(hip["length"])
     assert length == int(ref["length"]) and length < 2**22  # some rain left the domain
@@ -109,25 +120,19 @@ def test_full_size_displacement_then_collisions(hip_backend_class, oracle_backen
 
 @pytest.mark.parametrize("n_sd,steps,thin", [(2**20, 12, None), (2**16, 12, 0.02),
                                              (2**16, 40, 100.0), (2**24, 2, None)])
-def test_many_steps_in_one_call_equal_oracle(n_sd, steps, thin, hip_backend_class,
-                                             oracle_backend_class):
-    """`Particulator.run(n)` of the single-cell non-adaptive box = one `sdm_collision_run` call: n
-    time steps without the host in between.  `thin` (a cell volume): multiplicities of 1..3, so
-    that super-droplets die -- in every step (0.02) or once in a few steps (100) -- and the
+def test_many_steps_in_one_call_equal_oracle(n_sd, steps, thin, hip_engine, oracle_engine):
+    """`run(n)` of the single-cell non-adaptive box = one `sdm_collision_run` call: n time steps
+    without the host in between.  `thin` (a cell volume): multiplicities of 1..3, so that
+    super-droplets die - in every step (0.02) or once in a few steps (100) - and the
     device-gated compaction has to run in the middle of a call."""
     snaps = []
-    for backend_class in (hip_backend_class, oracle_backend_class):
-        particulator, dynamic = make_box(backend_class, "shima", n_sd=n_sd, adaptive=False,
-                                         dt=200.0 if thin else None)
-        if thin:
-            mult = particulator.attributes["multiplicity"]
-            mult.upload((1 + np.arange(n_sd) % 3).astype(np.int64))
-            particulator.attributes.mark_updated("multiplicity")
-            particulator.environment.mesh.dv = thin * n_sd / 2**16
-        run(particulator, 1)
-        run(particulator, steps)
-        run(particulator, 5)
-        snaps.append(snapshot(particulator, dynamic))
+    for engine in (hip_engine, oracle_engine):
+        runner = make_box(engine, "shima", n_sd=n_sd, adaptive=False,
+                          dt=200.0 if thin else None, thin=thin)
+        run(runner, 1)
+        run(runner, steps)
+        run(runner, 5)
+        snaps.append(runner.snapshot())
     assert_same(snaps[0], snaps[1])
     if thin:
         assert int(snaps[0]["length"]) < n_sd
@@ -140,52 +145,77 @@ def test_many_steps_in_one_call_equal_oracle(n_sd, steps, thin, hip_backend_clas
     ("shima", 2**12, 60, 200.0, 0.02),     # below the look-ahead's size threshold
     ("berry_breakup", 2**15, 40, None, None),
     ("straub", 2**14, 12, None, None),
+    ("straub_rain", 2**14, 12, None, None),
 ])
-def test_adaptive_steps_in_one_call_equal_oracle(name, n_sd, steps, dt, thin, hip_backend_class,
-                                                 oracle_backend_class):
-    """`Particulator.run(n)` of an adaptive single-cell box in one `sdm_collision_run` call: the
-    head of each next sub-step (draw, shuffle build, probabilities) is launched ahead of the
-    read-back that decides whether it continues the time step or opens the next one; state,
-    counters and sub-step statistics equal the oracle's step-by-step run"""
+def test_adaptive_steps_in_one_call_equal_oracle(name, n_sd, steps, dt, thin, hip_engine,
+                                                 oracle_engine):
+    """`run(n)` of an adaptive single-cell box in one `sdm_collision_run` call: the head of each
+    next sub-step (draw, shuffle build, probabilities) is launched ahead of the read-back that
+    decides whether it continues the time step or opens the next one; state, counters and
+    sub-step statistics equal the oracle's step-by-step run"""
     snaps = []
-    for backend_class in (hip_backend_class, oracle_backend_class):
-        particulator, dynamic = make_box(backend_class, name, n_sd=n_sd, adaptive=True, dt=dt)
-        if thin:
-            mult = particulator.attributes["multiplicity"]
-            mult.upload((1 + np.arange(n_sd) % 3).astype(np.int64))
-            particulator.attributes.mark_updated("multiplicity")
-            particulator.environment.mesh.dv = thin * n_sd / 2**16
-        run(particulator, 1)
-        run(particulator, steps)
-        run(particulator, 3)
-        snaps.append(snapshot(particulator, dynamic))
+    for engine in (hip_engine, oracle_engine):
+        runner = make_box(engine, name, n_sd=n_sd, adaptive=True, dt=dt, thin=thin)
+        run(runner, 1)
+        run(runner, steps)
+        run(runner, 3)
+        snaps.append(runner.snapshot())
     assert_same(snaps[0], snaps[1], float_rtol=0.0 if name == "shima" else 1e-12)
     assert snaps[0]["stats_n_substep"][0] >= steps + 4
-    if dt:
+    if dt or name == "straub_rain":
         assert snaps[0]["stats_n_substep"][0] > steps + 4
     if thin:
         assert int(snaps[0]["length"]) < n_sd
 
 
 @pytest.mark.parametrize("n_sd", [2**21 - 2, 2**21 - 1, 2**20 - 3])
-def test_record_layouts_at_their_size_limits(n_sd, hip_backend_class, oracle_backend_class):
+def test_record_layouts_at_their_size_limits(n_sd, hip_engine, oracle_engine):
     """the shuffle records switch layout with the size (21-bit fields with four inline hits up to
     2^21 - 2 positions, 24-bit fields with three above): same permutation and state either side
     of the limit, and for an odd count (an unpaired last position)"""
     snaps = []
-    for backend_class in (hip_backend_class, oracle_backend_class):
-        particulator, dynamic = make_box(backend_class, "shima", n_sd=n_sd, adaptive=False)
-        run(particulator, 3)
-        snaps.append(snapshot(particulator, dynamic))
+    for engine in (hip_engine, oracle_engine):
+        runner = make_box(engine, "shima", n_sd=n_sd, adaptive=False)
+        run(runner, 3)
+        snaps.append(runner.snapshot())
     assert_same(snaps[0], snaps[1])
 
 
-def test_shima_box_3600_steps_equal_oracle(hip_backend_class, oracle_backend_class):
+def test_shima_box_3600_steps_equal_oracle(hip_engine, oracle_engine):
     """the whole Shima-2009 experiment (3600 steps of 1 s) in one library call at 2^16
     super-droplets: permutation, multiplicities, masses and counters identical to the oracle's"""
     snaps = []
-    for backend_class in (hip_backend_class, oracle_backend_class):
-        particulator, dynamic = make_box(backend_class, "shima", n_sd=2**16, adaptive=False)
-        run(particulator, 3600)
-        snaps.append(snapshot(particulator, dynamic))
+    for engine in (hip_engine, oracle_engine):
+        runner = make_box(engine, "shima", n_sd=2**16, adaptive=False)
+        run(runner, 3600)
+        snaps.append(runner.snapshot())
     assert_same(snaps[0], snaps[1])
+
+
+def test_host_slower_than_the_device_by_a_sub_step(oracle_engine):
+    """the polled control block is double-buffered (sub-step k + 1 is launched, and publishes,
+    before the host has read sub-step k's block): with the host delayed by 300 us before every
+    wait (SDM_DEBUG_BOX_DELAY_US, read at context creation - hence the child process) a 4 x 4
+    adaptive run still equals the oracle"""
+    script = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from pysdm_amd.engine import HipEngine\n"
+        "from tests.trajectory import setup_from_golden\n"
+        "runner, _, _ = setup_from_golden('traj_multicell_geometric_4x4', HipEngine.get())\n"
+        "runner.run(40)\n"
+        "snap = runner.snapshot()\n"
+        "np.savez(sys.argv[1], **snap)\n" % os.path.dirname(os.path.dirname(
+            os.path.abspath(__file__))))
+    import tempfile  # pylint: disable=import-outside-toplevel
+
+    from .trajectory import setup_from_golden  # pylint: disable=import-outside-toplevel
+
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "delayed.npz")
+        env = dict(os.environ, SDM_DEBUG_BOX_DELAY_US="300")
+        subprocess.check_call([sys.executable, "-c", script, out], env=env)
+        delayed = dict(np.load(out))
+    runner, _, _ = setup_from_golden("traj_multicell_geometric_4x4", oracle_engine)
+    runner.run(40)
+    assert_same(delayed, runner.snapshot())

@@ -1,12 +1,11 @@
 """the backend object of this package driven by the UNMODIFIED reference
 front-end (PySDM's own Builder / Particulator / ParticleAttributes / Index / PairwiseStorage /
-Collision / Displacement) instead of this package's mirror of it.
+Collision / Displacement) (this package has no front-end of its own: its host layer is the Population / runner API).
 
 Only meaningful where the reference is importable, i.e. in the build container (it does not
 travel to the GPU box, and there is no GPU here): the backend plugged in is therefore the CPU
-oracle -- the interface twin of `HIP` (same base class, method names, signatures, Storage and
-Random contracts; tests/test_abi.py checks the twin relation) -- and the expected values are the
-committed goldens.  Skipped wherever PySDM cannot be imported."""
+oracle - the same PySDM-shaped class `HIP` is (pysdm_amd/backends/pysdm_shaped.py), bound to the
+oracle's implementation of include/sdm_hip.h - and the expected values are the committed goldens.  Skipped wherever PySDM cannot be imported."""
 import os
 import sys
 import warnings
@@ -147,19 +146,67 @@ def test_reference_frontend_breakup(ref, plugged):
     _run(particulator, gold, float_rtol=1e-12)
 
 
-def test_this_packages_dynamic_under_reference_builder(ref, plugged):
-    """the route to the fused step in a PySDM installation: PySDM's Builder and Particulator,
-    this package's Coalescence (here on its method-by-method route: no GPU in this container)"""
-    from pysdm_amd.dynamics.collisions import Coalescence, Golovin  # pylint: disable=import-outside-toplevel
+@pytest.mark.parametrize("name", ["traj_golovin_n1024_s44_a1", "traj_golovin_deaths_adaptive",
+                                  "traj_golovin_optrand", "traj_golovin_global"])
+def test_fused_step_under_reference_builder(name, ref, plugged):
+    """the route to the fused step in a PySDM installation: PySDM's Builder, Particulator and
+    ParticleAttributes, PySDM's own Coalescence object wrapped by `fuse` - each time step is one
+    `sdm_collision_step` on PySDM's arrays (here of the oracle library: no GPU in this container)"""
+    from pysdm_amd.pysdm_plugin import fuse  # pylint: disable=import-outside-toplevel
 
-    gold = _gold("traj_golovin_n1024_s44_a1")
+    gold = _gold(name)
     cfg = gold["cfg"]
+    kwargs = {}
+    if "global" in name:
+        kwargs["croupier"] = "global"
+    if "optrand" in name:
+        kwargs["optimized_random"] = True
     builder = ref["PySDM"].Builder(
         n_sd=int(cfg[0]), backend=plugged(ref["PySDM"].Formulae(seed=int(cfg[1]))),
         environment=ref["Box"](dt=cfg[3], dv=cfg[4]))
-    builder.add_dynamic(Coalescence(collision_kernel=Golovin(b=cfg[5]), adaptive=bool(cfg[2])))
+    builder.add_dynamic(fuse(ref["dynamics"].Coalescence(
+        collision_kernel=ref["kernels"].Golovin(b=cfg[5]), adaptive=bool(cfg[2]), **kwargs)))
     particulator = builder.build({"volume": gold["init/volume"],
                                   "multiplicity": gold["init/multiplicity"]})
+    _run(particulator, gold)
+
+
+def test_fused_breakup_and_multicell_under_reference_builder(ref, plugged):
+    from pysdm_amd.pysdm_plugin import fuse  # pylint: disable=import-outside-toplevel
+
+    gold = _gold("traj_breakup_straub_rain_hab1")
+    cfg = gold["cfg"]
+    formulae = ref["PySDM"].Formulae(
+        seed=int(cfg[1]), fragmentation_function="Straub2010Nf", handle_all_breakups=bool(cfg[5]),
+        terminal_velocity="GunnKinzer1949")
+    builder = ref["PySDM"].Builder(n_sd=int(cfg[0]), backend=plugged(formulae),
+                                   environment=ref["Box"](dt=cfg[3], dv=cfg[4]))
+    builder.add_dynamic(fuse(ref["dynamics"].Collision(
+        collision_kernel=ref["kernels"].Geometric(),
+        coalescence_efficiency=ref["ec"].Straub2010Ec(),
+        breakup_efficiency=ref["eb"].ConstEb(1.0),
+        fragmentation_function=ref["frag"].Straub2010Nf(vmin=(0.01e-3) ** 3 * np.pi / 6,
+                                                        nfmax=10000),
+        adaptive=True, warn_overflows=False)))
+    particulator = builder.build({"volume": gold["init/volume"],
+                                  "multiplicity": gold["init/multiplicity"]})
+    _run(particulator, gold, float_rtol=1e-12)
+
+    gold = _gold("traj_multicell_geometric_4x4")
+    cfg = gold["cfg"]
+    grid = tuple(int(g) for g in gold["grid"])
+    env = ref["Box"](dt=cfg[3], dv=cfg[4])
+    env.mesh = ref["Mesh"](grid, size=tuple(float(g) for g in grid))
+    env.mesh.dv = cfg[4]
+    builder = ref["PySDM"].Builder(
+        n_sd=int(cfg[0]), environment=env,
+        backend=plugged(ref["PySDM"].Formulae(seed=44, terminal_velocity="GunnKinzer1949")))
+    builder.add_dynamic(fuse(ref["dynamics"].Coalescence(
+        collision_kernel=ref["kernels"].Geometric(collection_efficiency=1),
+        adaptive=bool(cfg[2]), optimized_random=bool(cfg[6]))))
+    particulator = builder.build({"volume": gold["init/volume"],
+                                  "multiplicity": gold["init/multiplicity"],
+                                  "cell id": gold["init/cell_id"]})
     _run(particulator, gold)
 
 
