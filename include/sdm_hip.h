@@ -312,6 +312,27 @@ typedef struct sdm_step_cfg {
   double gk_factor;
 } sdm_step_cfg;
 
+/* ---- sharding of a multi-cell domain over several processes (one per GPU) -------------------
+ * Pairs never span cells (pair_methods.py:34-55), so cells can be divided among processes; what
+ * remains global in the reference's algorithm is (i) the position of a cell's super-droplets in
+ * the sorted permutation - it indexes the random stream (random_generator_optimizer.py:37-48,
+ * index_methods.py:32-43) and, through `normalize`'s raw look-up (collisions_methods.py:633-662),
+ * the probabilities -, (ii) the order of the cells (`cell_idx.sort_by_key(dt_left)`,
+ * collision.py:183) and the working length (`adaptive_sdm_end`, collisions_methods.py:313-328),
+ * (iii) the compaction that fills the holes left by dead super-droplets with super-droplets from
+ * the end of the permutation (collisions_methods.py:664-680).  In sharded mode every process holds
+ * arrays of the GLOBAL shape (ids, positions, cell_start, cell_idx are global; 288 GB of HBM make
+ * that free) but computes only the cells it owns; the library calls `exchange` where global data is
+ * needed: after every sub-step a sum over processes of (masked dt_left, "someone died"), and -
+ * only when a super-droplet died - a sum of the masked permutation, after which compaction and
+ * counting sort run replicated.  The concatenation of the owned cells equals the one-process
+ * result bit for bit.                                                                          */
+#define SDM_XCHG_SUM_F64 1 /* buffer = device double[count]: in-place sum over all processes */
+#define SDM_XCHG_SUM_I64 2 /* buffer = device int64[count] */
+/* must order the collective after the work already enqueued on the ctx stream and make its result
+ * visible to work enqueued later on that stream; returns 0 on success */
+typedef int (*sdm_exchange_fn)(void *user, int what, void *device_buffer, int64_t count);
+
 typedef struct sdm_step_state {
   int64_t *idx;               /* [n_sd] current permutation */
   int64_t *tmp_idx;           /* [n_sd] counting-sort / shuffle double buffer */
@@ -342,6 +363,13 @@ typedef struct sdm_step_state {
   int64_t known_valid;
   uint64_t rng_offset;        /* doubles already drawn from the coll. stream (host-tracked) */
   uint64_t rng_offset_breakup;/* doubles already drawn from the proc/frag streams */
+  /* sharded mode (see above; all NULL = this process owns every cell).  Requires the local
+   * croupier and cells of at most 6144 super-droplets (the per-cell kernels). */
+  const uint8_t *cell_owned;  /* [n_cell] by cell id: 1 = computed by this process */
+  sdm_exchange_fn exchange;
+  void *exchange_user;
+  double *xchg_cells;         /* [n_cell + 8] scratch for the per-cell exchange */
+  int64_t *xchg_idx;          /* [n_sd] scratch for the permutation exchange */
 } sdm_step_state;
 
 typedef struct sdm_step_result {

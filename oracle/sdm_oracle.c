@@ -20,6 +20,12 @@
 
 #define API __attribute__((visibility("default")))
 
+/* OpenMP (the `_omp` build, bench.py's cpu_baseline at several threads): the loops the reference's
+ * Numba backend runs under `prange` carry `omp parallel for`; what it runs serially stays serial
+ * (shuffle within a cell, the middle loop of the adaptive scaling, compaction, counting sort).
+ * Counters are integer atomics: results do not depend on the thread count.  Without -fopenmp the
+ * pragmas are ignored and this file is the serial checker. */
+
 typedef unsigned __int128 u128;
 
 /* ------------------------------------------------------------------------------------------
@@ -85,7 +91,8 @@ API void oracle_shuffle_global(int64_t *idx, int64_t length, const double *u01) 
 }
 
 API void oracle_shuffle_local(int64_t *idx, const double *u01, const int64_t *cell_start,
-                              int64_t n_cell) { /* :32-43 */
+                              int64_t n_cell) { /* :32-43 ; prange over the cells */
+#pragma omp parallel for schedule(dynamic, 4)
   for (int64_t c = 0; c < n_cell; ++c) {
     for (int64_t i = cell_start[c + 1] - 1; i > cell_start[c]; --i) {
       const int64_t j = (int64_t)((double)cell_start[c] +
@@ -149,6 +156,7 @@ API void oracle_counting_sort_by_cell_id(int64_t *new_idx, const int64_t *idx,
 API void oracle_find_pairs(const int64_t *cell_start, uint8_t *is_first_in_pair,
                            const int64_t *cell_id, const int64_t *cell_idx,
                            const int64_t *idx, int64_t length) { /* :34-55 */
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < length - 1; ++i) {
     const int same = cell_id[idx[i]] == cell_id[idx[i + 1]];
     const int64_t d = i - cell_start[cell_idx[cell_id[idx[i]]]];
@@ -162,6 +170,7 @@ API void oracle_find_pairs(const int64_t *cell_start, uint8_t *is_first_in_pair,
 API void oracle_sort_within_pair_by_attr_i64(int64_t *idx, int64_t length,
                                              const uint8_t *flag,
                                              const int64_t *attr) { /* :126-140 */
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < length - 1; ++i)
     if (flag[i] && attr[idx[i]] < attr[idx[i + 1]]) {
       const int64_t t = idx[i];
@@ -172,6 +181,7 @@ API void oracle_sort_within_pair_by_attr_i64(int64_t *idx, int64_t length,
 
 API void oracle_sort_within_pair_by_attr_f64(int64_t *idx, int64_t length,
                                              const uint8_t *flag, const double *attr) {
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < length - 1; ++i)
     if (flag[i] && attr[idx[i]] < attr[idx[i + 1]]) {
       const int64_t t = idx[i];
@@ -194,14 +204,18 @@ static inline double pair_op(int op, double a, double b) {
 
 API void oracle_pair_op_f64(int op, double *out, int64_t n_out, const double *in,
                             const uint8_t *flag, const int64_t *idx, int64_t length) {
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n_out; ++i) out[i] = 0;
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < length - 1; ++i)
     if (flag[i]) out[i / 2] = pair_op(op, in[idx[i]], in[idx[i + 1]]);
 }
 
 API void oracle_pair_op_i64(int op, double *out, int64_t n_out, const int64_t *in,
                             const uint8_t *flag, const int64_t *idx, int64_t length) {
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n_out; ++i) out[i] = 0;
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < length - 1; ++i)
     if (flag[i]) {
       const int64_t a = in[idx[i]], b = in[idx[i + 1]];
@@ -243,6 +257,7 @@ API void oracle_normalize(double *prob, int64_t n_prob, const int64_t *cell_id,
                        (double)(sd_num / 2);
   }
   /* NB: cell_id is indexed by the PAIR index d (raw SD #d) -- reference quirk, replicated */
+#pragma omp parallel for schedule(static)
   for (int64_t d = 0; d < n_prob; ++d) prob[d] *= norm_factor[cell_idx[cell_id[d]]];
 }
 
@@ -277,6 +292,7 @@ API void oracle_scale_prob_for_adaptive_sdm_gamma(
     /* Python min(a, b) = b if b < a else a: a NaN stats_dt_min (initial fill) stays NaN */
     stats_dt_min[cid] = dt_optimal < stats_dt_min[cid] ? dt_optimal : stats_dt_min[cid];
   }
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < length / 2; ++i) {
     int64_t j, k;
     if (pair_indices(i, idx, flag, prob, &j, &k)) continue;
@@ -294,6 +310,7 @@ API void oracle_compute_gamma(const double *prob, const double *rand, const int6
                               int64_t length, const int64_t *multiplicity,
                               const int64_t *cell_id, int64_t *collision_rate_deficit,
                               int64_t *collision_rate, const uint8_t *flag, double *out) {
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < length / 2; ++i) {
     out[i] = ceil(prob[i] - rand[i]);
     int64_t j, k;
@@ -302,8 +319,11 @@ API void oracle_compute_gamma(const double *prob, const double *rand, const int6
     const int64_t gi = (int64_t)out[i];
     const int64_t g = gi < prop ? gi : prop;
     const int64_t cid = cell_id[j];
-    collision_rate[cid] += g * multiplicity[k];
-    collision_rate_deficit[cid] += (gi - g) * multiplicity[k];
+    const int64_t hit = g * multiplicity[k], missed = (gi - g) * multiplicity[k];
+#pragma omp atomic
+    collision_rate[cid] += hit;
+#pragma omp atomic
+    collision_rate_deficit[cid] += missed;
     out[i] = (double)g;
   }
 }
@@ -325,8 +345,16 @@ static inline void coalesce(int64_t i, int64_t j, int64_t k, int64_t cid, int64_
                             const double *gamma, double *attributes, int64_t n_attr,
                             int64_t n_sd, int64_t *coalescence_rate) {
   /* atomic_add(int64 array, float) -> in-place add with cast back to int64 */
+#ifdef _OPENMP
+  {  /* gamma and multiplicities are integer-valued: the same number, added atomically */
+    const int64_t add = (int64_t)(gamma[i] * (double)multiplicity[k]);
+#pragma omp atomic
+    coalescence_rate[cid] += add;
+  }
+#else
   coalescence_rate[cid] = (int64_t)((double)coalescence_rate[cid] +
                                     gamma[i] * (double)multiplicity[k]);
+#endif
   const double new_n = (double)multiplicity[j] - gamma[i] * (double)multiplicity[k];
   if (new_n > 0) {
     multiplicity[j] = (int64_t)new_n;
@@ -354,6 +382,7 @@ API void oracle_collision_coalescence(int64_t *multiplicity, const int64_t *idx,
                                       const double *gamma, int64_t *healthy,
                                       const int64_t *cell_id, int64_t *coalescence_rate,
                                       const uint8_t *flag) {
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < length / 2; ++i) {
     int64_t j, k;
     if (pair_indices(i, idx, flag, gamma, &j, &k)) continue;
@@ -433,7 +462,13 @@ static void round_multiplicities_to_ints_and_update_attributes(int64_t j, int64_
 }
 
 static inline void atomic_add_i64_f64(int64_t *arr, int64_t i, double v) {
+#ifdef _OPENMP
+  const int64_t add = (int64_t)v; /* integer-valued by construction (counts of droplets) */
+#pragma omp atomic
+  arr[i] += add;
+#else
   arr[i] = (int64_t)((double)arr[i] + v);
+#endif
 }
 
 /* :135-175 ; returns overflow flag */
@@ -450,7 +485,11 @@ static int break_up(int64_t i, int64_t j, int64_t k, int64_t cid, int64_t *multi
   const double gamma_deficit = gamma[i] - (double)gamma_j_k;
   get_new_multiplicities_and_update_attributes(j, k, attributes, n_attr, n_sd, multiplicity,
                                                take_from_j, new_mult_k, &nj, &nk);
-  breakup_rate[cid] += gamma_j_k * multiplicity[k]; /* int * int */
+  {
+    const int64_t broke = gamma_j_k * multiplicity[k]; /* int * int */
+#pragma omp atomic
+    breakup_rate[cid] += broke;
+  }
   atomic_add_i64_f64(breakup_rate_deficit, cid, gamma_deficit * (double)multiplicity[k]);
   round_multiplicities_to_ints_and_update_attributes(j, k, nj, nk, attributes, n_attr, n_sd,
                                                      multiplicity);
@@ -505,6 +544,7 @@ API int64_t oracle_collision_coalescence_breakup(
     const uint8_t *flag, int64_t max_multiplicity, const double *particle_mass,
     int handle_all_breakups) {
   int64_t n_overflow = 0;
+#pragma omp parallel for schedule(static) reduction(+ : n_overflow)
   for (int64_t i = 0; i < length / 2; ++i) {
     int64_t j, k;
     if (pair_indices(i, idx, flag, gamma, &j, &k)) continue;
@@ -575,6 +615,7 @@ API void oracle_linear_collection_efficiency(const double *params, double *outpu
 /* a-9  PySDM/backends/impl_numba/methods/terminal_velocity_methods.py:14-30 */
 API void oracle_interpolation(double *output, const double *radius, int64_t n, double factor,
                               const double *b, const double *c) {
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i) {
     if (radius[i] < 0) {
       output[i] = 0;
@@ -590,6 +631,7 @@ API void oracle_interpolation(double *output, const double *radius, int64_t n, d
 /* physics_methods.py:107-131 + physics/particle_shape_and_density/liquid_spheres.py:18-23 */
 API void oracle_volume_of_water_mass(double *volume, const double *mass, int64_t n,
                                      double rho_w) {
+#pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i) volume[i] = mass[i] / rho_w;
 }
 API void oracle_mass_of_water_volume(double *mass, const double *volume, int64_t n,

@@ -32,7 +32,8 @@
 #endif
 
 struct sdm_ctx {
-  int dummy;
+  char *arena; /* scratch of the fused entry points, kept between calls (first touch is slow) */
+  size_t arena_bytes;
 };
 
 /* thread count of the OpenMP build (the serial build ignores it) */
@@ -57,7 +58,11 @@ API int sdm_ctx_create(sdm_ctx **out, int device) {
   *out = (sdm_ctx *)calloc(1, sizeof(sdm_ctx));
   return *out ? SDM_OK : SDM_E_NOMEM;
 }
-API int sdm_ctx_destroy(sdm_ctx *ctx) { free(ctx); return SDM_OK; }
+API int sdm_ctx_destroy(sdm_ctx *ctx) {
+  if (ctx) free(ctx->arena);
+  free(ctx);
+  return SDM_OK;
+}
 API int sdm_ctx_set_stream(sdm_ctx *ctx, void *s) { (void)ctx; (void)s; return SDM_OK; }
 API int sdm_ctx_synchronize(sdm_ctx *ctx) { (void)ctx; return SDM_OK; }
 API const char *sdm_last_error(void) { return g_err; }
@@ -481,7 +486,9 @@ static const double *box_radius(Box *B) { /* attributes/physics/radius.py:15-17 
   if (!B->have_radius) {
     const double *v = box_volume(B);
     const double inv = 1 / (3.141592653589793 * 4 / 3);
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < B->N; ++i) B->radius[i] = v[i] * inv;
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < B->N; ++i) B->radius[i] = signed_power(B->radius[i], 1.0 / 3);
     B->have_radius = 1;
   }
@@ -511,19 +518,19 @@ static const double *box_velocity(Box *B) { /* terminal_velocity.py + gunn_and_k
 static void pw_op(Box *B, int op, double *out, const double *attr) {
   oracle_pair_op_f64(op, out, B->P, attr, B->flag, B->idx, B->work);
 }
-static void pw_scale(Box *B, double *a, double s) { for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] * s; }
-static void pw_shift(Box *B, double *a, double s) { for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] + s; }
-static void pw_div_s(Box *B, double *a, double s) { for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] / s; }
-static void pw_pow(Box *B, double *a, double p) { for (int64_t i = 0; i < B->P; ++i) a[i] = signed_power(a[i], p); }
-static void pw_mul(Box *B, double *a, const double *b) { for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] * b[i]; }
-static void pw_add(Box *B, double *a, const double *b) { for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] + b[i]; }
-static void pw_sub(Box *B, double *a, const double *b) { for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] - b[i]; }
-static void pw_div(Box *B, double *a, const double *b) { for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] / b[i]; }
+static void pw_scale(Box *B, double *a, double s) { _Pragma("omp parallel for schedule(static)") for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] * s; }
+static void pw_shift(Box *B, double *a, double s) { _Pragma("omp parallel for schedule(static)") for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] + s; }
+static void pw_div_s(Box *B, double *a, double s) { _Pragma("omp parallel for schedule(static)") for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] / s; }
+static void pw_pow(Box *B, double *a, double p) { _Pragma("omp parallel for schedule(static)") for (int64_t i = 0; i < B->P; ++i) a[i] = signed_power(a[i], p); }
+static void pw_mul(Box *B, double *a, const double *b) { _Pragma("omp parallel for schedule(static)") for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] * b[i]; }
+static void pw_add(Box *B, double *a, const double *b) { _Pragma("omp parallel for schedule(static)") for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] + b[i]; }
+static void pw_sub(Box *B, double *a, const double *b) { _Pragma("omp parallel for schedule(static)") for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] - b[i]; }
+static void pw_div(Box *B, double *a, const double *b) { _Pragma("omp parallel for schedule(static)") for (int64_t i = 0; i < B->P; ++i) a[i] = a[i] / b[i]; }
 static void pw_div_nz(Box *B, double *a, const double *b) { /* divide_if_not_zero */
-  for (int64_t i = 0; i < B->P; ++i) if (b[i] != 0.0) a[i] = a[i] / b[i];
+  _Pragma("omp parallel for schedule(static)") for (int64_t i = 0; i < B->P; ++i) if (b[i] != 0.0) a[i] = a[i] / b[i];
 }
-static void pw_exp(Box *B, double *a) { for (int64_t i = 0; i < B->P; ++i) a[i] = exp(a[i]); }
-static void pw_fill(Box *B, double *a, double s) { for (int64_t i = 0; i < B->P; ++i) a[i] = s; }
+static void pw_exp(Box *B, double *a) { _Pragma("omp parallel for schedule(static)") for (int64_t i = 0; i < B->P; ++i) a[i] = exp(a[i]); }
+static void pw_fill(Box *B, double *a, double s) { _Pragma("omp parallel for schedule(static)") for (int64_t i = 0; i < B->P; ++i) a[i] = s; }
 static void pw_copy(Box *B, double *a, const double *b) { memcpy(a, b, sizeof(double) * B->P); }
 
 #define PI_ 3.141592653589793
@@ -782,6 +789,40 @@ static void draw(const sdm_step_cfg *cfg, uint64_t offset, double *out, int64_t 
   oracle_pcg64_fill(st, out, n);
 }
 
+/* Sharded mode (include/sdm_hip.h): the oracle runs every stage over the global arrays, as always,
+ * but lets only the pairs of owned cells collide and keeps only the owned cells' bookkeeping; what
+ * the other processes computed arrives through the caller's exchange, exactly where the product
+ * library exchanges it: after the update of a sub-step the owned cells' dt_left and "someone
+ * died", and - if someone did - the permutation, put together from every process's segments with
+ * the dead marked by the flag value (the other processes never saw their multiplicities). */
+static int box_shard_sync(Box *B) {
+  sdm_step_state *st = B->st;
+  const uint8_t *owned = st->cell_owned;
+  double *x = st->xchg_cells;
+  if (!st->exchange || !x || !st->xchg_idx) FAIL(SDM_E_ARG, "sharded mode: exchange missing");
+  for (int64_t k = 0; k < B->C; ++k) x[k] = (B->cfg->adaptive && owned[k]) ? st->dt_left[k] : 0.0;
+  x[B->C] = B->healthy ? 0.0 : 1.0;
+  if (st->exchange(st->exchange_user, SDM_XCHG_SUM_F64, x, B->C + 1))
+    FAIL(SDM_E_HIP, "exchange callback failed");
+  if (B->cfg->adaptive)
+    for (int64_t k = 0; k < B->C; ++k) st->dt_left[k] = x[k];
+  if (x[B->C] > 0) {
+    B->healthy = 0;
+    int64_t *y = st->xchg_idx;
+    for (int64_t i = 0; i < B->N; ++i) {
+      y[i] = 0;
+      if (i < B->valid) {
+        const int64_t sd = B->idx[i];
+        if (sd < B->N && owned[st->cell_id[sd]]) y[i] = st->multiplicity[sd] == 0 ? B->N : sd;
+      }
+    }
+    if (st->exchange(st->exchange_user, SDM_XCHG_SUM_I64, y, B->N))
+      FAIL(SDM_E_HIP, "exchange callback failed");
+    memcpy(B->idx, y, sizeof(int64_t) * (size_t)B->N);
+  }
+  return SDM_OK;
+}
+
 /* collision.py:196-234 `step` */
 static int box_step(Box *B, int64_t shift_len) {
   const sdm_step_cfg *c = B->cfg;
@@ -827,6 +868,17 @@ static int box_step(Box *B, int64_t shift_len) {
     if (box_fragments(B, B->nfrag, B->fmass, B->rand_frag)) return SDM_E_ARG;
   }
   /* collision.py:273-290 compute_gamma */
+  const uint8_t *owned = st->cell_owned;  /* sharded mode: see box_shard_sync */
+  double *keep = NULL;
+  if (owned && c->adaptive) {  /* the bookkeeping of other processes' cells is theirs */
+    keep = (double *)malloc(sizeof(double) * 3 * (size_t)B->C);
+    if (!keep) return SDM_E_NOMEM;
+    for (int64_t k = 0; k < B->C; ++k) {
+      keep[k] = st->dt_left[k];
+      keep[B->C + k] = st->stats_dt_min[k];
+      keep[2 * B->C + k] = (double)st->stats_n_substep[k];
+    }
+  }
   if (c->adaptive) {
     oracle_scale_prob_for_adaptive_sdm_gamma(prob, B->idx, B->work, st->multiplicity,
                                              st->cell_id, st->dt_left, B->C, c->dt, c->dt_min,
@@ -835,6 +887,18 @@ static int box_step(Box *B, int64_t shift_len) {
   } else {
     pw_div_s(B, prob, (double)c->substeps);
   }
+  if (keep) {
+    for (int64_t k = 0; k < B->C; ++k)
+      if (!owned[k]) {
+        st->dt_left[k] = keep[k];
+        st->stats_dt_min[k] = keep[B->C + k];
+        st->stats_n_substep[k] = (int64_t)keep[2 * B->C + k];
+      }
+    free(keep);
+  }
+  if (owned)  /* pairs of cells this process does not own: no collision here */
+    for (int64_t i = 0; i + 1 < B->work; ++i)
+      if (B->flag[i] && !owned[st->cell_id[B->idx[i]]]) prob[i / 2] = 0.0;
   oracle_compute_gamma(prob, B->rand, B->idx, B->work, st->multiplicity, st->cell_id,
                        st->collision_rate_deficit, st->collision_rate, B->flag, prob);
   /* particulator.py:157-213 collision_coalescence_breakup + sanitize */
@@ -849,6 +913,10 @@ static int box_step(Box *B, int64_t shift_len) {
                                  B->N, prob, &B->healthy, st->cell_id, st->coalescence_rate,
                                  B->flag);
   }
+  if (owned) {
+    const int rc = box_shard_sync(B);
+    if (rc) return rc;
+  }
   box_sanitize(B);
   B->have_volume = B->have_radius = B->have_velocity = B->have_area = 0;
   ++B->n_sub;
@@ -862,7 +930,8 @@ static void *take(char **cursor, size_t bytes) {
 }
 
 /* one `Collision.__call__` (collision.py:174-194) */
-static int box_time_step(const sdm_step_cfg *cfg, sdm_step_state *st, sdm_step_result *res) {
+static int box_time_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st,
+                         sdm_step_result *res) {
   if (!cfg || !st || !res) FAIL(SDM_E_ARG, "sdm_collision_step: null argument");
   Box B;
   memset(&B, 0, sizeof(B));
@@ -886,7 +955,13 @@ static int box_time_step(const sdm_step_cfg *cfg, sdm_step_state *st, sdm_step_r
                        (12 + 9) * (pw_bytes + 64) + 6 * (pw_bytes + 64) +
                        4 * (sizeof(double) * (size_t)B.N + 64) +
                        sizeof(double) * (size_t)(B.C + 8) + 4096;
-  char *arena = (char *)malloc(total);
+  if (!ctx) FAIL(SDM_E_ARG, "null context");
+  if (ctx->arena_bytes < total) {
+    free(ctx->arena);
+    ctx->arena = (char *)malloc(total);
+    ctx->arena_bytes = ctx->arena ? total : 0;
+  }
+  char *arena = ctx->arena;
   if (!arena) FAIL(SDM_E_NOMEM, "oracle scratch allocation failed");
   char *cur = arena;
   B.flag = (uint8_t *)take(&cur, (size_t)B.N + 1);
@@ -905,10 +980,7 @@ static int box_time_step(const sdm_step_cfg *cfg, sdm_step_state *st, sdm_step_r
   B.radius = (double *)take(&cur, sizeof(double) * (size_t)B.N);
   B.velocity = (double *)take(&cur, sizeof(double) * (size_t)B.N);
   B.area = (double *)take(&cur, sizeof(double) * (size_t)B.N);
-  if ((size_t)(cur - arena) > total) {
-    free(arena);
-    FAIL(SDM_E_NOMEM, "oracle scratch under-sized");
-  }
+  if ((size_t)(cur - arena) > total) FAIL(SDM_E_NOMEM, "oracle scratch under-sized");
   int rc = SDM_OK;
   box_sanitize(&B);  /* a state handed over unhealthy is compacted first */
   if (!cfg->adaptive) {
@@ -926,7 +998,6 @@ static int box_time_step(const sdm_step_cfg *cfg, sdm_step_state *st, sdm_step_r
     oracle_identity_index(st->cell_idx, B.C);  /* reset_cell_idx */
     box_sort_by_cell(&B);
   }
-  free(arena);
   if (rc) FAIL(rc, "oracle: unsupported kernel / efficiency / fragmentation code");
   st->ctl[0] = B.valid;
   st->ctl[1] = B.work;
@@ -948,13 +1019,13 @@ static int box_time_step(const sdm_step_cfg *cfg, sdm_step_state *st, sdm_step_r
 
 API int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st,
                            sdm_step_result *res, int flags) {
-  (void)ctx; (void)flags;
-  return box_time_step(cfg, st, res);
+  (void)flags;
+  return box_time_step(ctx, cfg, st, res);
 }
 
 API int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st,
                           sdm_step_result *res, int flags, int64_t n_steps) {
-  (void)ctx; (void)flags;
+  (void)flags;
   sdm_step_result total;
   memset(&total, 0, sizeof(total));
   total.valid_n_sd = -1;
@@ -962,7 +1033,7 @@ API int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   total.rng_offset_breakup = st->rng_offset_breakup;
   for (int64_t s = 0; s < n_steps; ++s) {
     sdm_step_result one;
-    const int rc = box_time_step(cfg, st, &one);
+    const int rc = box_time_step(ctx, cfg, st, &one);
     if (rc) return rc;
     if (one.idx_swapped) {
       int64_t *t = st->idx; st->idx = st->tmp_idx; st->tmp_idx = t;

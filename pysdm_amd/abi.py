@@ -56,7 +56,14 @@ class StepState(ctypes.Structure):  # == sdm_step_state
         ("breakup_rate_deficit", c_ptr), ("gk_a", c_ptr), ("gk_b", c_ptr), ("ctl", c_ptr),
         ("nm", c_ptr), ("known_valid", c_i64), ("rng_offset", c_u64),
         ("rng_offset_breakup", c_u64),
+        ("cell_owned", c_ptr), ("exchange", c_ptr), ("exchange_user", c_ptr),
+        ("xchg_cells", c_ptr), ("xchg_idx", c_ptr),
     ]
+
+
+# sdm_exchange_fn
+ExchangeFn = ctypes.CFUNCTYPE(c_int, c_ptr, c_int, c_ptr, c_i64)
+XCHG_SUM_F64, XCHG_SUM_I64 = 1, 2
 
 
 class StepResult(ctypes.Structure):  # == sdm_step_result

@@ -57,6 +57,8 @@ class CollisionRunner:  # pylint: disable=too-many-instance-attributes
         self.steps_done = 0
         self.descriptor = setup.descriptor(self.constants)
         self.gamma_hook = None  # chain route only, see pysdm_amd.chain
+        self.shard = None       # set by pysdm_amd.sharding.attach
+        self.counts_global_pairs = False
         self._law_name = terminal_velocity
         self._law = None
         self._chain = None
@@ -135,6 +137,8 @@ class CollisionRunner:  # pylint: disable=too-many-instance-attributes
             if self.descriptor["needs_gk"]:
                 state.gk_a, state.gk_b = address(self.law.a), address(self.law.b)
             state.known_valid = -1
+            if self.shard is not None:
+                self.shard.fill(state, address)
             self._address = address
             self._state = state
         state.idx = self._address(pop.perm)
@@ -179,10 +183,16 @@ class CollisionRunner:  # pylint: disable=too-many-instance-attributes
                 flags |= MIRROR_VALID  # only the permutation / cell ids changed since
             self._state = None
         state, result = self._step_state(), self._result
-        if n_steps == 1:
-            eng.call("sdm_collision_step", self.step_cfg(), state, result, flags)
-        else:
-            eng.call("sdm_collision_run", self.step_cfg(), state, result, flags, int(n_steps))
+        try:
+            if n_steps == 1:
+                eng.call("sdm_collision_step", self.step_cfg(), state, result, flags)
+            else:
+                eng.call("sdm_collision_run", self.step_cfg(), state, result, flags,
+                         int(n_steps))
+        except RuntimeError as failure:
+            if self.shard is not None and self.shard.error is not None:
+                raise RuntimeError("exchange between the processes failed") from self.shard.error
+            raise failure
         if result.idx_swapped:
             pop.swap_buffers()
         self.offset, self.offset_breakup = result.rng_offset, result.rng_offset_breakup

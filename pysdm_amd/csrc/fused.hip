@@ -50,6 +50,8 @@ struct FusedArgs {
       *breakup_rate_deficit;
   const double *gk_a, *gk_b;
   int64_t *ctl;
+  // sharded mode (sdm_hip.h): by cell id, 1 = this process computes the cell; NULL = all
+  const uint8_t *cell_owned;
   // scratch
   // PCG64 streams, evaluated in the kernels (no u01 arrays): `s_rand` = state of the collision
   // generator at the first draw of `rand` (after pairs_rand), `s_rand_b` = state of the
@@ -879,7 +881,7 @@ k_cells_end(sdm_step_cfg cfg, FusedArgs A, int bookkeeping, int64_t *__restrict_
   bool nz = false;
   if (c < cfg.n_cell) {
     double left = A.dt_left[c];
-    if (bookkeeping && ran) {
+    if (bookkeeping && ran && (!A.cell_owned || A.cell_owned[c])) {
       const double m = A.cell_min[c];
       double t = A.dt_todo[c];
       if (m < t) t = m;
@@ -956,6 +958,10 @@ struct CellArgs {
   u128 s_u01;  // PCG64 state at draw 0 of the sub-step's u01 window
   int n_tail_blocks;
   const int64_t *gate;  // NULL, or a word written by k_cells_begin: 0 = this sub-step does not run
+  // sharded mode: segments of cells this process does not own are copied through unchanged (their
+  // content is only required to hold the cell's members) - needed when idx_out is not known to
+  // hold them already
+  int copy_others;
 };
 
 #ifdef CELL_PROFILE
@@ -991,6 +997,11 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   const int64_t lo = A.cell_start[blockIdx.x], hi = A.cell_start[blockIdx.x + 1];
   const int n = (int)(hi - lo);
   if (n == 0) return;
+  if (A.cell_owned && !A.cell_owned[A.cell_id[X.idx_in[lo]]]) {  // another process's cell
+    if (X.copy_others)
+      for (int li = tid; li < n; li += CELL_THREADS) X.idx_out[lo + li] = X.idx_in[lo + li];
+    return;
+  }
   if (n > CELL_CAP) {  // never taken: the host enables this path only below the cap
     if (tid == 0) A.ctl[7] = 1;
     for (int li = tid; li < n; li += CELL_THREADS) X.idx_out[lo + li] = X.idx_in[lo + li];
@@ -1289,6 +1300,11 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   const int64_t lo = A.cell_start[blockIdx.x], hi = A.cell_start[blockIdx.x + 1];
   const int n = (int)(hi - lo);
   if (n == 0) return;
+  if (A.cell_owned && !A.cell_owned[A.cell_id[X.idx_in[lo]]]) {  // another process's cell
+    if (X.copy_others)
+      for (int li = tid; li < n; li += CELL2_THREADS) X.idx_out[lo + li] = X.idx_in[lo + li];
+    return;
+  }
   if (n > CELL2_CAP) {  // never taken: the host enables this path only below the cap
     if (tid == 0) A.ctl[7] = 1;
     for (int li = tid; li < n; li += CELL2_THREADS) X.idx_out[lo + li] = X.idx_in[lo + li];
@@ -1593,6 +1609,41 @@ __global__ void k_set_work(int64_t *ctl, const int64_t *end, int64_t *box, int64
 }
 __global__ void k_reset_work(int64_t *ctl) { ctl[CTL_WORK] = ctl[CTL_VALID]; }
 // multi-cell: reset_working_length + reset_cell_idx (identity; un-sorts) in one launch
+// ---- sharded mode: what crosses process boundaries ---------------------------------------------
+// after the per-cell bookkeeping of a sub-step: x[c] = dt_left[c] of the cells this process owns
+// (0 elsewhere), x[C] = 1 if a super-droplet of this process died; summed over the processes by the
+// caller's exchange, then written back for every cell
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_shard_pack(FusedArgs A, int64_t n_cell, int adaptive, double *__restrict__ x) {
+  const int64_t c = TID();
+  if (c < n_cell) x[c] = (adaptive && A.cell_owned[c]) ? A.dt_left[c] : 0.0;
+  if (c == n_cell) x[c] = A.ctl[CTL_HEALTHY] == 0 ? 1.0 : 0.0;
+}
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_shard_unpack(FusedArgs A, int64_t n_cell, int adaptive, const double *__restrict__ x) {
+  const int64_t c = TID();
+  if (c < n_cell && adaptive) A.dt_left[c] = x[c];
+  if (c == n_cell && x[c] > 0) A.ctl[CTL_HEALTHY] = 0;
+}
+// the permutation with everything but this process's segments zeroed (workgroup k: segment k;
+// the others: the dead tail); the sum over the processes is the whole permutation
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_shard_mask_idx(FusedArgs A, const int64_t *__restrict__ idx, int64_t n_cell, int64_t n_sd,
+                 int64_t *__restrict__ out) {
+  const int64_t b = blockIdx.x;
+  if (b < n_cell) {
+    const int64_t lo = A.cell_start[b], hi = A.cell_start[b + 1];
+    if (hi == lo) return;
+    const bool mine = A.cell_owned[A.cell_id[idx[lo]]] != 0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += SDM_BLOCK) out[i] = mine ? idx[i] : 0;
+    return;
+  }
+  const int64_t n_tail = gridDim.x - n_cell;
+  for (int64_t i = A.cell_start[n_cell] + (b - n_cell) * SDM_BLOCK + threadIdx.x; i < n_sd;
+       i += n_tail * SDM_BLOCK)
+    out[i] = 0;
+}
+
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_step_close(int64_t *ctl, int64_t *__restrict__ cell_idx, int64_t n_cell, int64_t *gate_len,
              int64_t *__restrict__ seg_size) {
@@ -1772,6 +1823,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   A.gk_a = st->gk_a;
   A.gk_b = st->gk_b;
   A.ctl = st->ctl;
+  A.cell_owned = st->cell_owned;
   A.rng_inc = rng_inc;
   A.rng_tab = ctx->pcg_tab;
   A.prob = S.prob;
@@ -1983,6 +2035,51 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     LAUNCH_CHECK();
     return SDM_OK;
   };
+  // ---- sharded mode (sdm_hip.h): this process computes the cells it owns on arrays of the global
+  // shape.  After the kernels of a sub-step: sum over the processes of the owned cells' dt_left
+  // and of "a super-droplet died"; if one died anywhere, the permutation is put together again
+  // from the processes' segments, so that the compaction and the counting sort that follow run
+  // on identical, complete data everywhere.
+  const bool sharded = st->cell_owned != nullptr;
+  if (sharded) {
+    if (!st->exchange || !st->xchg_cells || !st->xchg_idx) {
+      sdm_set_error("sharded mode: exchange callback and its two buffers are required");
+      return SDM_E_ARG;
+    }
+    if (!cell_path || !cfg->croupier_local) {
+      sdm_set_error("sharded mode needs the local croupier and cells of at most %d "
+                    "super-droplets (largest: %lld)", CELL_CAP, (long long)max_cell);
+      return SDM_E_ARG;
+    }
+  }
+  auto shard_sync = [&](int64_t *perm) -> int {
+    const dim3 g((unsigned)grid_for(C + 1));
+    hipLaunchKernelGGL(k_shard_pack, g, blk, 0, s, A, C, cfg->adaptive, st->xchg_cells);
+    LAUNCH_CHECK();
+    if (st->exchange(st->exchange_user, SDM_XCHG_SUM_F64, st->xchg_cells, C + 1) != 0) {
+      sdm_set_error("sharded mode: the exchange callback failed (per-cell sum)");
+      return SDM_E_HIP;
+    }
+    hipLaunchKernelGGL(k_shard_unpack, g, blk, 0, s, A, C, cfg->adaptive, st->xchg_cells);
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemcpyAsync(ctx->mailbox, st->xchg_cells + C, sizeof(double),
+                           hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    double died;
+    memcpy(&died, ctx->mailbox, sizeof(double));
+    if (died > 0) {
+      hipLaunchKernelGGL(k_shard_mask_idx, dim3((unsigned)(C + 64)), blk, 0, s, A, perm, C, N,
+                         st->xchg_idx);
+      LAUNCH_CHECK();
+      if (st->exchange(st->exchange_user, SDM_XCHG_SUM_I64, st->xchg_idx, N) != 0) {
+        sdm_set_error("sharded mode: the exchange callback failed (permutation sum)");
+        return SDM_E_HIP;
+      }
+      HIP_TRY(hipMemcpyAsync(perm, st->xchg_idx, sizeof(int64_t) * (size_t)N,
+                             hipMemcpyDeviceToDevice, s));
+    }
+    return SDM_OK;
+  };
   // Multi-cell per-cell route, adaptive: the same idea with a device-side gate.  Sub-step k + 1
   // is launched before the host waits for the control block of sub-step k; its first kernel
   // (k_cells_begin) looks at what k left - work to do and no compaction (state still sorted) - and
@@ -1991,6 +2088,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   // counting sort and a fresh working length before the next sub-step.
   if (cell_path && cfg->adaptive && work_host != 0) {
     int64_t launched = 0;  // sub-steps launched in this time step (the draw window shifts by it)
+    bool shard_resorted = false;
     auto launch_substep = [&](bool gated, int64_t *seq_out) -> int {
       if (!cfg->optimized_random || launched == 0) {  // (c), as in the loop below
         draw_off = off;
@@ -2014,6 +2112,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       X.s_u01 = sdm_pcg_advance_host(rng_state, rng_inc, u01_off);
       X.n_tail_blocks = 64;
       X.gate = S.end2 + 3;
+      X.copy_others = sharded && launched == 0;  // (see CellArgs; once per time step suffices...
+      if (sharded && shard_resorted) { X.copy_others = 1; shard_resorted = false; }  // ...or sort)
       A.idx = alt;
       {
         const int r = launch_cell_kernel(X);
@@ -2029,6 +2129,15 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         LAUNCH_CHECK();
         std::swap(A.list_count, A.list_count_next);
       }
+      if (sharded) {
+        // bookkeeping of the owned cells first; the working length needs every cell's dt_left
+        hipLaunchKernelGGL(k_cells_end, dim3(grid_for(C)), blk, 0, s, *cfg, A, 1, S.end2,
+                           (int64_t *)nullptr, (int64_t)0);
+        LAUNCH_CHECK();
+        const int r = shard_sync(cur);
+        if (r) return r;
+        HIP_TRY(hipMemsetAsync(S.end2, 0, sizeof(int64_t), s));
+      }
       {
         PhaseScope ph(ctx, SDM_PHASE_SANITIZE);
         const int r = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl,
@@ -2036,8 +2145,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         if (r) return r;
       }
       *seq_out = ++ctx->poll_seq;
-      hipLaunchKernelGGL(k_cells_end, dim3(grid_for(C)), blk, 0, s, *cfg, A, 1, S.end2,
-                         ctx->box_dev, *seq_out);
+      hipLaunchKernelGGL(k_cells_end, dim3(grid_for(C)), blk, 0, s, *cfg, A, sharded ? 0 : 1,
+                         S.end2, ctx->box_dev, *seq_out);
       LAUNCH_CHECK();
       ++launched;
       return SDM_OK;
@@ -2049,7 +2158,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       const uint64_t keep[4] = {off, off_b, draw_off, draw_off_b};
       int64_t seq_next = 0;
       // (not in timing mode: a sub-step that falls through would count as a launch)
-      const bool ahead = !ctx->timing;
+      // (nor in sharded mode: every sub-step ends with an exchange the host takes part in)
+      const bool ahead = !ctx->timing && !sharded;
       if (ahead) {
         rc = launch_substep(true, &seq_next);
         if (rc) return rc;
@@ -2073,6 +2183,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         // from the new cell_start (particle_attributes.py cell_start getter)
         if (ahead) take_back();
         sorted_host = 0;
+        shard_resorted = true;
         hipLaunchKernelGGL(k_reset_work, one, one, 0, s, st->ctl);  // sanitize left work = valid
         LAUNCH_CHECK();
         rc = cond_sort(ctx, cfg, st, cur, S, &sorted_host);
@@ -2147,6 +2258,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       X.s_u01 = sdm_pcg_advance_host(rng_state, rng_inc, u01_off);
       X.n_tail_blocks = 64;
       X.gate = nullptr;
+      X.copy_others = sharded ? 1 : 0;
       A.idx = alt;
       {
         const int r = launch_cell_kernel(X);
@@ -2228,6 +2340,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
                          A);
       LAUNCH_CHECK();
       std::swap(A.list_count, A.list_count_next);  // it left the other set of counts cleared
+    }
+    if (sharded) {
+      rc = shard_sync(cur);
+      if (rc) return rc;
     }
     // (g) sanitize (particle_attributes.py:67-73), decided on the device by the healthy word
     {

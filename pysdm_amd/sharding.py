@@ -1,1 +1,158 @@
-"""placeholder (rewritten below in this round)"""
+"""Cells of a multi-cell domain over the GPUs of one node: one process per GPU, `torch.distributed`
+(backend "nccl" = RCCL over xGMI on GPUs, "gloo" in the CPU tests) for what crosses processes.
+
+The sharded run reproduces the ONE-process run bit for bit (same seed, same random stream): see
+include/sdm_hip.h ("sharding") for what is global in the algorithm and how the library handles it.
+In short: every process holds the columns at their global shape (ids, positions, `cell_start`,
+`cell_idx` keep their global meaning; memory is not the constraint on a 288-GB part) but runs the
+per-cell kernels only on the contiguous block of cells it owns.  Per sub-step one tiny all-reduce
+(n_cell + 1 doubles: the owned cells' `dt_left`, and whether a super-droplet died anywhere); when
+one did, one all-reduce of the permutation (n_sd int64), after which compaction and counting sort
+run replicated.  No super-droplet payload crosses processes in a collision step: a cell's
+super-droplets live, and stay, with the cell's owner.
+
+`attach(runner, rank, world)` turns a CollisionRunner over the global population into this
+process's share of it; `gather(runner)` assembles the global state from the owners (diagnostics,
+tests).  Migration of super-droplets between owners after a displacement step amounts to
+re-declaring ownership by the new cell ids plus an all-reduce of the masked attribute columns -
+`refresh_after_displacement`.
+"""
+import ctypes
+
+import numpy as np
+
+from . import abi
+
+
+def cell_block(n_cell, rank, world_size):
+    """contiguous block [first, last) of cells owned by `rank` (sizes differ by at most one)"""
+    base, extra = divmod(n_cell, world_size)
+    first = rank * base + min(rank, extra)
+    return first, first + base + (1 if rank < extra else 0)
+
+
+class Shard:  # pylint: disable=too-many-instance-attributes
+    """ownership mask + the exchange callback the library calls (sdm_exchange_fn)"""
+
+    def __init__(self, engine, n_sd, n_cell, rank, world, group=None):
+        import torch  # pylint: disable=import-outside-toplevel
+        import torch.distributed as dist  # pylint: disable=import-outside-toplevel
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.engine, self.rank, self.world = engine, rank, world
+        self.first, self.last = cell_block(n_cell, rank, world)
+        mask = np.zeros(n_cell, dtype=np.uint8)
+        mask[self.first:self.last] = 1
+        self.owned_host = mask.astype(bool)
+        self.owned = engine.upload(mask)
+        self.x_cells = engine.zeros(n_cell + 8, np.float64)
+        self.x_idx = engine.zeros(n_sd, np.int64)
+        self.calls = {abi.XCHG_SUM_F64: 0, abi.XCHG_SUM_I64: 0}
+        self.error = None
+        self.callback = abi.ExchangeFn(self._exchange)  # keep alive as long as the shard
+
+    def _as_tensor(self, array):
+        return array if hasattr(array, "data_ptr") else self.torch.from_numpy(array)
+
+    def _exchange(self, _user, what, pointer, count):
+        try:
+            buffer = self.x_cells if what == abi.XCHG_SUM_F64 else self.x_idx
+            address = buffer.data_ptr() if hasattr(buffer, "data_ptr") else buffer.ctypes.data
+            if address != pointer:
+                raise RuntimeError("exchange called with a foreign buffer")
+            self.calls[what] += 1
+            tensor = self._as_tensor(buffer)[:count]
+            if tensor.is_cuda and self.dist.get_backend(self.group) != "nccl":
+                # rehearsal on one card (several processes, gloo): through the host.  `.cpu()`
+                # waits for the library's stream, `copy_` is enqueued on it
+                host = tensor.cpu()
+                self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group)
+                tensor.copy_(host)
+            else:
+                # RCCL: enqueued behind the work already on the current (= the library's) stream,
+                # and later work on that stream waits for it
+                self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM, group=self.group)
+            return 0
+        except Exception as error:  # pylint: disable=broad-except
+            self.error = error  # (exceptions cannot cross the C frame: reported by the runner)
+            return 1
+
+    def fill(self, state, address):
+        state.cell_owned = address(self.owned)
+        state.exchange = ctypes.cast(self.callback, ctypes.c_void_p)
+        state.exchange_user = None
+        state.xchg_cells = address(self.x_cells)
+        state.xchg_idx = address(self.x_idx)
+
+    def sum(self, array):
+        """all-reduce (sum) of a host array; returns the host result"""
+        tensor = self.torch.from_numpy(np.ascontiguousarray(array).copy())
+        if hasattr(self.x_cells, "data_ptr") and self.dist.get_backend(self.group) == "nccl":
+            tensor = tensor.to(self.x_cells.device)
+        self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM, group=self.group)
+        return tensor.cpu().numpy()
+
+
+def attach(runner, rank, world, group=None):
+    """`runner`: a fused-route CollisionRunner over the GLOBAL population (identical on every
+    process); afterwards it computes this process's block of cells"""
+    if runner.route != "fused":
+        raise ValueError("sharding drives the fused route")
+    pop = runner.population
+    runner.shard = Shard(runner.engine, pop.n_sd, pop.n_cell, rank, world, group)
+    runner.read_back = True
+    runner.counts_global_pairs = True  # every process counts the pairs of all cells
+    runner._state = None  # pylint: disable=protected-access
+    return runner
+
+
+def owned_droplets(runner):
+    """boolean mask over the global super-droplet ids: those living in this process's cells"""
+    cell_id = runner.engine.download(runner.population.cell_id)
+    return runner.shard.owned_host[cell_id]
+
+
+def gather(runner):
+    """the global snapshot put together from the owners: multiplicities / attributes of every
+    super-droplet from the process owning its cell, per-cell diagnostics from the cell's owner;
+    permutation and cell_start are global already.  Identical on every process."""
+    shard = runner.shard
+    snap = runner.snapshot()
+    mine = owned_droplets(runner)
+    snap["multiplicity"] = shard.sum(np.where(mine, snap["multiplicity"], 0))
+    snap["attributes"] = shard.sum(np.where(mine[None, :], snap["attributes"], 0.0))
+    # the permutation: each owner's segments (the other segments hold the right members in an
+    # arbitrary order on this process)
+    length = int(snap["length"])
+    idx = snap["idx"][:length]
+    live_mine = mine[idx]
+    snap["idx"] = np.concatenate([shard.sum(np.where(live_mine, idx, 0)), snap["idx"][length:]])
+    for key in ("collision_rate", "collision_rate_deficit", "coalescence_rate", "breakup_rate",
+                "breakup_rate_deficit"):
+        if key in snap:
+            snap[key] = shard.sum(np.where(shard.owned_host, snap[key], 0))
+    if runner.setup.adaptive:  # (non-adaptive: the constant every process holds)
+        snap["stats_n_substep"] = shard.sum(np.where(shard.owned_host, snap["stats_n_substep"], 0))
+        owned_min = np.where(shard.owned_host, snap["stats_dt_min"], 0.0)
+        snap["stats_dt_min"] = shard.sum(owned_min)
+    return snap
+
+
+def make_sharded_box(engine, name, *, rank, world, n_sd=None, adaptive=None, seed=44, dt=None,
+                     group=None):
+    """configuration `name` (a multi-cell one) with its cells divided over `world` processes"""
+    from . import cases  # pylint: disable=import-outside-toplevel
+
+    runner = cases.make_box(engine, name, n_sd=n_sd, adaptive=adaptive, seed=seed, dt=dt)
+    if runner.population.n_cell < world:
+        raise ValueError("fewer cells than processes")
+    return attach(runner, rank, world, group)
+
+
+def refresh_after_displacement(runner, displacement):
+    """after a replicated displacement step the cell ids changed on every process alike; the
+    super-droplets that entered this process's cells bring their state from the previous owner:
+    an all-reduce of the columns masked by the PREVIOUS ownership (`previous`: the mask from
+    `owned_droplets` taken before the displacement)"""
+    raise NotImplementedError(
+        "see DESIGN.md section 5: the collision step shards; a sharded displacement step is next")

@@ -40,12 +40,15 @@ def runner_for(name, engine, route="fused"):
     return cases.make_box(engine, case, n_sd=n_sd, route=route)
 
 
-def check(name, engine, route="fused", float_exact=None, steps_limit=None):
+def check(name, engine, route="fused", float_exact=None, steps_limit=None, prepare=None,
+          snapshot=None):
     """runs case `name` and compares with the reference's digest after each recorded step.
     Integer columns by SHA-256; masses by SHA-256 where the path is free of transcendental
     functions feeding attributes (coalescence), else moments at 1e-12"""
     gold = np.load(os.path.join(GOLDEN, f"digest_{name}.npz"))
     runner = runner_for(name, engine, route)
+    if prepare is not None:  # e.g. pysdm_amd.sharding.attach
+        prepare(runner)
     pop, down = runner.population, engine.download
     breakup = runner.setup.breakup
     float_exact = (not breakup) if float_exact is None else float_exact
@@ -60,7 +63,7 @@ def check(name, engine, route="fused", float_exact=None, steps_limit=None):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             runner.run(step - runner.steps_done)
-        snap = runner.snapshot()
+        snap = runner.snapshot() if snapshot is None else snapshot(runner)
         tag = f"{name} step {step}"
         length = int(snap["length"])
         assert length == int(gold[f"step{step}/length"]), tag

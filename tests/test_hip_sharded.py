@@ -1,0 +1,84 @@
+"""The sharded mode on HIP: two processes (one card - the GPU box has one -, rank-to-rank traffic
+over gloo; on a node the same code runs one process per GPU over RCCL), each computing half of
+the cells.  The state put together from the owners equals (i) the UNSHARDED reference goldens of
+the 4 x 4 grids, (ii) the reference's digest of the 32 x 32 grid, (iii) the one-process HIP run
+where super-droplets die and the permutation has to be put together across the processes."""
+import os
+import socket
+import warnings
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pysdm_amd import sharding
+
+from . import digests
+from .test_sharding import CASES, sharded_run_equals_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, errors):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from pysdm_amd import cases  # pylint: disable=import-outside-toplevel
+        from pysdm_amd.engine import HipEngine  # pylint: disable=import-outside-toplevel
+
+        engine = HipEngine.get(0)
+        for name in CASES:
+            sharded_run_equals_golden(name, engine, rank, world)
+        # 32 x 32 cells against the reference's digest
+        digests.check("kinematic2d_64percell", engine,
+                      prepare=lambda runner: sharding.attach(runner, rank, world),
+                      snapshot=sharding.gather)
+        # deaths (compaction + re-sort run replicated after the permutation exchange)
+        for adaptive in (True, False):
+            single = cases.make_box(engine, "shima", n_sd=2**13, adaptive=adaptive, dt=200.0,
+                                    thin=0.02, grid=(4, 4))
+            shard = cases.make_box(engine, "shima", n_sd=2**13, adaptive=adaptive, dt=200.0,
+                                   thin=0.02, grid=(4, 4))
+            sharding.attach(shard, rank, world)
+            for steps in (1, 4, 3):
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    single.run(steps)
+                    shard.run(steps)
+                got, ref = sharding.gather(shard), single.snapshot()
+                length = int(ref["length"])
+                assert int(got["length"]) == length < 2**13
+                for key, value in ref.items():
+                    if key == "stats_dt_min" and not adaptive:
+                        continue
+                    mine = got[key]
+                    if key == "idx":
+                        value, mine = value[:length], mine[:length]
+                    np.testing.assert_array_equal(mine, value, err_msg=f"{adaptive} {key}")
+            assert shard.shard.calls[2] > 0
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as exc:  # pylint: disable=broad-except
+        errors.put(f"rank {rank}: {exc!r}")
+        raise
+
+
+@pytest.mark.timeout(900)
+def test_two_processes_sharded_on_hip_equal_the_unsharded_reference(hip_engine):  # pylint: disable=unused-argument
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    errors = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, errors)) for r in range(2)]
+    for proc in procs:
+        proc.start()
+    for proc in procs:
+        proc.join(800)
+    failed = [p.exitcode for p in procs if p.exitcode != 0]
+    messages = []
+    while not errors.empty():
+        messages.append(errors.get())
+    assert not failed and not messages, f"{failed} {messages}"
