@@ -190,15 +190,33 @@ def main():
         p = torch.tensor([float(pairs)], dtype=torch.float64, device=reduce_device)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            if not getattr(runner, "counts_global_pairs", False):
+            if not runner.counts_global_pairs:
                 dist.all_reduce(p, op=dist.ReduceOp.SUM)
         reps.append((float(p.item()) / float(t.item()), float(t.item()), float(p.item())))
+    # multi-cell workload: digest of the global state (put together from the owners when sharded),
+    # so that runs with different --gpus can be compared: the sharded run reproduces the
+    # one-process run bit for bit
+    state_digest = None
+    if pop.n_cell > 1:
+        import hashlib
+
+        from pysdm_amd import sharding
+
+        snap = sharding.gather(runner) if runner.shard is not None else runner.snapshot()
+        live = snap["idx"][: int(snap["length"])]
+        state_digest = hashlib.sha256(
+            np.ascontiguousarray(live).tobytes()
+            + np.ascontiguousarray(snap["multiplicity"]).tobytes()
+            + np.ascontiguousarray(snap["attributes"]).tobytes()).hexdigest()
     rates = [r[0] for r in reps]
     median_rate = statistics.median(rates)
     _, elapsed_max, pairs_total = min(reps, key=lambda r: abs(r[0] - median_rate))
 
     roofline = None
     baseline = None
+    sharded_run = runner.shard is not None
+    if sharded_run and rank != 0:  # every process takes part in every step of a sharded run
+        runner.run(args.roofline_steps)
     if rank == 0:
         # ---- per-kernel durations, HIP events on the library's own stream (separate pass)
         engine.call("sdm_ctx_set_timing", 1)
@@ -265,6 +283,7 @@ def main():
                 "seed": 44,
                 "route": "fused sdm_collision_run",
             },
+            "state_digest": state_digest,
             "repetitions": {"n": len(reps), "reported": "median",
                             "values": [round(r, 1) for r in rates]},
             "shima_box_3600_steps_s": elapsed_max / args.steps * 3600,

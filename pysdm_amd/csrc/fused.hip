@@ -1634,7 +1634,10 @@ k_shard_mask_idx(FusedArgs A, const int64_t *__restrict__ idx, int64_t n_cell, i
   if (b < n_cell) {
     const int64_t lo = A.cell_start[b], hi = A.cell_start[b + 1];
     if (hi == lo) return;
-    const bool mine = A.cell_owned[A.cell_id[idx[lo]]] != 0;
+    // (a flagged entry - value n_sd, a super-droplet that just died - can only have been written
+    // by the owner: this process)
+    const int64_t first = idx[lo];
+    const bool mine = first >= n_sd || A.cell_owned[A.cell_id[first]] != 0;
     for (int64_t i = lo + threadIdx.x; i < hi; i += SDM_BLOCK) out[i] = mine ? idx[i] : 0;
     return;
   }
@@ -1884,7 +1887,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     work_host = ctx->carry.valid;
     sorted_host = 1;
     max_cell = ctx->carry.max_cell;
-  } else if (cfg->adaptive || read_back) {
+  } else if (cfg->adaptive || read_back || st->cell_owned) {  // (sharded: the per-cell route)
     bool sorted_now = false;
     if (C > 1 && cfg->croupier_local) {
       // The route depends on the largest cell, which is known only for a sorted state - and a

@@ -511,6 +511,161 @@ k_bin_build(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
   }
 }
 
+// ---- two-launch build (round 2): no count matrix, no column scan, no global scatter -----------
+// K1': per event tile: own-event targets -> jarr; the tile's events ordered by target bin in LDS
+// and written back *in place* (tile-major, coalesced), with the tile's bin offsets toff[tile][0..nb].
+// K4': one workgroup per bin gathers its runs - for every tile the events toff[t][b]..toff[t][b+1]
+// of that tile's segment, ~16 events = two 64-B sectors each, the same granularity the scatter
+// wrote at - and assembles the records as k_bin_build does.  The order of the events inside a bin
+// is irrelevant (the walk takes the minimum over a position's candidates).
+template <bool RNG>
+__global__ void __launch_bounds__(BIN_THREADS)
+k_bin_sort(int2 *__restrict__ events, int32_t *__restrict__ toff, int32_t *__restrict__ jarr,
+           int n_bins, const double *__restrict__ u01, const int64_t *__restrict__ cell_start,
+           int64_t n_cell, const int64_t *__restrict__ p_length, int64_t length_arg, u128 s_off,
+           u128 inc, const u128 *__restrict__ tab) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int32_t *lstart = (int32_t *)smem;                      // n_bins + 1
+  int32_t *lcount = lstart + n_bins + 1;                  // n_bins
+  int2 *ev_buf = (int2 *)(lcount + ((n_bins + 1) & ~1));  // EV_TILE
+  __shared__ u128 s_slot;
+  const int64_t length = p_length ? *p_length : length_arg;
+  const int64_t tile_first = (int64_t)blockIdx.x * EV_TILE;
+  int32_t *my_off = toff + (int64_t)blockIdx.x * (n_bins + 1);
+  if (tile_first >= length) {
+    for (int b = threadIdx.x; b <= n_bins; b += BIN_THREADS) my_off[b] = 0;
+    return;
+  }
+  for (int b = threadIdx.x; b < n_bins; b += BIN_THREADS) lcount[b] = 0;
+  if (RNG && threadIdx.x == 0) s_slot = pcg_jump(s_off, tab, (uint64_t)blockIdx.x * EV_TILE);
+  __syncthreads();
+  const u128 s_tile = RNG ? s_slot : 0;
+  const int64_t first = tile_first + (int64_t)threadIdx.x * EV_PER_THREAD;
+  int32_t j[EV_PER_THREAD];
+  targets_run<RNG, EV_PER_THREAD>(first, length, u01, cell_start, n_cell, s_tile, inc, tab, j);
+#pragma unroll
+  for (int e = 0; e < EV_PER_THREAD; ++e) {
+    if (j[e] >= 0) atomicAdd(&lcount[j[e] >> BIN_SHIFT], 1);
+    if (first + e < length) jarr[first + e] = j[e];
+  }
+  __syncthreads();
+  {  // lstart = exclusive scan of lcount; lcount reset to serve as the placement cursor
+    const int per = (n_bins + BIN_THREADS - 1) / BIN_THREADS;
+    const int b0 = threadIdx.x * per;
+    int sum = 0;
+    for (int k = 0; k < per; ++k)
+      if (b0 + k < n_bins) sum += lcount[b0 + k];
+    int all;
+    int run = block_excl_scan(sum, &all);
+    for (int k = 0; k < per; ++k)
+      if (b0 + k < n_bins) {
+        lstart[b0 + k] = run;
+        run += lcount[b0 + k];
+        lcount[b0 + k] = 0;
+      }
+    if (threadIdx.x == 0) lstart[n_bins] = all;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < EV_PER_THREAD; ++e)
+    if (j[e] >= 0) {
+      const int b = j[e] >> BIN_SHIFT;
+      ev_buf[lstart[b] + atomicAdd(&lcount[b], 1)] = make_int2((int)(first + e), j[e]);
+    }
+  __syncthreads();
+  const int n_ev = lstart[n_bins];
+  for (int t = threadIdx.x; t < n_ev; t += BIN_THREADS) events[tile_first + t] = ev_buf[t];
+  for (int b = threadIdx.x; b <= n_bins; b += BIN_THREADS) my_off[b] = lstart[b];
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(BIN_THREADS)
+k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
+             int32_t *__restrict__ ovf_next, const int2 *__restrict__ events,
+             const int32_t *__restrict__ toff, const int32_t *__restrict__ jarr, int n_bins,
+             int n_tiles, const int64_t *__restrict__ idx0, const int64_t *__restrict__ p_length,
+             int64_t length_arg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int SLOTS = FMT == SDM_REC_P21 ? 4 : (FMT == SDM_REC_P24 ? 3 : 2);
+  int32_t *run_pre = (int32_t *)smem;                   // n_tiles + 1: events of tiles < t
+  int32_t *run_lo = run_pre + ((n_tiles + 1 + 3) & ~3); // n_tiles: where tile t's run starts
+  int32_t *slot = run_lo + ((n_tiles + 3) & ~3);        // SLOTS x BIN_POS, then BIN_POS list heads
+  int32_t *head = slot + SLOTS * BIN_POS;
+  const int64_t length = p_length ? *p_length : length_arg;
+  const int64_t base = (int64_t)blockIdx.x * BIN_POS;
+  if (base >= length) return;
+  const int bin = blockIdx.x;
+  {  // run lengths of this bin, tile by tile, and their exclusive scan
+    const int per = (n_tiles + BIN_THREADS - 1) / BIN_THREADS;
+    const int t0 = threadIdx.x * per;
+    int sum = 0;
+    for (int k = 0; k < per; ++k) {
+      const int t = t0 + k;
+      if (t < n_tiles) {
+        const int32_t *row = toff + (int64_t)t * (n_bins + 1) + bin;
+        const int a = row[0], b = row[1];
+        run_lo[t] = t * EV_TILE + a;  // (index into `events`: below 2^31 for every supported size)
+        run_pre[t] = b - a;
+        sum += b - a;
+      }
+    }
+    int all;
+    int run = block_excl_scan(sum, &all);
+    for (int k = 0; k < per; ++k) {
+      const int t = t0 + k;
+      if (t < n_tiles) {
+        const int v = run_pre[t];
+        run_pre[t] = run;
+        run += v;
+      }
+    }
+    if (threadIdx.x == 0) run_pre[n_tiles] = all;
+  }
+  for (int q = threadIdx.x; q < (SLOTS + 1) * BIN_POS; q += BIN_THREADS) slot[q] = -1;
+  __syncthreads();
+  // hits on this bin's positions: the first SLOTS inline (claimed by compare-and-swap), rest listed
+  const int n_ev = run_pre[n_tiles];
+  for (int e = threadIdx.x; e < n_ev; e += BIN_THREADS) {
+    int lo = 0, hi = n_tiles;  // largest t with run_pre[t] <= e
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (run_pre[mid] <= e) lo = mid; else hi = mid;
+    }
+    const int2 ev = events[(int64_t)run_lo[lo] + (e - run_pre[lo])];
+    const int q = ev.y - (int)base;
+    bool placed = false;
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k)
+      if (!placed) placed = atomicCAS(&slot[k * BIN_POS + q], -1, ev.x) == -1;
+    if (!placed) ovf_next[ev.x] = atomicExch(&head[q], ev.x);  // -1 terminated, built entirely here
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < BIN_POS; q += BIN_THREADS) {
+    const int64_t p = base + q;
+    if (p >= length) break;
+    const int32_t h = head[q];
+    const int32_t id = (int32_t)idx0[p];
+    if (FMT == SDM_REC_P21) {
+      PackRec21 r;
+      p21_pack(r.lo, r.hi, jarr[p], slot[q], slot[BIN_POS + q], slot[2 * BIN_POS + q],
+               slot[(SLOTS - 1) * BIN_POS + q], id, h >= 0);
+      ((PackRec21 *)rec_out)[p] = r;
+    } else if (FMT == SDM_REC_P24) {
+      PackRec24 r;
+      p24_pack(r.lo, r.hi, jarr[p], slot[q], slot[BIN_POS + q], slot[2 * BIN_POS + q], id, h >= 0);
+      ((PackRec24 *)rec_out)[p] = r;
+    } else {
+      PackRec r;
+      r.j = jarr[p];
+      r.s0 = slot[q];
+      r.s1 = slot[BIN_POS + q];
+      r.val = id | (h >= 0 ? (int32_t)0x80000000 : 0);
+      ((PackRec *)rec_out)[p] = r;
+    }
+    if (h >= 0) ovf_head[p] = h;
+  }
+}
+
 // backward walk over packed records; positions [length, n_total) are copied through
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_trace_packed(int64_t *__restrict__ out, const int64_t *__restrict__ idx0,
@@ -534,8 +689,7 @@ static int ev_tile_count(int64_t n) { return (int)((n + EV_TILE - 1) / EV_TILE);
 static size_t binned_scratch_bytes(int64_t n) {
   const size_t nb = (size_t)bin_count(n), nt = (size_t)ev_tile_count(n);
   return carve_size(sizeof(PackRec) * n) + 3 * carve_size(sizeof(int32_t) * n) +
-         carve_size(sizeof(int2) * n) + carve_size(sizeof(int32_t) * nb * nt) +
-         carve_size(sizeof(int32_t) * (nb + 1));
+         carve_size(sizeof(int2) * (nt * EV_TILE)) + carve_size(sizeof(int32_t) * (nb + 1) * nt);
 }
 
 // usable while the count matrix stays small and LDS holds the per-bin arrays of K3
@@ -557,39 +711,38 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
   int32_t *ovf_head = cv.take<int32_t>(length_bound);
   int32_t *ovf_next = cv.take<int32_t>(length_bound);
   int32_t *jarr = cv.take<int32_t>(length_bound);
-  int2 *events = cv.take<int2>(length_bound);
-  int32_t *cnt = cv.take<int32_t>((size_t)nb * nt);
-  int32_t *total = cv.take<int32_t>(nb + 1);
+  int2 *events = cv.take<int2>((size_t)nt * EV_TILE);
+  int32_t *toff = cv.take<int32_t>((size_t)(nb + 1) * nt);
   const dim3 block(BIN_THREADS);
-  const size_t lds_hist = sizeof(int32_t) * (size_t)(nb + 1);
-  const size_t lds_scatter = sizeof(int32_t) * (size_t)(2 * (nb + 1) + ((nb + 1) & ~1)) +
-                             (sizeof(int2) + sizeof(int32_t)) * EV_TILE;
-  const size_t lds_build =
-      sizeof(int32_t) * (size_t)(((nb + 1 + 3) & ~3) + (slots + 1) * BIN_POS);
-  if (lds_scatter > 65536)  // gfx950 has 160 KiB of LDS per CU; > 64 KiB dynamic needs opting in
-    HIP_TRY(hipFuncSetAttribute((const void *)k_bin_scatter,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scatter));
+  const size_t lds_sort = sizeof(int32_t) * (size_t)((nb + 1) + ((nb + 1) & ~1) + 2) +
+                          sizeof(int2) * EV_TILE;
+  const size_t lds_build = sizeof(int32_t) * (size_t)(((nt + 1 + 3) & ~3) + ((nt + 3) & ~3) +
+                                                      (slots + 1) * BIN_POS);
+  // gfx950 has 160 KiB of LDS per CU; > 64 KiB dynamic needs opting in (per kernel and device)
+  if (lds_sort > 65536) {
+    HIP_TRY(hipFuncSetAttribute((const void *)k_bin_sort<true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_bin_sort<false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
+  }
   if (lds_build > 65536)
-    HIP_TRY(hipFuncSetAttribute(fmt == SDM_REC_P21   ? (const void *)k_bin_build<SDM_REC_P21>
-                                : fmt == SDM_REC_P24 ? (const void *)k_bin_build<SDM_REC_P24>
-                                                     : (const void *)k_bin_build<SDM_REC_PLAIN>,
+    HIP_TRY(hipFuncSetAttribute(fmt == SDM_REC_P21   ? (const void *)k_bin_build2<SDM_REC_P21>
+                                : fmt == SDM_REC_P24 ? (const void *)k_bin_build2<SDM_REC_P24>
+                                                     : (const void *)k_bin_build2<SDM_REC_PLAIN>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
   {
     PhaseScope ph(ctx, SDM_PHASE_SHUFFLE_BUILD);
     if (u01)
-      hipLaunchKernelGGL((k_bin_count<false>), dim3(nt), dim3(K1_THREADS), lds_hist, ctx->stream, cnt, jarr,
-                         nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc,
+      hipLaunchKernelGGL((k_bin_sort<false>), dim3(nt), block, lds_sort, ctx->stream, events, toff,
+                         jarr, nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc,
                          ctx->pcg_tab);
     else
-      hipLaunchKernelGGL((k_bin_count<true>), dim3(nt), dim3(K1_THREADS), lds_hist, ctx->stream, cnt, jarr,
-                         nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc,
+      hipLaunchKernelGGL((k_bin_sort<true>), dim3(nt), block, lds_sort, ctx->stream, events, toff,
+                         jarr, nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc,
                          ctx->pcg_tab);
-    hipLaunchKernelGGL(k_bin_colscan, dim3(nb), block, 0, ctx->stream, cnt, total, nb, nt);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(nt), block, lds_scatter, ctx->stream, events, cnt,
-                       total, jarr, nb, p_length, length_bound);
 #define BUILD_LAUNCH(F)                                                                        \
-  hipLaunchKernelGGL(k_bin_build<F>, dim3(nb), block, lds_build, ctx->stream, (void *)rec, ovf_head, \
-                     ovf_next, events, total, jarr, nb, idx0, p_length, length_bound)
+  hipLaunchKernelGGL(k_bin_build2<F>, dim3(nb), block, lds_build, ctx->stream, (void *)rec,    \
+                     ovf_head, ovf_next, events, toff, jarr, nb, nt, idx0, p_length, length_bound)
     if (fmt == SDM_REC_P21) BUILD_LAUNCH(SDM_REC_P21);
     else if (fmt == SDM_REC_P24) BUILD_LAUNCH(SDM_REC_P24);
     else BUILD_LAUNCH(SDM_REC_PLAIN);
