@@ -37,6 +37,18 @@ struct sdm_ctx {
   // word (9.8 us against 15.4 us for hipMemcpyAsync + hipStreamSynchronize, measured)
   int64_t *box_dev;
   int64_t poll_seq;
+  // fused.hip, sdm_collision_run: time steps of a one-cell non-adaptive box replayed as a hipGraph
+  // (two steps per graph: the permutation buffers are back in their roles).  The kernels of a
+  // replayed step cannot get the stream positions as arguments: they read them from `gwords`
+  // ({doubles drawn from the collision stream, from the breakup streams}), advanced on the device
+  // at the end of every sub-step.
+  uint64_t *gwords;        // device, 4 words
+  void *own_stream, *own_event;  // hipStream_t / hipEvent_t of the replays
+  uint64_t graph_calls;
+  bool graph_capture;      // collision_step is being captured: device-side stream positions
+  void *graph_exec;        // hipGraphExec_t of the cached two-step graph (NULL: none)
+  void *graph_key;         // what the cached graph was captured for (memcmp'ed)
+  size_t graph_key_bytes;
   bool cell_attr_done;     // fused.hip: large-LDS attribute of the per-cell kernels set on this device
   int compact_grid;        // index.hip: workgroups of k_compact_persistent that are co-resident here
   int debug_box_delay_us;  // SDM_DEBUG_BOX_DELAY_US (tests): the host sleeps before each wait
@@ -77,7 +89,7 @@ struct sdm_ctx {
 // follows it never share a slot.
 #define SDM_BOX 16         // first mailbox word of slot 0
 #define SDM_BOX_STRIDE 16  // words between the two slots
-#define SDM_MAILBOX_WORDS 64
+#define SDM_MAILBOX_WORDS 64  // (words 48..63: stream positions handed to graph replays)
 int sdm_wait_box(sdm_ctx *ctx, int64_t seq);  // ctx.hip
 // waits for publication `seq` and copies its eight words; fails if the slot was overwritten while
 // it was read (cannot happen with one publication in flight ahead: checked, not assumed)

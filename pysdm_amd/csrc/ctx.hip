@@ -91,6 +91,11 @@ extern "C" int sdm_ctx_destroy(sdm_ctx *ctx) {
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   if (ctx->dscal) (void)hipFree(ctx->dscal);
   if (ctx->cnt_slots) (void)hipFree(ctx->cnt_slots);
+  if (ctx->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)ctx->graph_exec);
+  free(ctx->graph_key);
+  if (ctx->gwords) (void)hipFree(ctx->gwords);
+  if (ctx->own_event) (void)hipEventDestroy((hipEvent_t)ctx->own_event);
+  if (ctx->own_stream) (void)hipStreamDestroy((hipStream_t)ctx->own_stream);
   if (ctx->ev) {
     for (int i = 0; i < SDM_MAX_EVENTS; ++i) (void)hipEventDestroy(ctx->ev[i]);
     delete[] ctx->ev;

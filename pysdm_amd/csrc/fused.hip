@@ -52,6 +52,11 @@ struct FusedArgs {
   int64_t *ctl;
   // sharded mode (sdm_hip.h): by cell id, 1 = this process computes the cell; NULL = all
   const uint8_t *cell_owned;
+  // graph replay (common.h: gwords): s_rand / s_rand_b are then the generators' initial states and
+  // the stream positions come from the device ({collision stream, breakup streams}); rand_extra =
+  // distance from a draw's first u01 to its first `rand` (n_sd + shift)
+  const uint64_t *dev_off;
+  uint64_t rand_extra;
   // scratch
   // PCG64 streams, evaluated in the kernels (no u01 arrays): `s_rand` = state of the collision
   // generator at the first draw of `rand` (after pairs_rand), `s_rand_b` = state of the
@@ -144,8 +149,8 @@ __global__ void __launch_bounds__(SDM_CNT_SLOTS) k_fold_counters(FusedArgs A) {
 
 // one draw per thread: element (block_first + tid) of the stream starting at `s_base`
 __device__ __forceinline__ double stream_draw(u128 s_base, u128 inc, const u128 *__restrict__ tab,
-                                              u128 *lds_slot) {
-  if (threadIdx.x == 0) *lds_slot = pcg_jump(s_base, tab, (uint64_t)blockIdx.x * SDM_BLOCK);
+                                              u128 *lds_slot, uint64_t add = 0) {
+  if (threadIdx.x == 0) *lds_slot = pcg_jump(s_base, tab, (uint64_t)blockIdx.x * SDM_BLOCK + add);
   __syncthreads();
   u128 state = pcg_jump(*lds_slot, tab, (uint64_t)threadIdx.x);
   state = state * pcg_mult() + inc;
@@ -703,8 +708,11 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_all(sdm_step_cfg cfg, FusedA
   const int64_t W = A.ctl[CTL_WORK];
   const int64_t d = TID();
   if (d == 0) A.ctl[CTL_PAIRS] += W / 2;  // lets a caller count pairs without reading back per step
-  const double u = stream_draw(A.s_rand, A.rng_inc, A.rng_tab, &lds[0]);
-  const double u_b = BREAKUP ? stream_draw(A.s_rand_b, A.rng_inc, A.rng_tab, &lds[1]) : 0.0;
+  const double u = stream_draw(A.s_rand, A.rng_inc, A.rng_tab, &lds[0],
+                               A.dev_off ? A.dev_off[0] + A.rand_extra : 0);
+  const double u_b = BREAKUP ? stream_draw(A.s_rand_b, A.rng_inc, A.rng_tab, &lds[1],
+                                           A.dev_off ? A.dev_off[1] : 0)
+                             : 0.0;
   PairInfo R;
   R.have = false; R.off = 2; R.prob = 0; R.j = R.k = 0;
   if (d < (cfg.n_sd + 1) / 2) R = pair_prob_body<KERNEL, BREAKUP>(cfg, A, d, W, u_b);
@@ -2246,6 +2254,12 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     }
     A.s_rand = sdm_pcg_advance_host(rng_state, rng_inc, draw_off + (uint64_t)(N + shift));
     A.s_rand_b = sdm_pcg_advance_host(rng_state, rng_inc, draw_off_b);
+    if (ctx->graph_capture) {  // stream positions from the device (see common.h: gwords)
+      A.s_rand = rng_state;
+      A.s_rand_b = rng_state;
+      A.dev_off = ctx->gwords;
+      A.rand_extra = (uint64_t)(N + shift);
+    }
     // (d) permutation (particle_attributes.py:98-105).  shuffle_local visits every cell of
     // cell_start, also those beyond a cut working length (index_methods.py:35); shuffle_global
     // covers the working length (index.py:43-45).  u01[i] = draw (window shift + i).
@@ -2273,7 +2287,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       // single cell: event records only; the pair kernels walk them (2 positions per thread)
       ShuffleViews views;
       rc = sdm_shuffle_build_async(ctx, S.shuffle, cur, st->cell_start, C, p_shuffle_len, N,
-                                   cfg->rng_state_inc, u01_off, &views, N);
+                                   cfg->rng_state_inc, u01_off, &views, N,
+                                   ctx->graph_capture ? ctx->gwords : nullptr);
       if (rc) return rc;
       A.rec = views.rec;
       A.rec_fmt = views.fmt;
@@ -2353,7 +2368,12 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       PhaseScope ph(ctx, SDM_PHASE_SANITIZE);
       // one adaptive cell: the kernel also ends the sub-step (collision.py:185-187: working
       // length = whole cell while dt_left > 0) and publishes the control block for the host
-      CompactEpilogue epilogue = {nullptr, nullptr, nullptr, 0};
+      CompactEpilogue epilogue = {nullptr, nullptr, nullptr, 0, nullptr, 0, 0};
+      if (ctx->graph_capture) {
+        epilogue.gwords = ctx->gwords;
+        epilogue.advance = (uint64_t)(N + shift + P);
+        epilogue.advance_b = cfg->enable_breakup ? (uint64_t)P : 0;
+      }
       if (C == 1 && cfg->adaptive) {
         box_seq = ++ctx->poll_seq;
         epilogue.dt_left = st->dt_left;
@@ -2511,6 +2531,122 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
 // observes the intermediate states (PySDM/particulator.py:50-56).  state->idx / tmp_idx are
 // exchanged in place whenever a step leaves the permutation in the other buffer; the result holds
 // the totals, idx_swapped the parity over the whole run.
+// ---- graph replay of a run (one cell, non-adaptive) ----------------------------------------------
+// Such a time step is four or five launches with no host decision in between; at small n_sd the
+// host's launch rate, not the GPU, sets the pace (2^16 super-droplets: 44 us per step for ~15 us of
+// kernel time).  Two consecutive steps - after which the two permutation buffers are back in their
+// roles - are captured once into a hipGraph and replayed; the only per-step inputs, the stream
+// positions, live on the device (common.h: gwords).  The capture runs on a stream of the
+// library's own (the caller's may be the legacy default stream, which cannot be captured),
+// ordered against the caller's stream by events.
+struct GraphKey {
+  sdm_step_cfg cfg;
+  const void *ptr[12];
+  const void *arena;
+  size_t arena_bytes;
+};
+
+static bool graph_eligible(sdm_ctx *ctx, const sdm_step_cfg *cfg, const sdm_step_state *st,
+                           int64_t n_steps) {
+  // Opt-in (SDM_GRAPH_REPLAY=1): measured on this runtime (ROCm 7.2, MI355X; profiles/README.md)
+  // the replay is SLOWER than plain launches - 52.8 against 44.2 us per step at 2^16
+  // super-droplets, 99 against 89 us at 2^20: a graph launch re-submits its kernel nodes one by
+  // one with more overhead than hipLaunchKernel, and the step is bound by the dispatch latency
+  // between dependent kernels (~11 us each at small sizes), not by the host.
+  static const bool enabled = getenv("SDM_GRAPH_REPLAY") != nullptr;
+  return enabled && cfg->n_cell == 1 && !cfg->adaptive && cfg->croupier_local &&
+         !cfg->optimized_random && !ctx->timing && !st->cell_owned && n_steps >= 8 &&
+         sdm_shuffle_can_split(cfg->n_sd, false);
+}
+
+static int graph_replay(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st,
+                        int64_t n_double_steps) {
+  GraphKey key;
+  memset(&key, 0, sizeof(key));
+  key.cfg = *cfg;
+  const void *ptrs[12] = {st->idx, st->tmp_idx, st->multiplicity, st->attributes, st->cell_id,
+                          st->cell_start, st->ctl, st->nm, st->collision_rate,
+                          st->coalescence_rate, st->breakup_rate, st->gk_a};
+  memcpy(key.ptr, ptrs, sizeof(ptrs));
+  key.arena = ctx->arena;
+  key.arena_bytes = ctx->arena_bytes;
+  hipStream_t caller = ctx->stream;
+  if (!ctx->own_stream) {
+    HIP_TRY(hipStreamCreateWithFlags((hipStream_t *)&ctx->own_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags((hipEvent_t *)&ctx->own_event, hipEventDisableTiming));
+    HIP_TRY(hipMalloc((void **)&ctx->gwords, sizeof(uint64_t) * 4));
+  }
+  hipStream_t own = (hipStream_t)ctx->own_stream;
+  hipEvent_t ev = (hipEvent_t)ctx->own_event;
+  const bool cached = ctx->graph_exec && ctx->graph_key_bytes == sizeof(key) &&
+                      memcmp(ctx->graph_key, &key, sizeof(key)) == 0;
+  if (!cached) {
+    if (ctx->graph_exec) {
+      (void)hipGraphExecDestroy((hipGraphExec_t)ctx->graph_exec);
+      ctx->graph_exec = nullptr;
+    }
+    const uint64_t off = st->rng_offset, off_b = st->rng_offset_breakup;
+    const int64_t known = st->known_valid;
+    int64_t *const idx = st->idx, *const tmp = st->tmp_idx;
+    hipGraph_t graph = nullptr;
+    ctx->stream = own;
+    ctx->graph_capture = true;
+    int rc = SDM_OK;
+    hipError_t e = hipStreamBeginCapture(own, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+      for (int half = 0; half < 2 && rc == SDM_OK; ++half) {
+        sdm_step_result one;
+        rc = collision_step(ctx, cfg, st, &one, 0, false, true);
+        if (rc == SDM_OK && one.idx_swapped) {
+          int64_t *t = st->idx; st->idx = st->tmp_idx; st->tmp_idx = t;
+        }
+      }
+      e = hipStreamEndCapture(own, &graph);
+    }
+    ctx->graph_capture = false;
+    ctx->stream = caller;
+    const bool roles_back = st->idx == idx && st->tmp_idx == tmp;
+    st->idx = idx;
+    st->tmp_idx = tmp;
+    st->rng_offset = off;
+    st->rng_offset_breakup = off_b;
+    st->known_valid = known;
+    if (rc != SDM_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    HIP_TRY(e);
+    if (!roles_back) {  // (a step that does not exchange the buffers: not expected on this route)
+      (void)hipGraphDestroy(graph);
+      return 1;  // caller falls back to plain launches
+    }
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    HIP_TRY(e);
+    ctx->graph_exec = exec;
+    free(ctx->graph_key);
+    ctx->graph_key = malloc(sizeof(key));
+    if (!ctx->graph_key) return SDM_E_NOMEM;
+    memcpy(ctx->graph_key, &key, sizeof(key));
+    ctx->graph_key_bytes = sizeof(key);
+  }
+  // stream positions of the first replayed step, then the replays, between the caller's work
+  uint64_t words[4] = {st->rng_offset, st->rng_offset_breakup, 0, 0};
+  // (four rotating slots: an earlier call's asynchronous copy may not have run yet)
+  int64_t *slot = ctx->mailbox + 48 + 4 * (ctx->graph_calls++ & 3);
+  memcpy(slot, words, sizeof(words));
+  HIP_TRY(hipEventRecord(ev, caller));
+  HIP_TRY(hipStreamWaitEvent(own, ev, 0));
+  HIP_TRY(hipMemcpyAsync(ctx->gwords, slot, sizeof(words), hipMemcpyHostToDevice, own));
+  for (int64_t k = 0; k < n_double_steps; ++k)
+    HIP_TRY(hipGraphLaunch((hipGraphExec_t)ctx->graph_exec, own));
+  HIP_TRY(hipEventRecord(ev, own));
+  HIP_TRY(hipStreamWaitEvent(caller, ev, 0));
+  const int64_t N = cfg->n_sd, P = N / 2;
+  const uint64_t sub = (uint64_t)(2 * n_double_steps) * (uint64_t)cfg->substeps;
+  st->rng_offset += sub * (uint64_t)(N + P);
+  if (cfg->enable_breakup) st->rng_offset_breakup += sub * (uint64_t)P;
+  return SDM_OK;
+}
+
 extern "C" int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st,
                                  sdm_step_result *res, int flags, int64_t n_steps) {
   ARG_TRY(ctx && res && st && n_steps >= 0);
@@ -2522,7 +2658,23 @@ extern "C" int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step
   total.rng_offset = st->rng_offset;
   total.rng_offset_breakup = st->rng_offset_breakup;
   bool pairs_known = true;
+  const bool replay = cfg && graph_eligible(ctx, cfg, st, n_steps);
   for (int64_t step = 0; step < n_steps; ++step) {
+    if (replay && step == 1) {
+      // steps 1 .. 2k replayed two at a time; step 0 (allocations, a fresh control block) and
+      // the tail (read-back, counters folded) launch as usual
+      const int64_t doubles = (n_steps - 2) / 2;
+      const int rc = graph_replay(ctx, cfg, st, doubles);
+      if (rc < 0) return rc;
+      if (rc == 0) {
+        step += 2 * doubles - 1;
+        total.n_substeps += 2 * doubles * cfg->substeps;
+        pairs_known = false;  // (counted on the device: control word 5)
+        total.rng_offset = st->rng_offset;
+        total.rng_offset_breakup = st->rng_offset_breakup;
+        continue;
+      }
+    }
     sdm_step_result one;
     const bool last = step == n_steps - 1;
     // read the control block back only after the last step

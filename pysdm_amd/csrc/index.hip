@@ -166,7 +166,8 @@ static bool binned_ok(int64_t n, bool global);
 static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *idx0,
                                 const double *u01, const int64_t *cell_start, int64_t n_cell,
                                 const int64_t *p_length, int64_t length_bound, int64_t n_total,
-                                u128 s_off, u128 inc, ShuffleViews *views, int64_t id_bound = -1);
+                                u128 s_off, u128 inc, ShuffleViews *views, int64_t id_bound = -1,
+                                const uint64_t *dev_off = nullptr);
 
 // out-of-place core: out[0:length) = shuffled idx0[0:length), out[length:n_total) = idx0[...].
 // u01 == nullptr: draws generated in the kernel from (rng_state_inc, rng_offset).
@@ -224,9 +225,10 @@ int sdm_shuffle_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *
 
 // ---------------------------------------------------------------------------------------
 // Binned build (local croupier): the same event records without a single global atomic.
-// Positions are cut into tiles of BIN_POS; an event (i, j_i) is routed to the tile of its target
-// j_i (count -> column scan -> scatter, all ranking done with LDS atomics), then one workgroup per
-// tile assembles the records of its BIN_POS positions in LDS and writes them out whole:
+// Positions are cut into bins of BIN_POS; an event (i, j_i) has to reach the bin of its target
+// j_i: every event tile orders its events by target bin in LDS and writes them back tile-major
+// (k_bin_sort), then one workgroup per bin gathers its runs from all tiles, assembles the records
+// of its BIN_POS positions in LDS and writes them out whole (k_bin_build2):
 //   PackRec {own target j (-1 none), first hit s0 (-1 none), second hit s1 (-1 none),
 //            initial content of the position (int32) | bit 31 = "more hits in the overflow list"}
 // so the backward walk needs no separate gather of the initial content.  u01 comes either from
@@ -318,201 +320,9 @@ __device__ __forceinline__ int block_excl_scan(int v, int *total) {
   return base + incl - v;
 }
 
-// K1: per event tile (EV_TILE positions): own-event targets -> jarr, histogram of their target
-// bins -> cnt[tile][bin]
-template <bool RNG>
-__global__ void __launch_bounds__(K1_THREADS)
-k_bin_count(int32_t *__restrict__ cnt, int32_t *__restrict__ jarr, int n_bins,
-            const double *__restrict__ u01, const int64_t *__restrict__ cell_start,
-            int64_t n_cell, const int64_t *__restrict__ p_length, int64_t length_arg, u128 s_off,
-            u128 inc, const u128 *__restrict__ tab) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int32_t *hist = (int32_t *)smem;
-  __shared__ u128 s_slot;
-  const int64_t length = p_length ? *p_length : length_arg;
-  for (int b = threadIdx.x; b < n_bins; b += K1_THREADS) hist[b] = 0;
-  if (RNG) {
-    if (threadIdx.x == 0) s_slot = pcg_jump(s_off, tab, (uint64_t)blockIdx.x * EV_TILE);
-  }
-  __syncthreads();
-  const u128 s_tile = RNG ? s_slot : 0;
-  const int64_t first = (int64_t)blockIdx.x * EV_TILE + (int64_t)threadIdx.x * K1_PER_THREAD;
-  int32_t j[K1_PER_THREAD];
-  targets_run<RNG, K1_PER_THREAD>(first, length, u01, cell_start, n_cell, s_tile, inc, tab, j);
-#pragma unroll
-  for (int e = 0; e < K1_PER_THREAD; ++e) {
-    if (j[e] >= 0) atomicAdd(&hist[j[e] >> BIN_SHIFT], 1);
-    if (first + e < length) jarr[first + e] = j[e];
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < n_bins; b += K1_THREADS)
-    cnt[(int64_t)blockIdx.x * n_bins + b] = hist[b];
-}
-
-// K2: one workgroup per bin: exclusive scan down the event tiles (column of cnt) -> pre,
-// column total -> total[bin]
-__global__ void __launch_bounds__(BIN_THREADS)
-k_bin_colscan(int32_t *__restrict__ cnt, int32_t *__restrict__ total, int n_bins, int n_tiles) {
-  const int bin = blockIdx.x;
-  const int per = (n_tiles + BIN_THREADS - 1) / BIN_THREADS;
-  const int t0 = threadIdx.x * per;
-  int sum = 0;
-  for (int k = 0; k < per; ++k) {
-    const int t = t0 + k;
-    if (t < n_tiles) sum += cnt[(int64_t)t * n_bins + bin];
-  }
-  int all;
-  int run = block_excl_scan(sum, &all);
-  for (int k = 0; k < per; ++k) {
-    const int t = t0 + k;
-    if (t < n_tiles) {
-      const int v = cnt[(int64_t)t * n_bins + bin];
-      cnt[(int64_t)t * n_bins + bin] = run;
-      run += v;
-    }
-  }
-  if (threadIdx.x == 0) total[bin] = all;
-}
-
-// exclusive scan of total[0:n_bins) into LDS (every workgroup of K3 / K4 does its own)
-__device__ __forceinline__ void bin_starts(const int32_t *__restrict__ total, int n_bins,
-                                           int32_t *start /* LDS, n_bins + 1 */) {
-  const int per = (n_bins + BIN_THREADS - 1) / BIN_THREADS;
-  const int b0 = threadIdx.x * per;
-  int sum = 0;
-  for (int k = 0; k < per; ++k)
-    if (b0 + k < n_bins) sum += total[b0 + k];
-  int all;
-  int run = block_excl_scan(sum, &all);
-  for (int k = 0; k < per; ++k)
-    if (b0 + k < n_bins) {
-      start[b0 + k] = run;
-      run += total[b0 + k];
-    }
-  if (threadIdx.x == 0) start[n_bins] = all;
-  __syncthreads();
-}
-
-// K3: route every event to its target bin's segment.  The tile's events are first ordered by
-// bin in LDS so that each (tile, bin) run leaves as consecutive lanes -> consecutive addresses.
-__global__ void __launch_bounds__(BIN_THREADS)
-k_bin_scatter(int2 *__restrict__ events, const int32_t *__restrict__ pre,
-              const int32_t *__restrict__ total, const int32_t *__restrict__ jarr, int n_bins,
-              const int64_t *__restrict__ p_length, int64_t length_arg) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int32_t *gbase = (int32_t *)smem;          // n_bins + 1 : global slot of this tile's run
-  int32_t *lstart = gbase + n_bins + 1;      // n_bins + 1 : local slot of the run
-  int32_t *lcount = lstart + n_bins + 1;     // n_bins
-  int2 *ev_buf = (int2 *)(lcount + ((n_bins + 1) & ~1));  // EV_TILE
-  int32_t *gdst = (int32_t *)(ev_buf + EV_TILE);            // EV_TILE
-  const int64_t length = p_length ? *p_length : length_arg;
-  const int64_t tile_first = (int64_t)blockIdx.x * EV_TILE;
-  if (tile_first >= length) return;
-  bin_starts(total, n_bins, gbase);
-  for (int b = threadIdx.x; b < n_bins; b += BIN_THREADS) {
-    gbase[b] += pre[(int64_t)blockIdx.x * n_bins + b];
-    lcount[b] = 0;
-  }
-  __syncthreads();
-  int32_t j[EV_PER_THREAD];
-#pragma unroll
-  for (int e = 0; e < EV_PER_THREAD; ++e) {
-    const int64_t i = tile_first + e * BIN_THREADS + threadIdx.x;
-    j[e] = i < length ? jarr[i] : -1;
-    if (j[e] >= 0) atomicAdd(&lcount[j[e] >> BIN_SHIFT], 1);
-  }
-  __syncthreads();
-  {  // lstart = exclusive scan of lcount; lcount reset to serve as the placement cursor
-    const int per = (n_bins + BIN_THREADS - 1) / BIN_THREADS;
-    const int b0 = threadIdx.x * per;
-    int sum = 0;
-    for (int k = 0; k < per; ++k)
-      if (b0 + k < n_bins) sum += lcount[b0 + k];
-    int all;
-    int run = block_excl_scan(sum, &all);
-    for (int k = 0; k < per; ++k)
-      if (b0 + k < n_bins) {
-        lstart[b0 + k] = run;
-        run += lcount[b0 + k];
-        lcount[b0 + k] = 0;
-      }
-    if (threadIdx.x == 0) lstart[n_bins] = all;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < EV_PER_THREAD; ++e)
-    if (j[e] >= 0) {
-      const int b = j[e] >> BIN_SHIFT;
-      const int r = atomicAdd(&lcount[b], 1);
-      const int ls = lstart[b] + r;
-      ev_buf[ls] = make_int2((int)(tile_first + e * BIN_THREADS + threadIdx.x), j[e]);
-      gdst[ls] = gbase[b] + r;
-    }
-  __syncthreads();
-  const int n_ev = lstart[n_bins];
-  for (int t = threadIdx.x; t < n_ev; t += BIN_THREADS) events[gdst[t]] = ev_buf[t];
-}
-
-// K4: one workgroup per bin (BIN_POS positions): assemble and write its records.
-// FMT: record layout (shuffle_device.h: 2, 4 or 3 inline hits)
-template <int FMT>
-__global__ void __launch_bounds__(BIN_THREADS)
-k_bin_build(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
-            int32_t *__restrict__ ovf_next, const int2 *__restrict__ events,
-            const int32_t *__restrict__ total, const int32_t *__restrict__ jarr, int n_bins,
-            const int64_t *__restrict__ idx0, const int64_t *__restrict__ p_length,
-            int64_t length_arg) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int SLOTS = FMT == SDM_REC_P21 ? 4 : (FMT == SDM_REC_P24 ? 3 : 2);
-  int32_t *start = (int32_t *)smem;                 // n_bins + 1
-  int32_t *slot = start + ((n_bins + 1 + 3) & ~3);  // SLOTS x BIN_POS, then BIN_POS list heads
-  int32_t *head = slot + SLOTS * BIN_POS;
-  const int64_t length = p_length ? *p_length : length_arg;
-  const int64_t base = (int64_t)blockIdx.x * BIN_POS;
-  if (base >= length) return;
-  bin_starts(total, n_bins, start);
-  for (int q = threadIdx.x; q < (SLOTS + 1) * BIN_POS; q += BIN_THREADS) slot[q] = -1;
-  __syncthreads();
-  // hits on this bin's positions: the first SLOTS inline (claimed by compare-and-swap), rest listed
-  const int ev_first = start[blockIdx.x], ev_last = start[blockIdx.x + 1];
-  for (int t = ev_first + threadIdx.x; t < ev_last; t += BIN_THREADS) {
-    const int2 ev = events[t];
-    const int q = ev.y - (int)base;
-    bool placed = false;
-#pragma unroll
-    for (int k = 0; k < SLOTS; ++k)
-      if (!placed) placed = atomicCAS(&slot[k * BIN_POS + q], -1, ev.x) == -1;
-    if (!placed) ovf_next[ev.x] = atomicExch(&head[q], ev.x);  // -1 terminated, built entirely here
-  }
-  __syncthreads();
-  for (int q = threadIdx.x; q < BIN_POS; q += BIN_THREADS) {
-    const int64_t p = base + q;
-    if (p >= length) break;
-    const int32_t h = head[q];
-    const int32_t id = (int32_t)idx0[p];
-    if (FMT == SDM_REC_P21) {
-      PackRec21 r;
-      p21_pack(r.lo, r.hi, jarr[p], slot[q], slot[BIN_POS + q], slot[2 * BIN_POS + q],
-               slot[(SLOTS - 1) * BIN_POS + q], id, h >= 0);
-      ((PackRec21 *)rec_out)[p] = r;
-    } else if (FMT == SDM_REC_P24) {
-      PackRec24 r;
-      p24_pack(r.lo, r.hi, jarr[p], slot[q], slot[BIN_POS + q], slot[2 * BIN_POS + q], id, h >= 0);
-      ((PackRec24 *)rec_out)[p] = r;
-    } else {
-      PackRec r;
-      r.j = jarr[p];
-      r.s0 = slot[q];
-      r.s1 = slot[BIN_POS + q];
-      r.val = id | (h >= 0 ? (int32_t)0x80000000 : 0);
-      ((PackRec *)rec_out)[p] = r;
-    }
-    if (h >= 0) ovf_head[p] = h;
-  }
-}
-
-// ---- two-launch build (round 2): no count matrix, no column scan, no global scatter -----------
-// K1': per event tile: own-event targets -> jarr; the tile's events ordered by target bin in LDS
+// ---- two launches (round 1 had four: count -> column scan -> scatter -> build; the count matrix,
+// its scan and the global scatter are gone: 32.5 -> 28.5 us of kernel time at 2^20, two launches
+// less).  K1': per event tile: own-event targets -> jarr; the tile's events ordered by target bin in LDS
 // and written back *in place* (tile-major, coalesced), with the tile's bin offsets toff[tile][0..nb].
 // K4': one workgroup per bin gathers its runs - for every tile the events toff[t][b]..toff[t][b+1]
 // of that tile's segment, ~16 events = two 64-B sectors each, the same granularity the scatter
@@ -523,7 +333,7 @@ __global__ void __launch_bounds__(BIN_THREADS)
 k_bin_sort(int2 *__restrict__ events, int32_t *__restrict__ toff, int32_t *__restrict__ jarr,
            int n_bins, const double *__restrict__ u01, const int64_t *__restrict__ cell_start,
            int64_t n_cell, const int64_t *__restrict__ p_length, int64_t length_arg, u128 s_off,
-           u128 inc, const u128 *__restrict__ tab) {
+           u128 inc, const u128 *__restrict__ tab, const uint64_t *__restrict__ dev_off) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int32_t *lstart = (int32_t *)smem;                      // n_bins + 1
   int32_t *lcount = lstart + n_bins + 1;                  // n_bins
@@ -537,7 +347,10 @@ k_bin_sort(int2 *__restrict__ events, int32_t *__restrict__ toff, int32_t *__res
     return;
   }
   for (int b = threadIdx.x; b < n_bins; b += BIN_THREADS) lcount[b] = 0;
-  if (RNG && threadIdx.x == 0) s_slot = pcg_jump(s_off, tab, (uint64_t)blockIdx.x * EV_TILE);
+  // dev_off (graph replay): s_off is the generator's initial state, the stream position comes
+  // from the device
+  if (RNG && threadIdx.x == 0)
+    s_slot = pcg_jump(s_off, tab, (uint64_t)blockIdx.x * EV_TILE + (dev_off ? dev_off[0] : 0));
   __syncthreads();
   const u128 s_tile = RNG ? s_slot : 0;
   const int64_t first = tile_first + (int64_t)threadIdx.x * EV_PER_THREAD;
@@ -699,7 +512,8 @@ static bool binned_ok(int64_t n, bool global) { return !global && n >= 2 && bin_
 static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *idx0,
                                 const double *u01, const int64_t *cell_start, int64_t n_cell,
                                 const int64_t *p_length, int64_t length_bound, int64_t n_total,
-                                u128 s_off, u128 inc, ShuffleViews *views, int64_t id_bound) {
+                                u128 s_off, u128 inc, ShuffleViews *views, int64_t id_bound,
+                                const uint64_t *dev_off) {
   // id_bound: the ids in idx0 are below it (-1: unknown); decides the record layout
   const int64_t both = id_bound > length_bound ? id_bound : length_bound;
   const int fmt = id_bound < 0 ? SDM_REC_PLAIN
@@ -735,11 +549,11 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
     if (u01)
       hipLaunchKernelGGL((k_bin_sort<false>), dim3(nt), block, lds_sort, ctx->stream, events, toff,
                          jarr, nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc,
-                         ctx->pcg_tab);
+                         ctx->pcg_tab, (const uint64_t *)nullptr);
     else
       hipLaunchKernelGGL((k_bin_sort<true>), dim3(nt), block, lds_sort, ctx->stream, events, toff,
                          jarr, nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc,
-                         ctx->pcg_tab);
+                         ctx->pcg_tab, dev_off);
 #define BUILD_LAUNCH(F)                                                                        \
   hipLaunchKernelGGL(k_bin_build2<F>, dim3(nb), block, lds_build, ctx->stream, (void *)rec,    \
                      ovf_head, ovf_next, events, toff, jarr, nb, nt, idx0, p_length, length_bound)
@@ -773,14 +587,16 @@ bool sdm_shuffle_can_split(int64_t n, bool global) { return binned_ok(n, global)
 int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
                             const int64_t *cell_start, int64_t n_cell, const int64_t *p_length,
                             int64_t length_bound, const uint64_t *rng_state_inc,
-                            uint64_t rng_offset, ShuffleViews *views, int64_t id_bound) {
+                            uint64_t rng_offset, ShuffleViews *views, int64_t id_bound,
+                            const uint64_t *dev_off) {
   int rc = sdm_pcg_prepare(ctx, rng_state_inc);
   if (rc) return rc;
   const u128 st = (((u128)rng_state_inc[0]) << 64) | rng_state_inc[1];
   const u128 inc = (((u128)rng_state_inc[2]) << 64) | rng_state_inc[3];
-  const u128 s_off = sdm_pcg_advance_host(st, inc, rng_offset);
+  // dev_off: the kernels add the stream position themselves (graph replay)
+  const u128 s_off = dev_off ? st : sdm_pcg_advance_host(st, inc, rng_offset);
   return shuffle_binned_async(ctx, scratch, nullptr, idx0, nullptr, cell_start, n_cell, p_length,
-                              length_bound, 0, s_off, inc, views, id_bound);
+                              length_bound, 0, s_off, inc, views, id_bound, dev_off);
 }
 
 size_t sdm_shuffle_scratch(int64_t n) {
@@ -984,6 +800,10 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
                      int n_tiles, int64_t *__restrict__ ctl, int32_t *__restrict__ holes,
                      int64_t *__restrict__ fillers, int64_t *__restrict__ cell_start_single,
                      unsigned int *__restrict__ bar, CompactEpilogue E) {
+  if (E.gwords && blockIdx.x == 0 && threadIdx.x == 0) {  // this sub-step's draws are consumed
+    E.gwords[0] += E.advance;
+    E.gwords[1] += E.advance_b;
+  }
   if (fctl[FCTL_HEALTHY] != 0) {
     if (E.dt_left && blockIdx.x == 0) compact_epilogue(E, fctl);
     return;
@@ -1113,7 +933,7 @@ int sdm_compact_fused_async(sdm_ctx *ctx, char *scratch, const int64_t *multipli
                             int64_t *idx, int64_t length_bound, int64_t flag, int64_t *fctl,
                             int64_t *ctl, int64_t *cell_start_single, bool flag_only,
                             const CompactEpilogue *epilogue) {
-  CompactEpilogue E = {nullptr, nullptr, nullptr, 0};
+  CompactEpilogue E = {nullptr, nullptr, nullptr, 0, nullptr, 0, 0};
   if (epilogue) E = *epilogue;
   Carver cv(scratch);
   const int n_tiles = (int)grid_for(length_bound, SDM_WAVE);
