@@ -78,7 +78,13 @@ def cpu_baseline(workload, n_sd, adaptive, seconds_budget=8.0):
     box, bounded sample: once with 1 thread, once with all cores"""
     from oracle.engine import OracleEngine
 
-    n_threads = os.cpu_count() or 1
+    # the host cores this process may use (the GPU box gives a 16-core share per GPU; an OpenMP team
+    # wider than that only adds scheduling noise to loops this short)
+    try:
+        n_threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n_threads = os.cpu_count() or 1
+    n_threads = max(1, min(n_threads, 16))
     results = {}
     for threads in sorted({1, n_threads}):
         engine = OracleEngine.get(threads=threads)

@@ -5,19 +5,26 @@ import warnings
 
 import torch
 
-from pysdm_amd.backends import HIP
-from pysdm_amd.examples import make_kinematic_flow
+from pysdm_amd.cases import make_kinematic_flow
+from pysdm_amd.engine import HipEngine
 
-particulator, displacement, collision = make_kinematic_flow(HIP)
+displacement, collisions = make_kinematic_flow(HipEngine.get())
+
+
+def run(steps):
+    for _ in range(steps):
+        displacement.run()
+        collisions.run(1)
+
+
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
-    particulator.run(5)
+    run(5)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     steps = 30
-    particulator.run(steps)
-    _ = particulator.attributes.super_droplet_count
+    run(steps)
     torch.cuda.synchronize()
 print(f"{(time.perf_counter() - t0) / steps * 1e3:.3f} ms per step; super-droplets left",
-      particulator.attributes.super_droplet_count, "substeps/cell",
-      collision.stats_n_substep.to_ndarray()[:4])
+      collisions.population.live, "substeps/cell",
+      collisions.engine.download(collisions.stats_n_substep)[:4])

@@ -2063,7 +2063,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       return SDM_E_ARG;
     }
   }
-  auto shard_sync = [&](int64_t *perm) -> int {
+  auto shard_cells = [&]() -> int {  // owned cells' dt_left + "someone died", summed
     const dim3 g((unsigned)grid_for(C + 1));
     hipLaunchKernelGGL(k_shard_pack, g, blk, 0, s, A, C, cfg->adaptive, st->xchg_cells);
     LAUNCH_CHECK();
@@ -2073,23 +2073,29 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     }
     hipLaunchKernelGGL(k_shard_unpack, g, blk, 0, s, A, C, cfg->adaptive, st->xchg_cells);
     LAUNCH_CHECK();
+    return SDM_OK;
+  };
+  auto shard_perm = [&](int64_t *perm) -> int {  // the permutation from the segments' owners
+    hipLaunchKernelGGL(k_shard_mask_idx, dim3((unsigned)(C + 64)), blk, 0, s, A, perm, C, N,
+                       st->xchg_idx);
+    LAUNCH_CHECK();
+    if (st->exchange(st->exchange_user, SDM_XCHG_SUM_I64, st->xchg_idx, N) != 0) {
+      sdm_set_error("sharded mode: the exchange callback failed (permutation sum)");
+      return SDM_E_HIP;
+    }
+    HIP_TRY(hipMemcpyAsync(perm, st->xchg_idx, sizeof(int64_t) * (size_t)N,
+                           hipMemcpyDeviceToDevice, s));
+    return SDM_OK;
+  };
+  auto shard_sync = [&](int64_t *perm) -> int {  // both, the second if the first says so
+    int r = shard_cells();
+    if (r) return r;
     HIP_TRY(hipMemcpyAsync(ctx->mailbox, st->xchg_cells + C, sizeof(double),
                            hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     double died;
     memcpy(&died, ctx->mailbox, sizeof(double));
-    if (died > 0) {
-      hipLaunchKernelGGL(k_shard_mask_idx, dim3((unsigned)(C + 64)), blk, 0, s, A, perm, C, N,
-                         st->xchg_idx);
-      LAUNCH_CHECK();
-      if (st->exchange(st->exchange_user, SDM_XCHG_SUM_I64, st->xchg_idx, N) != 0) {
-        sdm_set_error("sharded mode: the exchange callback failed (permutation sum)");
-        return SDM_E_HIP;
-      }
-      HIP_TRY(hipMemcpyAsync(perm, st->xchg_idx, sizeof(int64_t) * (size_t)N,
-                             hipMemcpyDeviceToDevice, s));
-    }
-    return SDM_OK;
+    return died > 0 ? shard_perm(perm) : SDM_OK;
   };
   // Multi-cell per-cell route, adaptive: the same idea with a device-side gate.  Sub-step k + 1
   // is launched before the host waits for the control block of sub-step k; its first kernel
@@ -2145,11 +2151,11 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         hipLaunchKernelGGL(k_cells_end, dim3(grid_for(C)), blk, 0, s, *cfg, A, 1, S.end2,
                            (int64_t *)nullptr, (int64_t)0);
         LAUNCH_CHECK();
-        const int r = shard_sync(cur);
+        const int r = shard_cells();
         if (r) return r;
         HIP_TRY(hipMemsetAsync(S.end2, 0, sizeof(int64_t), s));
       }
-      {
+      if (!sharded) {  // (sharded: after the read-back, and only if a super-droplet died)
         PhaseScope ph(ctx, SDM_PHASE_SANITIZE);
         const int r = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl,
                                               S.cctl, nullptr, true);
@@ -2189,6 +2195,17 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       have_ctl = true;
       ++n_sub;
       n_pairs += work_host / 2;
+      if (sharded && last_ctl[CTL_HEALTHY] == 0) {
+        // a super-droplet died somewhere: the permutation is put together from the owners'
+        // segments, then the compaction runs on identical data everywhere
+        rc = shard_perm(cur);
+        if (rc) return rc;
+        PhaseScope ph(ctx, SDM_PHASE_SANITIZE);
+        rc = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl, S.cctl,
+                                     nullptr, true);
+        if (rc) return rc;
+        last_ctl[CTL_SORTED] = 0;
+      }
       if (last_ctl[CTL_SORTED] == 0) {
         // a compaction happened in sub-step k: sort by cell, then the end of the working range
         // from the new cell_start (particle_attributes.py cell_start getter)

@@ -12,10 +12,11 @@ run replicated.  No super-droplet payload crosses processes in a collision step:
 super-droplets live, and stay, with the cell's owner.
 
 `attach(runner, rank, world)` turns a CollisionRunner over the global population into this
-process's share of it; `gather(runner)` assembles the global state from the owners (diagnostics,
-tests).  Migration of super-droplets between owners after a displacement step amounts to
-re-declaring ownership by the new cell ids plus an all-reduce of the masked attribute columns -
-`refresh_after_displacement`.
+process's share of it; `gather(runner)` assembles the global state from the owners on the host
+(diagnostics, tests); `complete_state(runner)` does so on the device, for a replicated stage
+between sharded collision steps - the displacement step: ownership is by cell, so the
+super-droplets it moves into another process's cells change hands right there (migration needs
+no further step).
 """
 import ctypes
 
@@ -149,10 +150,38 @@ def make_sharded_box(engine, name, *, rank, world, n_sd=None, adaptive=None, see
     return attach(runner, rank, world, group)
 
 
-def refresh_after_displacement(runner, displacement):
-    """after a replicated displacement step the cell ids changed on every process alike; the
-    super-droplets that entered this process's cells bring their state from the previous owner:
-    an all-reduce of the columns masked by the PREVIOUS ownership (`previous`: the mask from
-    `owned_droplets` taken before the displacement)"""
-    raise NotImplementedError(
-        "see DESIGN.md section 5: the collision step shards; a sharded displacement step is next")
+def complete_state(runner):
+    """makes this process's columns complete again after sharded collision steps: every
+    super-droplet's multiplicity and extensive attributes from the owner of its cell, the
+    permutation from the owners of its segments (all-reduces of the masked columns, on the
+    device).  Afterwards every process holds the same, whole state - what a replicated stage
+    (the displacement step, a read-out) needs; the next sharded collision step goes on from it
+    (the cell ids may have changed meanwhile: ownership is by cell, so super-droplets that moved
+    into another process's cells have thereby changed hands - this is the migration step).
+    Cost: one all-reduce each of n_sd int64 (permutation, multiplicity) and n_attr x n_sd float64."""
+    shard, pop = runner.shard, runner.population
+    torch_like = hasattr(pop.cell_id, "data_ptr")
+    owned = shard.owned if torch_like else shard.owned_host
+    mine = owned[pop.cell_id].bool() if torch_like else owned[pop.cell_id]
+
+    def total(array):
+        tensor = shard._as_tensor(array)  # pylint: disable=protected-access
+        if tensor.is_cuda and shard.dist.get_backend(shard.group) != "nccl":
+            host = tensor.cpu()
+            shard.dist.all_reduce(host, op=shard.dist.ReduceOp.SUM, group=shard.group)
+            tensor.copy_(host)
+        else:
+            shard.dist.all_reduce(tensor, op=shard.dist.ReduceOp.SUM, group=shard.group)
+
+    live = pop.perm[: pop.live]
+    live_mine = mine[live]
+    live *= live_mine  # (in place: a view of the permutation)
+    total(live)
+    pop.multiplicity *= mine
+    total(pop.multiplicity)
+    pop.extensive *= mine  # broadcast over the attribute rows
+    total(pop.extensive)
+    pop.touch_state()  # the mirror of the fused step is rebuilt from the columns
+    return runner
+
+

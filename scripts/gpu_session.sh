@@ -1,8 +1,12 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests/test_hip_full_size.py tests/test_hip_parity.py -m gpu -x -q -k "many_steps or 3600 or c_abi or record_layouts or trajectories or digests" > gpurun_out/r02_gputest_d.log 2>&1 || { tail -60 gpurun_out/r02_gputest_d.log; exit 1; }
-tail -3 gpurun_out/r02_gputest_d.log
-python bench.py --no-cpu-baseline > gpurun_out/r02_bench_d.json 2>gpurun_out/r02_bench_d.err || { tail -20 gpurun_out/r02_bench_d.err; exit 1; }
-cut -c1-700 gpurun_out/r02_bench_d.json
-for n in 16384 65536 262144; do python bench.py --no-cpu-baseline --n-sd $n --steps 1000 > gpurun_out/r02_bench_d_$n.json 2>/dev/null; cut -c1-330 gpurun_out/r02_bench_d_$n.json; echo; done
-SDM_NO_GRAPH=1 python bench.py --no-cpu-baseline --n-sd 65536 --steps 1000 > gpurun_out/r02_bench_d_65536_nograph.json 2>/dev/null; cut -c1-330 gpurun_out/r02_bench_d_65536_nograph.json
+python -m pytest tests -m gpu -x -q > gpurun_out/r02_gputest_e.log 2>&1 || { tail -60 gpurun_out/r02_gputest_e.log; exit 1; }
+tail -3 gpurun_out/r02_gputest_e.log
+export SDM_BENCH_DIST_BACKEND=gloo SDM_BENCH_ALL_ON_DEVICE0=1
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --workload kinematic2d --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/r02_rehearsal_n2_kinematic2d.json 2>gpurun_out/r02_rehearsal_n2.err || { tail -30 gpurun_out/r02_rehearsal_n2.err; exit 1; }
+cut -c1-500 gpurun_out/r02_rehearsal_n2_kinematic2d.json
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 2 --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/r02_rehearsal_n2_shima.json 2>gpurun_out/r02_rehearsal_n2s.err || { tail -30 gpurun_out/r02_rehearsal_n2s.err; exit 1; }
+cut -c1-400 gpurun_out/r02_rehearsal_n2_shima.json
+unset SDM_BENCH_DIST_BACKEND SDM_BENCH_ALL_ON_DEVICE0
+python bench.py --workload kinematic2d --steps 40 --warmup 5 > gpurun_out/r02_bench_kinematic2d_cpu.json 2>/dev/null; python -c "
+import json; d=json.load(open('gpurun_out/r02_bench_kinematic2d_cpu.json')); print(d['value'], d['cpu_baseline'])"

@@ -18,7 +18,9 @@ CASES = ("disp1d_implicit_sed", "disp2d_implicit_sed", "disp2d_explicit", "disp3
          "disp2d_collide")
 
 
-def run_case(name, engine, route="fused"):
+def run_case(name, engine, route="fused", shard=None):
+    """`shard` = (rank, world): the collision step sharded over the processes, the displacement
+    step replicated on the state completed from the owners (pysdm_amd.sharding)"""
     gold = np.load(os.path.join(GOLDEN, f"traj_{name}.npz"))
     n_sd, dt, explicit, sed, adaptive, collide, steps = gold["cfg"]
     steps = int(steps)
@@ -39,6 +41,10 @@ def run_case(name, engine, route="fused"):
         collisions = CollisionRunner(
             population, R.CollisionSetup.coalescence(R.Geometric(), adaptive=True, seed=44),
             dt=float(dt), dv=dv, route=route)
+    if shard is not None:
+        from pysdm_amd import sharding  # pylint: disable=import-outside-toplevel
+
+        sharding.attach(collisions, *shard)
     displacement.set_courant(tuple(gold[f"courant/{d}"] for d in range(len(grid))))
     assert displacement.n_substeps == int(gold["n_substeps"])
     down = engine.download
@@ -48,6 +54,8 @@ def run_case(name, engine, route="fused"):
             displacement.run()
             if collisions is not None:
                 collisions.run(1)
+                if shard is not None:
+                    sharding.complete_state(collisions)
         population.compact()
         tag = f"{name} step {step}"
         length = population.live

@@ -1,30 +1,32 @@
 """soak (not collected by pytest; run by hand on an MI355X: python tests/soak.py): long runs at
 full size, HIP fused route against the oracle - the whole 3600-step Shima-2009 experiment at
-n_sd = 2^20, 400 adaptive steps, 200 steps of the Berry breakup box, 150 of the Straub box at
+n_sd = 2^20, 400 adaptive steps, 200 steps of the Berry breakup box, 150 of the Straub boxes at
 2^18, 40 steps of 32 x 32 cells at 2^20"""
-import sys, time, warnings
-import numpy as np
-sys.path.insert(0, ".")
-from oracle.backend import OracleBackend
-from pysdm_amd.backends import HIP
-from pysdm_amd.examples import make_box
-from tests.trajectory import snapshot
+import sys
+import time
+import warnings
 
-cases = [("shima", 2**20, False, 3600, None), ("shima", 2**20, True, 400, None),
-         ("berry_breakup", 2**20, True, 200, None), ("straub", 2**18, True, 150, None),
-         ("kinematic2d", 2**20, True, 40, None)]
-for name, n_sd, adaptive, steps, dt in cases:
+import numpy as np
+
+sys.path.insert(0, ".")
+from oracle.engine import OracleEngine  # noqa: E402
+from pysdm_amd.cases import make_box  # noqa: E402
+from pysdm_amd.engine import HipEngine  # noqa: E402
+
+cases = [("shima", 2**20, False, 3600), ("shima", 2**20, True, 400),
+         ("berry_breakup", 2**20, True, 200), ("straub", 2**18, True, 150),
+         ("straub_rain", 2**18, True, 150), ("kinematic2d", 2**20, True, 40)]
+for name, n_sd, adaptive, steps in cases:
     snaps = []
-    for backend in (HIP, OracleBackend):
+    for engine in (HipEngine.get(), OracleEngine.get()):
         t0 = time.time()
-        p, d = make_box(backend, name, n_sd=n_sd, adaptive=adaptive, dt=dt)
+        runner = make_box(engine, name, n_sd=n_sd, adaptive=adaptive)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            done = 0
             for chunk in (1, 7, steps - 8):
-                p.run(chunk)
-        snaps.append(snapshot(p, d))
-        print(name, backend.__name__, round(time.time() - t0, 1), "s", flush=True)
+                runner.run(chunk)
+        snaps.append(runner.snapshot())
+        print(name, engine.name, round(time.time() - t0, 1), "s", flush=True)
     a, b = snaps
     length = int(a["length"])
     worst = 0.0
@@ -39,4 +41,5 @@ for name, n_sd, adaptive, steps, dt in cases:
             assert err < 1e-11, (name, key, err)
         else:
             assert np.array_equal(value, ref), (name, key)
-    print("OK", name, "length", length, "of", n_sd, "substeps", b["stats_n_substep"][:3], "max rel err", worst, flush=True)
+    print("OK", name, "length", length, "of", n_sd, "substeps", b["stats_n_substep"][:3],
+          "max rel err", worst, flush=True)

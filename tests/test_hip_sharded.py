@@ -2,7 +2,8 @@
 over gloo; on a node the same code runs one process per GPU over RCCL), each computing half of
 the cells.  The state put together from the owners equals (i) the UNSHARDED reference goldens of
 the 4 x 4 grids, (ii) the reference's digest of the 32 x 32 grid, (iii) the one-process HIP run
-where super-droplets die and the permutation has to be put together across the processes."""
+where super-droplets die and the permutation has to be put together across the processes, (iv) the
+reference's golden of displacement + collisions, where super-droplets change owner every step."""
 import os
 import socket
 import warnings
@@ -58,6 +59,11 @@ def _worker(rank, world, port, errors):
                         value, mine = value[:length], mine[:length]
                     np.testing.assert_array_equal(mine, value, err_msg=f"{adaptive} {key}")
             assert shard.shard.calls[2] > 0
+        # replicated displacement on the completed state + sharded collisions (migration between
+        # the processes' cells every step) against the reference's golden
+        from . import displacement_cases  # pylint: disable=import-outside-toplevel
+
+        displacement_cases.run_case("disp2d_collide", engine, shard=(rank, world))
         dist.barrier()
         dist.destroy_process_group()
     except Exception as exc:  # pylint: disable=broad-except

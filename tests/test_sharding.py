@@ -90,6 +90,11 @@ def _worker(rank, world, port, errors):
                         value, mine = value[:length], mine[:length]
                     np.testing.assert_array_equal(mine, value, err_msg=f"{adaptive} {key}")
             assert shard.shard.calls[2] > 0  # the permutation did cross the processes
+        # displacement (replicated, on the completed state) + sharded collisions: super-droplets
+        # migrate between the processes' cells every step; against the reference's golden
+        from . import displacement_cases  # pylint: disable=import-outside-toplevel
+
+        displacement_cases.run_case("disp2d_collide", engine, shard=(rank, world))
         dist.barrier()
         dist.destroy_process_group()
     except Exception as exc:  # pylint: disable=broad-except
