@@ -25,8 +25,6 @@ from .terminal_velocity import LAWS
 READ_BACK, FRESH_CTL, MIRROR_VALID = 1, 2, 4
 _DEVICE_ERRORS = {1: "a cell is larger than the per-cell kernel's capacity",
                   2: "the grid barrier of the compaction kernel timed out (is the GPU shared "
-                     "with another process?)",
-                  3: "the grid barrier of the merged shuffle build timed out (is the GPU shared "
                      "with another process?)"}
 
 

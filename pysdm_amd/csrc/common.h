@@ -49,9 +49,6 @@ struct sdm_ctx {
   void *graph_exec;        // hipGraphExec_t of the cached two-step graph (NULL: none)
   void *graph_key;         // what the cached graph was captured for (memcmp'ed)
   size_t graph_key_bytes;
-  // index.hip: grid barrier of k_bin_sort_build (counts up; `generation` = workgroups launched so far)
-  void *bar2;
-  uint64_t bar2_generation;
   bool cell_attr_done;     // fused.hip: large-LDS attribute of the per-cell kernels set on this device
   int compact_grid;        // index.hip: workgroups of k_compact_persistent that are co-resident here
   int debug_box_delay_us;  // SDM_DEBUG_BOX_DELAY_US (tests): the host sleeps before each wait

@@ -94,7 +94,6 @@ extern "C" int sdm_ctx_destroy(sdm_ctx *ctx) {
   if (ctx->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)ctx->graph_exec);
   free(ctx->graph_key);
   if (ctx->gwords) (void)hipFree(ctx->gwords);
-  if (ctx->bar2) (void)hipFree(ctx->bar2);
   if (ctx->own_event) (void)hipEventDestroy((hipEvent_t)ctx->own_event);
   if (ctx->own_stream) (void)hipStreamDestroy((hipStream_t)ctx->own_stream);
   if (ctx->ev) {

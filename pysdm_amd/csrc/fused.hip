@@ -2305,7 +2305,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       ShuffleViews views;
       rc = sdm_shuffle_build_async(ctx, S.shuffle, cur, st->cell_start, C, p_shuffle_len, N,
                                    cfg->rng_state_inc, u01_off, &views, N,
-                                   ctx->graph_capture ? ctx->gwords : nullptr, st->ctl + 7);
+                                   ctx->graph_capture ? ctx->gwords : nullptr);
       if (rc) return rc;
       A.rec = views.rec;
       A.rec_fmt = views.fmt;

@@ -29,8 +29,7 @@ int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
                             const int64_t *cell_start, int64_t n_cell, const int64_t *p_length,
                             int64_t length_bound, const uint64_t *rng_state_inc,
                             uint64_t rng_offset, ShuffleViews *views,
-                            int64_t id_bound = -1, const uint64_t *dev_off = nullptr,
-                            int64_t *err_word = nullptr);  // (device word: 3 = barrier time-out)  // ids in idx0 are below it (-1: unknown)
+                            int64_t id_bound = -1, const uint64_t *dev_off = nullptr);  // ids in idx0 are below it (-1: unknown)
 // What ends an adaptive sub-step of a single cell (collision.py:185-187), done by the compaction
 // kernel's last act instead of a launch of its own: refused-breakup count of the counter slots
 // into fctl[4] (slots may be NULL), working length = dt_left[0] != 0 ? valid length : 0, control

@@ -167,7 +167,7 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
                                 const double *u01, const int64_t *cell_start, int64_t n_cell,
                                 const int64_t *p_length, int64_t length_bound, int64_t n_total,
                                 u128 s_off, u128 inc, ShuffleViews *views, int64_t id_bound = -1,
-                                const uint64_t *dev_off = nullptr, int64_t *err_word = nullptr);
+                                const uint64_t *dev_off = nullptr);
 
 // out-of-place core: out[0:length) = shuffled idx0[0:length), out[length:n_total) = idx0[...].
 // u01 == nullptr: draws generated in the kernel from (rng_state_inc, rng_offset).
@@ -329,12 +329,12 @@ __device__ __forceinline__ int block_excl_scan(int v, int *total) {
 // wrote at - and assembles the records as k_bin_build does.  The order of the events inside a bin
 // is irrelevant (the walk takes the minimum over a position's candidates).
 template <bool RNG>
-__device__ __forceinline__ void
-bin_sort_body(char *smem, int2 *__restrict__ events, int32_t *__restrict__ toff,
-              int32_t *__restrict__ jarr, int n_bins, const double *__restrict__ u01,
-              const int64_t *__restrict__ cell_start, int64_t n_cell,
-              const int64_t *__restrict__ p_length, int64_t length_arg, u128 s_off, u128 inc,
-              const u128 *__restrict__ tab, const uint64_t *__restrict__ dev_off) {
+__global__ void __launch_bounds__(BIN_THREADS)
+k_bin_sort(int2 *__restrict__ events, int32_t *__restrict__ toff, int32_t *__restrict__ jarr,
+           int n_bins, const double *__restrict__ u01, const int64_t *__restrict__ cell_start,
+           int64_t n_cell, const int64_t *__restrict__ p_length, int64_t length_arg, u128 s_off,
+           u128 inc, const u128 *__restrict__ tab, const uint64_t *__restrict__ dev_off) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   int32_t *lstart = (int32_t *)smem;                      // n_bins + 1
   int32_t *lcount = lstart + n_bins + 1;                  // n_bins
   int2 *ev_buf = (int2 *)(lcount + ((n_bins + 1) & ~1));  // EV_TILE
@@ -391,24 +391,14 @@ bin_sort_body(char *smem, int2 *__restrict__ events, int32_t *__restrict__ toff,
   for (int b = threadIdx.x; b <= n_bins; b += BIN_THREADS) my_off[b] = lstart[b];
 }
 
-template <bool RNG>
-__global__ void __launch_bounds__(BIN_THREADS)
-k_bin_sort(int2 *__restrict__ events, int32_t *__restrict__ toff, int32_t *__restrict__ jarr,
-           int n_bins, const double *__restrict__ u01, const int64_t *__restrict__ cell_start,
-           int64_t n_cell, const int64_t *__restrict__ p_length, int64_t length_arg, u128 s_off,
-           u128 inc, const u128 *__restrict__ tab, const uint64_t *__restrict__ dev_off) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bin_sort_body<RNG>(smem, events, toff, jarr, n_bins, u01, cell_start, n_cell, p_length,
-                     length_arg, s_off, inc, tab, dev_off);
-}
-
 template <int FMT>
-__device__ __forceinline__ void
-bin_build_body(char *smem, void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
-               int32_t *__restrict__ ovf_next, const int2 *__restrict__ events,
-               const int32_t *__restrict__ toff, const int32_t *__restrict__ jarr, int n_bins,
-               int n_tiles, const int64_t *__restrict__ idx0,
-               const int64_t *__restrict__ p_length, int64_t length_arg) {
+__global__ void __launch_bounds__(BIN_THREADS)
+k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
+             int32_t *__restrict__ ovf_next, const int2 *__restrict__ events,
+             const int32_t *__restrict__ toff, const int32_t *__restrict__ jarr, int n_bins,
+             int n_tiles, const int64_t *__restrict__ idx0, const int64_t *__restrict__ p_length,
+             int64_t length_arg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int SLOTS = FMT == SDM_REC_P21 ? 4 : (FMT == SDM_REC_P24 ? 3 : 2);
   int32_t *run_pre = (int32_t *)smem;                   // n_tiles + 1: events of tiles < t
   int32_t *run_lo = run_pre + ((n_tiles + 1 + 3) & ~3); // n_tiles: where tile t's run starts
@@ -489,55 +479,6 @@ bin_build_body(char *smem, void *__restrict__ rec_out, int32_t *__restrict__ ovf
   }
 }
 
-template <int FMT>
-__global__ void __launch_bounds__(BIN_THREADS)
-k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
-             int32_t *__restrict__ ovf_next, const int2 *__restrict__ events,
-             const int32_t *__restrict__ toff, const int32_t *__restrict__ jarr, int n_bins,
-             int n_tiles, const int64_t *__restrict__ idx0, const int64_t *__restrict__ p_length,
-             int64_t length_arg) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bin_build_body<FMT>(smem, rec_out, ovf_head, ovf_next, events, toff, jarr, n_bins, n_tiles, idx0,
-                      p_length, length_arg);
-}
-
-// Small boxes (at most SMALL_BUILD_TILES tiles = as many bins: EV_TILE == BIN_POS): both phases in
-// ONE launch, separated by a grid barrier - every workgroup is resident (one per CU at most).  A
-// step of a small box is bound by the dispatch latency between its dependent kernels (~11 us
-// each), not by their work: one launch less is a quarter of the step.  The barrier counts up
-// (`target` = the workgroups of all launches so far including this one, from the host), so
-// nothing has to be re-armed; every spin is bounded (on a time-out *err = 3 and the workgroup goes on - the records are then wrong, and the
-// host raises).
-#define SMALL_BUILD_TILES 128
-template <int FMT>
-__global__ void __launch_bounds__(BIN_THREADS)
-k_bin_sort_build(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
-                 int32_t *__restrict__ ovf_next, int2 *__restrict__ events,
-                 int32_t *__restrict__ toff, int32_t *__restrict__ jarr, int n_bins, int n_tiles,
-                 const int64_t *__restrict__ idx0, const int64_t *__restrict__ cell_start,
-                 int64_t n_cell, const int64_t *__restrict__ p_length, int64_t length_arg,
-                 u128 s_off, u128 inc, const u128 *__restrict__ tab,
-                 const uint64_t *__restrict__ dev_off, unsigned long long *__restrict__ bar,
-                 unsigned long long target, int64_t *__restrict__ err) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bin_sort_body<true>(smem, events, toff, jarr, n_bins, nullptr, cell_start, n_cell, p_length,
-                      length_arg, s_off, inc, tab, dev_off);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();  // release this workgroup's events and offsets
-    atomicAdd(bar, 1ull);
-    unsigned int spins = 0;
-    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 20)) { if (err) *err = 3; break; }
-    }
-  }
-  __syncthreads();
-  __threadfence();  // acquire: the other workgroups' events and offsets
-  bin_build_body<FMT>(smem, rec_out, ovf_head, ovf_next, events, toff, jarr, n_bins, n_tiles, idx0,
-                      p_length, length_arg);
-}
-
 // backward walk over packed records; positions [length, n_total) are copied through
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_trace_packed(int64_t *__restrict__ out, const int64_t *__restrict__ idx0,
@@ -572,7 +513,7 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
                                 const double *u01, const int64_t *cell_start, int64_t n_cell,
                                 const int64_t *p_length, int64_t length_bound, int64_t n_total,
                                 u128 s_off, u128 inc, ShuffleViews *views, int64_t id_bound,
-                                const uint64_t *dev_off, int64_t *err_word) {
+                                const uint64_t *dev_off) {
   // id_bound: the ids in idx0 are below it (-1: unknown); decides the record layout
   const int64_t both = id_bound > length_bound ? id_bound : length_bound;
   const int fmt = id_bound < 0 ? SDM_REC_PLAIN
@@ -603,36 +544,7 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
                                 : fmt == SDM_REC_P24 ? (const void *)k_bin_build2<SDM_REC_P24>
                                                      : (const void *)k_bin_build2<SDM_REC_PLAIN>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
-  // small boxes: both phases in one launch (k_bin_sort_build)
-  int cus = 0;
-  HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-  const bool merged = !u01 && nb == nt && nt <= SMALL_BUILD_TILES && nt <= cus;
-  if (merged) {
-    PhaseScope ph(ctx, SDM_PHASE_SHUFFLE_BUILD);
-    if (!ctx->bar2) {
-      HIP_TRY(hipMalloc((void **)&ctx->bar2, sizeof(unsigned long long) * 2));
-      HIP_TRY(hipMemsetAsync(ctx->bar2, 0, sizeof(unsigned long long) * 2, ctx->stream));
-      ctx->bar2_generation = 0;
-    }
-    const size_t lds = lds_sort > lds_build ? lds_sort : lds_build;
-#define MERGED_LAUNCH(F)                                                                         \
-  do {                                                                                           \
-    if (lds > 65536)                                                                             \
-      HIP_TRY(hipFuncSetAttribute((const void *)k_bin_sort_build<F>,                             \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
-    hipLaunchKernelGGL(k_bin_sort_build<F>, dim3(nt), block, lds, ctx->stream, (void *)rec,      \
-                       ovf_head, ovf_next, events, toff, jarr, nb, nt, idx0, cell_start, n_cell, \
-                       p_length, length_bound, s_off, inc, ctx->pcg_tab, dev_off,                \
-                       (unsigned long long *)ctx->bar2,                                          \
-                       (unsigned long long)(ctx->bar2_generation + nt), err_word);               \
-  } while (0)
-    if (fmt == SDM_REC_P21) MERGED_LAUNCH(SDM_REC_P21);
-    else if (fmt == SDM_REC_P24) MERGED_LAUNCH(SDM_REC_P24);
-    else MERGED_LAUNCH(SDM_REC_PLAIN);
-#undef MERGED_LAUNCH
-    LAUNCH_CHECK();
-    ctx->bar2_generation += nt;
-  } else {
+  {
     PhaseScope ph(ctx, SDM_PHASE_SHUFFLE_BUILD);
     if (u01)
       hipLaunchKernelGGL((k_bin_sort<false>), dim3(nt), block, lds_sort, ctx->stream, events, toff,
@@ -676,7 +588,7 @@ int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
                             const int64_t *cell_start, int64_t n_cell, const int64_t *p_length,
                             int64_t length_bound, const uint64_t *rng_state_inc,
                             uint64_t rng_offset, ShuffleViews *views, int64_t id_bound,
-                            const uint64_t *dev_off, int64_t *err_word) {
+                            const uint64_t *dev_off) {
   int rc = sdm_pcg_prepare(ctx, rng_state_inc);
   if (rc) return rc;
   const u128 st = (((u128)rng_state_inc[0]) << 64) | rng_state_inc[1];
@@ -684,7 +596,7 @@ int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
   // dev_off: the kernels add the stream position themselves (graph replay)
   const u128 s_off = dev_off ? st : sdm_pcg_advance_host(st, inc, rng_offset);
   return shuffle_binned_async(ctx, scratch, nullptr, idx0, nullptr, cell_start, n_cell, p_length,
-                              length_bound, 0, s_off, inc, views, id_bound, dev_off, err_word);
+                              length_bound, 0, s_off, inc, views, id_bound, dev_off);
 }
 
 size_t sdm_shuffle_scratch(int64_t n) {
