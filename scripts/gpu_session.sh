@@ -1,11 +1,11 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_hip_parity.py tests/test_hip_full_size.py -m gpu -x -q > gpurun_out/r02_gputest_f.log 2>&1 || { tail -60 gpurun_out/r02_gputest_f.log; exit 1; }
-tail -3 gpurun_out/r02_gputest_f.log
-for n in 16384 65536 262144 524288; do
-python bench.py --no-cpu-baseline --n-sd $n --steps 1000 --warmup 50 > gpurun_out/r02_bench_merged_n$n.json 2>/dev/null
-python -c "
-import json; d=json.load(open('gpurun_out/r02_bench_merged_n$n.json')); print($n, d['value'], d['ms_per_step'])"
+rm -rf gpurun_out/pc_*
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pc_stats -- python3 bench.py --steps 100 --warmup 10 --reps 1 --no-cpu-baseline --roofline-steps 5 > /dev/null 2>&1
+f=$(ls gpurun_out/pc_stats/*/*kernel_stats.csv); head -8 $f | cut -c1-160
+for c in FETCH_SIZE WRITE_SIZE TCC_REQ_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum; do
+rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pc_$c -- python3 bench.py --steps 30 --warmup 5 --reps 1 --no-cpu-baseline --roofline-steps 5 > /dev/null 2>&1
+python tests/pmc_summary.py gpurun_out/pc_$c $c > gpurun_out/r02_pmc_carried_$c.txt
+head -4 gpurun_out/r02_pmc_carried_$c.txt
 done
-python bench.py --no-cpu-baseline > gpurun_out/r02_bench_merged_default.json 2>/dev/null
-cut -c1-300 gpurun_out/r02_bench_merged_default.json
+rm -rf gpurun_out/pc_*
