@@ -51,7 +51,8 @@ WORKLOADS = {
 }
 
 
-def build_workload(name, engine, rank, world, n_sd=None, adaptive=None, read_back=True):
+def build_workload(name, engine, rank, world, n_sd=None, adaptive=None, read_back=True,
+                   ids_by_cell=False):
     from pysdm_amd import cases, sharding
 
     if name == "kinematic2d" and world > 1:
@@ -59,7 +60,7 @@ def build_workload(name, engine, rank, world, n_sd=None, adaptive=None, read_bac
                                          adaptive=adaptive)
     # 0-D boxes: every rank an independent realisation (seed 44 + rank)
     return cases.make_box(engine, name, n_sd=n_sd, adaptive=adaptive, seed=44 + rank,
-                          read_back=read_back)
+                          read_back=read_back, ids_by_cell=ids_by_cell)
 
 
 def cpu_model():
@@ -136,6 +137,9 @@ def main():
     parser.add_argument("--adaptive", type=int, default=None)
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--roofline-steps", type=int, default=50)
+    # measurement of a DIFFERENT workload (profiles/README.md): a cell's super-droplets get
+    # consecutive ids; the JSON line says so in config.workload
+    parser.add_argument("--ids-by-cell", action="store_true")
     args = parser.parse_args()
 
     import torch
@@ -161,7 +165,8 @@ def main():
 
     engine = HipEngine.get(local_rank)
     adaptive = None if args.adaptive is None else bool(args.adaptive)
-    runner = build_workload(args.workload, engine, rank, world, args.n_sd, adaptive)
+    runner = build_workload(args.workload, engine, rank, world, args.n_sd, adaptive,
+                            ids_by_cell=args.ids_by_cell)
     pop, setup = runner.population, runner.setup
     n_sd = pop.n_sd
     runner.run(1)  # allocates scratch, builds the mirror
@@ -284,7 +289,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": WORKLOADS[args.workload] + "; "
-                            + ("adaptive" if setup.adaptive else "non-adaptive"),
+                            + ("adaptive" if setup.adaptive else "non-adaptive")
+                            + ("; NOT the configuration: ids ordered by cell"
+                               if args.ids_by_cell else ""),
                 "n_sd": n_sd,
                 "seed": 44,
                 "route": "fused sdm_collision_run",

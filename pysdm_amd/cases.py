@@ -86,10 +86,12 @@ CONFIGS = {
 }
 
 
-def initial_state(name, n_sd=None, dv=None):
+def initial_state(name, n_sd=None, dv=None, ids_by_cell=False):
     """(volume, real-valued multiplicity, cell id or None, dv of the whole domain, grid or None)
     of configuration `name`; with another `n_sd` the domain volume is rescaled so that the
-    multiplicities stay those of the configuration, unless `dv` is given"""
+    multiplicities stay those of the configuration, unless `dv` is given.  `ids_by_cell`
+    (measurements only): the super-droplets of a cell get consecutive ids - a different, friendlier
+    workload than the configuration's (profiles/README.md, "ids by cell")"""
     cfg = CONFIGS[name]
     n_sd = n_sd or cfg["n_sd"]
     dv = cfg["dv"] * n_sd / cfg["n_sd"] if dv is None else dv
@@ -107,11 +109,14 @@ def initial_state(name, n_sd=None, dv=None):
         cell_id = rng.integers(0, n_cell, size=n_sd).astype(np.int64)
         order = rng.permutation(n_sd)
         volume, multiplicity = volume[order], multiplicity[order]
+        if ids_by_cell:
+            by_cell = np.argsort(cell_id, kind="stable")
+            volume, multiplicity, cell_id = volume[by_cell], multiplicity[by_cell], cell_id[by_cell]
     return volume, multiplicity, cell_id, dv, grid
 
 
 def make_box(engine, name, *, n_sd=None, adaptive=None, route="fused", seed=44, dt=None,
-             thin=None, grid=None, read_back=True, dv=None):
+             thin=None, grid=None, read_back=True, dv=None, ids_by_cell=False):
     """a CollisionRunner for configuration `name`.  `thin` (a cell volume per 2^16
     super-droplets) replaces the multiplicities by 1, 2, 3, 1, ... so that super-droplets die;
     `grid` turns a box configuration into a multi-cell one with uniform-random cell ids"""
@@ -120,11 +125,11 @@ def make_box(engine, name, *, n_sd=None, adaptive=None, route="fused", seed=44, 
         cfg = dict(cfg, grid=tuple(grid))
         CONFIGS["_tmp"] = cfg
         try:
-            volume, multiplicity, cell_id, dv, grid = initial_state("_tmp", n_sd, dv)
+            volume, multiplicity, cell_id, dv, grid = initial_state("_tmp", n_sd, dv, ids_by_cell)
         finally:
             del CONFIGS["_tmp"]
     else:
-        volume, multiplicity, cell_id, dv, grid = initial_state(name, n_sd, dv)
+        volume, multiplicity, cell_id, dv, grid = initial_state(name, n_sd, dv, ids_by_cell)
     n_sd = len(volume)
     adaptive = cfg["adaptive"] if adaptive is None else adaptive
     if thin is not None:

@@ -347,6 +347,14 @@ k_bin_sort(int2 *__restrict__ events, int32_t *__restrict__ toff, int32_t *__res
     return;
   }
   for (int b = threadIdx.x; b < n_bins; b += BIN_THREADS) lcount[b] = 0;
+  // the jump table in LDS: the two jump-aheads (thread 0 to the tile, every thread to its run)
+  // are chains of dependent table reads on the critical path of a one-workgroup-per-CU kernel
+  __shared__ u128 ltab[128];
+  if (RNG) {
+    if (threadIdx.x < 128) ltab[threadIdx.x] = tab[threadIdx.x];
+    __syncthreads();
+    tab = ltab;
+  }
   // dev_off (graph replay): s_off is the generator's initial state, the stream position comes
   // from the device
   if (RNG && threadIdx.x == 0)
