@@ -28,6 +28,11 @@ struct sdm_ctx {
   size_t arena_bytes;
   // PCG64 jump table: tab[b] = {A^(2^b), C_(2^b)} for the increment `tab_inc`
   u128 *pcg_tab;  // device, 64 x 2
+  // jump-aheads by the distances the kernels use most, as ready affine maps {multiplier,
+  // increment} (one 128-bit multiply-add instead of one per set bit of the distance): entries
+  // [0, PCG_AFF_SMALL) for distances 0, 1, 2, .., then PCG_AFF_TILES entries for multiples of
+  // PCG_AFF_STRIDE
+  u128 *pcg_aff;
   u128 tab_inc;
   bool tab_valid;
   // pinned host mailbox for scalar read-backs
@@ -51,6 +56,12 @@ struct sdm_ctx {
   size_t graph_key_bytes;
   bool cell_attr_done;     // fused.hip: large-LDS attribute of the per-cell kernels set on this device
   int compact_grid;        // index.hip: workgroups of k_compact_persistent that are co-resident here
+  int sort_resident;       // index.hip: likewise k_bin_sort (0: not asked yet, -1: unknown)
+  // fused.hip: the compaction that ends a sub-step is left to the next tile sort of the same run
+  struct {
+    bool active;
+    const void *owner;
+  } late_compact;
   int debug_box_delay_us;  // SDM_DEBUG_BOX_DELAY_US (tests): the host sleeps before each wait
   // fused.hip: what a multi-cell adaptive step knows at its end, for the next step of the same call
   // (valid length, an upper bound of the cell sizes; the state is sorted) - saves that step's
@@ -189,6 +200,14 @@ __host__ __device__ __forceinline__ double pcg_output(u128 state) {
   const unsigned r = (unsigned)(hi >> 58);
   const uint64_t v = (x >> r) | (x << ((64 - r) & 63));
   return (double)(v >> 11) * (1.0 / 9007199254740992.0);
+}
+
+#define PCG_AFF_SMALL 4097
+#define PCG_AFF_TILES 8192
+#define PCG_AFF_STRIDE 4096
+// state after the jump of entry k of ctx->pcg_aff
+__device__ __forceinline__ u128 pcg_apply(u128 state, const u128 *__restrict__ aff, int64_t k) {
+  return state * aff[2 * k] + aff[2 * k + 1];
 }
 
 // state after `delta` further draws, using the per-increment jump table

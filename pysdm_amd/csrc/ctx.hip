@@ -19,6 +19,7 @@ extern "C" int sdm_abi_version(void) { return 1; }
 
 static int ctx_allocate(sdm_ctx *ctx) {
   HIP_TRY(hipMalloc((void **)&ctx->pcg_tab, sizeof(u128) * 128));
+  HIP_TRY(hipMalloc((void **)&ctx->pcg_aff, sizeof(u128) * 2 * (PCG_AFF_SMALL + PCG_AFF_TILES)));
   HIP_TRY(hipHostMalloc((void **)&ctx->mailbox, sizeof(int64_t) * SDM_MAILBOX_WORDS,
                         hipHostMallocMapped | hipHostMallocCoherent));
   memset(ctx->mailbox, 0, sizeof(int64_t) * SDM_MAILBOX_WORDS);
@@ -88,6 +89,7 @@ extern "C" int sdm_ctx_destroy(sdm_ctx *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->arena) (void)hipFree(ctx->arena);
   if (ctx->pcg_tab) (void)hipFree(ctx->pcg_tab);
+  if (ctx->pcg_aff) (void)hipFree(ctx->pcg_aff);
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   if (ctx->dscal) (void)hipFree(ctx->dscal);
   if (ctx->cnt_slots) (void)hipFree(ctx->cnt_slots);
@@ -206,10 +208,30 @@ __global__ void k_pcg_table(u128 *tab, u128 inc) {
   }
 }
 
+// the affine maps of ctx->pcg_aff: the per-bit maps of `tab` commute, so their composition over
+// the set bits of a distance is the jump by that distance
+__global__ void __launch_bounds__(SDM_BLOCK) k_pcg_affine(u128 *aff, const u128 *tab) {
+  const int64_t k = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+  if (k >= PCG_AFF_SMALL + PCG_AFF_TILES) return;
+  uint64_t delta = k < PCG_AFF_SMALL ? (uint64_t)k
+                                     : (uint64_t)(k - PCG_AFF_SMALL) * PCG_AFF_STRIDE;
+  u128 mult = 1, plus = 0;
+  for (int b = 0; delta; ++b, delta >>= 1)
+    if (delta & 1) {
+      mult *= tab[2 * b];
+      plus = plus * tab[2 * b] + tab[2 * b + 1];
+    }
+  aff[2 * k] = mult;
+  aff[2 * k + 1] = plus;
+}
+
 int sdm_pcg_prepare(sdm_ctx *ctx, const uint64_t state_inc[4]) {
   const u128 inc = (((u128)state_inc[2]) << 64) | state_inc[3];
   if (!ctx->tab_valid || ctx->tab_inc != inc) {
     hipLaunchKernelGGL(k_pcg_table, dim3(1), dim3(1), 0, ctx->stream, ctx->pcg_tab, inc);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pcg_affine, dim3(grid_for(PCG_AFF_SMALL + PCG_AFF_TILES)),
+                       dim3(SDM_BLOCK), 0, ctx->stream, ctx->pcg_aff, ctx->pcg_tab);
     LAUNCH_CHECK();
     ctx->tab_inc = inc;
     ctx->tab_valid = true;

@@ -63,6 +63,7 @@ struct FusedArgs {
   // proc_rand / rand_frag generators (same seed, same position: identical values)
   u128 s_rand, s_rand_b, rng_inc;
   const u128 *rng_tab;
+  const u128 *rng_aff;  // ready jumps (common.h: pcg_aff); NULL while graph replay is captured
   double *prob;           // [P]
   uint8_t *pair_off;      // [P] 0: pair starts at 2d, 1: at 2d+1, 2: no pair
   int32_t *pair_cid;      // [P] raw cell id of the pair (n_cell > 1)
@@ -149,7 +150,18 @@ __global__ void __launch_bounds__(SDM_CNT_SLOTS) k_fold_counters(FusedArgs A) {
 
 // one draw per thread: element (block_first + tid) of the stream starting at `s_base`
 __device__ __forceinline__ double stream_draw(u128 s_base, u128 inc, const u128 *__restrict__ tab,
-                                              u128 *lds_slot, uint64_t add = 0) {
+                                              u128 *lds_slot, uint64_t add = 0,
+                                              const u128 *__restrict__ aff = nullptr) {
+  // ready affine maps (common.h: pcg_aff): block b starts b * SDM_BLOCK draws in =
+  // (b / PER) strides + (b % PER) * SDM_BLOCK, so two multiply-adds per thread and no exchange
+  // through LDS, instead of a bit-by-bit jump by thread 0 and another by every thread
+  constexpr int PER = PCG_AFF_STRIDE / SDM_BLOCK;
+  if (aff && add == 0 && blockIdx.x / PER < PCG_AFF_TILES) {
+    u128 state = pcg_apply(pcg_apply(s_base, aff, PCG_AFF_SMALL + (int64_t)(blockIdx.x / PER)),
+                           aff, (int64_t)(blockIdx.x % PER) * SDM_BLOCK + threadIdx.x);
+    state = state * pcg_mult() + inc;
+    return pcg_output(state);
+  }
   if (threadIdx.x == 0) *lds_slot = pcg_jump(s_base, tab, (uint64_t)blockIdx.x * SDM_BLOCK + add);
   __syncthreads();
   u128 state = pcg_jump(*lds_slot, tab, (uint64_t)threadIdx.x);
@@ -709,9 +721,9 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_all(sdm_step_cfg cfg, FusedA
   const int64_t d = TID();
   if (d == 0) A.ctl[CTL_PAIRS] += W / 2;  // lets a caller count pairs without reading back per step
   const double u = stream_draw(A.s_rand, A.rng_inc, A.rng_tab, &lds[0],
-                               A.dev_off ? A.dev_off[0] + A.rand_extra : 0);
+                               A.dev_off ? A.dev_off[0] + A.rand_extra : 0, A.rng_aff);
   const double u_b = BREAKUP ? stream_draw(A.s_rand_b, A.rng_inc, A.rng_tab, &lds[1],
-                                           A.dev_off ? A.dev_off[1] : 0)
+                                           A.dev_off ? A.dev_off[1] : 0, A.rng_aff)
                              : 0.0;
   PairInfo R;
   R.have = false; R.off = 2; R.prob = 0; R.j = R.k = 0;
@@ -928,8 +940,10 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_update(sdm_step_cfg cfg, Fus
   __shared__ u128 lds[2];
   const int64_t W = A.ctl[CTL_WORK];
   const int64_t d = TID();
-  const double u = stream_draw(A.s_rand, A.rng_inc, A.rng_tab, &lds[0]);
-  const double u_b = BREAKUP ? stream_draw(A.s_rand_b, A.rng_inc, A.rng_tab, &lds[1]) : 0.0;
+  const double u = stream_draw(A.s_rand, A.rng_inc, A.rng_tab, &lds[0], 0, A.rng_aff);
+  const double u_b = BREAKUP ? stream_draw(A.s_rand_b, A.rng_inc, A.rng_tab, &lds[1], 0,
+                                           A.rng_aff)
+                             : 0.0;
   const bool in_range = d < W / 2;
   double p = 0;
   int64_t off = 2;
@@ -1837,6 +1851,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   A.cell_owned = st->cell_owned;
   A.rng_inc = rng_inc;
   A.rng_tab = ctx->pcg_tab;
+  A.rng_aff = ctx->graph_capture ? nullptr : ctx->pcg_aff;
   A.prob = S.prob;
   A.pair_off = S.pair_off;
   A.pair_cid = S.pair_cid;
@@ -2243,6 +2258,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       }
     }
   }
+  // one cell whose shuffle is left to the pair kernels (records only, see (d))
+  const bool split_one = C == 1 && cfg->croupier_local && sdm_shuffle_can_split(N, false);
   for (;;) {
     if (!cfg->adaptive && n_sub >= cfg->substeps) break;
     if (cfg->adaptive && work_host == 0) break;
@@ -2303,9 +2320,17 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     } else if (split) {
       // single cell: event records only; the pair kernels walk them (2 positions per thread)
       ShuffleViews views;
+      // the previous sub-step of this run left its compaction to this tile sort (see (g))
+      SortPrologue prologue;
+      const bool late = ctx->late_compact.active && ctx->late_compact.owner == (const void *)st;
+      ctx->late_compact.active = false;
+      if (late)
+        sdm_compact_as_prologue(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl, S.cctl,
+                                st->cell_start, &prologue);
       rc = sdm_shuffle_build_async(ctx, S.shuffle, cur, st->cell_start, C, p_shuffle_len, N,
                                    cfg->rng_state_inc, u01_off, &views, N,
-                                   ctx->graph_capture ? ctx->gwords : nullptr);
+                                   ctx->graph_capture ? ctx->gwords : nullptr,
+                                   late ? &prologue : nullptr);
       if (rc) return rc;
       A.rec = views.rec;
       A.rec_fmt = views.fmt;
@@ -2398,9 +2423,20 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         epilogue.box = ctx->box_dev;
         epilogue.seq = box_seq;
       }
-      rc = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl, S.cctl,
-                                   C == 1 ? st->cell_start : nullptr, true, &epilogue);
-      if (rc) return rc;
+      // one cell, non-adaptive, and another sub-step of the same run follows: its tile sort does
+      // the compaction as a prologue (index.hip: k_bin_sort) - no launch here
+      static const bool late_off = getenv("SDM_NO_LATE_COMPACTION") != nullptr;  // (A/B runs)
+      const bool follows = n_sub + 1 < cfg->substeps || more_follow;
+      if (split_one && !cell_path && !cfg->adaptive && follows && !ctx->graph_capture &&
+          !late_off &&
+          sdm_shuffle_sort_can_compact(ctx, N)) {
+        ctx->late_compact.active = true;
+        ctx->late_compact.owner = st;
+      } else {
+        rc = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl, S.cctl,
+                                     C == 1 ? st->cell_start : nullptr, true, &epilogue);
+        if (rc) return rc;
+      }
       if (C > 1) sorted_host = -1;  // a compaction (decided on the device) un-sorts
     }
     ++n_sub;
@@ -2540,6 +2576,7 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   ARG_TRY(ctx != nullptr);
   ctx->ahead.active = false;
   ctx->carry.active = false;
+  ctx->late_compact.active = false;
   return collision_step(ctx, cfg, st, res, flags, true, false);
 }
 
@@ -2669,6 +2706,7 @@ extern "C" int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step
   ARG_TRY(ctx && res && st && n_steps >= 0);
   ctx->ahead.active = false;
   ctx->carry.active = false;
+  ctx->late_compact.active = false;
   sdm_step_result total;
   memset(&total, 0, sizeof(total));
   total.valid_n_sd = -1;

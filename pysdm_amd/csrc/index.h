@@ -25,11 +25,33 @@ int sdm_counting_sort_async(sdm_ctx *ctx, char *scratch, int64_t *new_idx, const
 int sdm_cell_start_from_counts_async(sdm_ctx *ctx, const int64_t *count, int64_t *cell_start,
                                      int64_t n_cell, const int64_t *p_gate);
 bool sdm_shuffle_can_split(int64_t n, bool global);
+// The compaction that ends the previous sub-step, done at the start of the tile sort instead of in
+// a launch of its own (one-cell non-adaptive runs).  While the state is healthy - nearly always -
+// that launch did nothing, at 4.7 us per time step.
+struct SortPrologue {
+  int64_t *fctl;  // NULL: no prologue
+  const int64_t *multiplicity;
+  int64_t *idx;
+  int64_t flag;
+  int32_t *wave_dead;
+  int n_tiles;
+  int64_t *ctl;
+  int32_t *holes;
+  int64_t *fillers;
+  int64_t *cell_start_single;
+  unsigned int *bar;
+};
+bool sdm_shuffle_sort_can_compact(sdm_ctx *ctx, int64_t length_bound);
+void sdm_compact_as_prologue(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity,
+                             int64_t *idx, int64_t length_bound, int64_t flag, int64_t *fctl,
+                             int64_t *ctl, int64_t *cell_start_single, SortPrologue *out);
 int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
                             const int64_t *cell_start, int64_t n_cell, const int64_t *p_length,
                             int64_t length_bound, const uint64_t *rng_state_inc,
                             uint64_t rng_offset, ShuffleViews *views,
-                            int64_t id_bound = -1, const uint64_t *dev_off = nullptr);  // ids in idx0 are below it (-1: unknown)
+                            int64_t id_bound = -1,  // ids in idx0 are below it (-1: unknown)
+                            const uint64_t *dev_off = nullptr,
+                            const SortPrologue *prologue = nullptr);
 // What ends an adaptive sub-step of a single cell (collision.py:185-187), done by the compaction
 // kernel's last act instead of a launch of its own: refused-breakup count of the counter slots
 // into fctl[4] (slots may be NULL), working length = dt_left[0] != 0 ? valid length : 0, control

@@ -167,7 +167,8 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
                                 const double *u01, const int64_t *cell_start, int64_t n_cell,
                                 const int64_t *p_length, int64_t length_bound, int64_t n_total,
                                 u128 s_off, u128 inc, ShuffleViews *views, int64_t id_bound = -1,
-                                const uint64_t *dev_off = nullptr);
+                                const uint64_t *dev_off = nullptr,
+                                const SortPrologue *prologue = nullptr);
 
 // out-of-place core: out[0:length) = shuffled idx0[0:length), out[length:n_total) = idx0[...].
 // u01 == nullptr: draws generated in the kernel from (rng_state_inc, rng_offset).
@@ -264,9 +265,11 @@ __device__ __forceinline__ void targets_run(int64_t first, int64_t length,
                                           const double *__restrict__ u01,
                                           const int64_t *__restrict__ cell_start, int64_t n_cell,
                                           u128 s_tile, u128 inc, const u128 *__restrict__ tab,
-                                          int32_t (&j)[PER]) {
+                                          int32_t (&j)[PER], int64_t one_cell_len = -1,
+                                          bool at_run = false) {
+  // at_run: s_tile is already the state at this thread's run
   u128 state = 0;
-  if (RNG) state = pcg_jump(s_tile, tab, (uint64_t)threadIdx.x * PER);
+  if (RNG) state = at_run ? s_tile : pcg_jump(s_tile, tab, (uint64_t)threadIdx.x * PER);
   const u128 mult = pcg_mult();
   int64_t lo = 0, hi = 0;
   bool have_cell = false;
@@ -283,9 +286,14 @@ __device__ __forceinline__ void targets_run(int64_t first, int64_t length,
     j[e] = -1;
     if (i >= length) continue;
     if (!have_cell || i >= hi) {
-      const int64_t c = n_cell == 1 ? 0 : find_cell(cell_start, n_cell, i);
-      lo = cell_start[c];
-      hi = cell_start[c + 1];
+      if (one_cell_len >= 0) {  // one cell [0, length): known to the caller (see k_bin_sort)
+        lo = 0;
+        hi = one_cell_len;
+      } else {
+        const int64_t c = n_cell == 1 ? 0 : find_cell(cell_start, n_cell, i);
+        lo = cell_start[c];
+        hi = cell_start[c + 1];
+      }
       have_cell = true;
     }
     if (i > lo) {
@@ -328,18 +336,31 @@ __device__ __forceinline__ int block_excl_scan(int v, int *total) {
 // of that tile's segment, ~16 events = two 64-B sectors each, the same granularity the scatter
 // wrote at - and assembles the records as k_bin_build does.  The order of the events inside a bin
 // is irrelevant (the walk takes the minimum over a position's candidates).
+// -DBIN_PROFILE (tuning builds only): phase time stamps of workgroup 7 of the two build kernels,
+// wall_clock64 ticks (100 MHz), read back through sdm_debug_bin_profile
+#ifdef BIN_PROFILE
+__device__ long long bin_prof[32];
+#define BIN_MARK(k) do { __syncthreads(); if (blockIdx.x == 7 && threadIdx.x == 0) bin_prof[k] = wall_clock64(); } while (0)
+extern "C" int sdm_debug_bin_profile(long long *out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(bin_prof), sizeof(long long) * 32) == hipSuccess ? 0 : -2;
+}
+#else
+#define BIN_MARK(k)
+#endif
+
+// `one_cell_len` >= 0: the single cell [0, length) as the caller knows it (cell_start not read)
 template <bool RNG>
-__global__ void __launch_bounds__(BIN_THREADS)
-k_bin_sort(int2 *__restrict__ events, int32_t *__restrict__ toff, int32_t *__restrict__ jarr,
-           int n_bins, const double *__restrict__ u01, const int64_t *__restrict__ cell_start,
-           int64_t n_cell, const int64_t *__restrict__ p_length, int64_t length_arg, u128 s_off,
-           u128 inc, const u128 *__restrict__ tab, const uint64_t *__restrict__ dev_off) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void
+bin_sort_body(char *smem, int2 *__restrict__ events, int32_t *__restrict__ toff,
+              int32_t *__restrict__ jarr, int n_bins, const double *__restrict__ u01,
+              const int64_t *__restrict__ cell_start, int64_t n_cell, int64_t length,
+              int64_t one_cell_len, u128 s_off, u128 inc, const u128 *__restrict__ tab,
+              const uint64_t *__restrict__ dev_off, const u128 *__restrict__ aff) {
   int32_t *lstart = (int32_t *)smem;                      // n_bins + 1
   int32_t *lcount = lstart + n_bins + 1;                  // n_bins
   int2 *ev_buf = (int2 *)(lcount + ((n_bins + 1) & ~1));  // EV_TILE
   __shared__ u128 s_slot;
-  const int64_t length = p_length ? *p_length : length_arg;
+  BIN_MARK(0);
   const int64_t tile_first = (int64_t)blockIdx.x * EV_TILE;
   int32_t *my_off = toff + (int64_t)blockIdx.x * (n_bins + 1);
   if (tile_first >= length) {
@@ -347,30 +368,48 @@ k_bin_sort(int2 *__restrict__ events, int32_t *__restrict__ toff, int32_t *__res
     return;
   }
   for (int b = threadIdx.x; b < n_bins; b += BIN_THREADS) lcount[b] = 0;
-  // the jump table in LDS: the two jump-aheads (thread 0 to the tile, every thread to its run)
-  // are chains of dependent table reads on the critical path of a one-workgroup-per-CU kernel
+  // The jump-aheads (to the tile, then to the thread's run) sit on the critical path of a
+  // one-workgroup-per-CU kernel.  Ready affine maps (ctx->pcg_aff) make them two 128-bit
+  // multiply-adds per thread and nothing to wait for (4.6 + 1.2 us of this kernel's 12.5 were
+  // the bit-by-bit jumps, `profiles/r02_bin_profile.txt`); otherwise bit by bit, the table in LDS
+  const bool ready = RNG && aff && !dev_off && EV_TILE == PCG_AFF_STRIDE &&
+                     (int64_t)blockIdx.x < PCG_AFF_TILES &&
+                     (BIN_THREADS - 1) * EV_PER_THREAD < PCG_AFF_SMALL;
   __shared__ u128 ltab[128];
-  if (RNG) {
+  u128 s_tile = 0;
+  if (ready) {
+    s_tile = pcg_apply(pcg_apply(s_off, aff, PCG_AFF_SMALL + (int64_t)blockIdx.x), aff,
+                       (int64_t)threadIdx.x * EV_PER_THREAD);
+    __syncthreads();  // lcount is zero before anyone counts
+  } else if (RNG) {
     if (threadIdx.x < 128) ltab[threadIdx.x] = tab[threadIdx.x];
     __syncthreads();
     tab = ltab;
+    // dev_off (graph replay): s_off is the generator's initial state, the stream position comes
+    // from the device
+    if (threadIdx.x == 0)
+      s_slot = pcg_jump(s_off, tab, (uint64_t)blockIdx.x * EV_TILE + (dev_off ? dev_off[0] : 0));
+    __syncthreads();
+    s_tile = s_slot;
+  } else {
+    __syncthreads();  // lcount is zero before anyone counts
   }
-  // dev_off (graph replay): s_off is the generator's initial state, the stream position comes
-  // from the device
-  if (RNG && threadIdx.x == 0)
-    s_slot = pcg_jump(s_off, tab, (uint64_t)blockIdx.x * EV_TILE + (dev_off ? dev_off[0] : 0));
-  __syncthreads();
-  const u128 s_tile = RNG ? s_slot : 0;
+  BIN_MARK(1);
+  BIN_MARK(2);
   const int64_t first = tile_first + (int64_t)threadIdx.x * EV_PER_THREAD;
   int32_t j[EV_PER_THREAD];
-  targets_run<RNG, EV_PER_THREAD>(first, length, u01, cell_start, n_cell, s_tile, inc, tab, j);
+  targets_run<RNG, EV_PER_THREAD>(first, length, u01, cell_start, n_cell, s_tile, inc, tab, j,
+                                  one_cell_len, ready);
+  BIN_MARK(3);
+  int rank[EV_PER_THREAD];  // arrival number of the event in its bin: its place in the bin's run
 #pragma unroll
   for (int e = 0; e < EV_PER_THREAD; ++e) {
-    if (j[e] >= 0) atomicAdd(&lcount[j[e] >> BIN_SHIFT], 1);
+    rank[e] = j[e] >= 0 ? atomicAdd(&lcount[j[e] >> BIN_SHIFT], 1) : 0;
     if (first + e < length) jarr[first + e] = j[e];
   }
   __syncthreads();
-  {  // lstart = exclusive scan of lcount; lcount reset to serve as the placement cursor
+  BIN_MARK(4);
+  {  // lstart = exclusive scan of lcount
     const int per = (n_bins + BIN_THREADS - 1) / BIN_THREADS;
     const int b0 = threadIdx.x * per;
     int sum = 0;
@@ -382,22 +421,35 @@ k_bin_sort(int2 *__restrict__ events, int32_t *__restrict__ toff, int32_t *__res
       if (b0 + k < n_bins) {
         lstart[b0 + k] = run;
         run += lcount[b0 + k];
-        lcount[b0 + k] = 0;
       }
     if (threadIdx.x == 0) lstart[n_bins] = all;
   }
   __syncthreads();
+  BIN_MARK(5);
 #pragma unroll
   for (int e = 0; e < EV_PER_THREAD; ++e)
     if (j[e] >= 0) {
       const int b = j[e] >> BIN_SHIFT;
-      ev_buf[lstart[b] + atomicAdd(&lcount[b], 1)] = make_int2((int)(first + e), j[e]);
+      ev_buf[lstart[b] + rank[e]] = make_int2((int)(first + e), j[e]);
     }
   __syncthreads();
+  BIN_MARK(6);
   const int n_ev = lstart[n_bins];
   for (int t = threadIdx.x; t < n_ev; t += BIN_THREADS) events[tile_first + t] = ev_buf[t];
   for (int b = threadIdx.x; b <= n_bins; b += BIN_THREADS) my_off[b] = lstart[b];
+  BIN_MARK(7);
 }
+
+// The compaction that ends the previous sub-step, done at the start of this kernel instead of in
+// a launch of its own (one-cell non-adaptive runs; defined after the compaction code below).
+// While the state is healthy - nearly always - that launch did nothing, at 4.7 us per time step.
+// (SortPrologue: index.h)
+template <bool RNG>
+__global__ void k_bin_sort(int2 *events, int32_t *toff, int32_t *jarr, int n_bins,
+                           const double *u01, const int64_t *cell_start, int64_t n_cell,
+                           const int64_t *p_length, int64_t length_arg, u128 s_off, u128 inc,
+                           const u128 *tab, const uint64_t *dev_off, SortPrologue P,
+                           const u128 *aff);
 
 template <int FMT>
 __global__ void __launch_bounds__(BIN_THREADS)
@@ -415,69 +467,88 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
   const int64_t length = p_length ? *p_length : length_arg;
   const int64_t base = (int64_t)blockIdx.x * BIN_POS;
   if (base >= length) return;
+  BIN_MARK(8);
   const int bin = blockIdx.x;
-  {  // run lengths of this bin, tile by tile, and their exclusive scan
-    const int per = (n_tiles + BIN_THREADS - 1) / BIN_THREADS;
-    const int t0 = threadIdx.x * per;
-    int sum = 0;
-    for (int k = 0; k < per; ++k) {
-      const int t = t0 + k;
-      if (t < n_tiles) {
-        const int32_t *row = toff + (int64_t)t * (n_bins + 1) + bin;
-        const int a = row[0], b = row[1];
-        run_lo[t] = t * EV_TILE + a;  // (index into `events`: below 2^31 for every supported size)
-        run_pre[t] = b - a;
-        sum += b - a;
-      }
-    }
-    int all;
-    int run = block_excl_scan(sum, &all);
-    for (int k = 0; k < per; ++k) {
-      const int t = t0 + k;
-      if (t < n_tiles) {
-        const int v = run_pre[t];
-        run_pre[t] = run;
-        run += v;
-      }
-    }
-    if (threadIdx.x == 0) run_pre[n_tiles] = all;
+  // (run_pre / run_lo: LDS of an earlier scheme - runs located by a scan and a binary search)
+  (void)run_pre;
+  constexpr int PER_POS = BIN_POS / BIN_THREADS;
+  // what the records need from memory besides the hits, requested now, used at the end
+  int64_t id_v[PER_POS];
+  int32_t j_v[PER_POS];
+#pragma unroll
+  for (int k = 0; k < PER_POS; ++k) {
+    const int64_t p = base + threadIdx.x + k * BIN_THREADS;
+    id_v[k] = p < length ? idx0[p] : 0;
+    j_v[k] = p < length ? jarr[p] : -1;
+  }
+  // this bin's run in every tile's segment: `tpt` threads share a tile (4 at 2^20
+  // super-droplets: runs hold ~16 events), each takes every tpt-th event of the run; the first
+  // RUN_AHEAD of them are requested before any is placed
+  const int tpt = n_tiles >= BIN_THREADS ? 1 : BIN_THREADS / n_tiles;
+  const int sub = threadIdx.x % tpt, t_step = BIN_THREADS / tpt;
+  const int t_first = threadIdx.x / tpt;
+  int a_first = 0, b_first = 0;
+  if (t_first < n_tiles) {
+    const int32_t *row = toff + (int64_t)t_first * (n_bins + 1) + bin;
+    a_first = row[0];
+    b_first = row[1];
   }
   for (int q = threadIdx.x; q < (SLOTS + 1) * BIN_POS; q += BIN_THREADS) slot[q] = -1;
-  __syncthreads();
+  BIN_MARK(9);
+  // LDS only: __syncthreads() would also wait for the global loads requested above
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  BIN_MARK(10);
   // hits on this bin's positions: the first SLOTS inline (claimed by compare-and-swap), rest listed
-  const int n_ev = run_pre[n_tiles];
-  for (int e = threadIdx.x; e < n_ev; e += BIN_THREADS) {
-    int lo = 0, hi = n_tiles;  // largest t with run_pre[t] <= e
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (run_pre[mid] <= e) lo = mid; else hi = mid;
+  constexpr int RUN_AHEAD = 8;
+  for (int t = t_first; t < n_tiles; t += t_step) {
+    int a = a_first, b = b_first;
+    if (t != t_first) {
+      const int32_t *row = toff + (int64_t)t * (n_bins + 1) + bin;
+      a = row[0];
+      b = row[1];
     }
-    const int2 ev = events[(int64_t)run_lo[lo] + (e - run_pre[lo])];
-    const int q = ev.y - (int)base;
-    bool placed = false;
+    const int2 *run = events + (int64_t)t * EV_TILE;  // (tile-major: the tile's own segment)
+    int2 ev[RUN_AHEAD];
 #pragma unroll
-    for (int k = 0; k < SLOTS; ++k)
-      if (!placed) placed = atomicCAS(&slot[k * BIN_POS + q], -1, ev.x) == -1;
-    if (!placed) ovf_next[ev.x] = atomicExch(&head[q], ev.x);  // -1 terminated, built entirely here
+    for (int k = 0; k < RUN_AHEAD; ++k) {
+      const int x = a + sub + k * tpt;
+      ev[k] = x < b ? run[x] : make_int2(-1, 0);
+    }
+    auto place = [&](int2 e) {
+      const int q = e.y - (int)base;
+      bool placed = false;
+#pragma unroll
+      for (int k = 0; k < SLOTS; ++k)
+        if (!placed) placed = atomicCAS(&slot[k * BIN_POS + q], -1, e.x) == -1;
+      if (!placed) ovf_next[e.x] = atomicExch(&head[q], e.x);  // -1 terminated, built entirely here
+    };
+#pragma unroll
+    for (int k = 0; k < RUN_AHEAD; ++k)
+      if (ev[k].x >= 0) place(ev[k]);
+    for (int x = a + sub + RUN_AHEAD * tpt; x < b; x += tpt) place(run[x]);
   }
   __syncthreads();
-  for (int q = threadIdx.x; q < BIN_POS; q += BIN_THREADS) {
+  BIN_MARK(11);
+#pragma unroll
+  for (int kq = 0; kq < PER_POS; ++kq) {
+    const int q = threadIdx.x + kq * BIN_THREADS;
     const int64_t p = base + q;
     if (p >= length) break;
     const int32_t h = head[q];
-    const int32_t id = (int32_t)idx0[p];
+    const int32_t id = (int32_t)id_v[kq];
+    const int32_t jp = j_v[kq];
     if (FMT == SDM_REC_P21) {
       PackRec21 r;
-      p21_pack(r.lo, r.hi, jarr[p], slot[q], slot[BIN_POS + q], slot[2 * BIN_POS + q],
+      p21_pack(r.lo, r.hi, jp, slot[q], slot[BIN_POS + q], slot[2 * BIN_POS + q],
                slot[(SLOTS - 1) * BIN_POS + q], id, h >= 0);
       ((PackRec21 *)rec_out)[p] = r;
     } else if (FMT == SDM_REC_P24) {
       PackRec24 r;
-      p24_pack(r.lo, r.hi, jarr[p], slot[q], slot[BIN_POS + q], slot[2 * BIN_POS + q], id, h >= 0);
+      p24_pack(r.lo, r.hi, jp, slot[q], slot[BIN_POS + q], slot[2 * BIN_POS + q], id, h >= 0);
       ((PackRec24 *)rec_out)[p] = r;
     } else {
       PackRec r;
-      r.j = jarr[p];
+      r.j = jp;
       r.s0 = slot[q];
       r.s1 = slot[BIN_POS + q];
       r.val = id | (h >= 0 ? (int32_t)0x80000000 : 0);
@@ -485,6 +556,7 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
     }
     if (h >= 0) ovf_head[p] = h;
   }
+  BIN_MARK(12);
 }
 
 // backward walk over packed records; positions [length, n_total) are copied through
@@ -521,7 +593,7 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
                                 const double *u01, const int64_t *cell_start, int64_t n_cell,
                                 const int64_t *p_length, int64_t length_bound, int64_t n_total,
                                 u128 s_off, u128 inc, ShuffleViews *views, int64_t id_bound,
-                                const uint64_t *dev_off) {
+                                const uint64_t *dev_off, const SortPrologue *prologue) {
   // id_bound: the ids in idx0 are below it (-1: unknown); decides the record layout
   const int64_t both = id_bound > length_bound ? id_bound : length_bound;
   const int fmt = id_bound < 0 ? SDM_REC_PLAIN
@@ -554,14 +626,18 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
   {
     PhaseScope ph(ctx, SDM_PHASE_SHUFFLE_BUILD);
+    SortPrologue no_prologue;
+    memset(&no_prologue, 0, sizeof(no_prologue));
     if (u01)
       hipLaunchKernelGGL((k_bin_sort<false>), dim3(nt), block, lds_sort, ctx->stream, events, toff,
                          jarr, nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc,
-                         ctx->pcg_tab, (const uint64_t *)nullptr);
+                         ctx->pcg_tab, (const uint64_t *)nullptr, no_prologue,
+                         (const u128 *)nullptr);
     else
       hipLaunchKernelGGL((k_bin_sort<true>), dim3(nt), block, lds_sort, ctx->stream, events, toff,
                          jarr, nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc,
-                         ctx->pcg_tab, dev_off);
+                         ctx->pcg_tab, dev_off, prologue ? *prologue : no_prologue,
+                         (const u128 *)ctx->pcg_aff);
 #define BUILD_LAUNCH(F)                                                                        \
   hipLaunchKernelGGL(k_bin_build2<F>, dim3(nb), block, lds_build, ctx->stream, (void *)rec,    \
                      ovf_head, ovf_next, events, toff, jarr, nb, nt, idx0, p_length, length_bound)
@@ -596,7 +672,7 @@ int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
                             const int64_t *cell_start, int64_t n_cell, const int64_t *p_length,
                             int64_t length_bound, const uint64_t *rng_state_inc,
                             uint64_t rng_offset, ShuffleViews *views, int64_t id_bound,
-                            const uint64_t *dev_off) {
+                            const uint64_t *dev_off, const SortPrologue *prologue) {
   int rc = sdm_pcg_prepare(ctx, rng_state_inc);
   if (rc) return rc;
   const u128 st = (((u128)rng_state_inc[0]) << 64) | rng_state_inc[1];
@@ -604,7 +680,7 @@ int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
   // dev_off: the kernels add the stream position themselves (graph replay)
   const u128 s_off = dev_off ? st : sdm_pcg_advance_host(st, inc, rng_offset);
   return shuffle_binned_async(ctx, scratch, nullptr, idx0, nullptr, cell_start, n_cell, p_length,
-                              length_bound, 0, s_off, inc, views, id_bound, dev_off);
+                              length_bound, 0, s_off, inc, views, id_bound, dev_off, prologue);
 }
 
 size_t sdm_shuffle_scratch(int64_t n) {
@@ -726,7 +802,11 @@ __device__ __forceinline__ bool sd_dead(const int64_t *__restrict__ multiplicity
 #ifndef COMPACT_THREADS
 #define COMPACT_THREADS 1024
 #endif
-#define COMPACT_WAVES (COMPACT_GRID * COMPACT_THREADS / SDM_WAVE)
+// capacity of the per-wavefront tables: the stand-alone kernel runs COMPACT_GRID workgroups, the
+// prologue of k_bin_sort as many as that kernel has (at most COMPACT_MAX_GROUPS)
+#define COMPACT_MAX_GROUPS 256
+#define COMPACT_WAVES (COMPACT_MAX_GROUPS * COMPACT_THREADS / SDM_WAVE)
+static_assert(COMPACT_GRID <= COMPACT_MAX_GROUPS && COMPACT_THREADS == BIN_THREADS, "shapes");
 
 __device__ __forceinline__ bool grid_barrier(unsigned int *bar, unsigned int target) {
   __shared__ bool ok;
@@ -801,21 +881,15 @@ __device__ __forceinline__ void compact_epilogue(const CompactEpilogue &E,
 
 // FLAG_ONLY: the caller guarantees that no live super-droplet has zero multiplicity (it entered
 // with a healthy state and only flags positions), so the random gather of multiplicities is skipped
+// the compaction proper, by every workgroup of the grid (all resident; at most COMPACT_MAX_GROUPS);
+// false: a grid barrier timed out (fctl[7] = 2).  *new_length: the length every workgroup computed
 template <bool FLAG_ONLY>
-__global__ void __launch_bounds__(COMPACT_THREADS)
-k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restrict__ idx,
-                     int64_t flag, int64_t *__restrict__ fctl, int32_t *__restrict__ wave_dead,
-                     int n_tiles, int64_t *__restrict__ ctl, int32_t *__restrict__ holes,
-                     int64_t *__restrict__ fillers, int64_t *__restrict__ cell_start_single,
-                     unsigned int *__restrict__ bar, CompactEpilogue E) {
-  if (E.gwords && blockIdx.x == 0 && threadIdx.x == 0) {  // this sub-step's draws are consumed
-    E.gwords[0] += E.advance;
-    E.gwords[1] += E.advance_b;
-  }
-  if (fctl[FCTL_HEALTHY] != 0) {
-    if (E.dt_left && blockIdx.x == 0) compact_epilogue(E, fctl);
-    return;
-  }
+__device__ __forceinline__ bool
+compact_run(const int64_t *__restrict__ multiplicity, int64_t *__restrict__ idx, int64_t flag,
+            int64_t *__restrict__ fctl, int32_t *__restrict__ wave_dead, int n_tiles,
+            int64_t *__restrict__ ctl, int32_t *__restrict__ holes, int64_t *__restrict__ fillers,
+            int64_t *__restrict__ cell_start_single, unsigned int *__restrict__ bar,
+            const CompactEpilogue &E, int64_t *new_length) {
   const int64_t length = fctl[FCTL_VALID];
   __shared__ int sm[COMPACT_THREADS / SDM_WAVE];
   __shared__ int excl[COMPACT_WAVES];
@@ -840,7 +914,7 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
 #define BARRIER_OR_FAIL(k)                                   \
   if (!grid_barrier(bar, (k) * gridDim.x)) {                 \
     if (threadIdx.x == 0) fctl[7] = 2; /* surfaced by the host as an error */ \
-    return;                                                  \
+    return false;                                            \
   }
   BARRIER_OR_FAIL(1)
   // exclusive scan of the chunk totals, by every workgroup for itself
@@ -878,6 +952,7 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
     total_dead = all;
   }
   const int64_t new_len = length - total_dead;
+  *new_length = new_len;
   // phase C: holes of the surviving prefix, live elements of the tail (from the end backwards)
   if (total_dead != 0) {
     int64_t before = excl[wave];  // dead positions ahead of the current tile
@@ -934,6 +1009,55 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
     }
   }
   if (last && E.dt_left) compact_epilogue(E, fctl);
+  return true;
+}
+
+template <bool FLAG_ONLY>
+__global__ void __launch_bounds__(COMPACT_THREADS)
+k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restrict__ idx,
+                     int64_t flag, int64_t *__restrict__ fctl, int32_t *__restrict__ wave_dead,
+                     int n_tiles, int64_t *__restrict__ ctl, int32_t *__restrict__ holes,
+                     int64_t *__restrict__ fillers, int64_t *__restrict__ cell_start_single,
+                     unsigned int *__restrict__ bar, CompactEpilogue E) {
+  if (E.gwords && blockIdx.x == 0 && threadIdx.x == 0) {  // this sub-step's draws are consumed
+    E.gwords[0] += E.advance;
+    E.gwords[1] += E.advance_b;
+  }
+  if (fctl[FCTL_HEALTHY] != 0) {
+    if (E.dt_left && blockIdx.x == 0) compact_epilogue(E, fctl);
+    return;
+  }
+  int64_t new_len;
+  (void)compact_run<FLAG_ONLY>(multiplicity, idx, flag, fctl, wave_dead, n_tiles, ctl, holes,
+                               fillers, cell_start_single, bar, E, &new_len);
+}
+
+// k_bin_sort (declared above): the tile sort of the shuffle build, with the previous sub-step's
+// compaction as its prologue when P.fctl is set.  Every workgroup reads the healthy word before
+// the last one to pass the final barrier of compact_run can set it again, so the branch is uniform
+// over the grid; afterwards each workgroup continues with the length it computed itself (the
+// committed words are for the kernels that follow).
+template <bool RNG>
+__global__ void __launch_bounds__(BIN_THREADS)
+k_bin_sort(int2 *__restrict__ events, int32_t *__restrict__ toff, int32_t *__restrict__ jarr,
+           int n_bins, const double *__restrict__ u01, const int64_t *__restrict__ cell_start,
+           int64_t n_cell, const int64_t *__restrict__ p_length, int64_t length_arg, u128 s_off,
+           u128 inc, const u128 *__restrict__ tab, const uint64_t *__restrict__ dev_off,
+           SortPrologue P, const u128 *__restrict__ aff) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int64_t length, one_cell_len = -1;
+  if (P.fctl && P.fctl[FCTL_HEALTHY] == 0) {
+    const CompactEpilogue none = {nullptr, nullptr, nullptr, 0, nullptr, 0, 0};
+    if (!compact_run<true>(P.multiplicity, P.idx, P.flag, P.fctl, P.wave_dead, P.n_tiles, P.ctl,
+                           P.holes, P.fillers, P.cell_start_single, P.bar, none, &length))
+      return;
+    one_cell_len = length;
+    __syncthreads();  // (compact_run's shared arrays are not touched below, smem is)
+  } else {
+    length = p_length ? *p_length : length_arg;
+  }
+  bin_sort_body<RNG>(smem, events, toff, jarr, n_bins, u01, cell_start, n_cell, length,
+                     one_cell_len, s_off, inc, tab, dev_off, aff);
 }
 
 // `bar`: 4 zero-initialised device words owned by the caller (persist across launches)
@@ -974,6 +1098,48 @@ int sdm_compact_fused_async(sdm_ctx *ctx, char *scratch, const int64_t *multipli
                        fillers, cell_start_single, bar, E);
   LAUNCH_CHECK();
   return SDM_OK;
+}
+
+// can the tile sort of a build over `length_bound` positions take the compaction as its prologue?
+// Its workgroups synchronise through a grid barrier then: all of them have to be resident at once
+bool sdm_shuffle_sort_can_compact(sdm_ctx *ctx, int64_t length_bound) {
+  if (!binned_ok(length_bound, false)) return false;
+  const int nb = bin_count(length_bound), nt = ev_tile_count(length_bound);
+  if (nt > COMPACT_MAX_GROUPS) return false;
+  if (ctx->sort_resident == 0) {
+    const size_t lds_sort = sizeof(int32_t) * (size_t)((nb + 1) + ((nb + 1) & ~1) + 2) +
+                            sizeof(int2) * EV_TILE;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bin_sort<true>, BIN_THREADS,
+                                                     lds_sort) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) !=
+            hipSuccess) {
+      (void)hipGetLastError();
+      ctx->sort_resident = -1;
+    } else {
+      ctx->sort_resident = per_cu * cus > 0 ? per_cu * cus : -1;
+    }
+  }
+  return nt <= ctx->sort_resident;
+}
+
+// the arguments of sdm_compact_fused_async(.., flag_only = true) as the prologue of the next tile
+// sort (sdm_shuffle_sort_can_compact)
+void sdm_compact_as_prologue(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity,
+                             int64_t *idx, int64_t length_bound, int64_t flag, int64_t *fctl,
+                             int64_t *ctl, int64_t *cell_start_single, SortPrologue *out) {
+  Carver cv(scratch);
+  out->fctl = fctl;
+  out->multiplicity = multiplicity;
+  out->idx = idx;
+  out->flag = flag;
+  out->n_tiles = (int)grid_for(length_bound, SDM_WAVE);
+  out->wave_dead = cv.take<int32_t>(COMPACT_WAVES);
+  out->holes = cv.take<int32_t>(length_bound);
+  out->fillers = cv.take<int64_t>(length_bound);
+  out->ctl = ctl;
+  out->cell_start_single = cell_start_single;
+  out->bar = (unsigned int *)(ctx->dscal + 12);
 }
 
 // after a timed-out grid barrier (error word 2) the workgroups returned without re-arming the

@@ -119,12 +119,15 @@ def test_full_size_displacement_then_collisions(hip_engine, oracle_engine):
 
 
 @pytest.mark.parametrize("n_sd,steps,thin", [(2**20, 12, None), (2**16, 12, 0.02),
-                                             (2**16, 40, 100.0), (2**24, 2, None)])
+                                             (2**16, 40, 100.0), (2**24, 2, None),
+                                             (2**20, 6, 0.02), (2**19 + 5, 6, 0.02),
+                                             (2**21, 4, 0.02)])
 def test_many_steps_in_one_call_equal_oracle(n_sd, steps, thin, hip_engine, oracle_engine):
     """`run(n)` of the single-cell non-adaptive box = one `sdm_collision_run` call: n time steps
     without the host in between.  `thin` (a cell volume): multiplicities of 1..3, so that
     super-droplets die - in every step (0.02) or once in a few steps (100) - and the
-    device-gated compaction has to run in the middle of a call."""
+    device-gated compaction has to run in the middle of a call: as the prologue of the next
+    step's tile sort up to 2^20 super-droplets (256 tiles), in a launch of its own above."""
     snaps = []
     for engine in (hip_engine, oracle_engine):
         runner = make_box(engine, "shima", n_sd=n_sd, adaptive=False,
