@@ -57,6 +57,12 @@ struct sdm_ctx {
   bool cell_attr_done;     // fused.hip: large-LDS attribute of the per-cell kernels set on this device
   int compact_grid;        // index.hip: workgroups of k_compact_persistent that are co-resident here
   int sort_resident;       // index.hip: likewise k_bin_sort (0: not asked yet, -1: unknown)
+  // fused.hip: which of the two sets of pair-list fill counts the previous step of the run left clean
+  struct {
+    bool active;
+    const void *owner;
+    int clean_set;
+  } lists;
   // fused.hip: the compaction that ends a sub-step is left to the next tile sort of the same run
   struct {
     bool active;

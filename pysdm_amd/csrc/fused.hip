@@ -1858,11 +1858,23 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   A.dt_todo = S.dt_todo;
   A.cell_min = S.cell_min;
   A.list = S.list;
-  A.list_count = S.list_count;
-  A.list_count_next = S.list_count + LIST_NL * SDM_CNT_STRIDE;
-  if (cfg->enable_breakup)  // both sets once per call (the arena is shared with other calls)
-    HIP_TRY(hipMemsetAsync(S.list_count, 0,
-                           sizeof(unsigned long long) * 2 * LIST_NL * SDM_CNT_STRIDE, ctx->stream));
+  {
+    // two sets of fill counts: a sub-step appends under one, its k_resolve_dense clears the other.
+    // Both cleared once per call (the arena is shared with other calls) - or not at all when the
+    // previous step of the same run says which set it left clean
+    int first_set = 0;
+    if (cfg->enable_breakup) {
+      if (ctx->lists.active && ctx->lists.owner == (const void *)st && !(flags & 2))
+        first_set = ctx->lists.clean_set;
+      else
+        HIP_TRY(hipMemsetAsync(S.list_count, 0,
+                               sizeof(unsigned long long) * 2 * LIST_NL * SDM_CNT_STRIDE,
+                               ctx->stream));
+    }
+    ctx->lists.active = false;
+    A.list_count = S.list_count + first_set * LIST_NL * SDM_CNT_STRIDE;
+    A.list_count_next = S.list_count + (1 - first_set) * LIST_NL * SDM_CNT_STRIDE;
+  }
   A.list_nl = 1;  // the per-cell kernel: one list (a cell's workgroup may hold up to P pairs)
   A.list_cap = P;
   A.block_min = S.block_min;
@@ -2538,6 +2550,11 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     hipLaunchKernelGGL(k_fold_counters, one, dim3(SDM_CNT_SLOTS), 0, s, A);
     LAUNCH_CHECK();
   }
+  if (cfg->enable_breakup && more_follow) {  // (A.list_count: the set the last sub-step left clean)
+    ctx->lists.active = true;
+    ctx->lists.owner = st;
+    ctx->lists.clean_set = A.list_count == S.list_count ? 0 : 1;
+  }
   res->n_substeps = n_sub;
   res->idx_swapped = swaps & 1;
   res->rng_offset = off;
@@ -2577,6 +2594,7 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   ctx->ahead.active = false;
   ctx->carry.active = false;
   ctx->late_compact.active = false;
+  ctx->lists.active = false;
   return collision_step(ctx, cfg, st, res, flags, true, false);
 }
 
@@ -2707,6 +2725,7 @@ extern "C" int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step
   ctx->ahead.active = false;
   ctx->carry.active = false;
   ctx->late_compact.active = false;
+  ctx->lists.active = false;
   sdm_step_result total;
   memset(&total, 0, sizeof(total));
   total.valid_n_sd = -1;
