@@ -1,12 +1,11 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/r02_gputest_m.log 2>&1 || { tail -60 gpurun_out/r02_gputest_m.log; exit 1; }
-tail -2 gpurun_out/r02_gputest_m.log
-for w in berry_breakup straub_rain straub; do
-python bench.py --workload $w --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/r02_bench_${w}_fold.json 2>/dev/null
+python bench.py --workload kinematic2d --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/exp_k2d_base2.json 2>/dev/null
 python -c "
-import json; d=json.load(open('gpurun_out/r02_bench_${w}_fold.json')); print('$w', d['value'], d['ms_per_step'], d['roofline']['phase_ms_per_step'])"
-done
-python bench.py --adaptive 1 --no-cpu-baseline > gpurun_out/r02_bench_shima_adaptive_fold.json 2>/dev/null
+import json; d=json.load(open('gpurun_out/exp_k2d_base2.json')); print('base', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['repetitions'])"
+SDM_EXPERIMENT_LAZY_SOA=1 python bench.py --workload kinematic2d --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/exp_k2d_lazy.json 2>/dev/null
 python -c "
-import json; d=json.load(open('gpurun_out/r02_bench_shima_adaptive_fold.json')); print('shima adaptive', d['value'], d['ms_per_step'], d['roofline']['phase_ms_per_step'])"
+import json; d=json.load(open('gpurun_out/exp_k2d_lazy.json')); print('lazy', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['repetitions'])"
+python bench.py --workload berry_breakup --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/r02_bench_berry_breakup_lists.json 2>/dev/null
+python -c "
+import json; d=json.load(open('gpurun_out/r02_bench_berry_breakup_lists.json')); print('berry', d['value'], d['ms_per_step'])"
