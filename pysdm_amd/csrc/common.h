@@ -56,18 +56,18 @@ struct sdm_ctx {
   size_t graph_key_bytes;
   bool cell_attr_done;     // fused.hip: large-LDS attribute of the per-cell kernels set on this device
   int compact_grid;        // index.hip: workgroups of k_compact_persistent that are co-resident here
-  int sort_resident;       // index.hip: likewise k_bin_sort (0: not asked yet, -1: unknown)
+  int build_resident;      // index.hip: likewise k_bin_build2 (0: not asked yet, -1: unknown)
+  // fused.hip: the pair kernel of the previous sub-step of this run sorted this one's events
+  struct {
+    bool active;
+    const void *owner;
+  } presorted;
   // fused.hip: which of the two sets of pair-list fill counts the previous step of the run left clean
   struct {
     bool active;
     const void *owner;
     int clean_set;
   } lists;
-  // fused.hip: the compaction that ends a sub-step is left to the next tile sort of the same run
-  struct {
-    bool active;
-    const void *owner;
-  } late_compact;
   int debug_box_delay_us;  // SDM_DEBUG_BOX_DELAY_US (tests): the host sleeps before each wait
   // fused.hip: what a multi-cell adaptive step knows at its end, for the next step of the same call
   // (valid length, an upper bound of the cell sizes; the state is sorted) - saves that step's

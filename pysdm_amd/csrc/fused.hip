@@ -14,6 +14,7 @@
 #include <algorithm>
 #include "common.h"
 #include "index.h"
+#include "shuffle_build.h"
 #include "physics.h"
 
 int sdm_adaptive_end_async(sdm_ctx *ctx, const double *dt_left, int64_t n_cell,
@@ -732,6 +733,53 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_all(sdm_step_cfg cfg, FusedA
   if (p != 0) p /= (double)cfg.substeps;  // collision.py:279
   pair_update_body<BREAKUP>(cfg, A, d, d < W / 2, p, u, u_b, true, R.off, R.j, R.k,
                             2 * d + R.off, true);
+}
+
+// The same with the tile sort of the NEXT sub-step's shuffle build on the side: the first
+// X.n_tiles workgroups sort (index.hip: k_bin_sort's body - generator arithmetic and LDS, which a
+// kernel that waits on random memory accesses has to spare), the others are the pair kernel in
+// workgroups of BIN_THREADS.  The sort is for the length this sub-step begins with; if a
+// super-droplet dies in it, the next build redoes it after the compaction (k_bin_build2).  Saves
+// that sub-step a 13-us kernel with its boundary (coalescence only: the pair lists of the
+// breakup route are sized for SDM_BLOCK-thread workgroups).
+struct SortAhead {
+  int2 *events;
+  int32_t *toff, *jarr;
+  int n_bins, n_tiles;
+  const int64_t *p_length;
+  u128 s_off;  // generator state at the next sub-step's first u01
+};
+
+// draw number `index` of the stream starting at s_base (ready jumps: common.h, pcg_aff)
+__device__ __forceinline__ double draw_at(u128 s_base, u128 inc, const u128 *__restrict__ aff,
+                                          int64_t index) {
+  u128 state = pcg_apply(pcg_apply(s_base, aff, PCG_AFF_SMALL + index / PCG_AFF_STRIDE), aff,
+                         index % PCG_AFF_STRIDE);
+  state = state * pcg_mult() + inc;
+  return pcg_output(state);
+}
+
+template <int KERNEL>
+__global__ void __launch_bounds__(BIN_THREADS)
+k_pair_all_sort(sdm_step_cfg cfg, FusedArgs A, SortAhead X) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < X.n_tiles) {
+    const int64_t length = *X.p_length;
+    bin_sort_body<true>(smem, X.events, X.toff, X.jarr, X.n_bins, nullptr, nullptr, 1, length,
+                        length, X.s_off, A.rng_inc, A.rng_tab, nullptr, A.rng_aff);
+    return;
+  }
+  const int64_t W = A.ctl[CTL_WORK];
+  const int64_t d = (int64_t)(blockIdx.x - X.n_tiles) * BIN_THREADS + threadIdx.x;
+  if (d == 0) A.ctl[CTL_PAIRS] += W / 2;
+  const double u = draw_at(A.s_rand, A.rng_inc, A.rng_aff, d);
+  PairInfo R;
+  R.have = false; R.off = 2; R.prob = 0; R.j = R.k = 0;
+  if (d < (cfg.n_sd + 1) / 2) R = pair_prob_body<KERNEL, false>(cfg, A, d, W, 0.0);
+  double p = R.prob;
+  if (p != 0) p /= (double)cfg.substeps;  // collision.py:279
+  pair_update_body<false>(cfg, A, d, d < W / 2, p, u, 0.0, true, R.off, R.j, R.k, 2 * d + R.off,
+                          true);
 }
 
 // ---- adaptive: probabilities first (per-cell min of the optimal dt is a global dependency) ---
@@ -2275,6 +2323,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   for (;;) {
     if (!cfg->adaptive && n_sub >= cfg->substeps) break;
     if (cfg->adaptive && work_host == 0) break;
+    bool sort_ahead = false;  // this sub-step's pair kernel sorts the next one's events
     if (head_ok) {
       if (!head_done) {
         rc = launch_head();
@@ -2332,17 +2381,18 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     } else if (split) {
       // single cell: event records only; the pair kernels walk them (2 positions per thread)
       ShuffleViews views;
-      // the previous sub-step of this run left its compaction to this tile sort (see (g))
+      // the pair kernel of the previous sub-step of this run sorted this one's events too
+      // (k_pair_all_sort): no k_bin_sort, and the compaction it skipped is the build's to do
       SortPrologue prologue;
-      const bool late = ctx->late_compact.active && ctx->late_compact.owner == (const void *)st;
-      ctx->late_compact.active = false;
-      if (late)
+      const bool presorted = ctx->presorted.active && ctx->presorted.owner == (const void *)st;
+      ctx->presorted.active = false;
+      if (presorted)
         sdm_compact_as_prologue(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl, S.cctl,
                                 st->cell_start, &prologue);
       rc = sdm_shuffle_build_async(ctx, S.shuffle, cur, st->cell_start, C, p_shuffle_len, N,
                                    cfg->rng_state_inc, u01_off, &views, N,
                                    ctx->graph_capture ? ctx->gwords : nullptr,
-                                   late ? &prologue : nullptr);
+                                   presorted ? &prologue : nullptr);
       if (rc) return rc;
       A.rec = views.rec;
       A.rec_fmt = views.fmt;
@@ -2376,7 +2426,41 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       // done by k_cell_step above
     } else if (!cfg->adaptive) {
       PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
-      DISPATCH_PAIR(k_pair_all, dim3(grid_for((N + 1) / 2)));
+      // another sub-step of the same run follows: its tile sort rides along (k_pair_all_sort)
+      static const bool presort_off = getenv("SDM_NO_PRESORT") != nullptr;  // (A/B runs)
+      sort_ahead = split_one && !cell_path && !cfg->enable_breakup && !cfg->optimized_random &&
+                   (n_sub + 1 < cfg->substeps || more_follow) && !ctx->graph_capture &&
+                   A.rng_aff && !presort_off && A.rec != nullptr &&
+                   (int64_t)grid_for(N, PCG_AFF_STRIDE) < PCG_AFF_TILES &&
+                   sdm_shuffle_presort_ok(ctx, N, N);
+      if (sort_ahead) {
+        SortBuffers B;
+        sdm_shuffle_sort_buffers(S.shuffle, N, &B);
+        SortAhead X;
+        X.events = B.events;
+        X.toff = B.toff;
+        X.jarr = B.jarr;
+        X.n_bins = B.n_bins;
+        X.n_tiles = B.n_tiles;
+        X.p_length = st->cell_start + C;
+        X.s_off = sdm_pcg_advance_host(rng_state, rng_inc, off);  // (off: the next draw's start)
+        const dim3 grid((unsigned)(B.n_tiles + grid_for((N + 1) / 2, BIN_THREADS)));
+        const dim3 big(BIN_THREADS);
+#define PAIR_SORT(K) hipLaunchKernelGGL((k_pair_all_sort<K>), grid, big, B.lds_bytes, s, *cfg, A, X)
+        switch (cfg->kernel) {
+          case SDM_KERNEL_GOLOVIN: PAIR_SORT(SDM_KERNEL_GOLOVIN); break;
+          case SDM_KERNEL_GEOMETRIC: PAIR_SORT(SDM_KERNEL_GEOMETRIC); break;
+          case SDM_KERNEL_PARAMETERIZED: PAIR_SORT(SDM_KERNEL_PARAMETERIZED); break;
+          case SDM_KERNEL_SIMPLE_GEOMETRIC: PAIR_SORT(SDM_KERNEL_SIMPLE_GEOMETRIC); break;
+          case SDM_KERNEL_LINEAR: PAIR_SORT(SDM_KERNEL_LINEAR); break;
+          default: PAIR_SORT(SDM_KERNEL_CONSTANT);
+        }
+#undef PAIR_SORT
+        ctx->presorted.active = true;
+        ctx->presorted.owner = st;
+      } else {
+        DISPATCH_PAIR(k_pair_all, dim3(grid_for((N + 1) / 2)));
+      }
       LAUNCH_CHECK();
     } else {
       if (C > 1) {  // one cell: k_cells_adaptive does this part too
@@ -2435,15 +2519,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         epilogue.box = ctx->box_dev;
         epilogue.seq = box_seq;
       }
-      // one cell, non-adaptive, and another sub-step of the same run follows: its tile sort does
-      // the compaction as a prologue (index.hip: k_bin_sort) - no launch here
-      static const bool late_off = getenv("SDM_NO_LATE_COMPACTION") != nullptr;  // (A/B runs)
-      const bool follows = n_sub + 1 < cfg->substeps || more_follow;
-      if (split_one && !cell_path && !cfg->adaptive && follows && !ctx->graph_capture &&
-          !late_off &&
-          sdm_shuffle_sort_can_compact(ctx, N)) {
-        ctx->late_compact.active = true;
-        ctx->late_compact.owner = st;
+      if (sort_ahead) {
+        // the next build runs the compaction itself if a super-droplet died (k_bin_build2)
       } else {
         rc = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl, S.cctl,
                                      C == 1 ? st->cell_start : nullptr, true, &epilogue);
@@ -2593,8 +2670,8 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   ARG_TRY(ctx != nullptr);
   ctx->ahead.active = false;
   ctx->carry.active = false;
-  ctx->late_compact.active = false;
   ctx->lists.active = false;
+  ctx->presorted.active = false;
   return collision_step(ctx, cfg, st, res, flags, true, false);
 }
 
@@ -2724,8 +2801,8 @@ extern "C" int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step
   ARG_TRY(ctx && res && st && n_steps >= 0);
   ctx->ahead.active = false;
   ctx->carry.active = false;
-  ctx->late_compact.active = false;
   ctx->lists.active = false;
+  ctx->presorted.active = false;
   sdm_step_result total;
   memset(&total, 0, sizeof(total));
   total.valid_n_sd = -1;

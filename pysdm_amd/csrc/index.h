@@ -25,9 +25,7 @@ int sdm_counting_sort_async(sdm_ctx *ctx, char *scratch, int64_t *new_idx, const
 int sdm_cell_start_from_counts_async(sdm_ctx *ctx, const int64_t *count, int64_t *cell_start,
                                      int64_t n_cell, const int64_t *p_gate);
 bool sdm_shuffle_can_split(int64_t n, bool global);
-// The compaction that ends the previous sub-step, done at the start of the tile sort instead of in
-// a launch of its own (one-cell non-adaptive runs).  While the state is healthy - nearly always -
-// that launch did nothing, at 4.7 us per time step.
+// The arguments of a compaction run by another kernel of the build (k_bin_build2's prologue)
 struct SortPrologue {
   int64_t *fctl;  // NULL: no prologue
   const int64_t *multiplicity;
@@ -41,7 +39,26 @@ struct SortPrologue {
   int64_t *cell_start_single;
   unsigned int *bar;
 };
-bool sdm_shuffle_sort_can_compact(sdm_ctx *ctx, int64_t length_bound);
+// k_bin_build2 after a tile sort done ahead of time (fused.hip: k_pair_all_sort): the compaction and
+// the re-sort it has to do itself when a super-droplet died in between
+struct BuildPrologue {
+  SortPrologue compact;  // compact.fctl == NULL: none
+  int2 *events;
+  int32_t *toff, *jarr;
+  u128 s_off, inc;
+  const u128 *tab, *aff;
+};
+// the buffers of a build, for a tile sort done elsewhere (same scratch, same size)
+struct SortBuffers {
+  int2 *events;
+  int32_t *toff, *jarr;
+  int n_bins, n_tiles;
+  size_t lds_bytes;
+};
+// true: builds over `length_bound` positions can take their tile sort from the previous pair kernel
+// (as many tiles as bins, all workgroups of the build resident at once for the rare re-sort)
+bool sdm_shuffle_presort_ok(sdm_ctx *ctx, int64_t length_bound, int64_t id_bound);
+void sdm_shuffle_sort_buffers(char *scratch, int64_t length_bound, SortBuffers *out);
 void sdm_compact_as_prologue(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity,
                              int64_t *idx, int64_t length_bound, int64_t flag, int64_t *fctl,
                              int64_t *ctl, int64_t *cell_start_single, SortPrologue *out);
@@ -51,7 +68,9 @@ int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
                             uint64_t rng_offset, ShuffleViews *views,
                             int64_t id_bound = -1,  // ids in idx0 are below it (-1: unknown)
                             const uint64_t *dev_off = nullptr,
-                            const SortPrologue *prologue = nullptr);
+                            // the tile sort was done ahead (k_pair_all_sort): what the build needs
+                            // for the compaction it may have to run first
+                            const SortPrologue *presorted = nullptr);
 // What ends an adaptive sub-step of a single cell (collision.py:185-187), done by the compaction
 // kernel's last act instead of a launch of its own: refused-breakup count of the counter slots
 // into fctl[4] (slots may be NULL), working length = dt_left[0] != 0 ? valid length : 0, control

@@ -3,6 +3,7 @@
 #include "common.h"
 #include "index.h"
 #include "shuffle_device.h"
+#include "shuffle_build.h"
 
 // ---------------------------------------------------------------------------------------
 // identity_index  (index_methods.py:14-20)
@@ -168,7 +169,7 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
                                 const int64_t *p_length, int64_t length_bound, int64_t n_total,
                                 u128 s_off, u128 inc, ShuffleViews *views, int64_t id_bound = -1,
                                 const uint64_t *dev_off = nullptr,
-                                const SortPrologue *prologue = nullptr);
+                                const SortPrologue *presorted = nullptr);
 
 // out-of-place core: out[0:length) = shuffled idx0[0:length), out[length:n_total) = idx0[...].
 // u01 == nullptr: draws generated in the kernel from (rng_state_inc, rng_offset).
@@ -235,329 +236,26 @@ int sdm_shuffle_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *
 // so the backward walk needs no separate gather of the initial content.  u01 comes either from
 // memory or from the PCG64 stream evaluated in place (16 consecutive draws per thread).
 // ---------------------------------------------------------------------------------------
-// Tile shapes (overridable at compile time for tuning runs: -DBIN_SHIFT=.. -DEV_TILE=.. ..).
-// Measured on MI355X at n_sd = 2^20 (profiles/README.md, "tile shapes"): 256 -> 1024 threads and
-// 2048 -> 4096 positions per bin took the build from 42 to 35 us; smaller or larger event tiles,
-// 8 PCG64 steps per thread and 8192-position bins were all slower.
-#ifndef BIN_SHIFT
-#define BIN_SHIFT 12
-#endif
-#define BIN_POS (1 << BIN_SHIFT)  // positions per bin (K4 workgroup)
-#ifndef BIN_THREADS
-#define BIN_THREADS 1024
-#endif
-#ifndef EV_TILE
-#define EV_TILE 4096     // events per K1 / K3 workgroup
-#endif
-#define EV_PER_THREAD (EV_TILE / BIN_THREADS)  // K3
-#ifndef K1_PER_THREAD
-#define K1_PER_THREAD 4  // K1: sequential PCG64 steps per thread kept short
-#endif
-#define K1_THREADS (EV_TILE / K1_PER_THREAD)
-static_assert(EV_PER_THREAD * BIN_THREADS == EV_TILE && K1_THREADS * K1_PER_THREAD == EV_TILE &&
-              K1_THREADS <= 1024 && BIN_THREADS % 64 == 0, "tile shapes");
-
-// PackRec and the backward walk live in shuffle_device.h (shared with the fused pair kernels)
-
-// own-event targets of BIN_PER_THREAD consecutive positions from `first` (local croupier)
-template <bool RNG, int PER>
-__device__ __forceinline__ void targets_run(int64_t first, int64_t length,
-                                          const double *__restrict__ u01,
-                                          const int64_t *__restrict__ cell_start, int64_t n_cell,
-                                          u128 s_tile, u128 inc, const u128 *__restrict__ tab,
-                                          int32_t (&j)[PER], int64_t one_cell_len = -1,
-                                          bool at_run = false) {
-  // at_run: s_tile is already the state at this thread's run
-  u128 state = 0;
-  if (RNG) state = at_run ? s_tile : pcg_jump(s_tile, tab, (uint64_t)threadIdx.x * PER);
-  const u128 mult = pcg_mult();
-  int64_t lo = 0, hi = 0;
-  bool have_cell = false;
-#pragma unroll
-  for (int e = 0; e < PER; ++e) {
-    const int64_t i = first + e;
-    double u = 0.0;
-    if (RNG) {
-      state = state * mult + inc;
-      u = pcg_output(state);
-    } else if (i < length) {
-      u = u01[i];
-    }
-    j[e] = -1;
-    if (i >= length) continue;
-    if (!have_cell || i >= hi) {
-      if (one_cell_len >= 0) {  // one cell [0, length): known to the caller (see k_bin_sort)
-        lo = 0;
-        hi = one_cell_len;
-      } else {
-        const int64_t c = n_cell == 1 ? 0 : find_cell(cell_start, n_cell, i);
-        lo = cell_start[c];
-        hi = cell_start[c + 1];
-      }
-      have_cell = true;
-    }
-    if (i > lo) {
-      const int64_t t = (int64_t)((double)lo + u * (double)(hi - lo));
-      // memory safety only: the reference would index past the cell with prob ~2^-43
-      j[e] = (int32_t)(t > hi - 1 ? hi - 1 : (t < lo ? lo : t));
-    }
-  }
-}
-
-// block-wide exclusive scan of one value per thread (BIN_THREADS threads); returns the exclusive
-// prefix, *total receives the block sum
-__device__ __forceinline__ int block_excl_scan(int v, int *total) {
-  __shared__ int wsum[BIN_THREADS / SDM_WAVE];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int incl = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
-  }
-  __syncthreads();  // protects wsum against the previous call
-  if (lane == 63) wsum[w] = incl;
-  __syncthreads();
-  int base = 0, sum = 0;
-#pragma unroll
-  for (int k = 0; k < BIN_THREADS / SDM_WAVE; ++k) {
-    if (k < w) base += wsum[k];
-    sum += wsum[k];
-  }
-  *total = sum;
-  return base + incl - v;
-}
-
-// ---- two launches (round 1 had four: count -> column scan -> scatter -> build; the count matrix,
-// its scan and the global scatter are gone: 32.5 -> 28.5 us of kernel time at 2^20, two launches
-// less).  K1': per event tile: own-event targets -> jarr; the tile's events ordered by target bin in LDS
-// and written back *in place* (tile-major, coalesced), with the tile's bin offsets toff[tile][0..nb].
-// K4': one workgroup per bin gathers its runs - for every tile the events toff[t][b]..toff[t][b+1]
-// of that tile's segment, ~16 events = two 64-B sectors each, the same granularity the scatter
-// wrote at - and assembles the records as k_bin_build does.  The order of the events inside a bin
-// is irrelevant (the walk takes the minimum over a position's candidates).
-// -DBIN_PROFILE (tuning builds only): phase time stamps of workgroup 7 of the two build kernels,
-// wall_clock64 ticks (100 MHz), read back through sdm_debug_bin_profile
+// (tile shapes, targets_run, block_excl_scan, bin_sort_body: shuffle_build.h)
 #ifdef BIN_PROFILE
 __device__ long long bin_prof[32];
-#define BIN_MARK(k) do { __syncthreads(); if (blockIdx.x == 7 && threadIdx.x == 0) bin_prof[k] = wall_clock64(); } while (0)
 extern "C" int sdm_debug_bin_profile(long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(bin_prof), sizeof(long long) * 32) == hipSuccess ? 0 : -2;
 }
-#else
-#define BIN_MARK(k)
 #endif
 
-// `one_cell_len` >= 0: the single cell [0, length) as the caller knows it (cell_start not read)
-template <bool RNG>
-__device__ __forceinline__ void
-bin_sort_body(char *smem, int2 *__restrict__ events, int32_t *__restrict__ toff,
-              int32_t *__restrict__ jarr, int n_bins, const double *__restrict__ u01,
-              const int64_t *__restrict__ cell_start, int64_t n_cell, int64_t length,
-              int64_t one_cell_len, u128 s_off, u128 inc, const u128 *__restrict__ tab,
-              const uint64_t *__restrict__ dev_off, const u128 *__restrict__ aff) {
-  int32_t *lstart = (int32_t *)smem;                      // n_bins + 1
-  int32_t *lcount = lstart + n_bins + 1;                  // n_bins
-  int2 *ev_buf = (int2 *)(lcount + ((n_bins + 1) & ~1));  // EV_TILE
-  __shared__ u128 s_slot;
-  BIN_MARK(0);
-  const int64_t tile_first = (int64_t)blockIdx.x * EV_TILE;
-  int32_t *my_off = toff + (int64_t)blockIdx.x * (n_bins + 1);
-  if (tile_first >= length) {
-    for (int b = threadIdx.x; b <= n_bins; b += BIN_THREADS) my_off[b] = 0;
-    return;
-  }
-  for (int b = threadIdx.x; b < n_bins; b += BIN_THREADS) lcount[b] = 0;
-  // The jump-aheads (to the tile, then to the thread's run) sit on the critical path of a
-  // one-workgroup-per-CU kernel.  Ready affine maps (ctx->pcg_aff) make them two 128-bit
-  // multiply-adds per thread and nothing to wait for (4.6 + 1.2 us of this kernel's 12.5 were
-  // the bit-by-bit jumps, `profiles/r02_bin_profile.txt`); otherwise bit by bit, the table in LDS
-  const bool ready = RNG && aff && !dev_off && EV_TILE == PCG_AFF_STRIDE &&
-                     (int64_t)blockIdx.x < PCG_AFF_TILES &&
-                     (BIN_THREADS - 1) * EV_PER_THREAD < PCG_AFF_SMALL;
-  __shared__ u128 ltab[128];
-  u128 s_tile = 0;
-  if (ready) {
-    s_tile = pcg_apply(pcg_apply(s_off, aff, PCG_AFF_SMALL + (int64_t)blockIdx.x), aff,
-                       (int64_t)threadIdx.x * EV_PER_THREAD);
-    __syncthreads();  // lcount is zero before anyone counts
-  } else if (RNG) {
-    if (threadIdx.x < 128) ltab[threadIdx.x] = tab[threadIdx.x];
-    __syncthreads();
-    tab = ltab;
-    // dev_off (graph replay): s_off is the generator's initial state, the stream position comes
-    // from the device
-    if (threadIdx.x == 0)
-      s_slot = pcg_jump(s_off, tab, (uint64_t)blockIdx.x * EV_TILE + (dev_off ? dev_off[0] : 0));
-    __syncthreads();
-    s_tile = s_slot;
-  } else {
-    __syncthreads();  // lcount is zero before anyone counts
-  }
-  BIN_MARK(1);
-  BIN_MARK(2);
-  const int64_t first = tile_first + (int64_t)threadIdx.x * EV_PER_THREAD;
-  int32_t j[EV_PER_THREAD];
-  targets_run<RNG, EV_PER_THREAD>(first, length, u01, cell_start, n_cell, s_tile, inc, tab, j,
-                                  one_cell_len, ready);
-  BIN_MARK(3);
-  int rank[EV_PER_THREAD];  // arrival number of the event in its bin: its place in the bin's run
-#pragma unroll
-  for (int e = 0; e < EV_PER_THREAD; ++e) {
-    rank[e] = j[e] >= 0 ? atomicAdd(&lcount[j[e] >> BIN_SHIFT], 1) : 0;
-    if (first + e < length) jarr[first + e] = j[e];
-  }
-  __syncthreads();
-  BIN_MARK(4);
-  {  // lstart = exclusive scan of lcount
-    const int per = (n_bins + BIN_THREADS - 1) / BIN_THREADS;
-    const int b0 = threadIdx.x * per;
-    int sum = 0;
-    for (int k = 0; k < per; ++k)
-      if (b0 + k < n_bins) sum += lcount[b0 + k];
-    int all;
-    int run = block_excl_scan(sum, &all);
-    for (int k = 0; k < per; ++k)
-      if (b0 + k < n_bins) {
-        lstart[b0 + k] = run;
-        run += lcount[b0 + k];
-      }
-    if (threadIdx.x == 0) lstart[n_bins] = all;
-  }
-  __syncthreads();
-  BIN_MARK(5);
-#pragma unroll
-  for (int e = 0; e < EV_PER_THREAD; ++e)
-    if (j[e] >= 0) {
-      const int b = j[e] >> BIN_SHIFT;
-      ev_buf[lstart[b] + rank[e]] = make_int2((int)(first + e), j[e]);
-    }
-  __syncthreads();
-  BIN_MARK(6);
-  const int n_ev = lstart[n_bins];
-  for (int t = threadIdx.x; t < n_ev; t += BIN_THREADS) events[tile_first + t] = ev_buf[t];
-  for (int b = threadIdx.x; b <= n_bins; b += BIN_THREADS) my_off[b] = lstart[b];
-  BIN_MARK(7);
-}
-
-// The compaction that ends the previous sub-step, done at the start of this kernel instead of in
-// a launch of its own (one-cell non-adaptive runs; defined after the compaction code below).
-// While the state is healthy - nearly always - that launch did nothing, at 4.7 us per time step.
-// (SortPrologue: index.h)
 template <bool RNG>
 __global__ void k_bin_sort(int2 *events, int32_t *toff, int32_t *jarr, int n_bins,
                            const double *u01, const int64_t *cell_start, int64_t n_cell,
                            const int64_t *p_length, int64_t length_arg, u128 s_off, u128 inc,
-                           const u128 *tab, const uint64_t *dev_off, SortPrologue P,
-                           const u128 *aff);
+                           const u128 *tab, const uint64_t *dev_off, const u128 *aff);
 
+// (BuildPrologue: index.h; the kernel is defined after the compaction code it may have to run)
 template <int FMT>
-__global__ void __launch_bounds__(BIN_THREADS)
-k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
-             int32_t *__restrict__ ovf_next, const int2 *__restrict__ events,
-             const int32_t *__restrict__ toff, const int32_t *__restrict__ jarr, int n_bins,
-             int n_tiles, const int64_t *__restrict__ idx0, const int64_t *__restrict__ p_length,
-             int64_t length_arg) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int SLOTS = FMT == SDM_REC_P21 ? 4 : (FMT == SDM_REC_P24 ? 3 : 2);
-  int32_t *run_pre = (int32_t *)smem;                   // n_tiles + 1: events of tiles < t
-  int32_t *run_lo = run_pre + ((n_tiles + 1 + 3) & ~3); // n_tiles: where tile t's run starts
-  int32_t *slot = run_lo + ((n_tiles + 3) & ~3);        // SLOTS x BIN_POS, then BIN_POS list heads
-  int32_t *head = slot + SLOTS * BIN_POS;
-  const int64_t length = p_length ? *p_length : length_arg;
-  const int64_t base = (int64_t)blockIdx.x * BIN_POS;
-  if (base >= length) return;
-  BIN_MARK(8);
-  const int bin = blockIdx.x;
-  // (run_pre / run_lo: LDS of an earlier scheme - runs located by a scan and a binary search)
-  (void)run_pre;
-  constexpr int PER_POS = BIN_POS / BIN_THREADS;
-  // what the records need from memory besides the hits, requested now, used at the end
-  int64_t id_v[PER_POS];
-  int32_t j_v[PER_POS];
-#pragma unroll
-  for (int k = 0; k < PER_POS; ++k) {
-    const int64_t p = base + threadIdx.x + k * BIN_THREADS;
-    id_v[k] = p < length ? idx0[p] : 0;
-    j_v[k] = p < length ? jarr[p] : -1;
-  }
-  // this bin's run in every tile's segment: `tpt` threads share a tile (4 at 2^20
-  // super-droplets: runs hold ~16 events), each takes every tpt-th event of the run; the first
-  // RUN_AHEAD of them are requested before any is placed
-  const int tpt = n_tiles >= BIN_THREADS ? 1 : BIN_THREADS / n_tiles;
-  const int sub = threadIdx.x % tpt, t_step = BIN_THREADS / tpt;
-  const int t_first = threadIdx.x / tpt;
-  int a_first = 0, b_first = 0;
-  if (t_first < n_tiles) {
-    const int32_t *row = toff + (int64_t)t_first * (n_bins + 1) + bin;
-    a_first = row[0];
-    b_first = row[1];
-  }
-  for (int q = threadIdx.x; q < (SLOTS + 1) * BIN_POS; q += BIN_THREADS) slot[q] = -1;
-  BIN_MARK(9);
-  // LDS only: __syncthreads() would also wait for the global loads requested above
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  BIN_MARK(10);
-  // hits on this bin's positions: the first SLOTS inline (claimed by compare-and-swap), rest listed
-  constexpr int RUN_AHEAD = 8;
-  for (int t = t_first; t < n_tiles; t += t_step) {
-    int a = a_first, b = b_first;
-    if (t != t_first) {
-      const int32_t *row = toff + (int64_t)t * (n_bins + 1) + bin;
-      a = row[0];
-      b = row[1];
-    }
-    const int2 *run = events + (int64_t)t * EV_TILE;  // (tile-major: the tile's own segment)
-    int2 ev[RUN_AHEAD];
-#pragma unroll
-    for (int k = 0; k < RUN_AHEAD; ++k) {
-      const int x = a + sub + k * tpt;
-      ev[k] = x < b ? run[x] : make_int2(-1, 0);
-    }
-    auto place = [&](int2 e) {
-      const int q = e.y - (int)base;
-      bool placed = false;
-#pragma unroll
-      for (int k = 0; k < SLOTS; ++k)
-        if (!placed) placed = atomicCAS(&slot[k * BIN_POS + q], -1, e.x) == -1;
-      if (!placed) ovf_next[e.x] = atomicExch(&head[q], e.x);  // -1 terminated, built entirely here
-    };
-#pragma unroll
-    for (int k = 0; k < RUN_AHEAD; ++k)
-      if (ev[k].x >= 0) place(ev[k]);
-    for (int x = a + sub + RUN_AHEAD * tpt; x < b; x += tpt) place(run[x]);
-  }
-  __syncthreads();
-  BIN_MARK(11);
-#pragma unroll
-  for (int kq = 0; kq < PER_POS; ++kq) {
-    const int q = threadIdx.x + kq * BIN_THREADS;
-    const int64_t p = base + q;
-    if (p >= length) break;
-    const int32_t h = head[q];
-    const int32_t id = (int32_t)id_v[kq];
-    const int32_t jp = j_v[kq];
-    if (FMT == SDM_REC_P21) {
-      PackRec21 r;
-      p21_pack(r.lo, r.hi, jp, slot[q], slot[BIN_POS + q], slot[2 * BIN_POS + q],
-               slot[(SLOTS - 1) * BIN_POS + q], id, h >= 0);
-      ((PackRec21 *)rec_out)[p] = r;
-    } else if (FMT == SDM_REC_P24) {
-      PackRec24 r;
-      p24_pack(r.lo, r.hi, jp, slot[q], slot[BIN_POS + q], slot[2 * BIN_POS + q], id, h >= 0);
-      ((PackRec24 *)rec_out)[p] = r;
-    } else {
-      PackRec r;
-      r.j = jp;
-      r.s0 = slot[q];
-      r.s1 = slot[BIN_POS + q];
-      r.val = id | (h >= 0 ? (int32_t)0x80000000 : 0);
-      ((PackRec *)rec_out)[p] = r;
-    }
-    if (h >= 0) ovf_head[p] = h;
-  }
-  BIN_MARK(12);
-}
+__global__ void k_bin_build2(void *rec_out, int32_t *ovf_head, int32_t *ovf_next,
+                             const int2 *events, const int32_t *toff, const int32_t *jarr,
+                             int n_bins, int n_tiles, const int64_t *idx0,
+                             const int64_t *p_length, int64_t length_arg, BuildPrologue P);
 
 // backward walk over packed records; positions [length, n_total) are copied through
 __global__ void __launch_bounds__(SDM_BLOCK)
@@ -593,7 +291,7 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
                                 const double *u01, const int64_t *cell_start, int64_t n_cell,
                                 const int64_t *p_length, int64_t length_bound, int64_t n_total,
                                 u128 s_off, u128 inc, ShuffleViews *views, int64_t id_bound,
-                                const uint64_t *dev_off, const SortPrologue *prologue) {
+                                const uint64_t *dev_off, const SortPrologue *presorted) {
   // id_bound: the ids in idx0 are below it (-1: unknown); decides the record layout
   const int64_t both = id_bound > length_bound ? id_bound : length_bound;
   const int fmt = id_bound < 0 ? SDM_REC_PLAIN
@@ -626,21 +324,30 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
   {
     PhaseScope ph(ctx, SDM_PHASE_SHUFFLE_BUILD);
-    SortPrologue no_prologue;
-    memset(&no_prologue, 0, sizeof(no_prologue));
+    BuildPrologue bp;
+    memset(&bp, 0, sizeof(bp));
+    if (presorted) {  // sorted by the previous pair kernel; what the build needs to redo it
+      bp.compact = *presorted;
+      bp.events = events;
+      bp.toff = toff;
+      bp.jarr = jarr;
+      bp.s_off = s_off;
+      bp.inc = inc;
+      bp.tab = ctx->pcg_tab;
+      bp.aff = ctx->pcg_aff;
+    } else
     if (u01)
       hipLaunchKernelGGL((k_bin_sort<false>), dim3(nt), block, lds_sort, ctx->stream, events, toff,
                          jarr, nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc,
-                         ctx->pcg_tab, (const uint64_t *)nullptr, no_prologue,
-                         (const u128 *)nullptr);
+                         ctx->pcg_tab, (const uint64_t *)nullptr, (const u128 *)nullptr);
     else
       hipLaunchKernelGGL((k_bin_sort<true>), dim3(nt), block, lds_sort, ctx->stream, events, toff,
                          jarr, nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc,
-                         ctx->pcg_tab, dev_off, prologue ? *prologue : no_prologue,
-                         (const u128 *)ctx->pcg_aff);
+                         ctx->pcg_tab, dev_off, (const u128 *)ctx->pcg_aff);
 #define BUILD_LAUNCH(F)                                                                        \
   hipLaunchKernelGGL(k_bin_build2<F>, dim3(nb), block, lds_build, ctx->stream, (void *)rec,    \
-                     ovf_head, ovf_next, events, toff, jarr, nb, nt, idx0, p_length, length_bound)
+                     ovf_head, ovf_next, events, toff, jarr, nb, nt, idx0, p_length, length_bound, \
+                     bp)
     if (fmt == SDM_REC_P21) BUILD_LAUNCH(SDM_REC_P21);
     else if (fmt == SDM_REC_P24) BUILD_LAUNCH(SDM_REC_P24);
     else BUILD_LAUNCH(SDM_REC_PLAIN);
@@ -672,7 +379,7 @@ int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
                             const int64_t *cell_start, int64_t n_cell, const int64_t *p_length,
                             int64_t length_bound, const uint64_t *rng_state_inc,
                             uint64_t rng_offset, ShuffleViews *views, int64_t id_bound,
-                            const uint64_t *dev_off, const SortPrologue *prologue) {
+                            const uint64_t *dev_off, const SortPrologue *presorted) {
   int rc = sdm_pcg_prepare(ctx, rng_state_inc);
   if (rc) return rc;
   const u128 st = (((u128)rng_state_inc[0]) << 64) | rng_state_inc[1];
@@ -680,7 +387,22 @@ int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
   // dev_off: the kernels add the stream position themselves (graph replay)
   const u128 s_off = dev_off ? st : sdm_pcg_advance_host(st, inc, rng_offset);
   return shuffle_binned_async(ctx, scratch, nullptr, idx0, nullptr, cell_start, n_cell, p_length,
-                              length_bound, 0, s_off, inc, views, id_bound, dev_off, prologue);
+                              length_bound, 0, s_off, inc, views, id_bound, dev_off, presorted);
+}
+
+void sdm_shuffle_sort_buffers(char *scratch, int64_t length_bound, SortBuffers *out) {
+  Carver cv(scratch);  // (the carve of shuffle_binned_async)
+  const int nb = bin_count(length_bound), nt = ev_tile_count(length_bound);
+  (void)cv.take<PackRec>(length_bound);
+  (void)cv.take<int32_t>(length_bound);
+  (void)cv.take<int32_t>(length_bound);
+  out->jarr = cv.take<int32_t>(length_bound);
+  out->events = cv.take<int2>((size_t)nt * EV_TILE);
+  out->toff = cv.take<int32_t>((size_t)(nb + 1) * nt);
+  out->n_bins = nb;
+  out->n_tiles = nt;
+  out->lds_bytes = sizeof(int32_t) * (size_t)((nb + 1) + ((nb + 1) & ~1) + 2) +
+                   sizeof(int2) * EV_TILE;
 }
 
 size_t sdm_shuffle_scratch(int64_t n) {
@@ -891,6 +613,9 @@ compact_run(const int64_t *__restrict__ multiplicity, int64_t *__restrict__ idx,
             int64_t *__restrict__ cell_start_single, unsigned int *__restrict__ bar,
             const CompactEpilogue &E, int64_t *new_length) {
   const int64_t length = fctl[FCTL_VALID];
+  // (bar[3]: the barrier k_bin_build2 passes after its re-sort; nobody touches it before this
+  // run's last barrier, every workgroup passes the first one after this store)
+  if (blockIdx.x == 0 && threadIdx.x == 0) bar[3] = 0;
   __shared__ int sm[COMPACT_THREADS / SDM_WAVE];
   __shared__ int excl[COMPACT_WAVES];
   const int lane = lane_id(), w = threadIdx.x / SDM_WAVE;
@@ -1032,32 +757,146 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
                                fillers, cell_start_single, bar, E, &new_len);
 }
 
-// k_bin_sort (declared above): the tile sort of the shuffle build, with the previous sub-step's
-// compaction as its prologue when P.fctl is set.  Every workgroup reads the healthy word before
-// the last one to pass the final barrier of compact_run can set it again, so the branch is uniform
-// over the grid; afterwards each workgroup continues with the length it computed itself (the
-// committed words are for the kernels that follow).
+// k_bin_sort (declared above): the tile sort of the shuffle build
 template <bool RNG>
 __global__ void __launch_bounds__(BIN_THREADS)
 k_bin_sort(int2 *__restrict__ events, int32_t *__restrict__ toff, int32_t *__restrict__ jarr,
            int n_bins, const double *__restrict__ u01, const int64_t *__restrict__ cell_start,
            int64_t n_cell, const int64_t *__restrict__ p_length, int64_t length_arg, u128 s_off,
            u128 inc, const u128 *__restrict__ tab, const uint64_t *__restrict__ dev_off,
-           SortPrologue P, const u128 *__restrict__ aff) {
+           const u128 *__restrict__ aff) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int64_t length, one_cell_len = -1;
-  if (P.fctl && P.fctl[FCTL_HEALTHY] == 0) {
+  const int64_t length = p_length ? *p_length : length_arg;
+  bin_sort_body<RNG>(smem, events, toff, jarr, n_bins, u01, cell_start, n_cell, length, -1, s_off,
+                     inc, tab, dev_off, aff);
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(BIN_THREADS)
+k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
+             int32_t *__restrict__ ovf_next, const int2 *__restrict__ events,
+             const int32_t *__restrict__ toff, const int32_t *__restrict__ jarr, int n_bins,
+             int n_tiles, const int64_t *__restrict__ idx0, const int64_t *__restrict__ p_length,
+             int64_t length_arg, BuildPrologue P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int SLOTS = FMT == SDM_REC_P21 ? 4 : (FMT == SDM_REC_P24 ? 3 : 2);
+  int32_t *run_pre = (int32_t *)smem;                   // n_tiles + 1: events of tiles < t
+  int32_t *run_lo = run_pre + ((n_tiles + 1 + 3) & ~3); // n_tiles: where tile t's run starts
+  int32_t *slot = run_lo + ((n_tiles + 3) & ~3);        // SLOTS x BIN_POS, then BIN_POS list heads
+  int32_t *head = slot + SLOTS * BIN_POS;
+  // P.compact.fctl: the events were sorted ahead, by the pair kernel of the previous sub-step, for
+  // the length that sub-step began with.  If a super-droplet died in it (rare), the compaction
+  // runs here, every workgroup sorts its tile again for the new length (n_tiles == n_bins on this
+  // route) and a further grid barrier separates that from the gathering of the runs
+  int64_t length;
+  if (P.compact.fctl && P.compact.fctl[FCTL_HEALTHY] == 0) {
     const CompactEpilogue none = {nullptr, nullptr, nullptr, 0, nullptr, 0, 0};
-    if (!compact_run<true>(P.multiplicity, P.idx, P.flag, P.fctl, P.wave_dead, P.n_tiles, P.ctl,
-                           P.holes, P.fillers, P.cell_start_single, P.bar, none, &length))
+    const SortPrologue &C = P.compact;
+    if (!compact_run<true>(C.multiplicity, C.idx, C.flag, C.fctl, C.wave_dead, C.n_tiles, C.ctl,
+                           C.holes, C.fillers, C.cell_start_single, C.bar, none, &length))
       return;
-    one_cell_len = length;
-    __syncthreads();  // (compact_run's shared arrays are not touched below, smem is)
+    __syncthreads();
+    bin_sort_body<true>(smem, P.events, P.toff, P.jarr, n_bins, nullptr, nullptr, 1, length, length,
+                        P.s_off, P.inc, P.tab, nullptr, P.aff);
+    if (!grid_barrier(C.bar + 3, gridDim.x)) {
+      if (threadIdx.x == 0) C.fctl[7] = 2;
+      return;
+    }
   } else {
     length = p_length ? *p_length : length_arg;
   }
-  bin_sort_body<RNG>(smem, events, toff, jarr, n_bins, u01, cell_start, n_cell, length,
-                     one_cell_len, s_off, inc, tab, dev_off, aff);
+  const int64_t base = (int64_t)blockIdx.x * BIN_POS;
+  if (base >= length) return;
+  BIN_MARK(8);
+  const int bin = blockIdx.x;
+  // (run_pre / run_lo: LDS of an earlier scheme - runs located by a scan and a binary search)
+  (void)run_pre;
+  constexpr int PER_POS = BIN_POS / BIN_THREADS;
+  // what the records need from memory besides the hits, requested now, used at the end
+  int64_t id_v[PER_POS];
+  int32_t j_v[PER_POS];
+#pragma unroll
+  for (int k = 0; k < PER_POS; ++k) {
+    const int64_t p = base + threadIdx.x + k * BIN_THREADS;
+    id_v[k] = p < length ? idx0[p] : 0;
+    j_v[k] = p < length ? jarr[p] : -1;
+  }
+  // this bin's run in every tile's segment: `tpt` threads share a tile (4 at 2^20
+  // super-droplets: runs hold ~16 events), each takes every tpt-th event of the run; the first
+  // RUN_AHEAD of them are requested before any is placed
+  const int tpt = n_tiles >= BIN_THREADS ? 1 : BIN_THREADS / n_tiles;
+  const int sub = threadIdx.x % tpt, t_step = BIN_THREADS / tpt;
+  const int t_first = threadIdx.x / tpt;
+  int a_first = 0, b_first = 0;
+  if (t_first < n_tiles) {
+    const int32_t *row = toff + (int64_t)t_first * (n_bins + 1) + bin;
+    a_first = row[0];
+    b_first = row[1];
+  }
+  for (int q = threadIdx.x; q < (SLOTS + 1) * BIN_POS; q += BIN_THREADS) slot[q] = -1;
+  BIN_MARK(9);
+  // LDS only: __syncthreads() would also wait for the global loads requested above
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  BIN_MARK(10);
+  // hits on this bin's positions: the first SLOTS inline (claimed by compare-and-swap), rest listed
+  constexpr int RUN_AHEAD = 8;
+  for (int t = t_first; t < n_tiles; t += t_step) {
+    int a = a_first, b = b_first;
+    if (t != t_first) {
+      const int32_t *row = toff + (int64_t)t * (n_bins + 1) + bin;
+      a = row[0];
+      b = row[1];
+    }
+    const int2 *run = events + (int64_t)t * EV_TILE;  // (tile-major: the tile's own segment)
+    int2 ev[RUN_AHEAD];
+#pragma unroll
+    for (int k = 0; k < RUN_AHEAD; ++k) {
+      const int x = a + sub + k * tpt;
+      ev[k] = x < b ? run[x] : make_int2(-1, 0);
+    }
+    auto place = [&](int2 e) {
+      const int q = e.y - (int)base;
+      bool placed = false;
+#pragma unroll
+      for (int k = 0; k < SLOTS; ++k)
+        if (!placed) placed = atomicCAS(&slot[k * BIN_POS + q], -1, e.x) == -1;
+      if (!placed) ovf_next[e.x] = atomicExch(&head[q], e.x);  // -1 terminated, built entirely here
+    };
+#pragma unroll
+    for (int k = 0; k < RUN_AHEAD; ++k)
+      if (ev[k].x >= 0) place(ev[k]);
+    for (int x = a + sub + RUN_AHEAD * tpt; x < b; x += tpt) place(run[x]);
+  }
+  __syncthreads();
+  BIN_MARK(11);
+#pragma unroll
+  for (int kq = 0; kq < PER_POS; ++kq) {
+    const int q = threadIdx.x + kq * BIN_THREADS;
+    const int64_t p = base + q;
+    if (p >= length) break;
+    const int32_t h = head[q];
+    const int32_t id = (int32_t)id_v[kq];
+    const int32_t jp = j_v[kq];
+    if (FMT == SDM_REC_P21) {
+      PackRec21 r;
+      p21_pack(r.lo, r.hi, jp, slot[q], slot[BIN_POS + q], slot[2 * BIN_POS + q],
+               slot[(SLOTS - 1) * BIN_POS + q], id, h >= 0);
+      ((PackRec21 *)rec_out)[p] = r;
+    } else if (FMT == SDM_REC_P24) {
+      PackRec24 r;
+      p24_pack(r.lo, r.hi, jp, slot[q], slot[BIN_POS + q], slot[2 * BIN_POS + q], id, h >= 0);
+      ((PackRec24 *)rec_out)[p] = r;
+    } else {
+      PackRec r;
+      r.j = jp;
+      r.s0 = slot[q];
+      r.s1 = slot[BIN_POS + q];
+      r.val = id | (h >= 0 ? (int32_t)0x80000000 : 0);
+      ((PackRec *)rec_out)[p] = r;
+    }
+    if (h >= 0) ovf_head[p] = h;
+  }
+  BIN_MARK(12);
 }
 
 // `bar`: 4 zero-initialised device words owned by the caller (persist across launches)
@@ -1100,31 +939,33 @@ int sdm_compact_fused_async(sdm_ctx *ctx, char *scratch, const int64_t *multipli
   return SDM_OK;
 }
 
-// can the tile sort of a build over `length_bound` positions take the compaction as its prologue?
-// Its workgroups synchronise through a grid barrier then: all of them have to be resident at once
-bool sdm_shuffle_sort_can_compact(sdm_ctx *ctx, int64_t length_bound) {
+bool sdm_shuffle_presort_ok(sdm_ctx *ctx, int64_t length_bound, int64_t id_bound) {
   if (!binned_ok(length_bound, false)) return false;
   const int nb = bin_count(length_bound), nt = ev_tile_count(length_bound);
-  if (nt > COMPACT_MAX_GROUPS) return false;
-  if (ctx->sort_resident == 0) {
-    const size_t lds_sort = sizeof(int32_t) * (size_t)((nb + 1) + ((nb + 1) & ~1) + 2) +
-                            sizeof(int2) * EV_TILE;
+  const int64_t both = id_bound > length_bound ? id_bound : length_bound;
+  if (nb != nt || nb > COMPACT_MAX_GROUPS || id_bound < 0 || both > P21_MAX) return false;
+  if (ctx->build_resident == 0) {
+    const size_t lds_build = sizeof(int32_t) * (size_t)(((nt + 1 + 3) & ~3) + ((nt + 3) & ~3) +
+                                                        5 * BIN_POS);
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bin_sort<true>, BIN_THREADS,
-                                                     lds_sort) != hipSuccess ||
+    if (hipFuncSetAttribute((const void *)k_bin_build2<SDM_REC_P21>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(lds_build > 65536 ? lds_build : 65536)) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bin_build2<SDM_REC_P21>,
+                                                     BIN_THREADS, lds_build) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) !=
             hipSuccess) {
       (void)hipGetLastError();
-      ctx->sort_resident = -1;
+      ctx->build_resident = -1;
     } else {
-      ctx->sort_resident = per_cu * cus > 0 ? per_cu * cus : -1;
+      ctx->build_resident = per_cu * cus > 0 ? per_cu * cus : -1;
     }
   }
-  return nt <= ctx->sort_resident;
+  return nb <= ctx->build_resident;
 }
 
-// the arguments of sdm_compact_fused_async(.., flag_only = true) as the prologue of the next tile
-// sort (sdm_shuffle_sort_can_compact)
+// the arguments of sdm_compact_fused_async(.., flag_only = true) for the prologue of the next
+// build (sdm_shuffle_presort_ok)
 void sdm_compact_as_prologue(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity,
                              int64_t *idx, int64_t length_bound, int64_t flag, int64_t *fctl,
                              int64_t *ctl, int64_t *cell_start_single, SortPrologue *out) {

@@ -126,8 +126,9 @@ def test_many_steps_in_one_call_equal_oracle(n_sd, steps, thin, hip_engine, orac
     """`run(n)` of the single-cell non-adaptive box = one `sdm_collision_run` call: n time steps
     without the host in between.  `thin` (a cell volume): multiplicities of 1..3, so that
     super-droplets die - in every step (0.02) or once in a few steps (100) - and the
-    device-gated compaction has to run in the middle of a call: as the prologue of the next
-    step's tile sort up to 2^20 super-droplets (256 tiles), in a launch of its own above."""
+    device-gated compaction has to run in the middle of a call: up to 2^20 super-droplets (256
+    tiles) inside the next step's record build, which also redoes the tile sort the pair kernel
+    did ahead for the old length (k_pair_all_sort / k_bin_build2); in a launch of its own above."""
     snaps = []
     for engine in (hip_engine, oracle_engine):
         runner = make_box(engine, "shima", n_sd=n_sd, adaptive=False,
