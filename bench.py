@@ -257,6 +257,9 @@ def main():
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel": dominant, "kernel_ms": dom_ms,
             "algorithmic_bytes_per_launch": bytes_per_pair * launch_pairs,
+            # the same bytes against the wall-clock time of a whole time step (all kernels)
+            "whole_step_frac": bytes_per_pair * pairs_total / world / elapsed_max / 1e9
+                               / HBM_PEAK_GBS,
             "phase_ms_per_step": {k: round(v, 5) for k, v in sorted(per_step.items())},
             "phase_sum_ms_per_step": round(sum(per_step.values()), 5),
             "timed_mode_ms_per_step": round(timed_wall_ms, 5),

@@ -1,27 +1,18 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-python bench.py > $O/r02_bench_shima.json 2>/dev/null
+timeout -k 10 1000 python -m pytest tests/test_hip_parity.py tests/test_hip_full_size.py -m gpu -x -q > gpurun_out/r02_gputest_q.log 2>&1 || { grep -v "^  File\|^Extension" gpurun_out/r02_gputest_q.log | tail -40; exit 1; }
+tail -2 gpurun_out/r02_gputest_q.log
+for w in berry_breakup; do
+python bench.py --workload $w --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/r02_bench_${w}_ride.json 2>/dev/null
 python -c "
-import json; d=json.load(open('$O/r02_bench_shima.json')); print('shima', d['value'], d['ms_per_step'], d['roofline']['frac'], d['cpu_baseline'])"
-rm -rf $O/pc_*
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/pc_stats -- python3 bench.py --steps 100 --warmup 10 --reps 1 --no-cpu-baseline --roofline-steps 5 > /dev/null 2>&1
-cp $(ls $O/pc_stats/*/*kernel_stats.csv) $O/r02_kernel_stats_shima.csv
-for c in FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum; do
-rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pc_$c -- python3 bench.py --steps 30 --warmup 5 --reps 1 --no-cpu-baseline --roofline-steps 5 > /dev/null 2>&1
-python tests/pmc_summary.py $O/pc_$c $c > $O/r02_pmc_shima_$c.txt
-head -3 $O/r02_pmc_shima_$c.txt
+import json; d=json.load(open('gpurun_out/r02_bench_${w}_ride.json')); print('$w', d['value'], d['ms_per_step'], d['roofline']['phase_ms_per_step'])"
+SDM_NO_PRESORT=1 python bench.py --workload $w --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/r02_bench_${w}_ride_off.json 2>/dev/null
+python -c "
+import json; d=json.load(open('gpurun_out/r02_bench_${w}_ride_off.json')); print('$w off', d['value'], d['ms_per_step'], d['roofline']['phase_ms_per_step'])"
 done
-rm -rf $O/pc_*
-for w in berry_breakup straub straub_rain kinematic2d; do
-python bench.py --workload $w --steps 40 --warmup 5 --no-cpu-baseline > $O/r02_bench_$w.json 2>/dev/null
+python bench.py --adaptive 1 --no-cpu-baseline > gpurun_out/r02_bench_shima_adaptive_ride.json 2>/dev/null
 python -c "
-import json; d=json.load(open('$O/r02_bench_$w.json')); print('$w', d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['kernel_ms'], d['roofline']['frac'])"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/pc_stats -- python3 bench.py --workload $w --steps 20 --warmup 3 --reps 1 --no-cpu-baseline --roofline-steps 5 > /dev/null 2>&1
-cp $(ls $O/pc_stats/*/*kernel_stats.csv) $O/r02_kernel_stats_$w.csv
-rm -rf $O/pc_stats
-done
-python bench.py --adaptive 1 --no-cpu-baseline > $O/r02_bench_shima_adaptive.json 2>/dev/null
+import json; d=json.load(open('gpurun_out/r02_bench_shima_adaptive_ride.json')); print('shima adaptive', d['value'], d['ms_per_step'])"
+python bench.py --adaptive 1 --n-sd 65536 --steps 1000 --no-cpu-baseline > gpurun_out/r02_bench_shima_adaptive_n65536_ride.json 2>/dev/null
 python -c "
-import json; d=json.load(open('$O/r02_bench_shima_adaptive.json')); print('shima adaptive', d['value'], d['ms_per_step'])"
+import json; d=json.load(open('gpurun_out/r02_bench_shima_adaptive_n65536_ride.json')); print('shima adaptive 2^16', d['value'], d['ms_per_step'])"
