@@ -116,10 +116,11 @@ def initial_state(name, n_sd=None, dv=None, ids_by_cell=False):
 
 
 def make_box(engine, name, *, n_sd=None, adaptive=None, route="fused", seed=44, dt=None,
-             thin=None, grid=None, read_back=True, dv=None, ids_by_cell=False):
+             thin=None, grid=None, read_back=True, dv=None, ids_by_cell=False, **setup_options):
     """a CollisionRunner for configuration `name`.  `thin` (a cell volume per 2^16
     super-droplets) replaces the multiplicities by 1, 2, 3, 1, ... so that super-droplets die;
-    `grid` turns a box configuration into a multi-cell one with uniform-random cell ids"""
+    `grid` turns a box configuration into a multi-cell one with uniform-random cell ids;
+    `setup_options` go to the CollisionSetup (substeps, croupier, optimized_random, ...)"""
     cfg = CONFIGS[name]
     if grid is not None:
         cfg = dict(cfg, grid=tuple(grid))
@@ -138,7 +139,7 @@ def make_box(engine, name, *, n_sd=None, adaptive=None, route="fused", seed=44, 
     population = Population(engine, multiplicity=multiplicity, volume=volume, cell_id=cell_id,
                             grid=grid)
     dv_cell = dv / population.n_cell
-    return CollisionRunner(population, cfg["make"](adaptive, seed=seed),
+    return CollisionRunner(population, cfg["make"](adaptive, seed=seed, **setup_options),
                            dt=dt or cfg.get("dt", 1.0), dv=dv_cell, route=route,
                            read_back=read_back)
 

@@ -142,6 +142,35 @@ def test_many_steps_in_one_call_equal_oracle(n_sd, steps, thin, hip_engine, orac
         assert int(snaps[0]["length"]) < n_sd
 
 
+@pytest.mark.parametrize("name,n_sd,thin,options", [
+    ("shima", 2**16, 0.02, dict(substeps=3)),               # sub-steps of one step, deaths
+    ("shima", 2**17, None, dict(substeps=2)),
+    ("shima", 2**16, 0.02, dict(optimized_random=True)),    # (no sort-ahead: draws are reused)
+    ("shima", 2**16, 0.02, dict(croupier="global")),        # shuffle_global: the generic route
+    ("kinematic2d", 2**16, None, dict()),                   # geometric kernel in ONE cell
+    ("berry_breakup", 2**16, None, dict()),                 # breakup without adaptivity
+])
+def test_non_adaptive_variants_in_one_call_equal_oracle(name, n_sd, thin, options, hip_engine,
+                                                        oracle_engine):
+    """the one-cell non-adaptive route in its variants - sub-steps (collision.py:279), reused
+    random numbers, the global croupier, a kernel that needs radii and terminal velocities, the
+    breakup branch - each as `run(n)` calls of several steps (the pair kernel of a step sorts the
+    next step's events: k_pair_all_sort), against the oracle's step-by-step run"""
+    snaps = []
+    for engine in (hip_engine, oracle_engine):
+        runner = make_box(engine, name, n_sd=n_sd, adaptive=False, thin=thin,
+                          dt=200.0 if thin else None,
+                          grid=(1, 1) if name == "kinematic2d" else None, **options)
+        run(runner, 1)
+        run(runner, 7)
+        run(runner, 2)
+        snaps.append(runner.snapshot())
+    breakup = "breakup" in name
+    assert_same(snaps[0], snaps[1], float_rtol=1e-12 if breakup else 0.0)
+    if thin:
+        assert int(snaps[0]["length"]) < n_sd
+
+
 @pytest.mark.parametrize("name,n_sd,steps,dt,thin", [
     ("shima", 2**16, 40, None, None),      # one sub-step per step
     ("shima", 2**16, 25, 400.0, None),     # several sub-steps per step
