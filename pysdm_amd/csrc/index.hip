@@ -308,8 +308,10 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
   const dim3 block(BIN_THREADS);
   const size_t lds_sort = sizeof(int32_t) * (size_t)((nb + 1) + ((nb + 1) & ~1) + 2) +
                           sizeof(int2) * EV_TILE;
-  const size_t lds_build = sizeof(int32_t) * (size_t)(((nt + 1 + 3) & ~3) + ((nt + 3) & ~3) +
-                                                      (slots + 1) * BIN_POS);
+  // (64 KB with three inline slots - two workgroups per CU - 80 KB with four; the prologue of a
+  // presorted build sorts in the same memory)
+  size_t lds_build = sizeof(int32_t) * (size_t)((slots + 1) * BIN_POS);
+  if (presorted && lds_sort > lds_build) lds_build = lds_sort;
   // gfx950 has 160 KiB of LDS per CU; > 64 KiB dynamic needs opting in (per kernel and device)
   if (lds_sort > 65536) {
     HIP_TRY(hipFuncSetAttribute((const void *)k_bin_sort<true>,
@@ -611,13 +613,14 @@ compact_run(const int64_t *__restrict__ multiplicity, int64_t *__restrict__ idx,
             int64_t *__restrict__ fctl, int32_t *__restrict__ wave_dead, int n_tiles,
             int64_t *__restrict__ ctl, int32_t *__restrict__ holes, int64_t *__restrict__ fillers,
             int64_t *__restrict__ cell_start_single, unsigned int *__restrict__ bar,
-            const CompactEpilogue &E, int64_t *new_length) {
+            const CompactEpilogue &E, int64_t *new_length, int *excl) {
   const int64_t length = fctl[FCTL_VALID];
   // (bar[3]: the barrier k_bin_build2 passes after its re-sort; nobody touches it before this
   // run's last barrier, every workgroup passes the first one after this store)
   if (blockIdx.x == 0 && threadIdx.x == 0) bar[3] = 0;
+  // excl: COMPACT_WAVES ints of LDS from the caller (16 KB: k_bin_build2 lends its dynamic memory,
+  // so that the code of this rare path does not cost it a workgroup per CU)
   __shared__ int sm[COMPACT_THREADS / SDM_WAVE];
-  __shared__ int excl[COMPACT_WAVES];
   const int lane = lane_id(), w = threadIdx.x / SDM_WAVE;
   const int wave = blockIdx.x * (COMPACT_THREADS / SDM_WAVE) + w;
   const int n_waves = (int)gridDim.x * (COMPACT_THREADS / SDM_WAVE);  // <= COMPACT_WAVES
@@ -753,8 +756,9 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
     return;
   }
   int64_t new_len;
+  __shared__ int excl[COMPACT_WAVES];
   (void)compact_run<FLAG_ONLY>(multiplicity, idx, flag, fctl, wave_dead, n_tiles, ctl, holes,
-                               fillers, cell_start_single, bar, E, &new_len);
+                               fillers, cell_start_single, bar, E, &new_len, excl);
 }
 
 // k_bin_sort (declared above): the tile sort of the shuffle build
@@ -780,9 +784,7 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
              int64_t length_arg, BuildPrologue P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int SLOTS = FMT == SDM_REC_P21 ? 4 : (FMT == SDM_REC_P24 ? 3 : 2);
-  int32_t *run_pre = (int32_t *)smem;                   // n_tiles + 1: events of tiles < t
-  int32_t *run_lo = run_pre + ((n_tiles + 1 + 3) & ~3); // n_tiles: where tile t's run starts
-  int32_t *slot = run_lo + ((n_tiles + 3) & ~3);        // SLOTS x BIN_POS, then BIN_POS list heads
+  int32_t *slot = (int32_t *)smem;  // SLOTS x BIN_POS, then BIN_POS list heads
   int32_t *head = slot + SLOTS * BIN_POS;
   // P.compact.fctl: the events were sorted ahead, by the pair kernel of the previous sub-step, for
   // the length that sub-step began with.  If a super-droplet died in it (rare), the compaction
@@ -793,7 +795,8 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
     const CompactEpilogue none = {nullptr, nullptr, nullptr, 0, nullptr, 0, 0};
     const SortPrologue &C = P.compact;
     if (!compact_run<true>(C.multiplicity, C.idx, C.flag, C.fctl, C.wave_dead, C.n_tiles, C.ctl,
-                           C.holes, C.fillers, C.cell_start_single, C.bar, none, &length))
+                           C.holes, C.fillers, C.cell_start_single, C.bar, none, &length,
+                           (int *)smem))
       return;
     __syncthreads();
     bin_sort_body<true>(smem, P.events, P.toff, P.jarr, n_bins, nullptr, nullptr, 1, length, length,
@@ -809,8 +812,6 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
   if (base >= length) return;
   BIN_MARK(8);
   const int bin = blockIdx.x;
-  // (run_pre / run_lo: LDS of an earlier scheme - runs located by a scan and a binary search)
-  (void)run_pre;
   constexpr int PER_POS = BIN_POS / BIN_THREADS;
   // what the records need from memory besides the hits, requested now, used at the end
   int64_t id_v[PER_POS];
@@ -945,8 +946,7 @@ bool sdm_shuffle_presort_ok(sdm_ctx *ctx, int64_t length_bound, int64_t id_bound
   const int64_t both = id_bound > length_bound ? id_bound : length_bound;
   if (nb != nt || nb > COMPACT_MAX_GROUPS || id_bound < 0 || both > P21_MAX) return false;
   if (ctx->build_resident == 0) {
-    const size_t lds_build = sizeof(int32_t) * (size_t)(((nt + 1 + 3) & ~3) + ((nt + 3) & ~3) +
-                                                        5 * BIN_POS);
+    const size_t lds_build = sizeof(int32_t) * (size_t)(5 * BIN_POS);
     int per_cu = 0, cus = 0;
     if (hipFuncSetAttribute((const void *)k_bin_build2<SDM_REC_P21>,
                             hipFuncAttributeMaxDynamicSharedMemorySize,
