@@ -15,7 +15,11 @@ from pysdm_amd.engine import HipEngine  # noqa: E402
 
 cases = [("shima", 2**20, False, 3600), ("shima", 2**20, True, 400),
          ("berry_breakup", 2**20, True, 200), ("straub", 2**18, True, 150),
-         ("straub_rain", 2**18, True, 150), ("kinematic2d", 2**20, True, 40)]
+         # (100 steps: with a third of the collisions breaking up, the masses of the two runs
+         # drift apart in the last bits - device libm against glibc - at ~1e-14 per step; around
+         # step 147 that changes how an adaptive time step divides into sub-steps, after which
+         # the runs consume different random numbers: profiles/tools/first_divergence.py)
+         ("straub_rain", 2**18, True, 100), ("kinematic2d", 2**20, True, 40)]
 for name, n_sd, adaptive, steps in cases:
     snaps = []
     for engine in (HipEngine.get(), OracleEngine.get()):
