@@ -2,7 +2,10 @@
 // (PySDM/dynamics/collisions/collision.py:174-234), all sub-steps, with the control state
 // (lengths, sorted / healthy flags) resident on the device.  Three routes per sub-step:
 //   one cell, non-adaptive:  shuffle record build (index.hip) -> k_pair_all (walks, pairing,
-//      sort-within-pair, kernel, probability, gamma, update, counters) -> gated compaction
+//      sort-within-pair, kernel, probability, gamma, update, counters) -> gated compaction;
+//      inside a run of several steps: k_bin_build2 -> k_pair_all_sort, two launches per step - the
+//      pair kernel carries the tile sort of the next step's build, the build the compaction (and
+//      the repeated sort) after the rare step in which a super-droplet died
 //   one cell, adaptive:  build -> k_pair_prob -> k_cells_adaptive (the per-cell minimum of the
 //      optimal sub-step is the one global dependency) -> k_pair_update [-> k_resolve_dense with
 //      breakup] -> compaction, whose epilogue closes the sub-step and publishes the control block;
