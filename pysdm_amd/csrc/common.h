@@ -228,6 +228,16 @@ __device__ __forceinline__ u128 pcg_jump(u128 state, const u128 *__restrict__ ta
   return state;
 }
 
+// the same through the ready affine maps when the distance is within their reach (two multiply-adds
+// instead of one per set bit, and no dependent table reads)
+__device__ __forceinline__ u128 pcg_jump_fast(u128 state, const u128 *__restrict__ tab,
+                                              const u128 *__restrict__ aff, uint64_t delta) {
+  if (aff && delta < (uint64_t)PCG_AFF_TILES * PCG_AFF_STRIDE)
+    return pcg_apply(pcg_apply(state, aff, PCG_AFF_SMALL + (int64_t)(delta / PCG_AFF_STRIDE)), aff,
+                     (int64_t)(delta % PCG_AFF_STRIDE));
+  return pcg_jump(state, tab, delta);
+}
+
 // wave-level reductions (all 64 lanes must participate)
 __device__ __forceinline__ double wave_min_f64(double v) {
 #pragma unroll

@@ -1101,9 +1101,9 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   }
   // long jump-aheads once per workgroup (three wavefronts, one each); threads then only jump by
   // their small offset inside the cell
-  if (tid == 64) s_rng[0] = pcg_jump(X.s_u01, A.rng_tab, (uint64_t)lo);
-  if (tid == 128) s_rng[1] = pcg_jump(A.s_rand, A.rng_tab, (uint64_t)(lo >> 1));
-  if (BREAKUP && tid == 192) s_rng[2] = pcg_jump(A.s_rand_b, A.rng_tab, (uint64_t)(lo >> 1));
+  if (tid == 64) s_rng[0] = pcg_jump_fast(X.s_u01, A.rng_tab, A.rng_aff, (uint64_t)lo);
+  if (tid == 128) s_rng[1] = pcg_jump_fast(A.s_rand, A.rng_tab, A.rng_aff, (uint64_t)(lo >> 1));
+  if (BREAKUP && tid == 192) s_rng[2] = pcg_jump_fast(A.s_rand_b, A.rng_tab, A.rng_aff, (uint64_t)(lo >> 1));
   __syncthreads();
   CELL_MARK(1);
   // shuffle_local events of this cell (index_methods.py:35-41): consecutive positions per thread
@@ -1111,7 +1111,7 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     const int chunk = (n + CELL_THREADS - 1) / CELL_THREADS;
     const int li0 = tid * chunk;
     if (li0 < n) {
-      u128 state = pcg_jump(s_rng[0], A.rng_tab, (uint64_t)li0);
+      u128 state = pcg_jump_fast(s_rng[0], A.rng_tab, A.rng_aff, (uint64_t)li0);
       const u128 mult = pcg_mult();
       for (int e = 0; e < chunk && li0 + e < n; ++e) {
         const int li = li0 + e;
@@ -1236,8 +1236,8 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   {
     const uint64_t dd0 = (uint64_t)(((lo + lp0 + 2 * (int64_t)(tid * CELL_MAXPAIR)) >> 1) -
                                     (lo >> 1));
-    st = pcg_jump(s_rng[1], A.rng_tab, dd0);
-    if (BREAKUP) sb = pcg_jump(s_rng[2], A.rng_tab, dd0);
+    st = pcg_jump_fast(s_rng[1], A.rng_tab, A.rng_aff, dd0);
+    if (BREAKUP) sb = pcg_jump_fast(s_rng[2], A.rng_tab, A.rng_aff, dd0);
   }
 #pragma unroll
   for (int r = 0; r < CELL_MAXPAIR; ++r) {
@@ -1403,16 +1403,16 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     s_cid = A.cell_id[val[0]];
     s_base = A.cell_start[A.cell_idx[s_cid]];
   }
-  if (tid == 64) s_rng[0] = pcg_jump(X.s_u01, A.rng_tab, (uint64_t)lo);
-  if (tid == 128) s_rng[1] = pcg_jump(A.s_rand, A.rng_tab, (uint64_t)(lo >> 1));
-  if (BREAKUP && tid == 192) s_rng[2] = pcg_jump(A.s_rand_b, A.rng_tab, (uint64_t)(lo >> 1));
+  if (tid == 64) s_rng[0] = pcg_jump_fast(X.s_u01, A.rng_tab, A.rng_aff, (uint64_t)lo);
+  if (tid == 128) s_rng[1] = pcg_jump_fast(A.s_rand, A.rng_tab, A.rng_aff, (uint64_t)(lo >> 1));
+  if (BREAKUP && tid == 192) s_rng[2] = pcg_jump_fast(A.s_rand_b, A.rng_tab, A.rng_aff, (uint64_t)(lo >> 1));
   __syncthreads();
   // shuffle_local events of this cell (index_methods.py:35-41): consecutive positions per thread
   {
     const int chunk = (n + CELL2_THREADS - 1) / CELL2_THREADS;
     const int li0 = tid * chunk;
     if (li0 < n) {
-      u128 state = pcg_jump(s_rng[0], A.rng_tab, (uint64_t)li0);
+      u128 state = pcg_jump_fast(s_rng[0], A.rng_tab, A.rng_aff, (uint64_t)li0);
       const u128 mult = pcg_mult();
       for (int e = 0; e < chunk && li0 + e < n; ++e) {
         const int li = li0 + e;
@@ -1541,8 +1541,8 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   {
     const uint64_t dd0 = (uint64_t)(((lo + lp0 + 2 * (int64_t)(tid * CELL2_MAXPAIR)) >> 1) -
                                     (lo >> 1));
-    u128 st = pcg_jump(s_rng[1], A.rng_tab, dd0), sb = 0;
-    if (BREAKUP) sb = pcg_jump(s_rng[2], A.rng_tab, dd0);
+    u128 st = pcg_jump_fast(s_rng[1], A.rng_tab, A.rng_aff, dd0), sb = 0;
+    if (BREAKUP) sb = pcg_jump_fast(s_rng[2], A.rng_tab, A.rng_aff, dd0);
 #pragma unroll
     for (int r = 0; r < CELL2_MAXPAIR; ++r) {
       const int lp = lp0 + 2 * (tid * CELL2_MAXPAIR + r);
