@@ -52,7 +52,7 @@ WORKLOADS = {
 
 
 def build_workload(name, engine, rank, world, n_sd=None, adaptive=None, read_back=True,
-                   ids_by_cell=False):
+                   ids_by_cell=False, grid=None):
     from pysdm_amd import cases, sharding
 
     if name == "kinematic2d" and world > 1:
@@ -60,7 +60,7 @@ def build_workload(name, engine, rank, world, n_sd=None, adaptive=None, read_bac
                                          adaptive=adaptive)
     # 0-D boxes: every rank an independent realisation (seed 44 + rank)
     return cases.make_box(engine, name, n_sd=n_sd, adaptive=adaptive, seed=44 + rank,
-                          read_back=read_back, ids_by_cell=ids_by_cell)
+                          read_back=read_back, ids_by_cell=ids_by_cell, grid=grid)
 
 
 def cpu_model():
@@ -140,6 +140,8 @@ def main():
     # measurement of a DIFFERENT workload (profiles/README.md): a cell's super-droplets get
     # consecutive ids; the JSON line says so in config.workload
     parser.add_argument("--ids-by-cell", action="store_true")
+    # another grid for the multi-cell workload (not the configuration either): e.g. 75 75
+    parser.add_argument("--grid", type=int, nargs=2, default=None)
     args = parser.parse_args()
 
     import torch
@@ -166,7 +168,7 @@ def main():
     engine = HipEngine.get(local_rank)
     adaptive = None if args.adaptive is None else bool(args.adaptive)
     runner = build_workload(args.workload, engine, rank, world, args.n_sd, adaptive,
-                            ids_by_cell=args.ids_by_cell)
+                            ids_by_cell=args.ids_by_cell, grid=args.grid)
     pop, setup = runner.population, runner.setup
     n_sd = pop.n_sd
     runner.run(1)  # allocates scratch, builds the mirror
@@ -294,7 +296,9 @@ def main():
                 "workload": WORKLOADS[args.workload] + "; "
                             + ("adaptive" if setup.adaptive else "non-adaptive")
                             + ("; NOT the configuration: ids ordered by cell"
-                               if args.ids_by_cell else ""),
+                               if args.ids_by_cell else "")
+                            + (f"; NOT the configuration: grid {args.grid[0]} x {args.grid[1]}"
+                               if args.grid else ""),
                 "n_sd": n_sd,
                 "seed": 44,
                 "route": "fused sdm_collision_run",

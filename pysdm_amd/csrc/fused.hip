@@ -1336,6 +1336,7 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
 #define CELL2_MAXPAIR ((CELL2_CAP / 2 + CELL2_THREADS - 1) / CELL2_THREADS)
 #define CELL2_BATCH 3
 #define CELL2_LDS_BYTES (CELL2_CAP * 14)
+#define CELL2_PACK 8  // cells per workgroup on the small-cell variant (one wavefront each)
 static_assert(CELL2_MAXPAIR % CELL2_BATCH == 0, "pairs are taken in whole batches");
 
 __device__ __forceinline__ int lds_exch16(uint32_t *words, int i, int v) {
@@ -1351,65 +1352,85 @@ __device__ __forceinline__ int lds_exch16(uint32_t *words, int i, int v) {
   return (int)((old >> sh) & 0xFFFFu);
 }
 
-template <int KERNEL, bool BREAKUP>
+// CPW cells per workgroup (1 or 8): a grid of many small cells - 75 x 75 with 64..128
+// super-droplets each is the reference's own 2-D example - would otherwise occupy one 512-thread
+// workgroup per cell (5625 workgroups = 11 rounds of the resident 512, each a chain of latencies:
+// 170 us per sub-step whatever the cell size).  With CPW = 8 a cell is one wavefront with its own
+// slice of LDS (CELL2_CAP / 8 = 704 positions); the barriers stay workgroup-wide (the cells of a
+// workgroup move in lockstep), the reductions and counters are per wavefront anyway.
+template <int KERNEL, bool BREAKUP, int CPW>
 __global__ void __launch_bounds__(CELL2_THREADS, 4)
 k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint32_t *hits = (uint32_t *)smem;                 // [CAP] two 16-bit hit slots, 0xFFFF = free
-  int32_t *out = (int32_t *)smem;                    // ... later the permuted ids
-  int32_t *val = (int32_t *)(smem + CELL2_CAP * 4);  // [CAP] ids before the shuffle
+  constexpr int T = CELL2_THREADS / CPW;  // threads per cell
+  constexpr int CAP = CELL2_CAP / CPW;    // positions per cell
+  static_assert(T % SDM_WAVE == 0 && CAP % 8 == 0 && CAP / T == CELL2_MAXPOS, "cell slices");
+  const int sub = threadIdx.x / T, tid = threadIdx.x % T;  // which cell of the workgroup, lane in it
+  char *cmem = smem + (size_t)sub * CAP * 14;
+  uint32_t *hits = (uint32_t *)cmem;                 // [CAP] two 16-bit hit slots, 0xFFFF = free
+  int32_t *out = (int32_t *)cmem;                    // ... later the permuted ids
+  int32_t *val = (int32_t *)(cmem + CAP * 4);        // [CAP] ids before the shuffle
   double *list_g = (double *)val;                    // ... later gamma of the colliding pairs
-  uint16_t *head = (uint16_t *)(smem + CELL2_CAP * 8);   // [CAP] overflow list heads
-  int32_t *list_lp = (int32_t *)head;                    // ... later their pair slots
-  int16_t *jown = (int16_t *)(smem + CELL2_CAP * 10);    // [CAP] own target
-  uint16_t *next = (uint16_t *)(smem + CELL2_CAP * 12);  // [CAP] overflow links
-  double *list_ub = (double *)jown;                      // ... later (breakup) their second draws
+  uint16_t *head = (uint16_t *)(cmem + CAP * 8);     // [CAP] overflow list heads
+  int32_t *list_lp = (int32_t *)head;                // ... later their pair slots
+  int16_t *jown = (int16_t *)(cmem + CAP * 10);      // [CAP] own target
+  uint16_t *next = (uint16_t *)(cmem + CAP * 12);    // [CAP] overflow links
+  double *list_ub = (double *)jown;                  // ... later (breakup) their second draws
   __shared__ double red[CELL2_THREADS / SDM_WAVE];
-  __shared__ int64_t s_cid, s_base;
-  __shared__ u128 s_rng[3];
-  __shared__ int s_ncoll;
+  __shared__ int64_t s_cid_[CPW], s_base_[CPW];
+  __shared__ u128 s_rng_[CPW][3];
+  __shared__ int s_ncoll_[CPW];
+  int64_t &s_cid = s_cid_[sub], &s_base = s_base_[sub];
+  u128 *s_rng = s_rng_[sub];
+  int &s_ncoll = s_ncoll_[sub];
   const int64_t C = cfg.n_cell, N = cfg.n_sd;
-  const int tid = threadIdx.x;
+  const int64_t n_cell_groups = (C + CPW - 1) / CPW;
   if (X.gate && X.gate[0] == 0) return;
-  if ((int64_t)blockIdx.x >= C) {  // dead tail [cell_start[C], N) is carried over unchanged
+  if ((int64_t)blockIdx.x >= n_cell_groups) {  // dead tail [cell_start[C], N) is carried over unchanged
     const int64_t from = A.cell_start[C];
-    for (int64_t i = from + ((int64_t)blockIdx.x - C) * CELL2_THREADS + tid; i < N;
-         i += (int64_t)X.n_tail_blocks * CELL2_THREADS)
+    for (int64_t i = from + ((int64_t)blockIdx.x - n_cell_groups) * CELL2_THREADS + threadIdx.x;
+         i < N; i += (int64_t)X.n_tail_blocks * CELL2_THREADS)
       X.idx_out[i] = X.idx_in[i];
     return;
   }
-  const int64_t lo = A.cell_start[blockIdx.x], hi = A.cell_start[blockIdx.x + 1];
-  const int n = (int)(hi - lo);
-  if (n == 0) return;
-  if (A.cell_owned && !A.cell_owned[A.cell_id[X.idx_in[lo]]]) {  // another process's cell
+  // a cell that has nothing to do here (beyond the grid, empty, another process's, too large)
+  // takes part in the barriers below with n = 0
+  const int64_t cell = (int64_t)blockIdx.x * CPW + sub;
+  int64_t lo = 0, hi = 0;
+  if (cell < C) { lo = A.cell_start[cell]; hi = A.cell_start[cell + 1]; }
+  int n = (int)(hi - lo);
+  if (n > 0 && A.cell_owned && !A.cell_owned[A.cell_id[X.idx_in[lo]]]) {  // another process's cell
     if (X.copy_others)
-      for (int li = tid; li < n; li += CELL2_THREADS) X.idx_out[lo + li] = X.idx_in[lo + li];
-    return;
+      for (int li = tid; li < n; li += T) X.idx_out[lo + li] = X.idx_in[lo + li];
+    n = 0;
   }
-  if (n > CELL2_CAP) {  // never taken: the host enables this path only below the cap
+  if (n > CAP) {  // never taken: the host enables this path only below the cap
     if (tid == 0) A.ctl[7] = 1;
-    for (int li = tid; li < n; li += CELL2_THREADS) X.idx_out[lo + li] = X.idx_in[lo + li];
-    return;
+    for (int li = tid; li < n; li += T) X.idx_out[lo + li] = X.idx_in[lo + li];
+    n = 0;
   }
   const int64_t W = A.ctl[CTL_WORK];
-  for (int li = tid; li < n; li += CELL2_THREADS) {
+  for (int li = tid; li < n; li += T) {
     val[li] = (int32_t)X.idx_in[lo + li];
     hits[li] = 0xFFFFFFFFu;
     head[li] = 0xFFFFu;
   }
-  if (tid == 0) s_ncoll = 0;
+  if (tid == 0) { s_ncoll = 0; s_cid = 0; s_base = 0; }
   __syncthreads();
-  if (tid == 0) {
-    s_cid = A.cell_id[val[0]];
-    s_base = A.cell_start[A.cell_idx[s_cid]];
+  if (n > 0) {
+    if (tid == 0) {
+      s_cid = A.cell_id[val[0]];
+      s_base = A.cell_start[A.cell_idx[s_cid]];
+    }
+    if (tid == 1) s_rng[0] = pcg_jump_fast(X.s_u01, A.rng_tab, A.rng_aff, (uint64_t)lo);
+    if (tid == 2) s_rng[1] = pcg_jump_fast(A.s_rand, A.rng_tab, A.rng_aff, (uint64_t)(lo >> 1));
+    if (BREAKUP && tid == 3)
+      s_rng[2] = pcg_jump_fast(A.s_rand_b, A.rng_tab, A.rng_aff, (uint64_t)(lo >> 1));
   }
-  if (tid == 64) s_rng[0] = pcg_jump_fast(X.s_u01, A.rng_tab, A.rng_aff, (uint64_t)lo);
-  if (tid == 128) s_rng[1] = pcg_jump_fast(A.s_rand, A.rng_tab, A.rng_aff, (uint64_t)(lo >> 1));
-  if (BREAKUP && tid == 192) s_rng[2] = pcg_jump_fast(A.s_rand_b, A.rng_tab, A.rng_aff, (uint64_t)(lo >> 1));
   __syncthreads();
   // shuffle_local events of this cell (index_methods.py:35-41): consecutive positions per thread
   {
-    const int chunk = (n + CELL2_THREADS - 1) / CELL2_THREADS;
+    const int chunk = (n + T - 1) / T;
     const int li0 = tid * chunk;
     if (li0 < n) {
       u128 state = pcg_jump_fast(s_rng[0], A.rng_tab, A.rng_aff, (uint64_t)li0);
@@ -1443,7 +1464,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   int32_t walked[CELL2_MAXPOS];
 #pragma unroll
   for (int w = 0; w < CELL2_MAXPOS; ++w) {
-    const int li = tid + w * CELL2_THREADS;
+    const int li = tid + w * T;
     walked[w] = 0;
     if (li < n) {
       int e = 0, q = li;
@@ -1467,7 +1488,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   __syncthreads();
 #pragma unroll
   for (int w = 0; w < CELL2_MAXPOS; ++w) {
-    const int li = tid + w * CELL2_THREADS;
+    const int li = tid + w * T;
     if (li < n) out[li] = walked[w];
   }
   __syncthreads();
@@ -1527,11 +1548,12 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   double scale = 1.0 / (double)cfg.substeps;
   if (cfg.adaptive) {  // workgroup minimum of the optimal sub-step (collisions_methods.py:357-368)
     const double m = wave_min_f64(my_min);
-    if ((tid & 63) == 0) red[tid >> 6] = m;
+    if ((tid & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    double bmin = red[0];
-    for (int w = 1; w < CELL2_THREADS / SDM_WAVE; ++w) bmin = red[w] < bmin ? red[w] : bmin;
-    if (tid == 0) A.cell_min[cid] = bmin;  // k_cells_end does the per-cell bookkeeping
+    const int w0 = sub * (T / SDM_WAVE);  // this cell's wavefronts
+    double bmin = red[w0];
+    for (int w = 1; w < T / SDM_WAVE; ++w) bmin = red[w0 + w] < bmin ? red[w0 + w] : bmin;
+    if (tid == 0 && n > 0) A.cell_min[cid] = bmin;  // k_cells_end does the per-cell bookkeeping
     const double l = A.dt_left[cid];
     double todo = cfg.dt_max < l ? cfg.dt_max : l;
     if (bmin < todo) todo = bmin;
@@ -1569,7 +1591,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   // update: one colliding pair per thread, state from the mirror (compute_gamma's clamp and
   // counters :566-585, coalescence :44-59)
   const int n_coll = s_ncoll;
-  for (int base = 0; base < n_coll; base += CELL2_THREADS) {
+  for (int base = 0; base < n_coll; base += T) {
     const int t = base + tid;
     const bool act = t < n_coll;
     int lp = 0;
@@ -1616,7 +1638,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     if (died & 2) out[lp + 1] = (int32_t)N;
   }
   __syncthreads();
-  for (int li = tid; li < n; li += CELL2_THREADS) X.idx_out[lo + li] = out[li];
+  for (int li = tid; li < n; li += T) X.idx_out[lo + li] = out[li];
 }
 
 // largest cell of a sorted state -> ctl[6]
@@ -2034,9 +2056,13 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       CELL_ATTR(SDM_KERNEL_LINEAR, false); CELL_ATTR(SDM_KERNEL_LINEAR, true);
 #undef CELL_ATTR
 #define CELL2_ATTR(K)                                                                           \
-  HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K, false>,                             \
+  HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K, false, 1>,                          \
                               hipFuncAttributeMaxDynamicSharedMemorySize, CELL2_LDS_BYTES));    \
-  HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K, true>,                              \
+  HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K, true, 1>,                           \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, CELL2_LDS_BYTES));    \
+  HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K, false, CELL2_PACK>,                 \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, CELL2_LDS_BYTES));    \
+  HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K, true, CELL2_PACK>,                  \
                               hipFuncAttributeMaxDynamicSharedMemorySize, CELL2_LDS_BYTES))
       CELL2_ATTR(SDM_KERNEL_GOLOVIN); CELL2_ATTR(SDM_KERNEL_GEOMETRIC);
       CELL2_ATTR(SDM_KERNEL_CONSTANT); CELL2_ATTR(SDM_KERNEL_PARAMETERIZED);
@@ -2112,11 +2138,16 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   auto launch_cell_kernel = [&](const CellArgs &X) -> int {
     PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
     const bool brk = cfg->enable_breakup != 0;
+    // small cells: CELL2_PACK of them per workgroup (k_cell_step2)
+    const bool packed = cell2 && max_cell >= 0 && max_cell <= CELL2_CAP / CELL2_PACK;
     const dim3 grid((unsigned)(C + X.n_tail_blocks));
+    const dim3 grid_p((unsigned)((C + CELL2_PACK - 1) / CELL2_PACK + X.n_tail_blocks));
 #define CELL_LAUNCH(K)                                                                        \
   do {                                                                                        \
-    if (cell2 && brk) hipLaunchKernelGGL((k_cell_step2<K, true>), grid, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
-    else if (cell2) hipLaunchKernelGGL((k_cell_step2<K, false>), grid, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
+    if (packed && brk) hipLaunchKernelGGL((k_cell_step2<K, true, CELL2_PACK>), grid_p, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
+    else if (packed) hipLaunchKernelGGL((k_cell_step2<K, false, CELL2_PACK>), grid_p, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
+    else if (cell2 && brk) hipLaunchKernelGGL((k_cell_step2<K, true, 1>), grid, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
+    else if (cell2) hipLaunchKernelGGL((k_cell_step2<K, false, 1>), grid, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
     else if (brk) hipLaunchKernelGGL((k_cell_step<K, true>), grid, dim3(CELL_THREADS), CELL_LDS_BYTES, s, *cfg, A, X); \
     else hipLaunchKernelGGL((k_cell_step<K, false>), grid, dim3(CELL_THREADS), CELL_LDS_BYTES, s, *cfg, A, X);    \
   } while (0)
