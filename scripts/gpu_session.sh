@@ -1,15 +1,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/r02_gputest_u.log 2>&1 || { grep -v "^  File\|^Extension" gpurun_out/r02_gputest_u.log | tail -40; exit 1; }
-tail -2 gpurun_out/r02_gputest_u.log
-python bench.py --workload kinematic2d --grid 75 75 --n-sd 720000 --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/r02_bench_kinematic2d_75x75x128.json 2>gpurun_out/err.txt || { tail -5 gpurun_out/err.txt; exit 1; }
-python -c "
-import json; d=json.load(open('gpurun_out/r02_bench_kinematic2d_75x75x128.json')); print('75x75x128', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['phase_ms_per_step'])"
-python bench.py --workload kinematic2d --grid 75 75 --n-sd 360000 --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/r02_bench_kinematic2d_75x75x64.json 2>gpurun_out/err.txt || { tail -5 gpurun_out/err.txt; exit 1; }
-python -c "
-import json; d=json.load(open('gpurun_out/r02_bench_kinematic2d_75x75x64.json')); print('75x75x64', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['phase_ms_per_step'])"
-for n in 65536 262144; do
-python bench.py --workload kinematic2d --n-sd $n --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/r02_bench_kinematic2d_n${n}_packed.json 2>/dev/null
-python -c "
-import json; d=json.load(open('gpurun_out/r02_bench_kinematic2d_n${n}_packed.json')); print($n, d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"
-done
+O=gpurun_out
+rm -rf $O/pc_stats
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/pc_stats -- python3 bench.py --workload kinematic2d --grid 75 75 --n-sd 720000 --steps 40 --warmup 5 --reps 1 --no-cpu-baseline --roofline-steps 3 > /dev/null 2>&1
+cp $(ls $O/pc_stats/*/*kernel_stats.csv) $O/r02_kernel_stats_kinematic2d_75x75x128_b.csv
+rm -rf $O/pc_stats
