@@ -1,5 +1,7 @@
 """kinematic flow (displacement + collisions, 2^22 super-droplets, 32 x 32 cells): time per step
-and, under rocprofv3, the kernel breakdown:  PYTHONPATH=. python profiles/tools/flow_profile.py"""
+and, under rocprofv3, the kernel breakdown:  PYTHONPATH=. python profiles/tools/flow_profile.py
+[n_sd nx ny]   (e.g. 720000 75 75: the grid of the reference's 2-D example, 128 per cell)"""
+import sys
 import time
 import warnings
 
@@ -8,7 +10,10 @@ import torch
 from pysdm_amd.cases import make_kinematic_flow
 from pysdm_amd.engine import HipEngine
 
-displacement, collisions = make_kinematic_flow(HipEngine.get())
+options = {}
+if len(sys.argv) > 3:
+    options = dict(n_sd=int(sys.argv[1]), grid=(int(sys.argv[2]), int(sys.argv[3])))
+displacement, collisions = make_kinematic_flow(HipEngine.get(), **options)
 
 
 def run(steps):

@@ -1,7 +1,8 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out
-rm -rf $O/pc_stats
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/pc_stats -- python3 bench.py --workload kinematic2d --grid 75 75 --n-sd 720000 --steps 40 --warmup 5 --reps 1 --no-cpu-baseline --roofline-steps 3 > /dev/null 2>&1
-cp $(ls $O/pc_stats/*/*kernel_stats.csv) $O/r02_kernel_stats_kinematic2d_75x75x128_b.csv
-rm -rf $O/pc_stats
+export PYTHONPATH=$GRAFT_REPO_ROOT
+rm -rf gpurun_out/pc_stats
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pc_stats -- python3 profiles/tools/flow_profile.py 720000 75 75 > gpurun_out/flow.txt 2>&1 || { tail -5 gpurun_out/flow.txt; exit 1; }
+tail -1 gpurun_out/flow.txt
+cp $(ls gpurun_out/pc_stats/*/*kernel_stats.csv) gpurun_out/r02_kernel_stats_flow_75x75x128.csv
+rm -rf gpurun_out/pc_stats
