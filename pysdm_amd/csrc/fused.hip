@@ -2272,16 +2272,31 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         if (r) return r;
         HIP_TRY(hipMemsetAsync(S.end2, 0, sizeof(int64_t), s));
       }
-      if (!sharded) {  // (sharded: after the read-back, and only if a super-droplet died)
-        PhaseScope ph(ctx, SDM_PHASE_SANITIZE);
-        const int r = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl,
-                                              S.cctl, nullptr, true);
-        if (r) return r;
-      }
       *seq_out = ++ctx->poll_seq;
-      hipLaunchKernelGGL(k_cells_end, dim3(grid_for(C)), blk, 0, s, *cfg, A, sharded ? 0 : 1,
-                         S.end2, ctx->box_dev, *seq_out);
-      LAUNCH_CHECK();
+      if (!sharded) {  // (sharded: after the read-back, and only if a super-droplet died)
+        // the compaction kernel's workgroups end the sub-step as well (index.hip: cells_end_body)
+        PhaseScope ph(ctx, SDM_PHASE_SANITIZE);
+        CompactEpilogue E;
+        memset(&E, 0, sizeof(E));
+        E.cells.n_cell = C;
+        E.cells.dt_left = st->dt_left;
+        E.cells.dt_todo = A.dt_todo;
+        E.cells.stats_dt_min = st->stats_dt_min;
+        E.cells.cell_min = A.cell_min;
+        E.cells.stats_n_substep = st->stats_n_substep;
+        E.cells.cell_start = st->cell_start;
+        E.cells.end2 = S.end2;
+        E.cells.ctl = st->ctl;
+        E.cells.box = ctx->box_dev;
+        E.cells.seq = *seq_out;
+        const int r = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl,
+                                              S.cctl, nullptr, true, &E);
+        if (r) return r;
+      } else {
+        hipLaunchKernelGGL(k_cells_end, dim3(grid_for(C)), blk, 0, s, *cfg, A, 0, S.end2,
+                           ctx->box_dev, *seq_out);
+        LAUNCH_CHECK();
+      }
       ++launched;
       return SDM_OK;
     };

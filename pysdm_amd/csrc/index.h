@@ -75,6 +75,18 @@ int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
 // kernel's last act instead of a launch of its own: refused-breakup count of the counter slots
 // into fctl[4] (slots may be NULL), working length = dt_left[0] != 0 ? valid length : 0, control
 // block published to the polled host box with sequence number `seq` (common.h:publish_ctl)
+// multi-cell per-cell route: what ends a sub-step after the compaction (fused.hip: k_cells_end -
+// per-cell adaptive bookkeeping, adaptive_sdm_end, publication of the control block), run by the
+// compaction kernel's own workgroups: one launch less per sub-step
+struct CellsEnd {
+  int64_t n_cell;  // 0: none
+  double *dt_left, *dt_todo, *stats_dt_min;
+  const double *cell_min;
+  int64_t *stats_n_substep;
+  const int64_t *cell_start;
+  int64_t *end2, *ctl, *box;
+  int64_t seq;
+};
 struct CompactEpilogue {
   const double *dt_left;  // NULL: no epilogue
   int64_t *slots;
@@ -83,6 +95,7 @@ struct CompactEpilogue {
   // graph replay (common.h: gwords): stream positions advanced by these at the kernel's start
   uint64_t *gwords;
   uint64_t advance, advance_b;
+  CellsEnd cells;
 };
 int sdm_compact_fused_async(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity,
                             int64_t *idx, int64_t length_bound, int64_t flag, int64_t *fctl,

@@ -605,6 +605,53 @@ __device__ __forceinline__ void compact_epilogue(const CompactEpilogue &E,
 
 // FLAG_ONLY: the caller guarantees that no live super-droplet has zero multiplicity (it entered
 // with a healthy state and only flags positions), so the random gather of multiplicities is skipped
+// k_cells_end (fused.hip) as a device function of this kernel's workgroups: per-cell adaptive
+// bookkeeping (collisions_methods.py:357-374), end2[0] = 1 + largest c with dt_left[c] != 0
+// (adaptive_sdm_end, :313-328), and by the workgroup that finishes last the working length and
+// the publication of the control block (as the compaction left it)
+__device__ __forceinline__ void cells_end_body(const CellsEnd &E) {
+  const bool ran = E.end2[3] != 0;  // (fused.hip: k_cells_begin - gated sub-steps)
+  const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t base = 0; base < E.n_cell; base += n_threads) {  // (uniform trip count)
+    const int64_t c = base + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool nz = false;
+    if (c < E.n_cell) {
+      double left = E.dt_left[c];
+      if (ran) {
+        const double m = E.cell_min[c];
+        double t = E.dt_todo[c];
+        if (m < t) t = m;
+        E.dt_todo[c] = t;
+        const double smin = E.stats_dt_min[c];
+        E.stats_dt_min[c] = m < smin ? m : smin;  // Python min(s, m): NaN-sticky
+        left -= t;
+        E.dt_left[c] = left;
+        if (t > 0) E.stats_n_substep[c] += 1;
+      }
+      nz = left != 0;
+    }
+    const unsigned long long mask = __ballot(nz);
+    if (mask && lane_id() == 0)
+      atomicMax((long long *)&E.end2[0], (long long)((c - lane_id()) + (63 - __clzll(mask)) + 1));
+  }
+  __shared__ bool last_cells;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    last_cells = atomicAdd((unsigned long long *)&E.end2[2], 1ull) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last_cells && threadIdx.x == 0) {
+    __threadfence();
+    const int64_t top = __hip_atomic_load(&E.end2[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int64_t end = top == 0 ? 0 : E.cell_start[top];
+    E.end2[1] = end;
+    E.end2[2] = 0;
+    if (ran) E.ctl[1] = end;  // (CTL_WORK)
+    publish_ctl(E.ctl, E.box, E.seq, ran ? end : E.ctl[1]);
+  }
+}
+
 // the compaction proper, by every workgroup of the grid (all resident; at most COMPACT_MAX_GROUPS);
 // false: a grid barrier timed out (fctl[7] = 2).  *new_length: the length every workgroup computed
 template <bool FLAG_ONLY>
@@ -753,12 +800,15 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
   }
   if (fctl[FCTL_HEALTHY] != 0) {
     if (E.dt_left && blockIdx.x == 0) compact_epilogue(E, fctl);
+    if (E.cells.n_cell) cells_end_body(E.cells);
     return;
   }
   int64_t new_len;
   __shared__ int excl[COMPACT_WAVES];
-  (void)compact_run<FLAG_ONLY>(multiplicity, idx, flag, fctl, wave_dead, n_tiles, ctl, holes,
-                               fillers, cell_start_single, bar, E, &new_len, excl);
+  if (compact_run<FLAG_ONLY>(multiplicity, idx, flag, fctl, wave_dead, n_tiles, ctl, holes,
+                             fillers, cell_start_single, bar, E, &new_len, excl) &&
+      E.cells.n_cell)
+    cells_end_body(E.cells);  // (its last workgroup publishes what the commit above left)
 }
 
 // k_bin_sort (declared above): the tile sort of the shuffle build
@@ -905,7 +955,8 @@ int sdm_compact_fused_async(sdm_ctx *ctx, char *scratch, const int64_t *multipli
                             int64_t *idx, int64_t length_bound, int64_t flag, int64_t *fctl,
                             int64_t *ctl, int64_t *cell_start_single, bool flag_only,
                             const CompactEpilogue *epilogue) {
-  CompactEpilogue E = {nullptr, nullptr, nullptr, 0, nullptr, 0, 0};
+  CompactEpilogue E;
+  memset(&E, 0, sizeof(E));
   if (epilogue) E = *epilogue;
   Carver cv(scratch);
   const int n_tiles = (int)grid_for(length_bound, SDM_WAVE);
