@@ -137,6 +137,8 @@ def main():
     parser.add_argument("--adaptive", type=int, default=None)
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--roofline-steps", type=int, default=50)
+    parser.add_argument("--skip-full-experiment", action="store_true",
+                        help="shima: do not run the 3600-step experiment after the timed region")
     # measurement of a DIFFERENT workload (profiles/README.md): a cell's super-droplets get
     # consecutive ids; the JSON line says so in config.workload
     parser.add_argument("--ids-by-cell", action="store_true")
@@ -144,13 +146,23 @@ def main():
     parser.add_argument("--grid", type=int, nargs=2, default=None)
     args = parser.parse_args()
 
+    from pysdm_amd import launch
+
+    if args.gpus > 1 and not launch.launched_by_torchrun():
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher - it
+        # starts the N ranks as children through torch.distributed.run, waits, and exits with
+        # their code.  Nothing here has touched the GPU (no torch import yet), and no process that
+        # has is ever re-executed; rank 0's JSON line goes to the inherited stdout.
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # rehearsal knobs (not used by the driver): several ranks on one card, collectives over gloo
     dist_backend = os.environ.get("SDM_BENCH_DIST_BACKEND", "nccl")
     if os.environ.get("SDM_BENCH_ALL_ON_DEVICE0") == "1":
@@ -161,6 +173,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(dist_backend)
+        # what the line reports as n_gpus is what the process group (RCCL) saw, not the flag
+        world = dist.get_world_size()
     reduce_device = "cuda" if dist_backend == "nccl" else "cpu"
 
     from pysdm_amd.engine import HipEngine
@@ -224,6 +238,24 @@ def main():
     rates = [r[0] for r in reps]
     median_rate = statistics.median(rates)
     _, elapsed_max, pairs_total = min(reps, key=lambda r: abs(r[0] - median_rate))
+
+    # metric part (ii): the Shima-2009 experiment itself (settings.py:14-33: 3600 steps of 1 s
+    # from the initial spectrum), run once and timed by the wall clock - not extrapolated
+    shima_box_s = None
+    if args.workload == "shima" and not args.skip_full_experiment:
+        box = build_workload(args.workload, engine, rank, world, args.n_sd, adaptive,
+                             read_back=False)
+        barrier()
+        t0 = time.perf_counter()
+        box.run(3600)
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=reduce_device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        shima_box_s = float(t.item())
+        box.sync()
+        shima_box_live = box.population.live
+        del box
 
     roofline = None
     baseline = None
@@ -306,7 +338,12 @@ def main():
             "state_digest": state_digest,
             "repetitions": {"n": len(reps), "reported": "median",
                             "values": [round(r, 1) for r in rates]},
-            "shima_box_3600_steps_s": elapsed_max / args.steps * 3600,
+            # measured: one run of the whole experiment (3600 steps from the initial state, one
+            # library call, mirror build included); null for the other workloads
+            "shima_box_3600_steps_s": shima_box_s,
+            "shima_box_3600_steps_live_sd": shima_box_live if shima_box_s is not None else None,
+            "shima_box_3600_steps_extrapolated_s": (elapsed_max / args.steps * 3600
+                                                    if args.workload == "shima" else None),
             "roofline": roofline,
             "cpu_baseline": baseline,
         }))
