@@ -255,6 +255,22 @@ int sdm_elementwise_f64(sdm_ctx *ctx, int op, double *out, const double *a, cons
                         double scalar, int64_t n);
 int sdm_elementwise_i64(sdm_ctx *ctx, int op, int64_t *out, const int64_t *a, const int64_t *b,
                         int64_t scalar, int64_t n);
+/* the path's transcendental functions, evaluated element-wise: out[i] = fn(a[i] [, b[i]]).
+ * The reference takes them from NumPy / libm (storage_impl.py:75-78 `power`, :48-49 `exp`,
+ * fragmentation_methods.py:12-48 log/exp/erf, physics/trivia.py:95-108 sinh/asinh/atanh); here
+ * they are ONE double-only implementation (csrc/sdm_math.h) compiled into this library and into
+ * the CPU checker alike, so that both return the same bits and breakup runs stay
+ * integer-identical however long they are.  b is read for SDM_MATH_POW only.                  */
+#define SDM_MATH_EXP 0
+#define SDM_MATH_LOG 1
+#define SDM_MATH_POW 2
+#define SDM_MATH_SINH 3
+#define SDM_MATH_ASINH 4
+#define SDM_MATH_ATANH 5
+#define SDM_MATH_ERF 6
+#define SDM_MATH_LOG1P 7
+int sdm_math_eval(sdm_ctx *ctx, int fn, double *out, const double *a, const double *b,
+                  int64_t n);
 /* reductions (storage_impl.py:24-31): *result is a host pointer; syncs. kind: 0 min, 1 max */
 int sdm_reduce_f64(sdm_ctx *ctx, int kind, const double *a, int64_t n, double *result);
 

@@ -20,6 +20,9 @@ from pysdm_amd.engine import Engine
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = [os.path.join(_HERE, name) for name in ("sdm_oracle_abi.c", "sdm_oracle.c")]
 HEADER = abi.HEADER_PATH
+# the transcendental functions are shared with the product (one implementation, same bits)
+MATH = [os.path.join(os.path.dirname(_HERE), "pysdm_amd", "csrc", name)
+        for name in ("sdm_math.h", "sdm_math_tables.h")]
 LIB_PATH = os.path.join(_HERE, "libsdm_oracle.so")
 LIB_PATH_OMP = os.path.join(_HERE, "libsdm_oracle_omp.so")
 _FLAGS = ["-O2", "-std=gnu11", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
@@ -29,7 +32,7 @@ _FLAGS = ["-O2", "-std=gnu11", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "
 def build(force=False):
     """compiles the serial checker and its OpenMP twin (same source; `prange` loops of the
     reference's Numba backend become `omp parallel for`) - used by bench.py's cpu_baseline"""
-    newest = max(os.path.getmtime(p) for p in SOURCES + [HEADER])
+    newest = max(os.path.getmtime(p) for p in SOURCES + [HEADER] + MATH)
     for path, extra in ((LIB_PATH, []), (LIB_PATH_OMP, ["-fopenmp"])):
         if force or not os.path.exists(path) or os.path.getmtime(path) < newest:
             subprocess.check_call(["gcc", *_FLAGS, *extra, "-o", path, SOURCES[0], "-lm"])

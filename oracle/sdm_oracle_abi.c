@@ -344,7 +344,7 @@ API int sdm_spectrum_moments(sdm_ctx *c, double *moment_0, double *moments,
 static inline double sign_of(double x) { return (double)((x > 0) - (x < 0)); }
 static inline double signed_power(double x, double p) { /* :75-78 */
   if (x != x) return x;
-  return sign_of(x) * (p == 2.0 ? x * x : pow(fabs(x), p));
+  return sign_of(x) * (p == 2.0 ? x * x : sdm_pow(fabs(x), p));
 }
 static inline double py_mod(double a, double b) { /* numpy's float % (npy_divmod) */
   double m = fmod(a, b);
@@ -371,11 +371,32 @@ API int sdm_elementwise_f64(sdm_ctx *c, int op, double *out, const double *a, co
       case SDM_EW_POW: r = signed_power(x, s); break;
       case SDM_EW_DIV_IF_NOT_ZERO: r = (y != 0.0) ? x / y : x; break;
       case SDM_EW_FLOOR: r = floor(x); break;
-      case SDM_EW_EXP: r = exp(x); break;
+      case SDM_EW_EXP: r = sdm_exp(x); break;
       case SDM_EW_ABS: r = fabs(x); break;
       case SDM_EW_FILL: r = y; break;
       case SDM_EW_ADD_MUL: r = x + s * b[i]; break;
       default: r = py_mod(x, y);
+    }
+    out[i] = r;
+  }
+  return SDM_OK;
+}
+API int sdm_math_eval(sdm_ctx *c, int fn, double *out, const double *a, const double *b,
+                      int64_t n) {
+  (void)c;
+  if (fn < SDM_MATH_EXP || fn > SDM_MATH_LOG1P) FAIL(SDM_E_ARG, "sdm_math_eval: unknown function");
+  for (int64_t i = 0; i < n; ++i) {
+    const double x = a[i];
+    double r;
+    switch (fn) {
+      case SDM_MATH_EXP: r = sdm_exp(x); break;
+      case SDM_MATH_LOG: r = sdm_log(x); break;
+      case SDM_MATH_POW: r = sdm_pow(x, b[i]); break;
+      case SDM_MATH_SINH: r = sdm_sinh(x); break;
+      case SDM_MATH_ASINH: r = sdm_asinh(x); break;
+      case SDM_MATH_ATANH: r = sdm_atanh(x); break;
+      case SDM_MATH_ERF: r = sdm_erf(x); break;
+      default: r = sdm_log1p(x);
     }
     out[i] = r;
   }
@@ -529,7 +550,7 @@ static void pw_div(Box *B, double *a, const double *b) { _Pragma("omp parallel f
 static void pw_div_nz(Box *B, double *a, const double *b) { /* divide_if_not_zero */
   _Pragma("omp parallel for schedule(static)") for (int64_t i = 0; i < B->P; ++i) if (b[i] != 0.0) a[i] = a[i] / b[i];
 }
-static void pw_exp(Box *B, double *a) { _Pragma("omp parallel for schedule(static)") for (int64_t i = 0; i < B->P; ++i) a[i] = exp(a[i]); }
+static void pw_exp(Box *B, double *a) { _Pragma("omp parallel for schedule(static)") for (int64_t i = 0; i < B->P; ++i) a[i] = sdm_exp(a[i]); }
 static void pw_fill(Box *B, double *a, double s) { _Pragma("omp parallel for schedule(static)") for (int64_t i = 0; i < B->P; ++i) a[i] = s; }
 static void pw_copy(Box *B, double *a, const double *b) { memcpy(a, b, sizeof(double) * B->P); }
 

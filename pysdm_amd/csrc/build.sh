@@ -13,7 +13,7 @@ pids=()
 for f in ctx index collisions fused displacement; do
   stale=0
   [ -f $f.o ] || stale=1
-  for dep in $f.hip common.h physics.h index.h shuffle_device.h shuffle_build.h ../../include/sdm_hip.h; do
+  for dep in $f.hip common.h sdm_math.h sdm_math_tables.h physics.h index.h shuffle_device.h shuffle_build.h ../../include/sdm_hip.h; do
     [ $stale = 1 ] || { [ $dep -nt $f.o ] && stale=1; } || true
   done
   if [ $stale = 1 ]; then

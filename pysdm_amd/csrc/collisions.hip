@@ -615,7 +615,7 @@ k_exp_fragmentation(double *__restrict__ n_fragment, double scale,
   const int64_t i = TID();
   if (i >= n) return;
   const double a = 1 - rand[i];
-  double fv = -scale * log(a > tol ? a : tol);
+  double fv = -scale * sdm_log(a > tol ? a : tol);
   double nf;
   fragmentation_limiters(nf, fv, vmin, nfmax, x_plus_y[i]);
   frag_volume[i] = fv;
@@ -670,7 +670,7 @@ k_feingold1988_fragmentation(double *__restrict__ n_fragment, double scale,
   const int64_t i = TID();
   if (i >= n) return;
   const double a = 1 - rand[i] * scale / x_plus_y[i];
-  double fv = -scale * log(a > fragtol ? a : fragtol), nf;
+  double fv = -scale * sdm_log(a > fragtol ? a : fragtol), nf;
   fragmentation_limiters(nf, fv, vmin, nfmax, x_plus_y[i]);
   frag_volume[i] = fv;
   n_fragment[i] = nf;
@@ -697,7 +697,7 @@ k_slams_fragmentation(double *__restrict__ n_fragment, double *__restrict__ frag
   if (i >= n) return;
   double p = 0.0, nf = 1;
   for (int k = 0; k < 22; ++k) {
-    p += 0.91 * pow((double)(k + 2), -1.56);
+    p += 0.91 * sdm_pow((double)(k + 2), -1.56);
     if (rand[i] < p) { nf = k + 2; break; }
   }
   probs[i] = p;
@@ -825,7 +825,7 @@ k_terminal_velocity(double *__restrict__ values, const double *__restrict__ radi
   const int64_t i = TID();
   if (i >= n) return;
   const double r = radius[i];
-  values[i] = r < K.k[3] ? K.k[0] * (r * r) : (r < K.k[4] ? K.k[1] * r : K.k[2] * pow(r, 0.5));
+  values[i] = r < K.k[3] ? K.k[0] * (r * r) : (r < K.k[4] ? K.k[1] * r : K.k[2] * sdm_pow(r, 0.5));
 }
 
 __global__ void __launch_bounds__(SDM_BLOCK)
@@ -834,7 +834,7 @@ k_power_series(double *__restrict__ values, const double *__restrict__ radius, i
   const int64_t i = TID();
   if (i >= n) return;
   double v = 0.0;
-  for (int j = 0; j < num_terms; ++j) v = v + T.prefactor[j] * pow(radius[i], T.power[j] * 3);
+  for (int j = 0; j < num_terms; ++j) v = v + T.prefactor[j] * sdm_pow(radius[i], T.power[j] * 3);
   values[i] = v;
 }
 
@@ -923,10 +923,10 @@ k_moments(double *__restrict__ moment_0, double *__restrict__ moments,
     }
     if (hi < 0) continue;  // nothing in range in this round
     const double w = !live ? 0.0 : (double)multiplicity[i] *
-                     (weighting_rank == 0 ? 1.0 : pow(weighting_attribute[i], weighting_rank));
+                     (weighting_rank == 0 ? 1.0 : sdm_pow(weighting_attribute[i], weighting_rank));
     double term[MOM_MAXR];
     for (int k = 0; k < MOM_MAXR; ++k)
-      term[k] = (live && k < n_pass) ? w * pow(attr_data[i], ranks[rank_first + k]) : 0.0;
+      term[k] = (live && k < n_pass) ? w * sdm_pow(attr_data[i], ranks[rank_first + k]) : 0.0;
     if (lo == hi) {  // the usual case after a collision step: sorted by cell, or one cell
       if (hi != cur) {
         flush();
@@ -965,10 +965,10 @@ k_spectrum_moments(double *__restrict__ moment_0, double *__restrict__ moments,
   for (int k = 0; k < n_bins; ++k)
     if (edges[k] <= x && x < edges[k + 1]) { bin = k; break; }
   if (bin < 0) return;
-  const double w = (double)multiplicity[i] * pow(weighting_attribute[i], weighting_rank);
+  const double w = (double)multiplicity[i] * sdm_pow(weighting_attribute[i], weighting_rank);
   const int64_t at = bin * n_cell + cell_id[i];
   atomicAdd(&moment_0[at], w);
-  atomicAdd(&moments[at], w * pow(attr_data[i], rank));
+  atomicAdd(&moments[at], w * sdm_pow(attr_data[i], rank));
 }
 
 __global__ void __launch_bounds__(SDM_BLOCK)

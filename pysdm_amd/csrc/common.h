@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "../../include/sdm_hip.h"
+#include "sdm_math.h"
 
 typedef unsigned __int128 u128;
 

@@ -325,17 +325,36 @@ k_ew_f64(int op, double *out, const double *a, const double *b, double s, int64_
     case SDM_EW_POW: {
       const double sg = (x > 0) - (x < 0);
       // exponent 2 (Geometric kernel, Berry Ec): the exact square, as numpy / libm give it
-      r = (x != x) ? x : sg * (s == 2.0 ? x * x : pow(fabs(x), s));
+      r = (x != x) ? x : sg * (s == 2.0 ? x * x : sdm_pow(fabs(x), s));
       break;
     }
     case SDM_EW_DIV_IF_NOT_ZERO: r = (y != 0.0) ? x / y : x; break;
     case SDM_EW_FLOOR: r = floor(x); break;
-    case SDM_EW_EXP: r = exp(x); break;
+    case SDM_EW_EXP: r = sdm_exp(x); break;
     case SDM_EW_ABS: r = fabs(x); break;
     case SDM_EW_FILL: r = y; break;
     case SDM_EW_ADD_MUL: r = x + s * b[i]; break;
     case SDM_EW_MOD: r = py_mod_f64(x, y); break;
     default: r = x;
+  }
+  out[i] = r;
+}
+
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_math_eval(int fn, double *out, const double *a, const double *b, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const double x = a[i];
+  double r;
+  switch (fn) {
+    case SDM_MATH_EXP: r = sdm_exp(x); break;
+    case SDM_MATH_LOG: r = sdm_log(x); break;
+    case SDM_MATH_POW: r = sdm_pow(x, b[i]); break;
+    case SDM_MATH_SINH: r = sdm_sinh(x); break;
+    case SDM_MATH_ASINH: r = sdm_asinh(x); break;
+    case SDM_MATH_ATANH: r = sdm_atanh(x); break;
+    case SDM_MATH_ERF: r = sdm_erf(x); break;
+    default: r = sdm_log1p(x);
   }
   out[i] = r;
 }
@@ -425,6 +444,17 @@ k_reduce_final(int kind, const double *partial, int np, const int *has_nan, doub
       v = kind == 0 ? (sm[w] < v ? sm[w] : v) : (sm[w] > v ? sm[w] : v);
     out[0] = *has_nan ? NAN : v;
   }
+}
+
+extern "C" int sdm_math_eval(sdm_ctx *ctx, int fn, double *out, const double *a, const double *b,
+                             int64_t n) {
+  ARG_TRY(ctx && n >= 0 && fn >= SDM_MATH_EXP && fn <= SDM_MATH_LOG1P);
+  ARG_TRY(n == 0 || (out && a && (b || fn != SDM_MATH_POW)));
+  if (n == 0) return SDM_OK;
+  hipLaunchKernelGGL(k_math_eval, dim3((unsigned)((n + SDM_BLOCK - 1) / SDM_BLOCK)), dim3(SDM_BLOCK),
+                     0, ctx->stream, fn, out, a, b, n);
+  LAUNCH_CHECK();
+  return SDM_OK;
 }
 
 extern "C" int sdm_reduce_f64(sdm_ctx *ctx, int kind, const double *a, int64_t n,

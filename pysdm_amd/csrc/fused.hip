@@ -274,7 +274,7 @@ __device__ __forceinline__ void breakup_params(const sdm_step_cfg &cfg, const Fu
         o += 1.0;
         o = signed_pow(o, -2.0);
         o *= 0.778;
-        o *= exp(e);
+        o *= sdm_exp(e);
         ec = dl < 0.4e-3 ? 1.0 : o;
         break;
       }
@@ -292,14 +292,14 @@ __device__ __forceinline__ void breakup_params(const sdm_step_cfg &cfg, const Fu
         Sc *= 3.14159265358979323846 * cfg.sgm_w;
         if (Sc != 0.0) We /= Sc;
         We *= -1.15;
-        ec = exp(We);
+        ec = sdm_exp(We);
       }
     }
     switch (cfg.frag) {
       case SDM_FRAG_ALWAYS_N: fm = (mj + mk) / cfg.frag_param[0]; break;
       case SDM_FRAG_EXPONENTIAL: {
         const double a = 1 - u_b;
-        double fv = -cfg.frag_param[0] * log(a > 1e-5 ? a : 1e-5), nf;
+        double fv = -cfg.frag_param[0] * sdm_log(a > 1e-5 ? a : 1e-5), nf;
         fragmentation_limiters(nf, fv, cfg.frag_vmin, cfg.frag_nfmax, vj + vk);
         fm = cfg.rho_w * fv;
         break;
@@ -313,7 +313,7 @@ __device__ __forceinline__ void breakup_params(const sdm_step_cfg &cfg, const Fu
       }
       case SDM_FRAG_FEINGOLD1988: {  // :487-499, physics/fragmentation_function/feingold1988.py
         const double a = 1 - u_b * cfg.frag_param[0] / (vj + vk);
-        double fv = -cfg.frag_param[0] * log(a > cfg.frag_param[1] ? a : cfg.frag_param[1]), nf;
+        double fv = -cfg.frag_param[0] * sdm_log(a > cfg.frag_param[1] ? a : cfg.frag_param[1]), nf;
         fragmentation_limiters(nf, fv, cfg.frag_vmin, cfg.frag_nfmax, vj + vk);
         fm = cfg.rho_w * fv;
         break;
@@ -321,7 +321,7 @@ __device__ __forceinline__ void breakup_params(const sdm_step_cfg &cfg, const Fu
       case SDM_FRAG_SLAMS: {  // :95-134
         double p = 0.0, nf = 1;
         for (int k = 0; k < 22; ++k) {
-          p += 0.91 * pow((double)(k + 2), -1.56);
+          p += 0.91 * sdm_pow((double)(k + 2), -1.56);
           if (u_b < p) { nf = k + 2; break; }
         }
         double fv = (vj + vk) / nf;

@@ -9,7 +9,7 @@
 // np.sign(x) * np.power(np.abs(x), p)   (storage_impl.py:75-78)
 __device__ __forceinline__ double signed_pow(double x, double p) {
   const double sg = (double)((x > 0) - (x < 0));
-  return (x != x) ? x : sg * pow(fabs(x), p);
+  return (x != x) ? x : sg * sdm_pow(fabs(x), p);
 }
 
 // `x **= 2` on a Storage: the sign survives (storage_impl.py:76-78), the square is exact
@@ -48,13 +48,13 @@ __device__ __forceinline__ double linear_collection_efficiency(const double *__r
   const double p = r_s / r;
   double out = 0.0;
   if (p != 0 && p != 1) {
-    const double G = pow(P[8] / r, P[12]) + P[9] + P[10] * r;
-    const double Gp = pow(1 - p, G);
+    const double G = sdm_pow(P[8] / r, P[12]) + P[9] + P[10] * r;
+    const double Gp = sdm_pow(1 - p, G);
     if (Gp != 0) {
-      const double D = P[2] / pow(r, P[3]);
-      const double E = P[4] / pow(r, P[5]);
-      const double F = pow(P[6] / r, P[11]) + P[7];
-      const double v = P[0] + P[1] * p + D / pow(p, F) + E / Gp;
+      const double D = P[2] / sdm_pow(r, P[3]);
+      const double E = P[4] / sdm_pow(r, P[5]);
+      const double F = sdm_pow(P[6] / r, P[11]) + P[7];
+      const double v = P[0] + P[1] * p + D / sdm_pow(p, F) + E / Gp;
       out = v > 0 ? v : 0;
     }
   }
@@ -81,7 +81,7 @@ __device__ __forceinline__ void fragmentation_limiters(double &n_fragment, doubl
 
 // physics/trivia.py:95-108
 __device__ __forceinline__ double erfinv_approx(double c, double VA, double Vb) {
-  return 2 * sqrt(VA) * sinh(asinh(atanh(c) / 2 / Vb / pow(VA, 1.5)) / 3);
+  return 2 * sqrt(VA) * sdm_sinh(sdm_asinh(sdm_atanh(c) / 2 / Vb / sdm_pow(VA, 1.5)) / 3);
 }
 
 
@@ -95,74 +95,74 @@ __device__ __forceinline__ double erfinv_approx(double c, double VA, double Vb) 
 struct LL82P { double H, mu, sigma; };
 
 __device__ inline struct LL82P ll82_gauss_fixed_point(double H, double mu, double upper) {
-  /* :22-30, :108-116, :150-158: sigma <- sqrt(2/pi)/H / (1 + erf((upper - mu)/(sqrt2 sigma))) */
+  /* :22-30, :108-116, :150-158: sigma <- sqrt(2/pi)/H / (1 + sdm_erf((upper - mu)/(sqrt2 sigma))) */
   double sigma = 1 / H;
   for (int r = 0; r < 10; ++r)
-    sigma = 1 / H * sqrt(2 / LL_PI) / (1 + erf((upper - mu) / (sqrt(2.0) * sigma)));
+    sigma = 1 / H * sqrt(2 / LL_PI) / (1 + sdm_erf((upper - mu) / (sqrt(2.0) * sigma)));
   struct LL82P p = {H, mu, sigma};
   return p;
 }
 
 __device__ inline struct LL82P ll82_f1(double CM, double dl, double dcoal) { /* :15-30 */
   const double dlCM = dl / CM;
-  return ll82_gauss_fixed_point(50.8 * pow(dlCM, -0.718), dlCM, dcoal / CM);
+  return ll82_gauss_fixed_point(50.8 * sdm_pow(dlCM, -0.718), dlCM, dcoal / CM);
 }
 
 __device__ inline struct LL82P ll82_f2(double CM, double ds) { /* :33-38 */
   const double dsCM = ds / CM;
-  const double H = 4.18 * pow(dsCM, -1.17);
+  const double H = 4.18 * sdm_pow(dsCM, -1.17);
   struct LL82P p = {H, dsCM, 1 / (sqrt(2 * LL_PI) * H)};
   return p;
 }
 
 __device__ inline struct LL82P ll82_f3(double CM, double ds, double dl) { /* :41-98 */
   const double dsCM = ds / CM, dlCM = dl / CM;
-  double Ff1 = (-2.25e4 * pow(dlCM - 0.403, 2.0) - 37.9) * pow(dsCM, 2.5) +
-               9.67 * pow(dlCM - 0.170, 2.0) + 4.95;
+  double Ff1 = (-2.25e4 * sdm_pow(dlCM - 0.403, 2.0) - 37.9) * sdm_pow(dsCM, 2.5) +
+               9.67 * sdm_pow(dlCM - 0.170, 2.0) + 4.95;
   Ff1 = PYMAX(0.0, Ff1);
-  const double Ff2 = 1.02e4 * pow(dsCM, 2.83) + 2;
-  const double ds0 = PYMAX(0.04, pow(Ff1 / 2.83, 1 / 1.02e4));
+  const double Ff2 = 1.02e4 * sdm_pow(dsCM, 2.83) + 2;
+  const double ds0 = PYMAX(0.04, sdm_pow(Ff1 / 2.83, 1 / 1.02e4));
   const double Ff = dsCM > ds0 ? PYMAX(2.0, Ff1) : PYMAX(2.0, Ff2);
   const double Dff3 = 0.241 * dsCM + 0.0129;
-  const double Pf301 = 1.68e5 * pow(dsCM, 2.33);
-  const double Pf302 = PYMAX(0.0, (43.4 * pow(dlCM + 1.81, 2.0) - 159.0) / dsCM -
-                                      3870 * pow(dlCM - 0.285, 2.0) - 58.1);
+  const double Pf301 = 1.68e5 * sdm_pow(dsCM, 2.33);
+  const double Pf302 = PYMAX(0.0, (43.4 * sdm_pow(dlCM + 1.81, 2.0) - 159.0) / dsCM -
+                                      3870 * sdm_pow(dlCM - 0.285, 2.0) - 58.1);
   const double alpha = (dsCM - ds0) / (0.2 * ds0);
   const double Pf303 = alpha * Pf301 + (1 - alpha) * Pf302;
   const double Pf0 = dsCM < ds0 ? Pf301 : (dsCM > 1.2 * ds0 ? Pf302 : Pf303);
   double sigma = 10 * Dff3;
-  double mu = log(Dff3) + sigma * sigma;
-  double H = Pf0 * Dff3 / exp(-0.5 * (sigma * sigma));
+  double mu = sdm_log(Dff3) + sigma * sigma;
+  double H = Pf0 * Dff3 / sdm_exp(-0.5 * (sigma * sigma));
   for (int r = 0; r < 10; ++r) {
     if (sigma == 0.0 || H == 0) {
-      struct LL82P z = {0.0, log(ds0), log(ds0)};
+      struct LL82P z = {0.0, sdm_log(ds0), sdm_log(ds0)};
       return z;
     }
-    sigma = sqrt(2 / LL_PI) * (Ff - 2) / H / (1 - erf((log(0.01) - mu) / sqrt(2.0) / sigma));
-    mu = log(Dff3) + sigma * sigma;
-    H = Pf0 * Dff3 / exp(-0.5 * (sigma * sigma));
+    sigma = sqrt(2 / LL_PI) * (Ff - 2) / H / (1 - sdm_erf((sdm_log(0.01) - mu) / sqrt(2.0) / sigma));
+    mu = sdm_log(Dff3) + sigma * sigma;
+    H = Pf0 * Dff3 / sdm_exp(-0.5 * (sigma * sigma));
   }
   struct LL82P p = {H, mu, sigma};
   return p;
 }
 
 __device__ inline struct LL82P ll82_s1(double CM, double dl, double ds, double dcoal) { /* :100-116 */
-  return ll82_gauss_fixed_point(100 * exp(-3.25 * (ds / CM)), dl / CM, dcoal / CM);
+  return ll82_gauss_fixed_point(100 * sdm_exp(-3.25 * (ds / CM)), dl / CM, dcoal / CM);
 }
 
 __device__ inline struct LL82P ll82_s2(double CM, double dl, double ds, double St) { /* :118-143 */
   const double dsCM = ds / CM, dlCM = dl / CM;
-  const double Dss2 = 0.254 * pow(dsCM, 0.413) * exp(3.53 * pow(dsCM, 2.51) * (dlCM - dsCM));
-  const double bstar = 14.2 * exp(-17.2 * dsCM);
-  const double Ps20 = 0.23 * pow(dsCM, -3.93) * pow(dlCM, bstar);
+  const double Dss2 = 0.254 * sdm_pow(dsCM, 0.413) * sdm_exp(3.53 * sdm_pow(dsCM, 2.51) * (dlCM - dsCM));
+  const double bstar = 14.2 * sdm_exp(-17.2 * dsCM);
+  const double Ps20 = 0.23 * sdm_pow(dsCM, -3.93) * sdm_pow(dlCM, bstar);
   double sigma = 10 * Dss2;
-  double mu = log(Dss2) + sigma * sigma;
-  double H = Ps20 * Dss2 / exp(-0.5 * (sigma * sigma));
-  const double Fs = 5 * erf((St - 2.52e-6) / (1.85e-6)) + 6;
+  double mu = sdm_log(Dss2) + sigma * sigma;
+  double H = Ps20 * Dss2 / sdm_exp(-0.5 * (sigma * sigma));
+  const double Fs = 5 * sdm_erf((St - 2.52e-6) / (1.85e-6)) + 6;
   for (int r = 0; r < 10; ++r) {
-    sigma = sqrt(2 / LL_PI) * (Fs - 1) / H / (1 - erf((log(0.01) - mu) / sqrt(2.0) / sigma));
-    mu = log(Dss2) + sigma * sigma;
-    H = Ps20 * Dss2 / exp(-0.5 * (sigma * sigma));
+    sigma = sqrt(2 / LL_PI) * (Fs - 1) / H / (1 - sdm_erf((sdm_log(0.01) - mu) / sqrt(2.0) / sigma));
+    mu = sdm_log(Dss2) + sigma * sigma;
+    H = Ps20 * Dss2 / sdm_exp(-0.5 * (sigma * sigma));
   }
   struct LL82P p = {H, mu, sigma};
   return p;
@@ -170,27 +170,27 @@ __device__ inline struct LL82P ll82_s2(double CM, double dl, double ds, double S
 
 __device__ inline struct LL82P ll82_d1(double CM, double W1, double dl, double dcoal, double CKE) {
   /* :145-160 */
-  const double mu = (dl / CM) * (1 - exp(-3.70 * (3.10 - W1)));
-  return ll82_gauss_fixed_point(1.58e-5 * pow(CKE, -1.22), mu, dcoal / CM);
+  const double mu = (dl / CM) * (1 - sdm_exp(-3.70 * (3.10 - W1)));
+  return ll82_gauss_fixed_point(1.58e-5 * sdm_pow(CKE, -1.22), mu, dcoal / CM);
 }
 
 __device__ inline struct LL82P ll82_d2(double CM, double ds, double dl, double CKE) { /* :162-193 */
   const double dsCM = ds / CM, dlCM = dl / CM;
-  const double Ddd2 = exp(-17.4 * dsCM - 0.671 * (dlCM - dsCM)) * dsCM;
-  const double bstar = 0.007 * pow(dsCM, -2.54);
-  const double Pd20 = 0.0884 * pow(dsCM, -2.52) * pow(dlCM - dsCM, bstar);
+  const double Ddd2 = sdm_exp(-17.4 * dsCM - 0.671 * (dlCM - dsCM)) * dsCM;
+  const double bstar = 0.007 * sdm_pow(dsCM, -2.54);
+  const double Pd20 = 0.0884 * sdm_pow(dsCM, -2.52) * sdm_pow(dlCM - dsCM, bstar);
   double sigma = 10 * Ddd2;
-  double mu = log(Ddd2) + sigma * sigma;
-  double H = Pd20 * Ddd2 / exp(-0.5 * (sigma * sigma));
-  const double Fd = PYMAX(1.0, 297.5 + 23.7 * log(CKE));
-  struct LL82P z = {0.0, log(Ddd2), log(Ddd2)};
+  double mu = sdm_log(Ddd2) + sigma * sigma;
+  double H = Pd20 * Ddd2 / sdm_exp(-0.5 * (sigma * sigma));
+  const double Fd = PYMAX(1.0, 297.5 + 23.7 * sdm_log(CKE));
+  struct LL82P z = {0.0, sdm_log(Ddd2), sdm_log(Ddd2)};
   if (Fd == 1.0) return z;
   for (int r = 0; r < 10; ++r) {
     if (sigma == 0.0 || H <= 0.1) return z;
     if (sigma >= 1.0) return z;
-    sigma = sqrt(2 / LL_PI) * (Fd - 1) / H / (1 - erf((log(0.01) - mu) / sqrt(2.0) / sigma));
-    mu = log(Ddd2) + sigma * sigma;
-    H = Pd20 * Ddd2 / exp(-0.5 * (sigma * sigma));
+    sigma = sqrt(2 / LL_PI) * (Fd - 1) / H / (1 - sdm_erf((sdm_log(0.01) - mu) / sqrt(2.0) / sigma));
+    mu = sdm_log(Ddd2) + sigma * sigma;
+    H = Pd20 * Ddd2 / sdm_exp(-0.5 * (sigma * sigma));
   }
   struct LL82P p = {H, mu, sigma};
   return p;
@@ -202,15 +202,15 @@ __device__ inline double ll82_fragment_volume(double CKE, double W, double W2, d
                                  double dcoal, double *rand, double *Rf, double *Rs, double *Rd,
                                  double tol, const double *K) {
   const double CM = K[0], PI = K[1], VA = K[2], Vb = K[3];
-  if (dl <= 0.4e-3) return pow(dcoal, 3.0) * PI / 6;
+  if (dl <= 0.4e-3) return sdm_pow(dcoal, 3.0) * PI / 6;
   if (ds == 0.0 || dl == 0.0) return 1e-18;
-  *Rf = CKE >= 0.893e-6 ? 1.11e-4 * pow(CKE, -0.654) : 1.0;
-  *Rs = W >= 0.86 ? 0.685 * (1 - exp(-1.63 * (W2 - 0.86))) : 0.0;
+  *Rf = CKE >= 0.893e-6 ? 1.11e-4 * sdm_pow(CKE, -0.654) : 1.0;
+  *Rs = W >= 0.86 ? 0.685 * (1 - sdm_exp(-1.63 * (W2 - 0.86))) : 0.0;
   *Rd = (*Rs + *Rf) > 1.0 ? 0.0 : 1.0 - *Rs - *Rf;
   double d;  /* fragment diameter in cm */
   if (*rand <= *Rf) {  /* filament breakup */
     const struct LL82P p1 = ll82_f1(CM, dl, dcoal), p2 = ll82_f2(CM, ds), p3 = ll82_f3(CM, ds, dl);
-    const double H1 = p1.H * p1.mu, H2 = p2.H * p2.mu, H3 = p3.H * exp(p3.mu);
+    const double H1 = p1.H * p1.mu, H2 = p2.H * p2.mu, H3 = p3.H * sdm_exp(p3.mu);
     const double Hsum = H1 + H2 + H3;
     *rand = *rand / *Rf;
     if (*rand <= H1 / Hsum) {
@@ -221,11 +221,11 @@ __device__ inline double ll82_fragment_volume(double CKE, double W, double W2, d
       d = p2.mu + sqrt(2.0) * p2.sigma * erfinv_approx(2 * X - 1, VA, Vb);
     } else {
       const double X = PYMIN((*rand * Hsum - H1 - H2) / H3, 1.0 - tol);
-      d = exp(p3.mu + sqrt(2.0) * p3.sigma * erfinv_approx(2 * X - 1, VA, Vb));
+      d = sdm_exp(p3.mu + sqrt(2.0) * p3.sigma * erfinv_approx(2 * X - 1, VA, Vb));
     }
   } else if (*rand <= *Rf + *Rs) {  /* sheet breakup */
     const struct LL82P p1 = ll82_s1(CM, dl, ds, dcoal), p2 = ll82_s2(CM, dl, ds, St);
-    const double H1 = p1.H * p1.mu, H2 = p2.H * exp(p2.mu);
+    const double H1 = p1.H * p1.mu, H2 = p2.H * sdm_exp(p2.mu);
     const double Hsum = H1 + H2;
     *rand = (*rand - *Rf) / (*Rs);
     if (*rand <= H1 / Hsum) {
@@ -233,7 +233,7 @@ __device__ inline double ll82_fragment_volume(double CKE, double W, double W2, d
       d = p1.mu + sqrt(2.0) * p1.sigma * erfinv_approx(2 * X - 1, VA, Vb);
     } else {
       const double X = PYMIN((*rand * Hsum - H1) / H2, 1.0 - tol);
-      d = exp(p2.mu + sqrt(2.0) * p2.sigma * erfinv_approx(2 * X - 1, VA, Vb));
+      d = sdm_exp(p2.mu + sqrt(2.0) * p2.sigma * erfinv_approx(2 * X - 1, VA, Vb));
     }
   } else {  /* disk breakup */
     const struct LL82P p1 = ll82_d1(CM, W, dl, dcoal, CKE), p2 = ll82_d2(CM, ds, dl, CKE);
@@ -245,11 +245,11 @@ __device__ inline double ll82_fragment_volume(double CKE, double W, double W2, d
       d = p1.mu + sqrt(2.0) * p1.sigma * erfinv_approx(2 * X - 1, VA, Vb);
     } else {
       const double X = PYMIN((*rand * Hsum - H1) / H2, 1 - tol);
-      d = exp(p2.mu + sqrt(2.0) * p2.sigma * erfinv_approx(2 * X - 1, VA, Vb));
+      d = sdm_exp(p2.mu + sqrt(2.0) * p2.sigma * erfinv_approx(2 * X - 1, VA, Vb));
     }
   }
   d = d * 0.01;  /* cm -> m */
-  return pow(d, 3.0) * PI / 6;
+  return sdm_pow(d, 3.0) * PI / 6;
 }
 
 struct StraubTmp { double Nr1, Nr2, Nr3, Nr4, Nrt, d34; };
@@ -270,22 +270,22 @@ __device__ __forceinline__ double straub_fragment_volume(double CW, double gam, 
   }
   T.Nr4 = 1.0;
   T.Nrt = T.Nr1 + T.Nr2 + T.Nr3 + T.Nr4;
-  const double sigma1 = sqrt(log(CW / 64 / 100 * CM * CM / 12 / pow(E_D1, 2.0) + 1));
-  const double mu1 = log(E_D1) - pow(sigma1, 2.0) / 2;
+  const double sigma1 = sqrt(sdm_log(CW / 64 / 100 * CM * CM / 12 / sdm_pow(E_D1, 2.0) + 1));
+  const double mu1 = sdm_log(E_D1) - sdm_pow(sigma1, 2.0) / 2;
   const double s2a = 7 * (CW - 21) * CM / 1000;
   const double sigma2 = (s2a > 0.0 ? s2a : 0.0) / sqrt(12.0);
   const double mu2 = MU2;
   const double sigma3 = (1 + 0.76 * sqrt(CW)) * CM / 100 / sqrt(12.0);
   const double mu3 = 0.9 * ds;
-  T.Nr1 = T.Nr1 * exp(3 * mu1 + 9 * pow(sigma1, 2.0) / 2);
-  T.Nr2 = T.Nr2 * (pow(mu2, 3.0) + 3 * mu2 * pow(sigma2, 2.0));
-  T.Nr3 = T.Nr3 * (pow(mu3, 3.0) + 3 * mu3 * pow(sigma3, 2.0));
-  T.Nr4 = v_max * 6 / PI + pow(ds, 3.0) - T.Nr1 - T.Nr2 - T.Nr3;
+  T.Nr1 = T.Nr1 * sdm_exp(3 * mu1 + 9 * sdm_pow(sigma1, 2.0) / 2);
+  T.Nr2 = T.Nr2 * (sdm_pow(mu2, 3.0) + 3 * mu2 * sdm_pow(sigma2, 2.0));
+  T.Nr3 = T.Nr3 * (sdm_pow(mu3, 3.0) + 3 * mu3 * sdm_pow(sigma3, 2.0));
+  T.Nr4 = v_max * 6 / PI + sdm_pow(ds, 3.0) - T.Nr1 - T.Nr2 - T.Nr3;
   if (T.Nr4 <= 0.0) {
     T.d34 = 0;
     T.Nr4 = 0;
   } else {
-    T.d34 = exp(log(T.Nr4) / 3);
+    T.d34 = sdm_exp(sdm_log(T.Nr4) / 3);
   }
   T.Nrt = T.Nr1 + T.Nr2 + T.Nr3 + T.Nr4;
   double diameter;
@@ -293,7 +293,7 @@ __device__ __forceinline__ double straub_fragment_volume(double CW, double gam, 
     diameter = 0.0;
   } else if (rand < T.Nr1 / T.Nrt) {
     const double X = rand * T.Nrt / T.Nr1;
-    diameter = exp(mu1 + sqrt(2.0) * sigma1 * erfinv_approx(X, VA, Vb));
+    diameter = sdm_exp(mu1 + sqrt(2.0) * sigma1 * erfinv_approx(X, VA, Vb));
   } else if (rand < (T.Nr2 + T.Nr1) / T.Nrt) {
     const double X = (rand * T.Nrt - T.Nr1) / T.Nr2;
     diameter = mu2 + sqrt(2.0) * sigma2 * erfinv_approx(X, VA, Vb);
@@ -303,7 +303,7 @@ __device__ __forceinline__ double straub_fragment_volume(double CW, double gam, 
   } else {
     diameter = T.d34;
   }
-  return pow(diameter, 3.0) * PI / 6;
+  return sdm_pow(diameter, 3.0) * PI / 6;
 }
 
 // ---- multiplicity / attribute update, collisions_methods.py:44-243 ----------------------

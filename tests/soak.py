@@ -1,7 +1,10 @@
 """soak (not collected by pytest; run by hand on an MI355X: python tests/soak.py): long runs at
 full size, HIP fused route against the oracle - the whole 3600-step Shima-2009 experiment at
-n_sd = 2^20, 400 adaptive steps, 200 steps of the Berry breakup box, 150 of the Straub boxes at
-2^18, 40 steps of 32 x 32 cells at 2^20"""
+n_sd = 2^20, 400 adaptive steps, 1000 steps of the Berry breakup box (into its late phase of long
+`break_up` loops), 400 of the Straub boxes at 2^18 (the rain spectrum: a third of the collisions
+break up), 40 steps of 32 x 32 cells at 2^20.  Everything must agree TO THE BIT, floats included:
+both sides take pow / exp / log / erf / ... from csrc/sdm_math.h (round 2 diverged at step 147 of
+the rain case - device libm against glibc - profiles/r02_first_divergence_straub_rain.txt)."""
 import sys
 import time
 import warnings
@@ -14,12 +17,10 @@ from pysdm_amd.cases import make_box  # noqa: E402
 from pysdm_amd.engine import HipEngine  # noqa: E402
 
 cases = [("shima", 2**20, False, 3600), ("shima", 2**20, True, 400),
-         ("berry_breakup", 2**20, True, 200), ("straub", 2**18, True, 150),
-         # (100 steps: with a third of the collisions breaking up, the masses of the two runs
-         # drift apart in the last bits - device libm against glibc - at ~1e-14 per step; around
-         # step 147 that changes how an adaptive time step divides into sub-steps, after which
-         # the runs consume different random numbers: profiles/tools/first_divergence.py)
-         ("straub_rain", 2**18, True, 100), ("kinematic2d", 2**20, True, 40)]
+         ("berry_breakup", 2**20, True, 1000), ("straub", 2**18, True, 400),
+         ("straub_rain", 2**18, True, 400), ("kinematic2d", 2**20, True, 40)]
+if len(sys.argv) > 1:
+    cases = [c for c in cases if c[0] in sys.argv[1:]]
 for name, n_sd, adaptive, steps in cases:
     snaps = []
     for engine in (HipEngine.get(), OracleEngine.get()):
@@ -42,7 +43,7 @@ for name, n_sd, adaptive, steps in cases:
             live = np.isfinite(ref) & (ref != 0)
             err = np.max(np.abs(value[live] - ref[live]) / np.abs(ref[live])) if live.any() else 0.0
             worst = max(worst, err)
-            assert err < 1e-11, (name, key, err)
+            assert np.array_equal(value, ref, equal_nan=True), (name, key, err)
         else:
             assert np.array_equal(value, ref), (name, key)
     print("OK", name, "length", length, "of", n_sd, "substeps", b["stats_n_substep"][:3],
