@@ -364,8 +364,12 @@ typedef struct sdm_step_state {
   int64_t *breakup_rate, *breakup_rate_deficit;                        /* [n_cell] or NULL */
   const double *gk_a, *gk_b;  /* Gunn-Kinzer table (or NULL) */
   /* device control block, int64[8]: {valid_n_sd, working_length, sorted, healthy, n_overflow,
-   * candidate pairs processed so far (single-cell non-adaptive steps), largest cell, error};
-   * kept device-resident between calls */
+   * candidate pairs processed so far (single-cell non-adaptive steps), largest cell, events};
+   * kept device-resident between calls.  Word 7: low byte = device-side error code (0 = none),
+   * bit 8 = "a cell's stats_dt_min became equal to dt_min" - the data-level event behind the
+   * reference's warning "adaptive time-step reached dt_min" (collision.py:276-277): the caller
+   * evaluates `amin(stats_dt_min) == dt_min`, warns, and clears the bit; n_overflow likewise
+   * stands for the "overflow" warning (collisions_methods.py:196-199) */
   int64_t *ctl;
   /* optional mirror kept by the library, caller-owned like all state (NULL = do not use):
    * [n_sd] x 32 B.  Records are {int64 multiplicity, double mass} (16-B stride) or, with the

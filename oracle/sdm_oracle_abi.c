@@ -905,6 +905,10 @@ static int box_step(Box *B, int64_t shift_len) {
                                              st->cell_id, st->dt_left, B->C, c->dt, c->dt_min,
                                              c->dt_max, B->flag, st->stats_n_substep,
                                              st->stats_dt_min);
+    /* collision.py:276-277: the event word tells the host to evaluate `stats_dt_min.amin() ==
+     * dt_min` (bit 8 of control word 7, as the product's kernels set it) */
+    for (int64_t k = 0; k < B->C; ++k)
+      if ((!owned || owned[k]) && st->stats_dt_min[k] == c->dt_min) st->ctl[7] |= 0x100;
   } else {
     pw_div_s(B, prob, (double)c->substeps);
   }

@@ -208,9 +208,18 @@ class CollisionRunner:  # pylint: disable=too-many-instance-attributes
     def _adopt(self, words):
         pop = self.population
         pop.live, pop.working, pop.ordered = int(words[0]), int(words[0]), bool(words[2])
-        if words[7] != 0:
+        error = int(words[7]) & 0xff
+        if error != 0:
             raise RuntimeError("libsdm_hip: device-side failure in the fused collision step: "
-                               + _DEVICE_ERRORS.get(int(words[7]), f"code {words[7]}"))
+                               + _DEVICE_ERRORS.get(error, f"code {error}"))
+        if int(words[7]) & 0x100:
+            # a cell's stats_dt_min became equal to dt_min in some sub-step: the reference's
+            # condition (collision.py:276-277; NaN entries, the initial state, silence it)
+            self.population.ctl[7] = 0
+            smallest = self.engine.scalar_out("sdm_reduce_f64", abi.c_f64, 0, self.stats_dt_min,
+                                              self.population.n_cell)
+            if smallest == self.dt_range[0]:
+                warnings.warn("adaptive time-step reached dt_min")
         if words[4] > 0 and self.setup.warn_overflows:
             warnings.warn("overflow")
             self.population.ctl[4] = 0

@@ -113,7 +113,16 @@ int sdm_wait_box(sdm_ctx *ctx, int64_t seq);  // ctx.hip
 // it was read (cannot happen with one publication in flight ahead: checked, not assumed)
 int sdm_read_box(sdm_ctx *ctx, int64_t seq, int64_t out[8]);
 
+// control word 7: low byte = device-side error code, bit 8 = event "a cell's stats_dt_min became
+// equal to dt_min" (the host then evaluates the reference's condition, collision.py:276-277)
+#define SDM_CTL7_ERROR_MASK 0xff
+#define SDM_CTL7_DT_MIN 0x100
+
 #ifdef __HIPCC__
+__device__ __forceinline__ void note_dt_min(int64_t *ctl, double stats_value, double dt_min) {
+  if (stats_value == dt_min) atomicOr((unsigned long long *)&ctl[7], (unsigned long long)SDM_CTL7_DT_MIN);
+}
+
 // last act of a one-thread epilogue: control block -> host-visible box, then the sequence number
 // (work: what the host is to see as working length, word 1)
 __device__ __forceinline__ void publish_ctl(const int64_t *ctl, int64_t *box, int64_t seq,
@@ -121,8 +130,10 @@ __device__ __forceinline__ void publish_ctl(const int64_t *ctl, int64_t *box, in
   if (!box) return;
   box += (seq & 1) * SDM_BOX_STRIDE;
   for (int w = 0; w < 8; ++w)
-    __hip_atomic_store(&box[w], w == 1 ? work : ctl[w], __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&box[w],
+                       w == 1 ? work
+                              : __hip_atomic_load(&ctl[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(&box[8], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 #endif

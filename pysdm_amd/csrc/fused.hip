@@ -865,7 +865,9 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_cells_adaptive(sdm_step_cfg cfg, 
   if (m < t) t = m;
   A.dt_todo[c] = t;
   const double s = A.stats_dt_min[c];
-  A.stats_dt_min[c] = m < s ? m : s;  // Python min(s, m): NaN-sticky
+  const double s_new = m < s ? m : s;  // Python min(s, m): NaN-sticky
+  A.stats_dt_min[c] = s_new;
+  note_dt_min(A.ctl, s_new, cfg.dt_min);
   A.dt_left[c] = l - t;
   if (t > 0) A.stats_n_substep[c] += 1;
 }
@@ -966,7 +968,9 @@ k_cells_end(sdm_step_cfg cfg, FusedArgs A, int bookkeeping, int64_t *__restrict_
       if (m < t) t = m;
       A.dt_todo[c] = t;
       const double smin = A.stats_dt_min[c];
-      A.stats_dt_min[c] = m < smin ? m : smin;  // Python min(s, m): NaN-sticky
+      const double s_new = m < smin ? m : smin;  // Python min(s, m): NaN-sticky
+      A.stats_dt_min[c] = s_new;
+      note_dt_min(A.ctl, s_new, cfg.dt_min);
       left -= t;
       A.dt_left[c] = left;
       if (t > 0) A.stats_n_substep[c] += 1;
@@ -2289,6 +2293,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         E.cells.ctl = st->ctl;
         E.cells.box = ctx->box_dev;
         E.cells.seq = *seq_out;
+        E.cells.dt_min = cfg->dt_min;
         const int r = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl,
                                               S.cctl, nullptr, true, &E);
         if (r) return r;
@@ -2709,7 +2714,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     }
     res->valid_n_sd = res->ctl[CTL_VALID];
     st->known_valid = res->valid_n_sd;
-    if (res->ctl[7] == 2) (void)sdm_compact_rearm(ctx);  // the caller raises; the ctx stays usable
+    if ((res->ctl[7] & SDM_CTL7_ERROR_MASK) == 2) (void)sdm_compact_rearm(ctx);  // the caller raises; the ctx stays usable
   } else {
     // one adaptive cell: the last sub-step's read-back told the valid length anyway - the next
     // step of the same run need not ask the device again

@@ -86,6 +86,7 @@ struct CellsEnd {
   const int64_t *cell_start;
   int64_t *end2, *ctl, *box;
   int64_t seq;
+  double dt_min;
 };
 struct CompactEpilogue {
   const double *dt_left;  // NULL: no epilogue

@@ -623,7 +623,9 @@ __device__ __forceinline__ void cells_end_body(const CellsEnd &E) {
         if (m < t) t = m;
         E.dt_todo[c] = t;
         const double smin = E.stats_dt_min[c];
-        E.stats_dt_min[c] = m < smin ? m : smin;  // Python min(s, m): NaN-sticky
+        const double s_new = m < smin ? m : smin;  // Python min(s, m): NaN-sticky
+        E.stats_dt_min[c] = s_new;
+        note_dt_min(E.ctl, s_new, E.dt_min);
         left -= t;
         E.dt_left[c] = left;
         if (t > 0) E.stats_n_substep[c] += 1;

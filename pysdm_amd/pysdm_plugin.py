@@ -165,11 +165,22 @@ class FusedCollision(Collision):
     """a PySDM dynamic (register / instantiate / __call__ protocol of PySDM's Builder) running
     the wrapped PySDM collision dynamic's configuration as the fused step"""
 
+    _OWN = ("inner", "particulator", "runner", "_state")
+
     def __init__(self, dynamic):
         self.inner = dynamic
         self.particulator = None
         self.runner = None
         self._state = None
+
+    def __setattr__(self, name, value):
+        # options belong to the wrapped dynamic: PySDM's SpinUp observer switches collisions off
+        # with setattr(particulator.dynamics["Collision"], "enable", False)
+        # (examples/PySDM_examples/Arabas_et_al_2015/spin_up.py), and that lands here
+        if name in self._OWN or "inner" not in self.__dict__:
+            object.__setattr__(self, name, value)
+        else:
+            setattr(self.__dict__["inner"], name, value)
 
     def register(self, builder):
         self.particulator = builder.particulator
@@ -197,6 +208,8 @@ class FusedCollision(Collision):
         return getattr(self.__dict__["inner"], name)
 
     def __call__(self):
+        if not self.inner.enable:  # collision.py:175
+            return
         part = self.particulator
         if self.runner is None:
             self._state = _AdoptedState(part)

@@ -74,14 +74,17 @@ def test_breakup_trajectories(name, route, hip_engine):
 def test_breakup_trajectories_equal_the_oracle_to_the_bit(name, route, hip_engine, oracle_engine):
     """the reference's values are reproduced to 1e-12 (its NumPy / libm transcendentals are not
     ours); the checker's are reproduced EXACTLY - efficiencies, fragment sizes and masses come from
-    csrc/sdm_math.h on both sides - and over four times the golden's length"""
+    csrc/sdm_math.h on both sides - and, on the fused route, over four times the golden's length
+    (the stage-by-stage route checks radii against the Gunn-Kinzer table's range like the
+    reference and would refuse the drops that grow beyond it)"""
     snaps = []
     for engine in (hip_engine, oracle_engine):
         runner, _, steps = setup_from_golden(name, engine, route=route)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             runner.run(steps[-1])
-            runner.run(3 * steps[-1])
+            if route == "fused":
+                runner.run(3 * steps[-1])
         snaps.append(runner.snapshot())
     assert_same(snaps[0], snaps[1])
 
@@ -268,3 +271,40 @@ def test_degenerate_sizes_and_operand_checks(kit, hip_engine):
         cell_id = kit.IndexedStorage.from_ndarray(idx, np.zeros(n_sd, dtype=np.int64))
         kit.backend.find_pairs(cell_start, flag, cell_id, kit.Index.identity_index(1), idx)
         assert flag.indicator.to_ndarray().sum() == 1
+
+
+@pytest.mark.parametrize("grid", [None, (4, 4)])
+def test_dt_min_event_travels_through_the_control_block(grid, hip_engine, oracle_engine):
+    """"adaptive time-step reached dt_min" (collision.py:276-277) on the fused route: the kernels
+    that update stats_dt_min set the event bit of control word 7; silent with the NaN initial
+    statistics, raised after a reset - one cell (k_cells_adaptive) and a grid (the per-cell
+    kernels + cells_end_body) - and the state equals the checker's"""
+    for reset in (False, True):
+        snaps, warned = [], []
+        for engine in (hip_engine, oracle_engine):
+            runner = make_box(engine, "shima", n_sd=2**12, adaptive=True, dt=200.0,
+                              dt_range=(100.0, 200.0), grid=grid)
+            if reset:
+                engine.fill(runner.stats_dt_min, 200.0)
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                runner.run(1)
+                runner.run(2)
+            warned.append(any("dt_min" in str(w.message) for w in caught))
+            snaps.append(runner.snapshot())
+        assert warned == [reset, reset]
+        assert_same(snaps[0], snaps[1])
+        if reset:
+            assert snaps[0]["stats_dt_min"].min() == 100.0
+
+
+@pytest.mark.parametrize("name", ["traj_golovin_n1024_s44_a1", "traj_multicell_geometric_4x4"])
+def test_fused_plugin_on_hip_storages(name, hip_backend_class):
+    """`pysdm_plugin.fuse` on the GPU (PySDM does not travel to the GPU box, so PySDM's
+    Particulator / ParticleAttributes are played by tests/pysdm_ducks.py, name-mangled members
+    and all): FusedCollision.__call__ adopts the torch-backed Storages in place, runs ONE
+    sdm_collision_step per call and hands permutation / length / sorted flag back - against the
+    reference's goldens"""
+    from . import pysdm_ducks  # pylint: disable=import-outside-toplevel
+
+    pysdm_ducks.fused_plugin_run(name, hip_backend_class)

@@ -57,3 +57,39 @@ def test_full_size_digests_of_the_reference(name, oracle_engine):
     if digests.n_sd_of(name) > 2**22:
         pytest.skip("beyond 2^22: GPU box only")
     digests.check(name, oracle_engine)
+
+
+def test_fused_route_reports_dt_min_like_the_stage_by_stage_route(oracle_engine):
+    """collision.py:276-277: "adaptive time-step reached dt_min" is raised when the smallest
+    `stats_dt_min` equals the lower end of dt_coal_range - never with the reference's NaN
+    initial values (NaN-sticky minimum), always once a user has reset the statistics and a cell
+    needs a sub-step at the limit.  Both routes must agree (the fused one learns it through the
+    event bit of the control block)."""
+    import warnings  # pylint: disable=import-outside-toplevel
+
+    from pysdm_amd.cases import make_box  # pylint: disable=import-outside-toplevel
+
+    outcomes = {}
+    for route in ("fused", "chain"):
+        for reset in (False, True):
+            runner = make_box(oracle_engine, "shima", n_sd=2**10, adaptive=True, route=route,
+                              dt=200.0, dt_range=(100.0, 200.0))
+            if reset:
+                oracle_engine.fill(runner.stats_dt_min, 200.0)
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                runner.run(2)
+            outcomes[route, reset] = any("dt_min" in str(w.message) for w in caught)
+            if reset:
+                assert oracle_engine.download(runner.stats_dt_min)[0] == 100.0
+    assert outcomes == {("fused", False): False, ("chain", False): False,
+                        ("fused", True): True, ("chain", True): True}
+
+
+@pytest.mark.parametrize("name", ["traj_golovin_n1024_s44_a1", "traj_multicell_geometric_4x4"])
+def test_fused_plugin_over_a_duck_particulator(name, oracle_backend_class):
+    """the CPU twin of tests/test_hip_parity.py::test_fused_plugin_on_hip_storages (the same
+    driver; under the real PySDM front-end: tests/test_reference_plugin.py)"""
+    from . import pysdm_ducks  # pylint: disable=import-outside-toplevel
+
+    pysdm_ducks.fused_plugin_run(name, oracle_backend_class)

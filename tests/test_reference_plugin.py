@@ -240,3 +240,35 @@ def test_reference_displacement_dynamic(ref, plugged):
                                    gold[f"step{step}/position"][:, live], rtol=1e-12, atol=1e-13)
         np.testing.assert_allclose(disp.precipitation_mass_in_last_step,
                                    float(gold[f"step{step}/precipitation"]), rtol=1e-12)
+
+
+def test_fused_dynamic_honours_enable(ref, plugged):
+    """collision.py:175 gates the step on `enable`; PySDM's SpinUp observer
+    (examples/PySDM_examples/Arabas_et_al_2015/spin_up.py) switches collisions off and on with
+    setattr(particulator.dynamics["Collision"], "enable", ...) - that object is the fused wrapper"""
+    from pysdm_amd.pysdm_plugin import fuse  # pylint: disable=import-outside-toplevel
+
+    gold = _gold("traj_golovin_n1024_s44_a1")
+    cfg = gold["cfg"]
+    builder = ref["PySDM"].Builder(
+        n_sd=int(cfg[0]), backend=plugged(ref["PySDM"].Formulae(seed=int(cfg[1]))),
+        environment=ref["Box"](dt=cfg[3], dv=cfg[4]))
+    builder.add_dynamic(fuse(ref["dynamics"].Coalescence(
+        collision_kernel=ref["kernels"].Golovin(b=cfg[5]), adaptive=bool(cfg[2]))))
+    particulator = builder.build({"volume": gold["init/volume"],
+                                  "multiplicity": gold["init/multiplicity"]})
+    dynamic = particulator.dynamics["Collision"]
+    setattr(dynamic, "enable", False)
+    assert dynamic.enable is False and dynamic.inner.enable is False
+    before = particulator.attributes["multiplicity"].to_ndarray(raw=True).copy()
+    particulator.run(3)  # spin-up: nothing may collide, no random number may be drawn
+    np.testing.assert_array_equal(particulator.attributes["multiplicity"].to_ndarray(raw=True),
+                                  before)
+    setattr(dynamic, "enable", True)
+    # ... and the run that follows is the golden from its first step
+    steps = sorted({int(k.split("/")[0][4:]) for k in gold.files if k.startswith("step")})
+    for step in steps:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            particulator.run(3 + step - particulator.n_steps)
+        _compare(particulator, dynamic, gold, step)
