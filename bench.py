@@ -116,6 +116,20 @@ def cpu_baseline(workload, n_sd, adaptive, seconds_budget=8.0):
     }
 
 
+def random_sector_ceiling(engine, n_sd, wide_records):
+    """random 16-byte reads out of a table with the footprint of the pair kernel's tables (16-B
+    shuffle records + 16- or 32-B {multiplicity, mass[, radius, velocity]} records per
+    super-droplet), timed with HIP events inside the library: (reads/s, GB/s of 64-B sectors)"""
+    table_records = n_sd * (3 if wide_records else 2)
+    n_reads = 4 * n_sd
+    ms, checksum = ctypes.c_double(), ctypes.c_uint64()
+    engine.call("sdm_calib_random_sectors", table_records, n_reads, 10, ms, checksum)
+    rate = n_reads / (ms.value * 1e-3)
+    return {"table_mib": table_records * 16 / 2**20, "reads_per_launch": n_reads,
+            "ms_per_launch": ms.value, "sector_misses_per_s": rate,
+            "gbs": rate * 64 / 1e9}
+
+
 def phase_timing(engine):
     n = 12
     ms = (ctypes.c_double * n)()
@@ -280,16 +294,35 @@ def main():
         launch_pairs = n_sd // 2
         bytes_per_pair = BYTES_PER_PAIR_BREAKUP if setup.breakup else BYTES_PER_PAIR
         achieved = bytes_per_pair * launch_pairs / (dom_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = misses = None
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(traffic_file):
             with open(traffic_file, encoding="utf-8") as f:
                 # measured offline with rocprofv3 --pmc (see profiles/README.md); per workload
-                traffic = json.load(f).get(args.workload, {}).get(dominant)
+                offline = json.load(f)
+            traffic = offline.get(args.workload, {}).get(dominant)
+            misses = offline.get("_tcc_miss_per_launch", {}).get(args.workload, {}).get(dominant)
+        # the access-pattern ceiling, measured now on this device with the kernel's own footprint:
+        # the path is random 64-B sector misses, which this part serves far below the streaming
+        # peak - both fractions are reported, the HBM one stays the contract figure
+        wide = setup.breakup or args.workload in ("kinematic2d", "berry_breakup", "straub",
+                                                  "straub_rain")
+        ceiling = random_sector_ceiling(engine, n_sd, wide)
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel": dominant, "kernel_ms": dom_ms,
+            # 64-B sectors under independent random access, same table footprint, same run
+            "random_sector_ceiling_gbs": ceiling["gbs"],
+            "random_sector_calibration": ceiling,
+            # the kernel's own sector traffic (L2 misses per launch x 64 B, offline PMC pass,
+            # profiles/traffic.json) over its duration, against that ceiling
+            "sector_traffic_gbs": (misses * 64 / (dom_ms * 1e-3) / 1e9
+                                   if misses and n_sd == 2**20 * (4 if args.workload == "kinematic2d" else 1)
+                                   else None),
+            "frac_of_ceiling": (misses * 64 / (dom_ms * 1e-3) / 1e9 / ceiling["gbs"]
+                                if misses and n_sd == 2**20 * (4 if args.workload == "kinematic2d" else 1)
+                                else None),
             "algorithmic_bytes_per_launch": bytes_per_pair * launch_pairs,
             # the same bytes against the wall-clock time of a whole time step (all kernels)
             "whole_step_frac": bytes_per_pair * pairs_total / world / elapsed_max / 1e9

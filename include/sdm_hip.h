@@ -57,6 +57,19 @@ int sdm_ctx_set_timing(sdm_ctx *ctx, int enable);
 int sdm_ctx_read_timing(sdm_ctx *ctx, double *ms, int64_t *count);
 const char *sdm_phase_name(int phase);
 
+/* measurement only: the ceiling of the path's access pattern on this device.  The single-cell pair
+ * kernel is bound by independent random 16-byte reads (shuffle records, {multiplicity, mass}
+ * records: one 64-B sector miss each), not by streaming bandwidth.  Times
+ * `repetitions` launches of a kernel that does nothing else - n_reads 16-byte reads at hashed
+ * indices out of a table of table_records x 16 B held in the ctx scratch arena (record i = {i,
+ * 2 i + 1}) - with HIP events on the ctx stream; *checksum = sum over all timed reads of both
+ * words mod 2^64 (read k of repetition r goes to record mix64(k ^ (r + 1) * 0x100000001b3) mod
+ * table_records, mix64 = the splitmix64 finaliser), so a caller can verify that the bytes were
+ * touched.  Synchronises.  (The reference has no counterpart: its timers are wall-clock,
+ * PySDM/impl/wall_timer.py.)                                                                  */
+int sdm_calib_random_sectors(sdm_ctx *ctx, int64_t table_records, int64_t n_reads,
+                             int repetitions, double *ms_per_launch, uint64_t *checksum);
+
 /* ---- a-1 RNG: NumPy PCG64 stream, PySDM/backends/impl_numba/random.py:13-19 ------------
  * out[i] = double number (offset + i) of the stream of PCG64 with the given state/inc
  * (state_inc = {state_hi, state_lo, inc_hi, inc_lo} of numpy.random.PCG64(seed).state).      */

@@ -616,15 +616,19 @@ API void oracle_linear_collection_efficiency(const double *params, double *outpu
 }
 
 /* a-9  PySDM/backends/impl_numba/methods/terminal_velocity_methods.py:14-30 */
+/* table_len: beyond the table the last row is used (the reference raises before it gets here,
+ * dynamics/terminal_velocity/gunn_and_kinzer.py:127-134; the product's kernels clamp likewise so
+ * that no read leaves the table - identical on both sides, tested on runs that grow past it) */
 API void oracle_interpolation(double *output, const double *radius, int64_t n, double factor,
-                              const double *b, const double *c) {
+                              const double *b, const double *c, int64_t table_len) {
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; ++i) {
     if (radius[i] < 0) {
       output[i] = 0;
     } else {
       const double x = factor * radius[i];
-      const int64_t r_id = (int64_t)x;
+      int64_t r_id = (int64_t)x;
+      if (table_len > 0 && r_id > table_len - 1) r_id = table_len - 1;
       const double r_rest = fmod(x, 1.0) / factor; /* x >= 0: Python % == fmod */
       output[i] = b[r_id] + r_rest * c[r_id];
     }

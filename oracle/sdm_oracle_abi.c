@@ -206,8 +206,8 @@ API int sdm_linear_collection_efficiency(sdm_ctx *c, const double params[13], do
 }
 API int sdm_interpolation(sdm_ctx *c, double *output, const double *radius, int64_t n,
                           double factor, const double *b, const double *cc, int64_t table_len) {
-  (void)c; (void)table_len;
-  oracle_interpolation(output, radius, n, factor, b, cc);
+  (void)c;
+  oracle_interpolation(output, radius, n, factor, b, cc, table_len);
   return SDM_OK;
 }
 API int sdm_volume_of_water_mass(sdm_ctx *c, double *volume, const double *mass, int64_t n,
@@ -381,6 +381,31 @@ API int sdm_elementwise_f64(sdm_ctx *c, int op, double *out, const double *a, co
   }
   return SDM_OK;
 }
+/* measurement entry of the product, restated serially so that the header stays fully exported
+ * and the GPU test has a checksum to compare with; its timing means nothing here */
+static uint64_t calib_mix(uint64_t x) {
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+API int sdm_calib_random_sectors(sdm_ctx *c, int64_t table_records, int64_t n_reads,
+                                 int repetitions, double *ms_per_launch, uint64_t *checksum) {
+  (void)c;
+  if (table_records < 1 || n_reads < 1 || repetitions < 1 || !ms_per_launch || !checksum)
+    FAIL(SDM_E_ARG, "sdm_calib_random_sectors: bad argument");
+  uint64_t total = 0;
+  for (int r = 0; r < repetitions; ++r) {
+    const uint64_t salt = (uint64_t)(r + 1) * 0x100000001b3ull;
+    for (int64_t k = 0; k < n_reads; ++k) {
+      const uint64_t at = calib_mix((uint64_t)k ^ salt) % (uint64_t)table_records;
+      total += at + (2 * at + 1);
+    }
+  }
+  *ms_per_launch = 0.0;
+  *checksum = total;
+  return SDM_OK;
+}
 API int sdm_math_eval(sdm_ctx *c, int fn, double *out, const double *a, const double *b,
                       int64_t n) {
   (void)c;
@@ -529,7 +554,7 @@ static const double *box_area(Box *B) { /* attributes/physics/area.py */
 static const double *box_velocity(Box *B) { /* terminal_velocity.py + gunn_and_kinzer.py:127-137 */
   if (!B->have_velocity) {
     oracle_interpolation(B->velocity, box_radius(B), B->N, B->cfg->gk_factor, B->st->gk_a,
-                         B->st->gk_b);
+                         B->st->gk_b, B->cfg->gk_table_len);
     B->have_velocity = 1;
   }
   return B->velocity;

@@ -81,3 +81,29 @@ def test_pysdm_shaped_backends_are_one_class(oracle_backend_class):
     assert public(HIP) == public(oracle_backend_class)
     assert {"shuffle_local", "find_pairs", "compute_gamma", "collision_coalescence_breakup",
             "moments", "calculate_displacement"} <= set(public(HIP))
+
+
+def test_random_sector_calibration_checksum(oracle_engine):
+    """sdm_calib_random_sectors (measurement entry behind bench.py's random-sector ceiling): the
+    checksum is the sum over the records the header says are read - checked here against an
+    independent numpy evaluation of the same hash (the GPU test compares the kernel with it)"""
+    import ctypes  # pylint: disable=import-outside-toplevel
+
+    table, reads, reps = 1000, 5000, 3
+    ms, checksum = ctypes.c_double(), ctypes.c_uint64()
+    oracle_engine.call("sdm_calib_random_sectors", table, reads, reps, ms, checksum)
+    assert checksum.value == expected_calibration_checksum(table, reads, reps)
+
+
+def expected_calibration_checksum(table, reads, reps):
+    total = np.uint64(0)
+    with np.errstate(over="ignore"):
+        for r in range(reps):
+            x = np.arange(reads, dtype=np.uint64) ^ np.uint64(((r + 1) * 0x100000001B3) % 2**64)
+            x = x + np.uint64(0x9E3779B97F4A7C15)
+            x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            x = x ^ (x >> np.uint64(31))
+            at = x % np.uint64(table)
+            total += np.sum(at + (np.uint64(2) * at + np.uint64(1)), dtype=np.uint64)
+    return int(total)

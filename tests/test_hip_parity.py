@@ -308,3 +308,19 @@ def test_fused_plugin_on_hip_storages(name, hip_backend_class):
     from . import pysdm_ducks  # pylint: disable=import-outside-toplevel
 
     pysdm_ducks.fused_plugin_run(name, hip_backend_class)
+
+
+def test_random_sector_calibration_touches_the_bytes_it_claims(hip_engine):
+    """the calibration kernel behind `roofline.random_sector_ceiling_gbs`: its checksum equals
+    the sum over the records the header says it reads (so the timed launches did read them), and
+    the rate it reports is a plausible one for this part"""
+    import ctypes  # pylint: disable=import-outside-toplevel
+
+    from .test_abi import expected_calibration_checksum  # pylint: disable=import-outside-toplevel
+
+    table, reads, reps = 2**21, 2**22, 3
+    ms, checksum = ctypes.c_double(), ctypes.c_uint64()
+    hip_engine.call("sdm_calib_random_sectors", table, reads, reps, ms, checksum)
+    assert checksum.value == expected_calibration_checksum(table, reads, reps)
+    rate = reads / (ms.value * 1e-3)  # 16-byte reads per second
+    assert 5e9 < rate < 1e12, rate
