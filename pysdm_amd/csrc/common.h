@@ -70,6 +70,11 @@ struct sdm_ctx {
     int clean_set;
   } lists;
   int debug_box_delay_us;  // SDM_DEBUG_BOX_DELAY_US (tests): the host sleeps before each wait
+  // fused.hip, cell-ordered working copy of a multi-step run: the kernels then see super-droplets
+  // under call-local labels (position in the sorted permutation at the start), except
+  // `normalize`'s raw look-up cell_id[pair slot] (collisions_methods.py:633-662), which keeps
+  // reading the caller's column
+  const int64_t *cell_id_raw;
   // fused.hip: what a multi-cell adaptive step knows at its end, for the next step of the same call
   // (valid length, an upper bound of the cell sizes; the state is sorted) - saves that step's
   // opening read-back

@@ -45,6 +45,7 @@ struct FusedArgs {
   int64_t *multiplicity;
   double *attributes;
   const int64_t *cell_id;
+  const int64_t *cell_id_raw;  // the caller's cell_id column (== cell_id unless a run relabelled)
   const int64_t *cell_idx;
   const int64_t *cell_start;
   double *dt_left;
@@ -432,7 +433,7 @@ __device__ __forceinline__ double pair_prob_value(const sdm_step_cfg &cfg, const
   }
   double prob = (double)sj.n;
   prob *= K;
-  prob *= norm_factor_of(cfg, A.cell_start, cfg.n_cell == 1 ? 0 : A.cell_idx[A.cell_id[d]]);
+  prob *= norm_factor_of(cfg, A.cell_start, cfg.n_cell == 1 ? 0 : A.cell_idx[A.cell_id_raw[d]]);
   return prob;
 }
 
@@ -1821,6 +1822,15 @@ static FusedScratch layout(char *base, const sdm_step_cfg *cfg) {
   return S;
 }
 
+// 32-B mirror records {multiplicity, mass, radius, velocity} where the kernel or the breakup
+// parts need radius / velocity, 16-B {multiplicity, mass} otherwise
+static bool mirror_is_wide(const sdm_step_cfg *cfg) {
+  return cfg->kernel == SDM_KERNEL_GEOMETRIC || cfg->kernel == SDM_KERNEL_PARAMETERIZED ||
+         cfg->kernel == SDM_KERNEL_SIMPLE_GEOMETRIC ||
+         (cfg->enable_breakup && (cfg->ec != SDM_EC_CONST || cfg->frag == SDM_FRAG_STRAUB2010 ||
+                                  cfg->frag == SDM_FRAG_LOWLIST1982));
+}
+
 // `known`: what the host knows about ctl[CTL_SORTED] (1 sorted, 0 unsorted, -1 unknown);
 // afterwards the device state is sorted in any case
 // `gated`: gate_len was already written (k_step_close)
@@ -1920,6 +1930,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   A.multiplicity = st->multiplicity;
   A.attributes = st->attributes;
   A.cell_id = st->cell_id;
+  A.cell_id_raw = ctx->cell_id_raw ? ctx->cell_id_raw : st->cell_id;
   A.cell_idx = st->cell_idx;
   A.cell_start = st->cell_start;
   A.dt_left = st->dt_left;
@@ -1974,11 +1985,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   const dim3 blk(SDM_BLOCK), one(1);
 
   A.nm = (double *)st->nm;
-  A.nm_wide = cfg->kernel == SDM_KERNEL_GEOMETRIC || cfg->kernel == SDM_KERNEL_PARAMETERIZED ||
-              cfg->kernel == SDM_KERNEL_SIMPLE_GEOMETRIC ||
-              (cfg->enable_breakup &&
-               (cfg->ec != SDM_EC_CONST || cfg->frag == SDM_FRAG_STRAUB2010 ||
-                cfg->frag == SDM_FRAG_LOWLIST1982));
+  A.nm_wide = mirror_is_wide(cfg);
   if (st->nm && (flags & 2) && !(flags & 4)) {
     hipLaunchKernelGGL(k_nm_init, dim3(grid_for(N)), blk, 0, s, *cfg, A);
     LAUNCH_CHECK();
@@ -2858,6 +2865,127 @@ static int graph_replay(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *s
   return SDM_OK;
 }
 
+// ---- cell-ordered working copy of a multi-step multi-cell run ------------------------------------
+// The per-cell kernels gather one {multiplicity, mass, radius, velocity} record per super-droplet
+// and sub-step BY ID - and ids are scattered over the whole population, so every gather is a
+// 64-B sector miss somewhere in n_sd x 32 B (the gather phase was bound by the chip-wide miss rate:
+// 32 % L2 hit rate, profiles/r02_pmc_kinematic2d_*).  Collisions never move a super-droplet to
+// another cell.  So for the steps of a run that follow the first one (which leaves the state
+// sorted by cell), the library works on a copy in which super-droplet i IS the one at position i
+// of that sorted permutation: ids of a cell are consecutive, a workgroup's gathers and updates
+// stay inside its cell's own window (4096 x 32 B = 128 KB: whole lines used, L2-resident), and the
+// kernels are the same - they only see other pointers.  At the end of the run the copy is
+// scattered back to the caller's columns and the permutation translated (idx = orig[idx']).
+// `normalize`'s quirk - the factor of the cell of RAW super-droplet d for pair slot d - keeps
+// reading the caller's cell_id (FusedArgs::cell_id_raw).
+struct Relabel {
+  bool on = false;
+  int64_t n_entry = 0;  // live super-droplets at entry (labels [0, n_entry) are in use)
+  int64_t *orig = nullptr, *perm_a = nullptr, *perm_b = nullptr, *multiplicity = nullptr,
+          *cell_id = nullptr;
+  double *attributes = nullptr;
+  void *nm = nullptr;
+  const char *arena = nullptr;  // where the copy was carved (the arena must not move meanwhile)
+  sdm_step_state inner;
+};
+
+static size_t relabel_bytes(const sdm_step_cfg *cfg) {
+  const size_t N = (size_t)cfg->n_sd;
+  return carve_size(N * 8) * (5 + (size_t)cfg->n_attr) + carve_size(N * 32) + 4096;
+}
+
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_relabel_enter(const int64_t *__restrict__ idx, int64_t n_sd, int64_t n_attr, int64_t n_entry,
+                const int64_t *__restrict__ multiplicity, const double *__restrict__ attributes,
+                const int64_t *__restrict__ cell_id, const double *__restrict__ nm, int nm_wide,
+                int64_t *__restrict__ orig, int64_t *__restrict__ perm_a,
+                int64_t *__restrict__ perm_b, int64_t *__restrict__ mult_i,
+                double *__restrict__ attr_i, int64_t *__restrict__ cid_i,
+                double *__restrict__ nm_i) {
+  const int64_t i = TID();
+  if (i >= n_sd) return;
+  const bool live = i < n_entry;
+  const int64_t o = live ? idx[i] : 0;
+  orig[i] = live ? o : n_sd;
+  perm_a[i] = perm_b[i] = live ? i : n_sd;  // beyond the live length: the "removed" value
+  mult_i[i] = live ? multiplicity[o] : 0;
+  cid_i[i] = live ? cell_id[o] : 0;
+  for (int64_t a = 0; a < n_attr; ++a) attr_i[a * n_sd + i] = live ? attributes[a * n_sd + o] : 0.0;
+  if (nm_wide)
+    ((double4 *)nm_i)[i] = live ? ((const double4 *)nm)[o] : make_double4(0, 0, 0, 0);
+  else
+    ((double2 *)nm_i)[i] = live ? ((const double2 *)nm)[o] : make_double2(0, 0);
+}
+
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_relabel_exit(int64_t *__restrict__ idx, const int64_t *__restrict__ perm, int64_t n_sd,
+               int64_t n_attr, int64_t n_entry, int64_t *__restrict__ multiplicity,
+               double *__restrict__ attributes, double *__restrict__ nm, int nm_wide,
+               const int64_t *__restrict__ orig, const int64_t *__restrict__ mult_i,
+               const double *__restrict__ attr_i, const double *__restrict__ nm_i) {
+  const int64_t i = TID();
+  if (i >= n_sd) return;
+  const int64_t v = perm[i];
+  idx[i] = v < n_sd ? orig[v] : n_sd;
+  if (i < n_entry) {
+    const int64_t o = orig[i];
+    multiplicity[o] = mult_i[i];
+    for (int64_t a = 0; a < n_attr; ++a) attributes[a * n_sd + o] = attr_i[a * n_sd + i];
+    if (nm_wide) ((double4 *)nm)[o] = ((const double4 *)nm_i)[i];
+    else ((double2 *)nm)[o] = ((const double2 *)nm_i)[i];
+  }
+}
+
+// after a step that left ctx->carry for `st` (sorted by cell, mirror current, per-cell route)
+static int relabel_enter(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st, Relabel *R) {
+  const int64_t N = cfg->n_sd;
+  const size_t base = carve_size(layout(nullptr, cfg).total);
+  Carver cv(ctx->arena + base);
+  R->orig = cv.take<int64_t>((size_t)N);
+  R->perm_a = cv.take<int64_t>((size_t)N);
+  R->perm_b = cv.take<int64_t>((size_t)N);
+  R->multiplicity = cv.take<int64_t>((size_t)N);
+  R->cell_id = cv.take<int64_t>((size_t)N);
+  R->attributes = cv.take<double>((size_t)(N * cfg->n_attr));
+  R->nm = cv.take<double>((size_t)(4 * N));
+  R->n_entry = ctx->carry.valid;
+  R->arena = ctx->arena;
+  hipLaunchKernelGGL(k_relabel_enter, dim3(grid_for(N)), dim3(SDM_BLOCK), 0, ctx->stream, st->idx,
+                     N, cfg->n_attr, R->n_entry, st->multiplicity, st->attributes, st->cell_id,
+                     (const double *)st->nm, mirror_is_wide(cfg) ? 1 : 0, R->orig, R->perm_a,
+                     R->perm_b, R->multiplicity, R->attributes, R->cell_id, (double *)R->nm);
+  LAUNCH_CHECK();
+  R->inner = *st;
+  R->inner.idx = R->perm_a;
+  R->inner.tmp_idx = R->perm_b;
+  R->inner.multiplicity = R->multiplicity;
+  R->inner.attributes = R->attributes;
+  R->inner.cell_id = R->cell_id;
+  R->inner.nm = R->nm;
+  ctx->cell_id_raw = st->cell_id;
+  // what the step just done left for the next one is as true of the copy
+  ctx->carry.owner = &R->inner;
+  if (ctx->lists.active) ctx->lists.owner = &R->inner;
+  R->on = true;
+  return SDM_OK;
+}
+
+static int relabel_exit(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st, Relabel *R) {
+  if (!R->on) return SDM_OK;
+  R->on = false;
+  ctx->cell_id_raw = nullptr;
+  const int64_t N = cfg->n_sd;
+  hipLaunchKernelGGL(k_relabel_exit, dim3(grid_for(N)), dim3(SDM_BLOCK), 0, ctx->stream, st->idx,
+                     R->inner.idx, N, cfg->n_attr, R->n_entry, st->multiplicity, st->attributes,
+                     (double *)st->nm, mirror_is_wide(cfg) ? 1 : 0, R->orig, R->multiplicity,
+                     R->attributes, (const double *)R->nm);
+  LAUNCH_CHECK();
+  st->rng_offset = R->inner.rng_offset;
+  st->rng_offset_breakup = R->inner.rng_offset_breakup;
+  st->known_valid = R->inner.known_valid;
+  return SDM_OK;
+}
+
 extern "C" int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *st,
                                  sdm_step_result *res, int flags, int64_t n_steps) {
   ARG_TRY(ctx && res && st && n_steps >= 0);
@@ -2872,6 +3000,18 @@ extern "C" int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step
   total.rng_offset_breakup = st->rng_offset_breakup;
   bool pairs_known = true;
   const bool replay = cfg && graph_eligible(ctx, cfg, st, n_steps);
+  // cell-ordered working copy (above): multi-cell adaptive runs of three steps or more on the
+  // per-cell route, one process (SDM_CELL_COPY=0 switches it off: measurements)
+  static const bool copy_enabled = !(getenv("SDM_CELL_COPY") && getenv("SDM_CELL_COPY")[0] == '0');
+  Relabel relabel;
+  const bool copy_wanted = copy_enabled && cfg && cfg->n_cell > 1 && cfg->adaptive &&
+                           cfg->croupier_local && !st->cell_owned && st->nm && n_steps >= 3 &&
+                           !ctx->graph_capture;
+  if (copy_wanted) {  // all scratch up front: the arena must not move once the copy lives in it
+    const int rc = sdm_reserve(ctx, carve_size(layout(nullptr, cfg).total) + relabel_bytes(cfg));
+    if (rc) return rc;
+  }
+  sdm_step_state *use = st;
   for (int64_t step = 0; step < n_steps; ++step) {
     if (replay && step == 1) {
       // steps 1 .. 2k replayed two at a time; step 0 (allocations, a fresh control block) and
@@ -2891,18 +3031,36 @@ extern "C" int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step
     sdm_step_result one;
     const bool last = step == n_steps - 1;
     // read the control block back only after the last step
-    const int rc = collision_step(ctx, cfg, st, &one, (last ? (flags & 1) : 0) |
-                                                      (step == 0 ? (flags & 2) : 0), last, !last);
+    int rc = collision_step(ctx, cfg, use, &one, (last ? (flags & 1) : 0) |
+                                                 (step == 0 ? (flags & 2) : 0), last, !last);
     if (rc) {
       ctx->ahead.active = false;
       ctx->carry.active = false;
+      (void)relabel_exit(ctx, cfg, st, &relabel);
       return rc;
     }
     if (one.idx_swapped) {
-      int64_t *t = st->idx;
-      st->idx = st->tmp_idx;
-      st->tmp_idx = t;
-      total.idx_swapped ^= 1;
+      int64_t *t = use->idx;
+      use->idx = use->tmp_idx;
+      use->tmp_idx = t;
+      if (use == st) total.idx_swapped ^= 1;  // (the copy's buffers are the library's own)
+    }
+    if (copy_wanted && !relabel.on && use == st && !last && ctx->carry.active &&
+        ctx->carry.owner == (const void *)st && ctx->carry.max_cell >= 0 &&
+        ctx->carry.max_cell <= CELL_CAP) {
+      rc = relabel_enter(ctx, cfg, st, &relabel);
+      if (rc) return rc;
+      use = &relabel.inner;
+    }
+    if (relabel.on && relabel.arena != ctx->arena) {  // (cannot happen: reserved up front)
+      sdm_set_error("the scratch arena moved under the cell-ordered working copy");
+      return SDM_E_HIP;
+    }
+    if (last && relabel.on) {
+      // (the read-back of the last step is through; the caller's columns are made current again)
+      rc = relabel_exit(ctx, cfg, st, &relabel);
+      if (rc) return rc;
+      use = st;
     }
     total.n_substeps += one.n_substeps;
     if (one.n_pairs < 0) pairs_known = false; else total.n_pairs += one.n_pairs;

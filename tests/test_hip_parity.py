@@ -324,3 +324,42 @@ def test_random_sector_calibration_touches_the_bytes_it_claims(hip_engine):
     assert checksum.value == expected_calibration_checksum(table, reads, reps)
     rate = reads / (ms.value * 1e-3)  # 16-byte reads per second
     assert 5e9 < rate < 1e12, rate
+
+
+@pytest.mark.parametrize("case", ["coalescence", "deaths", "breakup", "golovin_na"])
+def test_cell_ordered_working_copy_changes_nothing(case, hip_engine, oracle_engine):
+    """a multi-cell run of several steps in ONE library call works on a cell-ordered copy of the
+    state from its second step on (fused.hip: Relabel - call-local labels, scattered back and
+    translated at the end); the same steps one call at a time never do.  Both must leave the very
+    same state, counters and stream positions - and the checker's - also when super-droplets die
+    (compaction + re-sort inside the copy) and with breakup (k_resolve_dense on the copy)."""
+    def box(engine):
+        if case == "deaths":
+            return make_box(engine, "shima", n_sd=2**13, adaptive=True, dt=200.0, thin=0.02,
+                            grid=(4, 4))
+        if case == "breakup":
+            return make_box(engine, "straub_rain", n_sd=2**13, adaptive=True, dt=5.0, grid=(4, 4))
+        if case == "golovin_na":  # (non-adaptive: the copy is not used; the route must not care)
+            return make_box(engine, "shima", n_sd=2**13, adaptive=False, grid=(4, 4))
+        return make_box(engine, "kinematic2d", n_sd=2**15, grid=(4, 4))
+
+    runs = {}
+    for label, engine, chunks in (("one call", hip_engine, (9,)),
+                                  ("step by step", hip_engine, (1,) * 9),
+                                  ("mixed", hip_engine, (2, 4, 3)),
+                                  ("checker", oracle_engine, (9,))):
+        runner = box(engine)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for steps in chunks:
+                runner.run(steps)
+        runs[label] = (runner.snapshot(), runner.offset, runner.offset_breakup,
+                       runner.sub_steps_done)
+    reference = runs["checker"]
+    if case == "deaths":
+        assert int(reference[0]["length"]) < 2**13
+    if case == "breakup":
+        assert reference[0]["breakup_rate"].sum() > 0
+    for label in ("one call", "step by step", "mixed"):
+        assert_same(runs[label][0], reference[0])
+        assert runs[label][1:] == reference[1:], label
