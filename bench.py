@@ -63,6 +63,38 @@ def build_workload(name, engine, rank, world, n_sd=None, adaptive=None, read_bac
                           read_back=read_back, ids_by_cell=ids_by_cell, grid=grid)
 
 
+class Checkpoint:
+    """the state a repetition starts from, so that every repetition times the SAME K steps (an
+    adaptive or multi-cell workload evolves: later steps take other numbers of sub-steps, and
+    repetitions that simply follow one another are not comparable - round 2's 12.3 / 11.3 / 7.4e9
+    on the 32 x 32 grid were three different stretches of the simulation)"""
+
+    RUNNER = ("dt_left", "stats_dt_min", "stats_n_substep", "collision_rate",
+              "collision_rate_deficit", "coalescence_rate", "breakup_rate", "breakup_rate_deficit")
+    SCALARS = ("offset", "offset_breakup", "sub_steps_done", "pairs_done", "steps_done")
+
+    def __init__(self, runner):
+        pop = runner.population
+        self.columns = {name: getattr(pop, name).clone()
+                        for name in ("perm", "multiplicity", "extensive", "cell_order")}
+        self.diagnostics = {name: getattr(runner, name).clone() for name in self.RUNNER
+                            if getattr(runner, name) is not None}
+        self.scalars = {name: getattr(runner, name) for name in self.SCALARS}
+        self.live = pop.live
+
+    def restore(self, runner):
+        pop = runner.population
+        for name, saved in self.columns.items():
+            getattr(pop, name).copy_(saved)
+        for name, saved in self.diagnostics.items():
+            getattr(runner, name).copy_(saved)
+        for name, value in self.scalars.items():
+            setattr(runner, name, value)
+        pop.live = pop.working = self.live
+        pop.ordered = False
+        pop.touch_state()  # the next call starts from the host's view (control block, mirror)
+
+
 def cpu_model():
     try:
         for line in subprocess.check_output(["lscpu"], text=True).splitlines():
@@ -210,8 +242,17 @@ def main():
         torch.cuda.synchronize()
 
     runner.run(args.warmup)
-    reps = []
-    for _ in range(max(1, args.reps)):
+    runner.sync()
+    evolving = bool(setup.adaptive) or pop.n_cell > 1
+    checkpoint = Checkpoint(runner) if evolving and args.reps > 1 and runner.shard is None else None
+    reps, rep_substeps, comm = [], [], None
+    for rep in range(max(1, args.reps)):
+        if checkpoint is not None and rep > 0:
+            checkpoint.restore(runner)
+        substeps_before = runner.sub_steps_done
+        if runner.shard is not None:
+            comm_before = (runner.shard.calls[1], runner.shard.calls[2],
+                           runner.shard.bytes[1] + runner.shard.bytes[2])
         barrier()
         pairs_before = int(pop.ctl[5].item())  # the library's own count (control word 5)
         host_pairs_before = runner.pairs_done
@@ -234,6 +275,15 @@ def main():
             if not runner.counts_global_pairs:
                 dist.all_reduce(p, op=dist.ReduceOp.SUM)
         reps.append((float(p.item()) / float(t.item()), float(t.item()), float(p.item())))
+        rep_substeps.append(runner.sub_steps_done - substeps_before)
+        if runner.shard is not None:
+            shard = runner.shard
+            comm = {"f64_calls": shard.calls[1] - comm_before[0],
+                    "i64_calls": shard.calls[2] - comm_before[1],
+                    "bytes": shard.bytes[1] + shard.bytes[2] - comm_before[2],
+                    "bytes_per_step": (shard.bytes[1] + shard.bytes[2] - comm_before[2])
+                                      / args.steps,
+                    "backend": dist_backend}
     # multi-cell workload: digest of the global state (put together from the owners when sharded),
     # so that runs with different --gpus can be compared: the sharded run reproduces the
     # one-process run bit for bit
@@ -369,8 +419,14 @@ def main():
                 "route": "fused sdm_collision_run",
             },
             "state_digest": state_digest,
+            # sharded runs: what this rank handed to collectives during the LAST repetition
+            # (per-sub-step sums of n_cell + 1 + world doubles; dead positions when one died)
+            "comm": comm,
             "repetitions": {"n": len(reps), "reported": "median",
-                            "values": [round(r, 1) for r in rates]},
+                            "values": [round(r, 1) for r in rates],
+                            # sub-steps executed in each repetition's K steps (work per step)
+                            "substeps": rep_substeps,
+                            "same_steps_each_time": checkpoint is not None},
             # measured: one run of the whole experiment (3600 steps from the initial state, one
             # library call, mirror build included); null for the other workloads
             "shima_box_3600_steps_s": shima_box_s,

@@ -351,11 +351,16 @@ typedef struct sdm_step_cfg {
  * (iii) the compaction that fills the holes left by dead super-droplets with super-droplets from
  * the end of the permutation (collisions_methods.py:664-680).  In sharded mode every process holds
  * arrays of the GLOBAL shape (ids, positions, cell_start, cell_idx are global; 288 GB of HBM make
- * that free) but computes only the cells it owns; the library calls `exchange` where global data is
- * needed: after every sub-step a sum over processes of (masked dt_left, "someone died"), and -
- * only when a super-droplet died - a sum of the masked permutation, after which compaction and
- * counting sort run replicated.  The concatenation of the owned cells equals the one-process
- * result bit for bit.                                                                          */
+ * that free) but computes only the cells it owns, and of its permutation only the segments of
+ * those cells are exact: every other segment holds as many ids as the cell has members, each an
+ * id of that cell - all the replicated compaction and the stable counting sort need to put the
+ * owned segments into the reference's order.  The library calls `exchange` where global data is
+ * needed: after every sub-step a sum over processes of n_cell + 1 + shard_world doubles (masked
+ * dt_left; how many super-droplets died, in total and per process), and - only when one died -
+ * a sum of rank-disjoint slices holding the POSITIONS of the dead (exactly as many int64 as
+ * died): every process flags those positions and runs the compaction and the counting sort on its
+ * own copy.  No super-droplet payload and no permutation crosses processes in a collision step.
+ * The concatenation of the owned cells equals the one-process result bit for bit.            */
 #define SDM_XCHG_SUM_F64 1 /* buffer = device double[count]: in-place sum over all processes */
 #define SDM_XCHG_SUM_I64 2 /* buffer = device int64[count] */
 /* must order the collective after the work already enqueued on the ctx stream and make its result
@@ -401,8 +406,9 @@ typedef struct sdm_step_state {
   const uint8_t *cell_owned;  /* [n_cell] by cell id: 1 = computed by this process */
   sdm_exchange_fn exchange;
   void *exchange_user;
-  double *xchg_cells;         /* [n_cell + 8] scratch for the per-cell exchange */
-  int64_t *xchg_idx;          /* [n_sd] scratch for the permutation exchange */
+  double *xchg_cells;         /* [n_cell + 1 + shard_world] scratch for the per-cell exchange */
+  int64_t *xchg_idx;          /* [n_sd] scratch for the exchange of dead positions */
+  int32_t shard_rank, shard_world; /* this process's place among the processes (slices above) */
 } sdm_step_state;
 
 typedef struct sdm_step_result {

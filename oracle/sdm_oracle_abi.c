@@ -838,33 +838,48 @@ static void draw(const sdm_step_cfg *cfg, uint64_t offset, double *out, int64_t 
 /* Sharded mode (include/sdm_hip.h): the oracle runs every stage over the global arrays, as always,
  * but lets only the pairs of owned cells collide and keeps only the owned cells' bookkeeping; what
  * the other processes computed arrives through the caller's exchange, exactly where the product
- * library exchanges it: after the update of a sub-step the owned cells' dt_left and "someone
- * died", and - if someone did - the permutation, put together from every process's segments with
- * the dead marked by the flag value (the other processes never saw their multiplicities). */
+ * library exchanges it: after the update of a sub-step the owned cells' dt_left and how many
+ * super-droplets died (in total and per process), and - if any did - the POSITIONS of the dead,
+ * which every process flags in its own permutation before the reference's compaction runs on it.
+ * Of that permutation only the owned cells' segments are exact; the others hold ids of the right
+ * cell in the right number (the invariant stated in the header), which is all the compaction and
+ * the stable counting sort need. */
 static int box_shard_sync(Box *B) {
   sdm_step_state *st = B->st;
   const uint8_t *owned = st->cell_owned;
   double *x = st->xchg_cells;
+  const int world = st->shard_world, rank = st->shard_rank;
   if (!st->exchange || !x || !st->xchg_idx) FAIL(SDM_E_ARG, "sharded mode: exchange missing");
+  if (world < 1 || rank < 0 || rank >= world) FAIL(SDM_E_ARG, "sharded mode: rank / world");
   for (int64_t k = 0; k < B->C; ++k) x[k] = (B->cfg->adaptive && owned[k]) ? st->dt_left[k] : 0.0;
-  x[B->C] = B->healthy ? 0.0 : 1.0;
-  if (st->exchange(st->exchange_user, SDM_XCHG_SUM_F64, x, B->C + 1))
+  /* the dead of this process's cells: zero multiplicity among the live of an owned cell */
+  int64_t *y = st->xchg_idx;
+  int64_t mine = 0;
+  if (!B->healthy)
+    for (int64_t i = 0; i < B->valid; ++i) {
+      const int64_t sd = B->idx[i];
+      if (sd < B->N && owned[st->cell_id[sd]] && st->multiplicity[sd] == 0) ++mine;
+    }
+  x[B->C] = (double)mine;
+  for (int r = 0; r < world; ++r) x[B->C + 1 + r] = r == rank ? (double)mine : 0.0;
+  if (st->exchange(st->exchange_user, SDM_XCHG_SUM_F64, x, B->C + 1 + world))
     FAIL(SDM_E_HIP, "exchange callback failed");
   if (B->cfg->adaptive)
     for (int64_t k = 0; k < B->C; ++k) st->dt_left[k] = x[k];
-  if (x[B->C] > 0) {
+  const int64_t total = (int64_t)x[B->C];
+  if (total > 0) {
     B->healthy = 0;
-    int64_t *y = st->xchg_idx;
-    for (int64_t i = 0; i < B->N; ++i) {
-      y[i] = 0;
-      if (i < B->valid) {
-        const int64_t sd = B->idx[i];
-        if (sd < B->N && owned[st->cell_id[sd]]) y[i] = st->multiplicity[sd] == 0 ? B->N : sd;
-      }
+    int64_t before = 0;
+    for (int r = 0; r < rank; ++r) before += (int64_t)x[B->C + 1 + r];
+    for (int64_t i = 0; i < total; ++i) y[i] = 0;
+    int64_t at = before;
+    for (int64_t i = 0; i < B->valid && mine > 0; ++i) {
+      const int64_t sd = B->idx[i];
+      if (sd < B->N && owned[st->cell_id[sd]] && st->multiplicity[sd] == 0) y[at++] = i;
     }
-    if (st->exchange(st->exchange_user, SDM_XCHG_SUM_I64, y, B->N))
+    if (st->exchange(st->exchange_user, SDM_XCHG_SUM_I64, y, total))
       FAIL(SDM_E_HIP, "exchange callback failed");
-    memcpy(B->idx, y, sizeof(int64_t) * (size_t)B->N);
+    for (int64_t i = 0; i < total; ++i) B->idx[y[i]] = B->N;  /* flagged: removed by sanitize */
   }
   return SDM_OK;
 }

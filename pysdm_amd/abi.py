@@ -58,6 +58,7 @@ class StepState(ctypes.Structure):  # == sdm_step_state
         ("rng_offset_breakup", c_u64),
         ("cell_owned", c_ptr), ("exchange", c_ptr), ("exchange_user", c_ptr),
         ("xchg_cells", c_ptr), ("xchg_idx", c_ptr),
+        ("shard_rank", ctypes.c_int32), ("shard_world", ctypes.c_int32),
     ]
 
 

@@ -1718,14 +1718,47 @@ __global__ void k_set_work(int64_t *ctl, const int64_t *end, int64_t *box, int64
 __global__ void k_reset_work(int64_t *ctl) { ctl[CTL_WORK] = ctl[CTL_VALID]; }
 // multi-cell: reset_working_length + reset_cell_idx (identity; un-sorts) in one launch
 // ---- sharded mode: what crosses process boundaries ---------------------------------------------
-// after the per-cell bookkeeping of a sub-step: x[c] = dt_left[c] of the cells this process owns
-// (0 elsewhere), x[C] = 1 if a super-droplet of this process died; summed over the processes by the
-// caller's exchange, then written back for every cell
+// Invariant of a process's permutation: the segments of the cells it owns are exact; every other
+// segment holds as many ids as the cell has members, each of them an id of THAT cell (which ones,
+// and in which order, is the owner's business).  That is all the replicated compaction and the
+// stable counting sort need to put the owned segments in the reference's order
+// (collisions_methods.py:664-697): positions and cell sizes are global, ids only travel with
+// their cell.
+//
+// After the per-cell bookkeeping of a sub-step: x[c] = dt_left[c] of the cells this process owns
+// (0 elsewhere), x[C] = number of super-droplets that died in them, x[C + 1 + r] = the same,
+// filed under the process's rank r; summed over the processes by the caller's exchange, then
+// written back for every cell.
+// `dead`: positions of the flagged entries of the owned segments (a super-droplet that died was
+// flagged where it sits by the kernel that updated it: k_cell_step*, k_resolve_dense)
 __global__ void __launch_bounds__(SDM_BLOCK)
-k_shard_pack(FusedArgs A, int64_t n_cell, int adaptive, double *__restrict__ x) {
+k_shard_dead_list(FusedArgs A, const int64_t *__restrict__ idx, int64_t n_cell, int64_t n_sd,
+                  int64_t *__restrict__ dead, unsigned long long *__restrict__ n_dead) {
+  if (A.ctl[CTL_HEALTHY] != 0) return;  // nothing died in this process's cells
+  const int64_t lo = A.cell_start[blockIdx.x], hi = A.cell_start[blockIdx.x + 1];
+  if (hi == lo) return;
+  // (a flagged entry can only have been written by the owner: this process)
+  const int64_t first = idx[lo];
+  if (first < n_sd && !A.cell_owned[A.cell_id[first]]) return;
+  for (int64_t base = lo; base < hi; base += SDM_BLOCK) {
+    const int64_t i = base + threadIdx.x;
+    const bool is_dead = i < hi && idx[i] >= n_sd;
+    const unsigned long long m = __ballot(is_dead);
+    if (m == 0) continue;
+    const int lane = lane_id(), leader = __ffsll((long long)m) - 1;
+    unsigned long long at = 0;
+    if (lane == leader) at = atomicAdd(n_dead, (unsigned long long)__popcll(m));
+    at = __shfl((long long)at, leader, 64);
+    if (is_dead) dead[at + __popcll(m & ((1ull << lane) - 1))] = i;
+  }
+}
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_shard_pack(FusedArgs A, int64_t n_cell, int adaptive, double *__restrict__ x,
+             const unsigned long long *__restrict__ n_dead, int rank, int world) {
   const int64_t c = TID();
   if (c < n_cell) x[c] = (adaptive && A.cell_owned[c]) ? A.dt_left[c] : 0.0;
-  if (c == n_cell) x[c] = A.ctl[CTL_HEALTHY] == 0 ? 1.0 : 0.0;
+  if (c == n_cell) x[c] = (double)n_dead[0];
+  if (c > n_cell && c <= n_cell + world) x[c] = (c - n_cell - 1 == rank) ? (double)n_dead[0] : 0.0;
 }
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_shard_unpack(FusedArgs A, int64_t n_cell, int adaptive, const double *__restrict__ x) {
@@ -1733,26 +1766,19 @@ k_shard_unpack(FusedArgs A, int64_t n_cell, int adaptive, const double *__restri
   if (c < n_cell && adaptive) A.dt_left[c] = x[c];
   if (c == n_cell && x[c] > 0) A.ctl[CTL_HEALTHY] = 0;
 }
-// the permutation with everything but this process's segments zeroed (workgroup k: segment k;
-// the others: the dead tail); the sum over the processes is the whole permutation
+// this process's dead positions into its slice of the (zeroed) exchange buffer
 __global__ void __launch_bounds__(SDM_BLOCK)
-k_shard_mask_idx(FusedArgs A, const int64_t *__restrict__ idx, int64_t n_cell, int64_t n_sd,
-                 int64_t *__restrict__ out) {
-  const int64_t b = blockIdx.x;
-  if (b < n_cell) {
-    const int64_t lo = A.cell_start[b], hi = A.cell_start[b + 1];
-    if (hi == lo) return;
-    // (a flagged entry - value n_sd, a super-droplet that just died - can only have been written
-    // by the owner: this process)
-    const int64_t first = idx[lo];
-    const bool mine = first >= n_sd || A.cell_owned[A.cell_id[first]] != 0;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += SDM_BLOCK) out[i] = mine ? idx[i] : 0;
-    return;
-  }
-  const int64_t n_tail = gridDim.x - n_cell;
-  for (int64_t i = A.cell_start[n_cell] + (b - n_cell) * SDM_BLOCK + threadIdx.x; i < n_sd;
-       i += n_tail * SDM_BLOCK)
-    out[i] = 0;
+k_shard_dead_place(const int64_t *__restrict__ dead, int64_t n, int64_t *__restrict__ out) {
+  const int64_t i = TID();
+  if (i < n) out[i] = dead[i];
+}
+// every process flags the positions at which a super-droplet died anywhere (in a segment of
+// another process this removes SOME member of that cell from the local copy: see the invariant)
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_shard_flag(int64_t *__restrict__ idx, const int64_t *__restrict__ dead, int64_t n,
+             int64_t n_sd) {
+  const int64_t i = TID();
+  if (i < n) idx[dead[i]] = n_sd;
 }
 
 __global__ void __launch_bounds__(SDM_BLOCK)
@@ -1811,7 +1837,7 @@ static FusedScratch layout(char *base, const sdm_step_cfg *cfg) {
   S.seg_src = cv.take<int64_t>(C);
   S.gate_len = cv.take<int64_t>(4);
   S.cctl = cv.take<int64_t>(8);
-  S.end2 = cv.take<int64_t>(4);
+  S.end2 = cv.take<int64_t>(8);  // (word 4: sharded mode's count of dead positions)
   S.shuffle = base + cv.off;
   cv.off += carve_size(sdm_shuffle_scratch(N));
   S.sort = base + cv.off;
@@ -2185,17 +2211,31 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       sdm_set_error("sharded mode: exchange callback and its two buffers are required");
       return SDM_E_ARG;
     }
+    if (st->shard_world < 1 || st->shard_world > 64 || st->shard_rank < 0 ||
+        st->shard_rank >= st->shard_world) {
+      sdm_set_error("sharded mode: shard_rank / shard_world out of range");
+      return SDM_E_ARG;
+    }
     if (!cell_path || !cfg->croupier_local) {
       sdm_set_error("sharded mode needs the local croupier and cells of at most %d "
                     "super-droplets (largest: %lld)", CELL_CAP, (long long)max_cell);
       return SDM_E_ARG;
     }
   }
-  auto shard_cells = [&]() -> int {  // owned cells' dt_left + "someone died", summed
-    const dim3 g((unsigned)grid_for(C + 1));
-    hipLaunchKernelGGL(k_shard_pack, g, blk, 0, s, A, C, cfg->adaptive, st->xchg_cells);
+  // dead positions of this process (scratch: the sort's output buffer is free between sorts)
+  int64_t *shard_dead_pos = S.sorted_buf;
+  unsigned long long *shard_n_dead = (unsigned long long *)(S.end2 + 4);
+  const int world = sharded ? st->shard_world : 1, my_rank = sharded ? st->shard_rank : 0;
+  auto shard_cells = [&](const int64_t *perm) -> int {  // owned cells' dt_left + deaths, summed
+    HIP_TRY(hipMemsetAsync(shard_n_dead, 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_shard_dead_list, dim3((unsigned)C), blk, 0, s, A, perm, C, N,
+                       shard_dead_pos, shard_n_dead);
     LAUNCH_CHECK();
-    if (st->exchange(st->exchange_user, SDM_XCHG_SUM_F64, st->xchg_cells, C + 1) != 0) {
+    const dim3 g((unsigned)grid_for(C + 1 + world));
+    hipLaunchKernelGGL(k_shard_pack, g, blk, 0, s, A, C, cfg->adaptive, st->xchg_cells,
+                       shard_n_dead, my_rank, world);
+    LAUNCH_CHECK();
+    if (st->exchange(st->exchange_user, SDM_XCHG_SUM_F64, st->xchg_cells, C + 1 + world) != 0) {
       sdm_set_error("sharded mode: the exchange callback failed (per-cell sum)");
       return SDM_E_HIP;
     }
@@ -2203,27 +2243,45 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     LAUNCH_CHECK();
     return SDM_OK;
   };
-  auto shard_perm = [&](int64_t *perm) -> int {  // the permutation from the segments' owners
-    hipLaunchKernelGGL(k_shard_mask_idx, dim3((unsigned)(C + 64)), blk, 0, s, A, perm, C, N,
-                       st->xchg_idx);
-    LAUNCH_CHECK();
-    if (st->exchange(st->exchange_user, SDM_XCHG_SUM_I64, st->xchg_idx, N) != 0) {
-      sdm_set_error("sharded mode: the exchange callback failed (permutation sum)");
-      return SDM_E_HIP;
-    }
-    HIP_TRY(hipMemcpyAsync(perm, st->xchg_idx, sizeof(int64_t) * (size_t)N,
-                           hipMemcpyDeviceToDevice, s));
-    return SDM_OK;
-  };
-  auto shard_sync = [&](int64_t *perm) -> int {  // both, the second if the first says so
-    int r = shard_cells();
-    if (r) return r;
-    HIP_TRY(hipMemcpyAsync(ctx->mailbox, st->xchg_cells + C, sizeof(double),
+  // A super-droplet died somewhere: every process learns WHERE (positions are global) - one
+  // all-gather of the dead positions, as a sum of rank-disjoint slices of exactly their total
+  // number - and flags those positions in its own permutation; the compaction that follows then
+  // does the reference's swap-from-the-end (collisions_methods.py:664-680) on every process alike.
+  // (Round 2 summed the whole masked permutation here: n_sd int64 per death.)
+  auto shard_dead = [&](int64_t *perm) -> int {
+    HIP_TRY(hipMemcpyAsync(ctx->mailbox, st->xchg_cells + C, sizeof(double) * (size_t)(1 + world),
                            hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    double died;
-    memcpy(&died, ctx->mailbox, sizeof(double));
-    return died > 0 ? shard_perm(perm) : SDM_OK;
+    double counts[1 + 64];
+    memcpy(counts, ctx->mailbox, sizeof(double) * (size_t)(1 + world));
+    const int64_t total = (int64_t)counts[0];
+    if (total <= 0) return SDM_OK;
+    int64_t before = 0;
+    for (int r = 0; r < my_rank; ++r) before += (int64_t)counts[1 + r];
+    const int64_t mine = (int64_t)counts[1 + my_rank];
+    if (total > N || before + mine > total) {
+      sdm_set_error("sharded mode: inconsistent death counts (%lld of %lld)", (long long)mine,
+                    (long long)total);
+      return SDM_E_HIP;
+    }
+    HIP_TRY(hipMemsetAsync(st->xchg_idx, 0, sizeof(int64_t) * (size_t)total, s));
+    if (mine > 0) {
+      hipLaunchKernelGGL(k_shard_dead_place, dim3(grid_for(mine)), blk, 0, s, shard_dead_pos, mine,
+                         st->xchg_idx + before);
+      LAUNCH_CHECK();
+    }
+    if (st->exchange(st->exchange_user, SDM_XCHG_SUM_I64, st->xchg_idx, total) != 0) {
+      sdm_set_error("sharded mode: the exchange callback failed (dead positions)");
+      return SDM_E_HIP;
+    }
+    hipLaunchKernelGGL(k_shard_flag, dim3(grid_for(total)), blk, 0, s, perm, st->xchg_idx, total,
+                       N);
+    LAUNCH_CHECK();
+    return SDM_OK;
+  };
+  auto shard_sync = [&](int64_t *perm) -> int {  // both
+    const int r = shard_cells(perm);
+    return r ? r : shard_dead(perm);
   };
   // Multi-cell per-cell route, adaptive: the same idea with a device-side gate.  Sub-step k + 1
   // is launched before the host waits for the control block of sub-step k; its first kernel
@@ -2279,7 +2337,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         hipLaunchKernelGGL(k_cells_end, dim3(grid_for(C)), blk, 0, s, *cfg, A, 1, S.end2,
                            (int64_t *)nullptr, (int64_t)0);
         LAUNCH_CHECK();
-        const int r = shard_cells();
+        const int r = shard_cells(cur);
         if (r) return r;
         HIP_TRY(hipMemsetAsync(S.end2, 0, sizeof(int64_t), s));
       }
@@ -2342,7 +2400,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       if (sharded && last_ctl[CTL_HEALTHY] == 0) {
         // a super-droplet died somewhere: the permutation is put together from the owners'
         // segments, then the compaction runs on identical data everywhere
-        rc = shard_perm(cur);
+        rc = shard_dead(cur);
         if (rc) return rc;
         PhaseScope ph(ctx, SDM_PHASE_SANITIZE);
         rc = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl, S.cctl,

@@ -46,9 +46,10 @@ class Shard:  # pylint: disable=too-many-instance-attributes
         mask[self.first:self.last] = 1
         self.owned_host = mask.astype(bool)
         self.owned = engine.upload(mask)
-        self.x_cells = engine.zeros(n_cell + 8, np.float64)
+        self.x_cells = engine.zeros(n_cell + 1 + world, np.float64)
         self.x_idx = engine.zeros(n_sd, np.int64)
         self.calls = {abi.XCHG_SUM_F64: 0, abi.XCHG_SUM_I64: 0}
+        self.bytes = {abi.XCHG_SUM_F64: 0, abi.XCHG_SUM_I64: 0}  # payload handed to collectives
         self.error = None
         self.callback = abi.ExchangeFn(self._exchange)  # keep alive as long as the shard
 
@@ -62,6 +63,7 @@ class Shard:  # pylint: disable=too-many-instance-attributes
             if address != pointer:
                 raise RuntimeError("exchange called with a foreign buffer")
             self.calls[what] += 1
+            self.bytes[what] += 8 * int(count)
             tensor = self._as_tensor(buffer)[:count]
             if tensor.is_cuda and self.dist.get_backend(self.group) != "nccl":
                 # rehearsal on one card (several processes, gloo): through the host.  `.cpu()`
@@ -84,6 +86,7 @@ class Shard:  # pylint: disable=too-many-instance-attributes
         state.exchange_user = None
         state.xchg_cells = address(self.x_cells)
         state.xchg_idx = address(self.x_idx)
+        state.shard_rank, state.shard_world = self.rank, self.world
 
     def sum(self, array):
         """all-reduce (sum) of a host array; returns the host result"""
