@@ -80,7 +80,7 @@ class Checkpoint:
         self.diagnostics = {name: getattr(runner, name).clone() for name in self.RUNNER
                             if getattr(runner, name) is not None}
         self.scalars = {name: getattr(runner, name) for name in self.SCALARS}
-        self.live = pop.live
+        self.live, self.ordered = pop.live, pop.ordered
 
     def restore(self, runner):
         pop = runner.population
@@ -91,7 +91,9 @@ class Checkpoint:
         for name, value in self.scalars.items():
             setattr(runner, name, value)
         pop.live = pop.working = self.live
-        pop.ordered = False
+        # (sortedness as it was: an unsorted state would be sorted again under the cell order the
+        # adaptive scheme has just permuted - a different, equally valid trajectory)
+        pop.ordered = self.ordered
         pop.touch_state()  # the next call starts from the host's view (control block, mirror)
 
 

@@ -330,26 +330,56 @@ __device__ __forceinline__ void coalesce_pair(int64_t j, int64_t k, double gamma
   }
 }
 
-// :62-93
+// :62-93.  The reference's loop runs `int(gamma)` successive breakups of one pair, each depending
+// on the last in floating point (two roundings per iteration: there is no closed form), and late in
+// a breakup run gamma reaches 1e4..1e6 for single pairs - one lane walks the loop alone while its
+// kernel waits.  What can be saved is everything but the dependent arithmetic: the loop below
+// advances 8 iterations at a time without a branch (the values of an iteration that turns out to
+// be beyond the exit are simply not used) and tests the two exit conditions of all 8 at once;
+// the block in which an exit falls is walked again one iteration at a time.  Same operations, same
+// order, same results as the one-at-a-time loop (tests/micro_cases.py: the reference's breakup
+// answers; tests/test_hip_parity.py: long-gamma cases against the checker).
 __device__ __forceinline__ void compute_transfer_multiplicities(
     double gamma, int64_t nj, int64_t nk, double mj, double mk, double fragment_mass_i,
     int64_t max_multiplicity, double &take_from_j, double &new_mult_k, int64_t &gamma_j_k,
     bool &overflow) {
   overflow = false;
   gamma_j_k = 0;
-  double take_from_j_test = (double)nk;
+  double t = (double)nk;  // take_from_j_test
   take_from_j = 0;
-  double new_mult_k_test = ((mj + mk) / fragment_mass_i) * (double)nk;
+  double x = ((mj + mk) / fragment_mass_i) * (double)nk;  // new_mult_k_test
   new_mult_k = (double)nk;
   const int64_t g = (int64_t)gamma;
-  for (int64_t m = 0; m < g; ++m) {
-    if (new_mult_k_test > (double)max_multiplicity) { overflow = true; break; }
-    if (take_from_j_test > (double)nj) break;
-    take_from_j = take_from_j_test;
-    new_mult_k = new_mult_k_test;
+  const double r = mj / fragment_mass_i, top = (double)max_multiplicity, have = (double)nj;
+  int64_t m = 0;
+  constexpr int B = 8;
+  while (m + B <= g) {
+    double xs[B + 1], ts[B + 1];
+    xs[0] = x;
+    ts[0] = t;
+    bool exit_inside = false;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      exit_inside |= (xs[b] > top) | (ts[b] > have);
+      ts[b + 1] = ts[b] + xs[b];
+      xs[b + 1] = xs[b] * r + xs[b];
+    }
+    if (exit_inside) break;  // some iteration of this block leaves the loop: one at a time below
+    take_from_j = ts[B - 1];
+    new_mult_k = xs[B - 1];
+    m += B;
+    x = xs[B];
+    t = ts[B];
+  }
+  gamma_j_k = m;
+  for (; m < g; ++m) {
+    const bool over = x > top;
+    if (over | (t > have)) { overflow = over; break; }
+    take_from_j = t;
+    new_mult_k = x;
     gamma_j_k = m + 1;
-    take_from_j_test += new_mult_k_test;
-    new_mult_k_test = new_mult_k_test * (mj / fragment_mass_i) + new_mult_k_test;
+    t += x;
+    x = x * r + x;
   }
 }
 
