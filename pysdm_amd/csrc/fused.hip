@@ -926,7 +926,10 @@ k_cells_begin(sdm_step_cfg cfg, FusedArgs A, int64_t *__restrict__ cell_idx,
   // gated: the sub-step was launched ahead of the read-back of the previous one; it runs only if
   // that one left work to do and the state sorted (no compaction).  end2[3] tells the kernels
   // that follow (nothing they do changes the two words before this kernel has finished)
-  const bool run = !gated || (A.ctl[CTL_WORK] != 0 && A.ctl[CTL_SORTED] != 0);
+  // (sharded: a death is dealt with by the host - exchange of the dead positions, compaction -
+  // before the next sub-step may run; the compaction of one process un-sorts by itself)
+  const bool run = !gated || (A.ctl[CTL_WORK] != 0 && A.ctl[CTL_SORTED] != 0 &&
+                              (!A.cell_owned || A.ctl[CTL_HEALTHY] != 0));
   if (i == 0 && threadIdx.x == 0) end2[3] = run ? 1 : 0;
   if (!run) return;
   // fresh: first sub-step of a time step, dt_left[:] = dt (collision.py:180) happens here
@@ -1732,9 +1735,14 @@ __global__ void k_reset_work(int64_t *ctl) { ctl[CTL_WORK] = ctl[CTL_VALID]; }
 // `dead`: positions of the flagged entries of the owned segments (a super-droplet that died was
 // flagged where it sits by the kernel that updated it: k_cell_step*, k_resolve_dense)
 __global__ void __launch_bounds__(SDM_BLOCK)
-k_shard_dead_list(FusedArgs A, const int64_t *__restrict__ idx, int64_t n_cell, int64_t n_sd,
-                  int64_t *__restrict__ dead, unsigned long long *__restrict__ n_dead) {
+k_shard_dead_list(FusedArgs A, const int64_t *__restrict__ idx,
+                  const int64_t *__restrict__ idx_if_skipped, const int64_t *__restrict__ gate,
+                  int64_t n_cell, int64_t n_sd, int64_t *__restrict__ dead,
+                  unsigned long long *__restrict__ n_dead) {
   if (A.ctl[CTL_HEALTHY] != 0) return;  // nothing died in this process's cells
+  // a sub-step launched ahead that fell through on the device (k_cells_begin) wrote no
+  // permutation: the current one is still the previous sub-step's
+  if (gate && gate[0] == 0) idx = idx_if_skipped;
   const int64_t lo = A.cell_start[blockIdx.x], hi = A.cell_start[blockIdx.x + 1];
   if (hi == lo) return;
   // (a flagged entry can only have been written by the owner: this process)
@@ -2226,10 +2234,12 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   int64_t *shard_dead_pos = S.sorted_buf;
   unsigned long long *shard_n_dead = (unsigned long long *)(S.end2 + 4);
   const int world = sharded ? st->shard_world : 1, my_rank = sharded ? st->shard_rank : 0;
-  auto shard_cells = [&](const int64_t *perm) -> int {  // owned cells' dt_left + deaths, summed
+  // owned cells' dt_left + deaths, summed (perm_if_skipped / gate: see k_shard_dead_list)
+  auto shard_cells = [&](const int64_t *perm, const int64_t *perm_if_skipped = nullptr,
+                         const int64_t *gate = nullptr) -> int {
     HIP_TRY(hipMemsetAsync(shard_n_dead, 0, sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(k_shard_dead_list, dim3((unsigned)C), blk, 0, s, A, perm, C, N,
-                       shard_dead_pos, shard_n_dead);
+    hipLaunchKernelGGL(k_shard_dead_list, dim3((unsigned)C), blk, 0, s, A, perm, perm_if_skipped,
+                       gate, C, N, shard_dead_pos, shard_n_dead);
     LAUNCH_CHECK();
     const dim3 g((unsigned)grid_for(C + 1 + world));
     hipLaunchKernelGGL(k_shard_pack, g, blk, 0, s, A, C, cfg->adaptive, st->xchg_cells,
@@ -2337,7 +2347,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         hipLaunchKernelGGL(k_cells_end, dim3(grid_for(C)), blk, 0, s, *cfg, A, 1, S.end2,
                            (int64_t *)nullptr, (int64_t)0);
         LAUNCH_CHECK();
-        const int r = shard_cells(cur);
+        const int r = shard_cells(cur, alt, gated ? S.end2 + 3 : nullptr);
         if (r) return r;
         HIP_TRY(hipMemsetAsync(S.end2, 0, sizeof(int64_t), s));
       }
@@ -2377,13 +2387,18 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       const uint64_t keep[4] = {off, off_b, draw_off, draw_off_b};
       int64_t seq_next = 0;
       // (not in timing mode: a sub-step that falls through would count as a launch)
-      // (nor in sharded mode: every sub-step ends with an exchange the host takes part in)
-      const bool ahead = !ctx->timing && !sharded;
+      // Sharded runs launch ahead as well: the exchange of a sub-step is one more piece of work
+      // on the stream (an RCCL collective enqueued by the callback); a sub-step that falls through
+      // exchanges what the one before it did (same dt_left, same deaths), which changes nothing
+      const bool ahead = !ctx->timing;
       if (ahead) {
         rc = launch_substep(true, &seq_next);
         if (rc) return rc;
       }
+      bool taken_back = !ahead;
       auto take_back = [&]() {  // the sub-step launched ahead fell through on the device
+        if (taken_back) return;
+        taken_back = true;
         off = keep[0]; off_b = keep[1]; draw_off = keep[2]; draw_off_b = keep[3];
         { int64_t *t = cur; cur = alt; alt = t; }
         --swaps;
@@ -2398,8 +2413,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       ++n_sub;
       n_pairs += work_host / 2;
       if (sharded && last_ctl[CTL_HEALTHY] == 0) {
-        // a super-droplet died somewhere: the permutation is put together from the owners'
-        // segments, then the compaction runs on identical data everywhere
+        // a super-droplet died somewhere: every process flags the dead positions in its own
+        // permutation, then runs the compaction (the sub-step launched ahead fell through:
+        // k_cells_begin's gate)
+        take_back();
         rc = shard_dead(cur);
         if (rc) return rc;
         PhaseScope ph(ctx, SDM_PHASE_SANITIZE);
@@ -2411,7 +2428,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       if (last_ctl[CTL_SORTED] == 0) {
         // a compaction happened in sub-step k: sort by cell, then the end of the working range
         // from the new cell_start (particle_attributes.py cell_start getter)
-        if (ahead) take_back();
+        take_back();
         sorted_host = 0;
         shard_resorted = true;
         hipLaunchKernelGGL(k_reset_work, one, one, 0, s, st->ctl);  // sanitize left work = valid
@@ -2434,7 +2451,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       sorted_host = 1;
       work_host = last_ctl[CTL_WORK];
       if (work_host == 0) {
-        if (ahead) take_back();
+        take_back();
         break;
       }
       if (ahead) {
@@ -3059,12 +3076,12 @@ extern "C" int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step
   bool pairs_known = true;
   const bool replay = cfg && graph_eligible(ctx, cfg, st, n_steps);
   // cell-ordered working copy (above): multi-cell adaptive runs of three steps or more on the
-  // per-cell route, one process (SDM_CELL_COPY=0 switches it off: measurements)
+  // per-cell route (SDM_CELL_COPY=0 switches it off: measurements).  Sharded runs too: labels
+  // are a process's own business - only positions and per-cell numbers cross processes
   static const bool copy_enabled = !(getenv("SDM_CELL_COPY") && getenv("SDM_CELL_COPY")[0] == '0');
   Relabel relabel;
   const bool copy_wanted = copy_enabled && cfg && cfg->n_cell > 1 && cfg->adaptive &&
-                           cfg->croupier_local && !st->cell_owned && st->nm && n_steps >= 3 &&
-                           !ctx->graph_capture;
+                           cfg->croupier_local && st->nm && n_steps >= 3 && !ctx->graph_capture;
   if (copy_wanted) {  // all scratch up front: the arena must not move once the copy lives in it
     const int rc = sdm_reserve(ctx, carve_size(layout(nullptr, cfg).total) + relabel_bytes(cfg));
     if (rc) return rc;

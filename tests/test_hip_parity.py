@@ -363,3 +363,52 @@ def test_cell_ordered_working_copy_changes_nothing(case, hip_engine, oracle_engi
     for label in ("one call", "step by step", "mixed"):
         assert_same(runs[label][0], reference[0])
         assert runs[label][1:] == reference[1:], label
+
+
+def _long_breakup_case(engine, handle_all_breakups):
+    """pairs whose `break_up` loop (collisions_methods.py:62-132) runs 0 .. 3e5 successive
+    breakups: full blocks of the 8-at-a-time loop, exits in the middle of a block (the donor runs
+    out, the multiplicity limit is hit), gamma not a multiple of 8"""
+    rng = np.random.default_rng(17)
+    gammas = np.array([0, 1, 7, 8, 9, 15, 16, 17, 63, 64, 65, 1000, 4099, 30011, 100003, 300007],
+                      dtype=float)
+    pairs = 4 * len(gammas)
+    n_sd = 2 * pairs
+    gamma = np.tile(gammas, 4)
+    # donors j (even positions) with plenty / few droplets, receivers k
+    n_j = np.where(np.arange(pairs) % 4 < 2, 10**15, 3 * 10**6).astype(np.int64)
+    n_k = rng.integers(500, 1500, pairs).astype(np.int64)
+    multiplicity = np.empty(n_sd, dtype=np.int64)
+    multiplicity[0::2], multiplicity[1::2] = n_j, n_k
+    mass = np.empty(n_sd)
+    mass[0::2] = rng.uniform(0.5e-14, 2e-14, pairs)   # m_j / fragment mass ~ 1e-5
+    mass[1::2] = rng.uniform(0.5e-9, 2e-9, pairs)
+    fragment_mass = rng.uniform(0.8e-9, 1.2e-9, pairs)
+    up = engine.upload
+    state = {"multiplicity": up(multiplicity), "attributes": up(mass.reshape(1, -1).copy())}
+    counters = [engine.zeros(1, np.int64) for _ in range(3)]
+    healthy, overflow = engine.full(1, np.int64, 1), engine.zeros(1, np.int64)
+    flag = np.zeros(n_sd, dtype=np.uint8)
+    flag[0::2] = 1
+    results = []
+    for max_multiplicity in (2**62, 2500):  # (second round: the multiplicity limit ends loops)
+        engine.call("sdm_collision_coalescence_breakup", state["multiplicity"],
+                    up(np.arange(n_sd, dtype=np.int64)), n_sd, state["attributes"], 1, n_sd,
+                    up(gamma), up(np.full(pairs, 0.5)), up(np.zeros(pairs)), up(np.ones(pairs)),
+                    up(fragment_mass), healthy, up(np.zeros(n_sd, dtype=np.int64)), counters[0],
+                    counters[1], counters[2], up(flag), int(max_multiplicity),
+                    up(mass.copy()), int(handle_all_breakups), overflow)
+        results.append([engine.download(a).copy() for a in
+                        (state["multiplicity"], state["attributes"], *counters, overflow)])
+    return results
+
+
+@pytest.mark.parametrize("handle_all_breakups", [False, True])
+def test_long_breakup_loops_equal_the_checker(handle_all_breakups, hip_engine, oracle_engine):
+    got = _long_breakup_case(hip_engine, handle_all_breakups)
+    want = _long_breakup_case(oracle_engine, handle_all_breakups)
+    assert want[0][3][0] > 0  # breakups happened
+    assert want[1][5][0] > 0  # ... and with the low limit, refused ones
+    for round_got, round_want in zip(got, want):
+        for value, ref in zip(round_got, round_want):
+            np.testing.assert_array_equal(value, ref)
