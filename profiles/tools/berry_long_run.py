@@ -9,6 +9,9 @@ import time
 from pysdm_amd.cases import make_box
 from pysdm_amd.engine import HipEngine
 
+import sys
+
+TIMING = "--phases" in sys.argv  # per-phase HIP events (slower: no launch-ahead) or plain wall clock
 engine = HipEngine.get()
 runner = make_box(engine, "berry_breakup")
 runner.run(1)
@@ -17,7 +20,7 @@ name.restype = ctypes.c_char_p
 windows = []
 total_pairs, total_time = 0, 0.0
 for target in range(250, 1501, 250):
-    engine.call("sdm_ctx_set_timing", 1)
+    engine.call("sdm_ctx_set_timing", 1 if TIMING else 0)
     engine.synchronize()
     pairs0, sub0, t0 = runner.pairs_done, runner.sub_steps_done, time.perf_counter()
     steps = target - runner.steps_done
@@ -36,5 +39,7 @@ for target in range(250, 1501, 250):
                     "ms_per_step": elapsed / steps * 1e3,
                     "substeps_per_step": (runner.sub_steps_done - sub0) / steps,
                     "phase_ms_per_step (timing mode: no launch-ahead)": phases})
-print(json.dumps({"workload": "berry_breakup, n_sd=2^20, adaptive, steps 1..1500 (timing mode on)",
+print(json.dumps({"workload": "berry_breakup, n_sd=2^20, adaptive, steps 1..1500"
+                              + (" (timing mode on)" if TIMING else ""),
+                  "library": __import__("os").environ.get("SDM_HIP_LIB", "pysdm_amd/libsdm_hip.so"),
                   "sustained_pairs_per_s": total_pairs / total_time, "windows": windows}, indent=1))

@@ -174,6 +174,10 @@ class CollisionRunner:  # pylint: disable=too-many-instance-attributes
     def _run_fused(self, n_steps):
         pop, eng = self.population, self.engine
         flags = READ_BACK if self.read_back else 0
+        if pop.host_dirty and pop.bookkeeping_stale:
+            # steps without read-back left live / working / ordered behind the device's control
+            # block; the host view is about to be uploaded: bring it up to date first
+            self.sync()
         if pop.host_dirty:
             pop.compact()  # the fused compaction looks for flagged slots only
             eng.assign(pop.ctl, eng.upload(np.asarray(
@@ -202,12 +206,14 @@ class CollisionRunner:  # pylint: disable=too-many-instance-attributes
         pop.state_version += 1
         pop.mirror_version = pop.state_version
         pop.host_dirty = False
+        pop.bookkeeping_stale = not self.read_back
         if self.read_back:
             self._adopt(list(result.ctl))
 
     def _adopt(self, words):
         pop = self.population
         pop.live, pop.working, pop.ordered = int(words[0]), int(words[0]), bool(words[2])
+        pop.bookkeeping_stale = False
         error = int(words[7]) & 0xff
         if error != 0:
             raise RuntimeError("libsdm_hip: device-side failure in the fused collision step: "

@@ -2412,6 +2412,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       have_ctl = true;
       ++n_sub;
       n_pairs += work_host / 2;
+      if (last_ctl[7] & SDM_CTL7_ERROR_MASK) {  // device-side failure: the caller raises
+        take_back();
+        break;
+      }
       if (sharded && last_ctl[CTL_HEALTHY] == 0) {
         // a super-droplet died somewhere: every process flags the dead positions in its own
         // permutation, then runs the compaction (the sub-step launched ahead fell through:

@@ -807,10 +807,17 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
   }
   int64_t new_len;
   __shared__ int excl[COMPACT_WAVES];
-  if (compact_run<FLAG_ONLY>(multiplicity, idx, flag, fctl, wave_dead, n_tiles, ctl, holes,
-                             fillers, cell_start_single, bar, E, &new_len, excl) &&
-      E.cells.n_cell)
-    cells_end_body(E.cells);  // (its last workgroup publishes what the commit above left)
+  const bool done = compact_run<FLAG_ONLY>(multiplicity, idx, flag, fctl, wave_dead, n_tiles, ctl,
+                                           holes, fillers, cell_start_single, bar, E, &new_len,
+                                           excl);
+  if (E.cells.n_cell) {
+    if (done)
+      cells_end_body(E.cells);  // (its last workgroup publishes what the commit above left)
+    else if (blockIdx.x == 0 && threadIdx.x == 0)
+      // a grid barrier timed out (fctl[7] = 2, set by every workgroup that gave up - this one
+      // included): the host still gets its publication, carrying the error code
+      publish_ctl(fctl, E.cells.box, E.cells.seq, 0);
+  }
 }
 
 // k_bin_sort (declared above): the tile sort of the shuffle build

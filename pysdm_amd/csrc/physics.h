@@ -352,7 +352,11 @@ __device__ __forceinline__ void compute_transfer_multiplicities(
   const int64_t g = (int64_t)gamma;
   const double r = mj / fragment_mass_i, top = (double)max_multiplicity, have = (double)nj;
   int64_t m = 0;
+#ifdef SDM_BREAKUP_ONE_AT_A_TIME  // (A/B measurement build: profiles/README.md)
+  constexpr int B = 1 << 30;
+#else
   constexpr int B = 8;
+#endif
   while (m + B <= g) {
     double xs[B + 1], ts[B + 1];
     xs[0] = x;

@@ -83,6 +83,7 @@ class DisplacementRunner:  # pylint: disable=too-many-instance-attributes
     # ---- one call ------------------------------------------------------------------------------------
     def run(self):
         pop = self.population
+        pop.refresh_bookkeeping()  # (after fused collision steps without read-back)
         pop.compact()
         if self.route == "fused":
             self._run_fused()

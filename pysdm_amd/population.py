@@ -120,6 +120,7 @@ class Population:  # pylint: disable=too-many-instance-attributes
         # between calls; anything that changes them (or the columns) from the host side sets
         # `host_dirty`, and the next fused call starts from the host's view again
         self.host_dirty = True
+        self.bookkeeping_stale = False  # see refresh_bookkeeping
         self.mirror_version = None   # state_version the mirror records were built from
         if (multiplicity == 0).any():  # unused slots: compact them away before the first step
             self.compact(assume_unhealthy=True)
@@ -148,6 +149,7 @@ class Population:  # pylint: disable=too-many-instance-attributes
         self.state_version = self.cells_version = 0
         self._derived = {}
         self.host_dirty = True
+        self.bookkeeping_stale = False
         self.mirror_version = None
         return self
 
@@ -167,6 +169,16 @@ class Population:  # pylint: disable=too-many-instance-attributes
         self.ordered = False
         self.host_dirty = True
 
+    def refresh_bookkeeping(self):
+        """fused steps without read-back leave `live` / `working` / `ordered` behind the control
+        block on the device; whoever is about to use the host's view (a compaction, a
+        displacement step, an upload of the control block) calls this first"""
+        if self.bookkeeping_stale:
+            words = self.engine.download(self.ctl)
+            self.live = self.working = int(words[0])
+            self.ordered = bool(words[2])
+            self.bookkeeping_stale = False
+
     def swap_buffers(self):
         self.perm, self.perm_spare = self.perm_spare, self.perm
 
@@ -175,6 +187,7 @@ class Population:  # pylint: disable=too-many-instance-attributes
         """drops super-droplets with zero multiplicity or a flagged slot from the permutation
         (`sanitize`, particle_attributes.py:67-73)"""
         eng = self.engine
+        self.refresh_bookkeeping()
         if not assume_unhealthy and int(eng.download(self.healthy)[0]) != 0:
             return
         self.live = eng.scalar_out("sdm_remove_zero_n_or_flagged", ctypes.c_int64,

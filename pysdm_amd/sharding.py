@@ -176,14 +176,24 @@ def complete_state(runner):
         else:
             shard.dist.all_reduce(tensor, op=shard.dist.ReduceOp.SUM, group=shard.group)
 
+    # (masked with where / fill, not by multiplying: a NaN or inf left in a slot this process does
+    # not own - a dead or unused one, say - would poison the sum as 0 * NaN)
     live = pop.perm[: pop.live]
     live_mine = mine[live]
-    live *= live_mine  # (in place: a view of the permutation)
-    total(live)
-    pop.multiplicity *= mine
-    total(pop.multiplicity)
-    pop.extensive *= mine  # broadcast over the attribute rows
-    total(pop.extensive)
+    if torch_like:
+        live.masked_fill_(~live_mine, 0)  # (in place: a view of the permutation)
+        total(live)
+        pop.multiplicity.masked_fill_(~mine, 0)
+        total(pop.multiplicity)
+        pop.extensive.masked_fill_(~mine.unsqueeze(0).expand_as(pop.extensive), 0.0)
+        total(pop.extensive)
+    else:
+        live[~live_mine] = 0
+        total(live)
+        pop.multiplicity[~mine] = 0
+        total(pop.multiplicity)
+        pop.extensive[:, ~mine] = 0.0
+        total(pop.extensive)
     pop.touch_state()  # the mirror of the fused step is rebuilt from the columns
     return runner
 

@@ -1,0 +1,19 @@
+#!/bin/bash
+# A/B measurement builds of the library: scripts/build_variant.sh NAME "-DFLAG ..." writes
+# build_variants/libsdm_NAME.so (git-ignored; travels to the GPU box); use with SDM_HIP_LIB=...
+set -euo pipefail
+name=$1; shift
+root=$(cd "$(dirname "$0")/.." && pwd)
+out=$root/build_variants/libsdm_$name.so
+tmp=$(mktemp -d)
+mkdir -p "$root/build_variants"
+FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function"
+pids=()
+for f in ctx index collisions fused displacement calib; do
+  /opt/rocm/bin/hipcc $FLAGS "$@" -c "$root/pysdm_amd/csrc/$f.hip" -o "$tmp/$f.o" 2>/dev/null &
+  pids+=($!)
+done
+for pid in "${pids[@]}"; do wait "$pid"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined -o "$out" "$tmp"/*.o
+rm -rf "$tmp"
+echo "built $out"

@@ -2,6 +2,7 @@
 from the reference itself (tests/golden/gen_golden.py), on both routes of the host layer: the
 oracle's own C restatement of the driver loop ("fused") and the stage-by-stage chain.  Also pins
 it at full size through the reference's digests.  CPU only."""
+import numpy as np
 import pytest
 
 from . import digests, displacement_cases
@@ -93,3 +94,28 @@ def test_fused_plugin_over_a_duck_particulator(name, oracle_backend_class):
     from . import pysdm_ducks  # pylint: disable=import-outside-toplevel
 
     pysdm_ducks.fused_plugin_run(name, oracle_backend_class)
+
+
+def test_host_view_is_refreshed_after_steps_without_read_back(oracle_engine):
+    """steps without read-back leave live / working / ordered behind the device's control block;
+    a later host-side event (here: touch_state, as a displacement or an attribute edit does) makes
+    the next call upload the host's view - which must have been brought up to date first, or dead
+    slots would be re-admitted (collisions.py:177)"""
+    from pysdm_amd.cases import make_box  # pylint: disable=import-outside-toplevel
+
+    def box(read_back):
+        return make_box(oracle_engine, "shima", n_sd=2**11, adaptive=True, dt=200.0, thin=0.02,
+                        grid=(4, 4), read_back=read_back)
+
+    lazy, eager = box(False), box(True)
+    for runner in (lazy, eager):
+        runner.run(4)
+        runner.population.touch_state()
+        runner.run(2)
+        runner.population.compact()
+        runner.run(1)
+    lazy.sync()
+    assert eager.population.live < 2**11
+    a, b = lazy.snapshot(), eager.snapshot()
+    for key, value in b.items():
+        np.testing.assert_array_equal(a[key], value, err_msg=key)
