@@ -526,6 +526,10 @@ static int break_up_while(int64_t i, int64_t j, int64_t k, int64_t cid, int64_t 
                                       fragment_mass[i], max_multiplicity, &take_from_j,
                                       &new_mult_k, &g_int, &overflow);
       gamma_j_k = (double)g_int;
+      /* where not one breakup fits, the reference's loop never ends (gamma_deficit -= 0): the
+       * product leaves it (a hung wavefront can take the whole GPU down) and so does the checker;
+       * the remainder goes to the deficit below */
+      if (g_int == 0) break;
     }
     get_new_multiplicities_and_update_attributes(j, k, attributes, n_attr, n_sd, multiplicity,
                                                  take_from_j, new_mult_k, &nj, &nk);

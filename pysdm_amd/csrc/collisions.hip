@@ -460,6 +460,7 @@ __device__ bool break_up_while_pair(int64_t j, int64_t k, int64_t cid, double ga
                                       max_multiplicity, take_from_j, new_mult_k, g_int,
                                       overflow);
       gamma_j_k = (double)g_int;
+      if (g_int == 0) break;  // (safety deviation: fused.hip, resolve_collision)
     }
     add_i64(&breakup_rate[cid], (int64_t)(gamma_j_k * (double)multiplicity[k]));
     gamma_deficit -= gamma_j_k;

@@ -571,6 +571,11 @@ __device__ __forceinline__ int resolve_collision(const sdm_step_cfg &cfg, const 
                                             mass[j], mass[k], fm, cfg.max_multiplicity,
                                             take_from_j, new_mult_k, g_int, ovf);
             gamma_j_k = (double)g_int;
+            // safety deviation: when not one breakup fits (the multiplicity limit or the donor's
+            // count refuses the first already) the reference's loop never ends
+            // (collisions_methods.py:192-236: gamma_deficit -= 0) - a hung CPU thread there, a
+            // hung wavefront here; the rest goes to the deficit, as after any refused breakup
+            if (g_int == 0) break;
           }
           const int64_t add = (int64_t)(gamma_j_k * (double)A.multiplicity[k]);
           n_breakup += add;
@@ -1370,6 +1375,10 @@ template <int KERNEL, bool BREAKUP, int CPW>
 __global__ void __launch_bounds__(CELL2_THREADS, 4)
 k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef CELL_PROFILE
+  __shared__ long long cell_t[10];
+  if (blockIdx.x == 7 && threadIdx.x == 0) cell_t[0] = wall_clock64();
+#endif
   constexpr int T = CELL2_THREADS / CPW;  // threads per cell
   constexpr int CAP = CELL2_CAP / CPW;    // positions per cell
   static_assert(T % SDM_WAVE == 0 && CAP % 8 == 0 && CAP / T == CELL2_MAXPOS, "cell slices");
@@ -1436,6 +1445,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
       s_rng[2] = pcg_jump_fast(A.s_rand_b, A.rng_tab, A.rng_aff, (uint64_t)(lo >> 1));
   }
   __syncthreads();
+  CELL_MARK(0);
   // shuffle_local events of this cell (index_methods.py:35-41): consecutive positions per thread
   {
     const int chunk = (n + T - 1) / T;
@@ -1467,6 +1477,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     }
   }
   __syncthreads();
+  CELL_MARK(1);
   // backward walks (see index.hip), entirely in LDS; results stay in registers until every walk
   // is through with the hit words
   int32_t walked[CELL2_MAXPOS];
@@ -1500,6 +1511,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     if (li < n) out[li] = walked[w];
   }
   __syncthreads();
+  CELL_MARK(2);
   // pairs: positions p with (p - cell_start[cell_idx[cid]]) even and p + 1 in the same segment
   const int64_t cid = s_cid;
   const int lp0 = (int)((lo - s_base) & 1);
@@ -1553,6 +1565,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
       }
     }
   }
+  CELL_MARK(3);
   double scale = 1.0 / (double)cfg.substeps;
   if (cfg.adaptive) {  // workgroup minimum of the optimal sub-step (collisions_methods.py:357-368)
     const double m = wave_min_f64(my_min);
@@ -1567,6 +1580,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     if (bmin < todo) todo = bmin;
     scale = todo / cfg.dt;
   }
+  CELL_MARK(4);
   // gamma (collisions_methods.py:560): the pairs that collide are listed, over val / head
   {
     const uint64_t dd0 = (uint64_t)(((lo + lp0 + 2 * (int64_t)(tid * CELL2_MAXPAIR)) >> 1) -
@@ -1596,6 +1610,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     }
   }
   __syncthreads();
+  CELL_MARK(5);
   // update: one colliding pair per thread, state from the mirror (compute_gamma's clamp and
   // counters :566-585, coalescence :44-59)
   const int n_coll = s_ncoll;
@@ -1646,7 +1661,18 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     if (died & 2) out[lp + 1] = (int32_t)N;
   }
   __syncthreads();
+  CELL_MARK(6);
   for (int li = tid; li < n; li += T) X.idx_out[lo + li] = out[li];
+#ifdef CELL_PROFILE
+  __syncthreads();
+  if (blockIdx.x == 7 && threadIdx.x == 0) {
+    const long long t_end = wall_clock64();
+    printf("cell2 n=%d colliding=%d ticks(10ns): load+init %lld events %lld walks %lld gather+prob %lld "
+           "min %lld gamma %lld update %lld store %lld\n", n, s_ncoll_[0], cell_t[1] - cell_t[0],
+           cell_t[2] - cell_t[1], cell_t[3] - cell_t[2], cell_t[4] - cell_t[3],
+           cell_t[5] - cell_t[4], cell_t[6] - cell_t[5], cell_t[7] - cell_t[6], t_end - cell_t[7]);
+  }
+#endif
 }
 
 // largest cell of a sorted state -> ctl[6]

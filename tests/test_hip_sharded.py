@@ -30,14 +30,21 @@ def _worker(rank, world, port, errors):
         from pysdm_amd.engine import HipEngine  # pylint: disable=import-outside-toplevel
 
         engine = HipEngine.get(0)
+
+        def stage(text):  # (visible with pytest -s: which stage a stuck run was in)
+            print(f"[sharded worker {rank}] {text}", flush=True)
+
         for name in CASES:
+            stage(name)
             sharded_run_equals_golden(name, engine, rank, world)
+        stage("32 x 32 digest")
         # 32 x 32 cells against the reference's digest
         digests.check("kinematic2d_64percell", engine,
                       prepare=lambda runner: sharding.attach(runner, rank, world),
                       snapshot=sharding.gather)
-        # deaths (compaction + re-sort run replicated after the permutation exchange)
+        # deaths (compaction + re-sort run replicated after the exchange of the dead positions)
         for adaptive in (True, False):
+            stage(f"deaths, adaptive={adaptive}")
             single = cases.make_box(engine, "shima", n_sd=2**13, adaptive=adaptive, dt=200.0,
                                     thin=0.02, grid=(4, 4))
             shard = cases.make_box(engine, "shima", n_sd=2**13, adaptive=adaptive, dt=200.0,
@@ -63,7 +70,9 @@ def _worker(rank, world, port, errors):
         # the processes' cells every step) against the reference's golden
         from . import displacement_cases  # pylint: disable=import-outside-toplevel
 
+        stage("displacement + collisions")
         displacement_cases.run_case("disp2d_collide", engine, shard=(rank, world))
+        stage("done")
         dist.barrier()
         dist.destroy_process_group()
     except Exception as exc:  # pylint: disable=broad-except
