@@ -2416,7 +2416,9 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       // Sharded runs launch ahead as well: the exchange of a sub-step is one more piece of work
       // on the stream (an RCCL collective enqueued by the callback); a sub-step that falls through
       // exchanges what the one before it did (same dt_left, same deaths), which changes nothing
-      const bool ahead = !ctx->timing;
+      // (and they do so in timing mode too: the number of exchanges of a step must not depend on
+      // a switch that one process may have set and another not)
+      const bool ahead = !ctx->timing || sharded;
       if (ahead) {
         rc = launch_substep(true, &seq_next);
         if (rc) return rc;
