@@ -398,9 +398,12 @@ struct PairInfo {
 
 // collision probability of one (multiplicity-sorted) pair in slot d: kernel, max multiplicity,
 // normalisation (collision.py:249-254; cell of RAW super-droplet #d: reference quirk)
+// `norm`: the slot's normalisation factor when the caller has it already (the per-cell kernel
+// asks for it ahead of its LDS phases: three dependent look-ups off the critical path), else NULL
 template <int KERNEL>
 __device__ __forceinline__ double pair_prob_value(const sdm_step_cfg &cfg, const FusedArgs &A,
-                                                  int64_t d, const SD &sj, const SD &sk) {
+                                                  int64_t d, const SD &sj, const SD &sk,
+                                                  const double *norm = nullptr) {
   const double vj = volume_of_mass(sj.m, cfg.rho_w), vk = volume_of_mass(sk.m, cfg.rho_w);
   double K;
   if (KERNEL == SDM_KERNEL_GOLOVIN) {
@@ -433,7 +436,9 @@ __device__ __forceinline__ double pair_prob_value(const sdm_step_cfg &cfg, const
   }
   double prob = (double)sj.n;
   prob *= K;
-  prob *= norm_factor_of(cfg, A.cell_start, cfg.n_cell == 1 ? 0 : A.cell_idx[A.cell_id_raw[d]]);
+  prob *= norm ? *norm
+               : norm_factor_of(cfg, A.cell_start,
+                                cfg.n_cell == 1 ? 0 : A.cell_idx[A.cell_id_raw[d]]);
   return prob;
 }
 
@@ -1446,6 +1451,25 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   }
   __syncthreads();
   CELL_MARK(0);
+  // The normalisation factors of this thread's pair slots (collisions_methods.py:633-662: that of
+  // the cell of RAW super-droplet d for slot d - three dependent look-ups and three divisions per
+  // slot) depend on nothing the shuffle produces: requested here, they arrive while the LDS phases
+  // run instead of sitting on the critical path of the probability phase (20 of a cell's 52 us).
+  // (not with the parameterized kernels: their efficiency polynomial leaves no registers to
+  // carry six more doubles through the shuffle)
+  constexpr bool NORM_AHEAD = KERNEL != SDM_KERNEL_PARAMETERIZED;
+  const int lp0 = (int)((lo - s_base) & 1);
+  double pnorm[NORM_AHEAD ? CELL2_MAXPAIR : 1];
+  if (NORM_AHEAD) {
+#pragma unroll
+    for (int r = 0; r < CELL2_MAXPAIR; ++r) {
+      const int lp = lp0 + 2 * (tid * CELL2_MAXPAIR + r);
+      const bool valid = lp + 1 < n && lo + lp < W - 1;
+      pnorm[r] = valid ? norm_factor_of(cfg, A.cell_start,
+                                        A.cell_idx[A.cell_id_raw[(lo + lp) >> 1]])
+                       : 0.0;
+    }
+  }
   // shuffle_local events of this cell (index_methods.py:35-41): consecutive positions per thread
   {
     const int chunk = (n + T - 1) / T;
@@ -1479,8 +1503,12 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   __syncthreads();
   CELL_MARK(1);
   // backward walks (see index.hip), entirely in LDS; results stay in registers until every walk
-  // is through with the hit words
+  // is through with the hit words.  A walk is a chain of dependent LDS reads (~2.7 look-ups of
+  // three words each); a thread's walks advance in lockstep, one look-up each per round, so that
+  // the reads of all of them are in flight together instead of one chain after the other
+  // (SDM_CELL_WALKS_ONE_BY_ONE: the earlier form, for A/B measurements)
   int32_t walked[CELL2_MAXPOS];
+#ifdef SDM_CELL_WALKS_ONE_BY_ONE
 #pragma unroll
   for (int w = 0; w < CELL2_MAXPOS; ++w) {
     const int li = tid + w * T;
@@ -1504,6 +1532,54 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
       walked[w] = val[q];
     }
   }
+#else
+  {
+    int wq[CELL2_MAXPOS], we[CELL2_MAXPOS];
+    unsigned going = 0;  // bit w: walk w has not reached the start of its chain yet
+#pragma unroll
+    for (int w = 0; w < CELL2_MAXPOS; ++w) {
+      const int li = tid + w * T;
+      wq[w] = li < n ? li : 0;
+      we[w] = 0;
+      if (li < n) going |= 1u << w;
+    }
+    while (going) {
+      int jq[CELL2_MAXPOS], hd[CELL2_MAXPOS];
+      uint32_t hw[CELL2_MAXPOS];
+#pragma unroll
+      for (int w = 0; w < CELL2_MAXPOS; ++w) {
+        jq[w] = hd[w] = 0;
+        hw[w] = 0;
+        if (going & (1u << w)) {
+          jq[w] = jown[wq[w]];
+          hw[w] = hits[wq[w]];
+          hd[w] = head[wq[w]];
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < CELL2_MAXPOS; ++w) {
+        if (going & (1u << w)) {
+          const int q = wq[w], e = we[w];
+          int best = INT32_MAX;
+          if (q > e && jq[w] >= 0) best = q;
+          const int a = (int)(hw[w] & 0xFFFFu), b = (int)(hw[w] >> 16);
+          if (a != 0xFFFF && a > e && a < best) best = a;
+          if (b != 0xFFFF && b > e && b < best) best = b;
+          for (int t = hd[w]; t != 0xFFFF; t = next[t])
+            if (t > e && t < best) best = t;
+          if (best == INT32_MAX) {
+            going &= ~(1u << w);
+          } else {
+            wq[w] = (best == q) ? jq[w] : best;
+            we[w] = best;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < CELL2_MAXPOS; ++w) walked[w] = tid + w * T < n ? val[wq[w]] : 0;
+  }
+#endif
   __syncthreads();
 #pragma unroll
   for (int w = 0; w < CELL2_MAXPOS; ++w) {
@@ -1514,7 +1590,6 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   CELL_MARK(2);
   // pairs: positions p with (p - cell_start[cell_idx[cid]]) even and p + 1 in the same segment
   const int64_t cid = s_cid;
-  const int lp0 = (int)((lo - s_base) & 1);
   double pprob[CELL2_MAXPAIR];
   double my_min = INFINITY;
   const bool need_r = KERNEL == SDM_KERNEL_GEOMETRIC || KERNEL == SDM_KERNEL_PARAMETERIZED ||
@@ -1554,7 +1629,8 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
           out[lp] = (int32_t)pk[r];
           out[lp + 1] = (int32_t)pj[r];
         }
-        const double prob = pair_prob_value<KERNEL>(cfg, A, p >> 1, psj[r], psk[r]);
+        const double prob = pair_prob_value<KERNEL>(cfg, A, p >> 1, psj[r], psk[r],
+                                                    NORM_AHEAD ? &pnorm[b0 + r] : nullptr);
         pprob[b0 + r] = prob;
         if (cfg.adaptive && prob != 0) {
           const int64_t prop = psj[r].n / psk[r].n;
