@@ -246,7 +246,7 @@ def main():
     runner.run(args.warmup)
     runner.sync()
     evolving = bool(setup.adaptive) or pop.n_cell > 1
-    checkpoint = Checkpoint(runner) if evolving and args.reps > 1 and runner.shard is None else None
+    checkpoint = Checkpoint(runner) if evolving and args.reps > 1 else None
     reps, rep_substeps, comm = [], [], None
     for rep in range(max(1, args.reps)):
         if checkpoint is not None and rep > 0:

@@ -1474,6 +1474,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   {
     const int chunk = (n + T - 1) / T;
     const int li0 = tid * chunk;
+#ifdef SDM_CELL_EVENTS_ONE_BY_ONE  // (the earlier form, for A/B measurements)
     if (li0 < n) {
       u128 state = pcg_jump_fast(s_rng[0], A.rng_tab, A.rng_aff, (uint64_t)li0);
       const u128 mult = pcg_mult();
@@ -1499,6 +1500,66 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
         jown[li] = (int16_t)jt;
       }
     }
+#else
+    // the draws of a thread's positions are one sequential chain (the generator); claiming the
+    // hit slots is not: all targets first, then the slot words of all of them requested together,
+    // one compare-and-swap each issued back to back, and only what lost its race (or found both
+    // inline slots taken) goes through the retry loop
+    int jts[CELL2_MAXPOS];
+    if (li0 < n) {
+      u128 state = pcg_jump_fast(s_rng[0], A.rng_tab, A.rng_aff, (uint64_t)li0);
+      const u128 mult = pcg_mult();
+#pragma unroll
+      for (int e = 0; e < CELL2_MAXPOS; ++e) {
+        const int li = li0 + e;
+        jts[e] = -2;  // no such position
+        if (e < chunk && li < n) {
+          state = state * mult + A.rng_inc;
+          const double u = pcg_output(state);
+          int jt = -1;
+          if (li > 0) {
+            const int64_t t = (int64_t)((double)lo + u * (double)(hi - lo)) - lo;
+            jt = (int)(t > n - 1 ? n - 1 : (t < 0 ? 0 : t));
+          }
+          jts[e] = jt;
+          jown[li] = (int16_t)jt;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < CELL2_MAXPOS; ++e) jts[e] = -2;
+    }
+    uint32_t seen[CELL2_MAXPOS], want[CELL2_MAXPOS], got[CELL2_MAXPOS];
+#pragma unroll
+    for (int e = 0; e < CELL2_MAXPOS; ++e)
+      seen[e] = jts[e] >= 0 ? *(volatile uint32_t *)&hits[jts[e]] : 0u;
+#pragma unroll
+    for (int e = 0; e < CELL2_MAXPOS; ++e) {
+      const uint32_t li = (uint32_t)(li0 + e);
+      want[e] = seen[e];
+      if ((seen[e] & 0xFFFFu) == 0xFFFFu) want[e] = (seen[e] & 0xFFFF0000u) | li;
+      else if ((seen[e] >> 16) == 0xFFFFu) want[e] = (seen[e] & 0xFFFFu) | (li << 16);
+      got[e] = seen[e];
+      // (want == seen: both inline slots were taken when looked at - straight to the retry loop)
+      if (jts[e] >= 0 && want[e] != seen[e]) got[e] = atomicCAS(&hits[jts[e]], seen[e], want[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < CELL2_MAXPOS; ++e) {
+      if (jts[e] >= 0 && (want[e] == seen[e] || got[e] != seen[e])) {
+        const int li = li0 + e, jt = jts[e];
+        uint32_t old = got[e];
+        for (;;) {
+          uint32_t nw;
+          if ((old & 0xFFFFu) == 0xFFFFu) nw = (old & 0xFFFF0000u) | (uint32_t)li;
+          else if ((old >> 16) == 0xFFFFu) nw = (old & 0xFFFFu) | ((uint32_t)li << 16);
+          else { next[li] = (uint16_t)lds_exch16((uint32_t *)head, jt, li); break; }
+          const uint32_t prev = atomicCAS(&hits[jt], old, nw);
+          if (prev == old) break;
+          old = prev;
+        }
+      }
+    }
+#endif
   }
   __syncthreads();
   CELL_MARK(1);
