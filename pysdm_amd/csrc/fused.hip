@@ -1474,7 +1474,6 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   {
     const int chunk = (n + T - 1) / T;
     const int li0 = tid * chunk;
-#ifdef SDM_CELL_EVENTS_ONE_BY_ONE  // (the earlier form, for A/B measurements)
     if (li0 < n) {
       u128 state = pcg_jump_fast(s_rng[0], A.rng_tab, A.rng_aff, (uint64_t)li0);
       const u128 mult = pcg_mult();
@@ -1500,76 +1499,16 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
         jown[li] = (int16_t)jt;
       }
     }
-#else
-    // the draws of a thread's positions are one sequential chain (the generator); claiming the
-    // hit slots is not: all targets first, then the slot words of all of them requested together,
-    // one compare-and-swap each issued back to back, and only what lost its race (or found both
-    // inline slots taken) goes through the retry loop
-    int jts[CELL2_MAXPOS];
-    if (li0 < n) {
-      u128 state = pcg_jump_fast(s_rng[0], A.rng_tab, A.rng_aff, (uint64_t)li0);
-      const u128 mult = pcg_mult();
-#pragma unroll
-      for (int e = 0; e < CELL2_MAXPOS; ++e) {
-        const int li = li0 + e;
-        jts[e] = -2;  // no such position
-        if (e < chunk && li < n) {
-          state = state * mult + A.rng_inc;
-          const double u = pcg_output(state);
-          int jt = -1;
-          if (li > 0) {
-            const int64_t t = (int64_t)((double)lo + u * (double)(hi - lo)) - lo;
-            jt = (int)(t > n - 1 ? n - 1 : (t < 0 ? 0 : t));
-          }
-          jts[e] = jt;
-          jown[li] = (int16_t)jt;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < CELL2_MAXPOS; ++e) jts[e] = -2;
-    }
-    uint32_t seen[CELL2_MAXPOS], want[CELL2_MAXPOS], got[CELL2_MAXPOS];
-#pragma unroll
-    for (int e = 0; e < CELL2_MAXPOS; ++e)
-      seen[e] = jts[e] >= 0 ? *(volatile uint32_t *)&hits[jts[e]] : 0u;
-#pragma unroll
-    for (int e = 0; e < CELL2_MAXPOS; ++e) {
-      const uint32_t li = (uint32_t)(li0 + e);
-      want[e] = seen[e];
-      if ((seen[e] & 0xFFFFu) == 0xFFFFu) want[e] = (seen[e] & 0xFFFF0000u) | li;
-      else if ((seen[e] >> 16) == 0xFFFFu) want[e] = (seen[e] & 0xFFFFu) | (li << 16);
-      got[e] = seen[e];
-      // (want == seen: both inline slots were taken when looked at - straight to the retry loop)
-      if (jts[e] >= 0 && want[e] != seen[e]) got[e] = atomicCAS(&hits[jts[e]], seen[e], want[e]);
-    }
-#pragma unroll
-    for (int e = 0; e < CELL2_MAXPOS; ++e) {
-      if (jts[e] >= 0 && (want[e] == seen[e] || got[e] != seen[e])) {
-        const int li = li0 + e, jt = jts[e];
-        uint32_t old = got[e];
-        for (;;) {
-          uint32_t nw;
-          if ((old & 0xFFFFu) == 0xFFFFu) nw = (old & 0xFFFF0000u) | (uint32_t)li;
-          else if ((old >> 16) == 0xFFFFu) nw = (old & 0xFFFFu) | ((uint32_t)li << 16);
-          else { next[li] = (uint16_t)lds_exch16((uint32_t *)head, jt, li); break; }
-          const uint32_t prev = atomicCAS(&hits[jt], old, nw);
-          if (prev == old) break;
-          old = prev;
-        }
-      }
-    }
-#endif
   }
   __syncthreads();
   CELL_MARK(1);
   // backward walks (see index.hip), entirely in LDS; results stay in registers until every walk
-  // is through with the hit words.  A walk is a chain of dependent LDS reads (~2.7 look-ups of
-  // three words each); a thread's walks advance in lockstep, one look-up each per round, so that
-  // the reads of all of them are in flight together instead of one chain after the other
-  // (SDM_CELL_WALKS_ONE_BY_ONE: the earlier form, for A/B measurements)
+  // is through with the hit words.  (Advancing a thread's walks in lockstep - all their reads in
+  // flight together - and issuing the hit-slot claims of the events phase together were built and
+  // measured in round 3: both slower, 14 against 10.8 us and 13 against 7.2 us per cell; sixteen
+  // wavefronts per CU hide the LDS latency already, the extra instructions only add to the issue
+  // load.  profiles/r03_cell_lockstep_walks_experiment.patch)
   int32_t walked[CELL2_MAXPOS];
-#ifdef SDM_CELL_WALKS_ONE_BY_ONE
 #pragma unroll
   for (int w = 0; w < CELL2_MAXPOS; ++w) {
     const int li = tid + w * T;
@@ -1593,54 +1532,6 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
       walked[w] = val[q];
     }
   }
-#else
-  {
-    int wq[CELL2_MAXPOS], we[CELL2_MAXPOS];
-    unsigned going = 0;  // bit w: walk w has not reached the start of its chain yet
-#pragma unroll
-    for (int w = 0; w < CELL2_MAXPOS; ++w) {
-      const int li = tid + w * T;
-      wq[w] = li < n ? li : 0;
-      we[w] = 0;
-      if (li < n) going |= 1u << w;
-    }
-    while (going) {
-      int jq[CELL2_MAXPOS], hd[CELL2_MAXPOS];
-      uint32_t hw[CELL2_MAXPOS];
-#pragma unroll
-      for (int w = 0; w < CELL2_MAXPOS; ++w) {
-        jq[w] = hd[w] = 0;
-        hw[w] = 0;
-        if (going & (1u << w)) {
-          jq[w] = jown[wq[w]];
-          hw[w] = hits[wq[w]];
-          hd[w] = head[wq[w]];
-        }
-      }
-#pragma unroll
-      for (int w = 0; w < CELL2_MAXPOS; ++w) {
-        if (going & (1u << w)) {
-          const int q = wq[w], e = we[w];
-          int best = INT32_MAX;
-          if (q > e && jq[w] >= 0) best = q;
-          const int a = (int)(hw[w] & 0xFFFFu), b = (int)(hw[w] >> 16);
-          if (a != 0xFFFF && a > e && a < best) best = a;
-          if (b != 0xFFFF && b > e && b < best) best = b;
-          for (int t = hd[w]; t != 0xFFFF; t = next[t])
-            if (t > e && t < best) best = t;
-          if (best == INT32_MAX) {
-            going &= ~(1u << w);
-          } else {
-            wq[w] = (best == q) ? jq[w] : best;
-            we[w] = best;
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int w = 0; w < CELL2_MAXPOS; ++w) walked[w] = tid + w * T < n ? val[wq[w]] : 0;
-  }
-#endif
   __syncthreads();
 #pragma unroll
   for (int w = 0; w < CELL2_MAXPOS; ++w) {
