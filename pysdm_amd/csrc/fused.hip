@@ -3189,6 +3189,7 @@ extern "C" int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step
     }
     if (relabel.on && relabel.arena != ctx->arena) {  // (cannot happen: reserved up front)
       sdm_set_error("the scratch arena moved under the cell-ordered working copy");
+      ctx->cell_id_raw = nullptr;
       return SDM_E_HIP;
     }
     if (last && relabel.on) {
