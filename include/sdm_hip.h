@@ -69,6 +69,11 @@ const char *sdm_phase_name(int phase);
  * PySDM/impl/wall_timer.py.)                                                                  */
 int sdm_calib_random_sectors(sdm_ctx *ctx, int64_t table_records, int64_t n_reads,
                              int repetitions, double *ms_per_launch, uint64_t *checksum);
+/* the counterpart for stores: n_writes scattered 8-byte stores (same hash) into a table of
+ * table_words x 8 B - what delivering results to random positions would cost (used to price
+ * re-routings of the shuffle's walks).  Synchronises.                             */
+int sdm_calib_random_writes(sdm_ctx *ctx, int64_t table_words, int64_t n_writes, int repetitions,
+                            double *ms_per_launch);
 
 /* ---- a-1 RNG: NumPy PCG64 stream, PySDM/backends/impl_numba/random.py:13-19 ------------
  * out[i] = double number (offset + i) of the stream of PCG64 with the given state/inc

@@ -406,6 +406,14 @@ API int sdm_calib_random_sectors(sdm_ctx *c, int64_t table_records, int64_t n_re
   *checksum = total;
   return SDM_OK;
 }
+API int sdm_calib_random_writes(sdm_ctx *c, int64_t table_words, int64_t n_writes, int repetitions,
+                                double *ms_per_launch) {
+  (void)c;
+  if (table_words < 1 || n_writes < 1 || repetitions < 1 || !ms_per_launch)
+    FAIL(SDM_E_ARG, "sdm_calib_random_writes: bad argument");
+  *ms_per_launch = 0.0;  /* a measurement of the product's device; nothing to restate */
+  return SDM_OK;
+}
 API int sdm_math_eval(sdm_ctx *c, int fn, double *out, const double *a, const double *b,
                       int64_t n) {
   (void)c;

@@ -46,6 +46,48 @@ k_calib_random(const ulonglong2 *__restrict__ table, int64_t table_records, int6
     atomicAdd(&sums[(blockIdx.x & 63) * 16], acc);  // 64 slots, one cache line each
 }
 
+// the other side of the ledger when pricing a re-routing of the walks: what
+// n scattered 8-byte stores cost - results delivered to random positions instead of read from them
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_calib_random_write(unsigned long long *__restrict__ table, int64_t table_words, int64_t n_writes,
+                     uint64_t salt) {
+  const int64_t t = TID_FLAT();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t k = t * 4 + u;
+    if (k < n_writes)
+      table[calib_mix((uint64_t)k ^ salt) % (uint64_t)table_words] = (unsigned long long)k;
+  }
+}
+
+extern "C" int sdm_calib_random_writes(sdm_ctx *ctx, int64_t table_words, int64_t n_writes,
+                                       int repetitions, double *ms_per_launch) {
+  ARG_TRY(ctx && table_words >= 1 && n_writes >= 1 && repetitions >= 1 && ms_per_launch);
+  int rc = sdm_reserve(ctx, carve_size(sizeof(unsigned long long) * (size_t)table_words) + 512);
+  if (rc) return rc;
+  unsigned long long *table = (unsigned long long *)ctx->arena;
+  hipStream_t s = ctx->stream;
+  const dim3 grid(grid_for((n_writes + 3) / 4));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k_calib_random_write, grid, dim3(SDM_BLOCK), 0, s, table, table_words,
+                     n_writes, (uint64_t)0x5eed);
+  HIP_TRY(hipEventRecord(e0, s));
+  for (int r = 0; r < repetitions; ++r)
+    hipLaunchKernelGGL(k_calib_random_write, grid, dim3(SDM_BLOCK), 0, s, table, table_words,
+                       n_writes, (uint64_t)(r + 1) * 0x100000001b3ull);
+  HIP_TRY(hipEventRecord(e1, s));
+  LAUNCH_CHECK();
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  HIP_TRY(hipEventDestroy(e0));
+  HIP_TRY(hipEventDestroy(e1));
+  *ms_per_launch = (double)ms / repetitions;
+  return SDM_OK;
+}
+
 extern "C" int sdm_calib_random_sectors(sdm_ctx *ctx, int64_t table_records, int64_t n_reads,
                                         int repetitions, double *ms_per_launch,
                                         uint64_t *checksum) {
