@@ -53,3 +53,29 @@ def test_bench_starts_its_own_ranks_and_relays_their_failure():
     assert done.returncode != 0
     assert not [l for l in done.stdout.splitlines() if l.startswith("{")]
     assert "torch.distributed" in done.stderr or "ChildFailedError" in done.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_with_two_self_started_ranks_reproduces_the_one_rank_state(hip_engine):  # pylint: disable=unused-argument
+    """`python bench.py --gpus 2` with no launcher in the environment, on the one-GPU box (both
+    ranks on card 0, gloo between them - the rehearsal knobs): one JSON line, n_gpus = 2 as the
+    process group saw it, the sharded state's digest equal to the one-rank run's, and the
+    collectives of a step far below one n_sd-wide exchange"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(SDM_BENCH_DIST_BACKEND="gloo", SDM_BENCH_ALL_ON_DEVICE0="1")
+    common = ["--workload", "kinematic2d", "--n-sd", str(2**17), "--steps", "6", "--warmup", "2",
+              "--reps", "2", "--no-cpu-baseline", "--roofline-steps", "2"]
+    lines = {}
+    for gpus in (1, 2):
+        done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus",
+                               str(gpus), *common], env=env, capture_output=True, text=True,
+                              timeout=280, check=False)
+        assert done.returncode == 0, done.stderr[-2000:]
+        found = [json.loads(l) for l in done.stdout.splitlines() if l.startswith("{")]
+        assert len(found) == 1
+        lines[gpus] = found[0]
+    assert lines[1]["n_gpus"] == 1 and lines[2]["n_gpus"] == 2
+    assert lines[2]["state_digest"] == lines[1]["state_digest"]
+    assert lines[2]["scaling"] == "strong" and lines[2]["comm"]["f64_calls"] > 0
+    assert lines[2]["comm"]["bytes_per_step"] < 8 * 2**17  # (no n_sd-wide exchange)
