@@ -252,3 +252,26 @@ def test_host_slower_than_the_device_by_a_sub_step(oracle_engine):
     runner, _, _ = setup_from_golden("traj_multicell_geometric_4x4", oracle_engine)
     runner.run(40)
     assert_same(delayed, runner.snapshot())
+
+
+@pytest.mark.parametrize("n_sd,thin,steps", [(2**22, None, 5), (2**20, 0.02, 6)])
+def test_full_size_multi_cell_run_on_the_working_copy(n_sd, thin, steps, hip_engine,
+                                                      oracle_engine):
+    """32 x 32 cells at full size, several steps in ONE call: from the second step on the library
+    works on its cell-ordered copy of the state (fused.hip: Relabel) - state, counters and
+    sub-step statistics equal the checker's, also where super-droplets die (compaction and
+    counting sort inside the copy, labels translated back at the end)"""
+    snaps = []
+    for engine in (hip_engine, oracle_engine):
+        if thin is None:
+            runner = make_box(engine, "kinematic2d", n_sd=n_sd)
+        else:
+            runner = make_box(engine, "shima", n_sd=n_sd, adaptive=True, dt=200.0, thin=thin,
+                              grid=(32, 32))
+        run(runner, 1)
+        run(runner, steps)
+        snaps.append(runner.snapshot())
+    assert_same(snaps[0], snaps[1])
+    assert snaps[0]["collision_rate"].sum() > 0
+    if thin is not None:
+        assert int(snaps[0]["length"]) < n_sd
