@@ -1389,20 +1389,15 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   static_assert(T % SDM_WAVE == 0 && CAP % 8 == 0 && CAP / T == CELL2_MAXPOS, "cell slices");
   const int sub = threadIdx.x / T, tid = threadIdx.x % T;  // which cell of the workgroup, lane in it
   char *cmem = smem + (size_t)sub * CAP * 14;
-  // 14 B of LDS per position.  What a walk looks up at a position sits in ONE 8-byte word
-  // (one ds_read_b64 per look-up; three separate arrays cost three reads and were what bounded
-  // the walk phase: issue, not latency):
-  //   x = the two inline hit slots - low: bits 0-14 (0x7FFF = free), bit 15 = "more hits in the
-  //       overflow list"; high: bits 16-31 (0xFFFF = free) - claimed by CAS on the word
-  //   y = own target (int16, -1: none) | overflow link `next` << 16 - written once, by the
-  //       position's own thread
-  uint2 *rec = (uint2 *)cmem;                        // [CAP]
-  int32_t *out = (int32_t *)cmem;                    // ... later the permuted ids (first half)
-  double *list_ub = (double *)(cmem + CAP * 4);      // ... and (breakup) the pairs' second draws
-  int32_t *val = (int32_t *)(cmem + CAP * 8);        // [CAP] ids before the shuffle
+  uint32_t *hits = (uint32_t *)cmem;                 // [CAP] two 16-bit hit slots, 0xFFFF = free
+  int32_t *out = (int32_t *)cmem;                    // ... later the permuted ids
+  int32_t *val = (int32_t *)(cmem + CAP * 4);        // [CAP] ids before the shuffle
   double *list_g = (double *)val;                    // ... later gamma of the colliding pairs
-  uint16_t *head = (uint16_t *)(cmem + CAP * 12);    // [CAP] overflow list heads
+  uint16_t *head = (uint16_t *)(cmem + CAP * 8);     // [CAP] overflow list heads
   int32_t *list_lp = (int32_t *)head;                // ... later their pair slots
+  int16_t *jown = (int16_t *)(cmem + CAP * 10);      // [CAP] own target
+  uint16_t *next = (uint16_t *)(cmem + CAP * 12);    // [CAP] overflow links
+  double *list_ub = (double *)jown;                  // ... later (breakup) their second draws
   __shared__ double red[CELL2_THREADS / SDM_WAVE];
   __shared__ int64_t s_cid_[CPW], s_base_[CPW];
   __shared__ u128 s_rng_[CPW][3];
@@ -1439,7 +1434,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   const int64_t W = A.ctl[CTL_WORK];
   for (int li = tid; li < n; li += T) {
     val[li] = (int32_t)X.idx_in[lo + li];
-    rec[li].x = 0xFFFF7FFFu;  // (y is written by the events phase for every position)
+    hits[li] = 0xFFFFFFFFu;
     head[li] = 0xFFFFu;
   }
   if (tid == 0) { s_ncoll = 0; s_cid = 0; s_base = 0; }
@@ -1487,26 +1482,21 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
         state = state * mult + A.rng_inc;
         const double u = pcg_output(state);
         int jt = -1;
-        uint32_t link = 0xFFFFu;  // this event's successor in its target's overflow list
         if (li > 0) {
           const int64_t t = (int64_t)((double)lo + u * (double)(hi - lo)) - lo;
           jt = (int)(t > n - 1 ? n - 1 : (t < 0 ? 0 : t));
-          uint32_t old = *(volatile uint32_t *)&rec[jt].x;
+          uint32_t old = *(volatile uint32_t *)&hits[jt];
           for (;;) {
             uint32_t nw;
-            if ((old & 0x7FFFu) == 0x7FFFu) nw = (old & 0xFFFF8000u) | (uint32_t)li;
+            if ((old & 0xFFFFu) == 0xFFFFu) nw = (old & 0xFFFF0000u) | (uint32_t)li;
             else if ((old >> 16) == 0xFFFFu) nw = (old & 0xFFFFu) | ((uint32_t)li << 16);
-            else {
-              if (!(old & 0x8000u)) atomicOr(&rec[jt].x, 0x8000u);
-              link = (uint32_t)lds_exch16((uint32_t *)head, jt, li);
-              break;
-            }
-            const uint32_t prev = atomicCAS(&rec[jt].x, old, nw);
+            else { next[li] = (uint16_t)lds_exch16((uint32_t *)head, jt, li); break; }
+            const uint32_t prev = atomicCAS(&hits[jt], old, nw);
             if (prev == old) break;
             old = prev;
           }
         }
-        rec[li].y = ((uint32_t)jt & 0xFFFFu) | (link << 16);
+        jown[li] = (int16_t)jt;
       }
     }
   }
@@ -1517,7 +1507,9 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   // flight together - and issuing the hit-slot claims of the events phase together were built and
   // measured in round 3: both slower, 14 against 10.8 us and 13 against 7.2 us per cell; sixteen
   // wavefronts per CU hide the LDS latency already, the extra instructions only add to the issue
-  // load.  profiles/r03_cell_lockstep_walks_experiment.patch)
+  // load.  profiles/r03_cell_lockstep_walks_experiment.patch.  Likewise one 8-byte record per
+  // look-up - hit slots and an overflow flag | own target and link - instead of three arrays:
+  // parity-green, 126.6 against 122.7 us; profiles/r03_cell_packed_lds_record_experiment.patch)
   int32_t walked[CELL2_MAXPOS];
 #pragma unroll
   for (int w = 0; w < CELL2_MAXPOS; ++w) {
@@ -1527,15 +1519,14 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
       int e = 0, q = li;
       for (;;) {
         int best = INT32_MAX;
-        const uint2 r = rec[q];
-        const int jq = (int)(int16_t)(r.y & 0xFFFFu);
+        const int jq = jown[q];
         if (q > e && jq >= 0) best = q;
-        const int a = (int)(r.x & 0x7FFFu), b = (int)(r.x >> 16);
-        if (a != 0x7FFF && a > e && a < best) best = a;
+        const uint32_t h = hits[q];
+        const int a = (int)(h & 0xFFFFu), b = (int)(h >> 16);
+        if (a != 0xFFFF && a > e && a < best) best = a;
         if (b != 0xFFFF && b > e && b < best) best = b;
-        if (r.x & 0x8000u)
-          for (int t = head[q]; t != 0xFFFF; t = (int)(rec[t].y >> 16))
-            if (t > e && t < best) best = t;
+        for (int t = head[q]; t != 0xFFFF; t = next[t])
+          if (t > e && t < best) best = t;
         if (best == INT32_MAX) break;
         q = (best == q) ? jq : best;
         e = best;
