@@ -651,9 +651,11 @@ __device__ __forceinline__ int coalesce_known(const sdm_step_cfg &cfg, const Fus
     }
   }
   const int died = (sj.n == 0 ? 1 : 0) | (sk.n == 0 ? 2 : 0);
-  // (an atomic store: the workgroup that ends the sub-step inside the same kernel reads it)
-  if (died) __hip_atomic_store(&A.ctl[CTL_HEALTHY], (int64_t)0, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+  // (a returning atomic: the workgroup that ends the sub-step inside the same kernel reads it)
+  if (died) {
+    const unsigned long long was = atomicExch((unsigned long long *)&A.ctl[CTL_HEALTHY], 0ull);
+    asm volatile("" ::"v"(was));
+  }
   return died;
 }
 
@@ -1690,7 +1692,15 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     const int w0 = sub * (T / SDM_WAVE);  // this cell's wavefronts
     double bmin = red[w0];
     for (int w = 1; w < T / SDM_WAVE; ++w) bmin = red[w0 + w] < bmin ? red[w0 + w] : bmin;
-    if (tid == 0 && n > 0) A.cell_min[cid] = bmin;  // k_cells_end does the per-cell bookkeeping
+    if (tid == 0 && n > 0) {  // k_cells_end / cells_tail do the per-cell bookkeeping
+      if (X.tail_end2) {
+        const unsigned long long was = atomicExch((unsigned long long *)&A.cell_min[cid],
+                                                  (unsigned long long)__double_as_longlong(bmin));
+        asm volatile("" ::"v"(was));  // (wait for it: see the ticket at the end of the kernel)
+      } else {
+        A.cell_min[cid] = bmin;
+      }
+    }
     const double l = A.dt_left[cid];
     double todo = cfg.dt_max < l ? cfg.dt_max : l;
     if (bmin < todo) todo = bmin;
@@ -1780,19 +1790,18 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   CELL_MARK(6);
   for (int li = tid; li < n; li += T) X.idx_out[lo + li] = out[li];
   if (X.tail_end2) {  // this kernel ends the sub-step: the workgroup that finishes last does it
+    // No fences here: on this part an agent-scope fence writes back and invalidates the XCD's
+    // whole L2 - a thousand of them per launch cost three times the kernel (measured).  What the
+    // last workgroup needs from the others are two words per cell, and those travel as atomics:
+    // the cell minimum and a death's health word are RETURNING atomic exchanges (complete at the
+    // memory side before the wave goes on to the barrier below), read back with atomic loads
     __shared__ bool tail_mine;
-    __threadfence();  // every wave: its cell's minimum (and a death's health word) have landed
     __syncthreads();
-    if (threadIdx.x == 0) {
-      __threadfence();
+    if (threadIdx.x == 0)
       tail_mine = atomicAdd((unsigned long long *)&X.tail_end2[2], 1ull) ==
                   (unsigned long long)(n_cell_groups - 1);
-    }
     __syncthreads();
-    if (tail_mine) {
-      __threadfence();
-      cells_tail(cfg, A, X, smem);
-    }
+    if (tail_mine) cells_tail(cfg, A, X, smem);
   }
 #ifdef CELL_PROFILE
   __syncthreads();
@@ -2700,6 +2709,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       // one workgroup per cell does the whole sub-step of its cell (see k_cell_step); adaptive
       // steps took the loop above
       CellArgs X;
+      memset(&X, 0, sizeof(X));
       X.idx_in = cur;
       X.idx_out = alt;
       X.s_u01 = sdm_pcg_advance_host(rng_state, rng_inc, u01_off);
