@@ -6,5 +6,5 @@ from pysdm_amd.engine import HipEngine
 
 engine = HipEngine.get()
 runner = make_box(engine, "kinematic2d")
-runner.run(4)  # (one call of several steps: the cell-ordered working copy from the second step on)
+runner.run(14)  # (one call of several steps: the cell-ordered working copy from the second step on)
 engine.synchronize()

@@ -651,11 +651,7 @@ __device__ __forceinline__ int coalesce_known(const sdm_step_cfg &cfg, const Fus
     }
   }
   const int died = (sj.n == 0 ? 1 : 0) | (sk.n == 0 ? 2 : 0);
-  // (a returning atomic: the workgroup that ends the sub-step inside the same kernel reads it)
-  if (died) {
-    const unsigned long long was = atomicExch((unsigned long long *)&A.ctl[CTL_HEALTHY], 0ull);
-    asm volatile("" ::"v"(was));
-  }
+  if (died) A.ctl[CTL_HEALTHY] = 0;
   return died;
 }
 
@@ -1065,12 +1061,6 @@ struct CellArgs {
   // content is only required to hold the cell's members) - needed when idx_out is not known to
   // hold them already
   int copy_others;
-  // k_cell_step2 ending the sub-step itself (see cells_tail): NULL = the kernels around it do
-  int64_t *tail_end2;       // [1] end of the working range, [2] finish ticket
-  int64_t *tail_gate_next;  // word the NEXT sub-step's launch is gated on
-  int64_t *tail_cell_idx;
-  int64_t *tail_box;
-  int64_t tail_seq;
 };
 
 #ifdef CELL_PROFILE
@@ -1367,84 +1357,6 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
 #define CELL2_PACK 8  // cells per workgroup on the small-cell variant (one wavefront each)
 static_assert(CELL2_MAXPAIR % CELL2_BATCH == 0, "pairs are taken in whole batches");
 
-// ---- k_cell_step2 ending the sub-step itself ------------------------------------------------------
-// A sub-step of the per-cell route was three launches: k_cells_begin, the cell kernel, and the
-// (gated) compaction whose workgroups also did the per-cell bookkeeping and published the control
-// block - 4.5 + 10 us of kernels and two kernel boundaries around ~105 us of cell kernel.  In the
-// common case - coalescence only, nobody died - neither of the two small kernels has anything to
-// do that needs more than one workgroup, and both need ALL cells of the sub-step to be through.
-// So the workgroup of the cell kernel that finishes last (a ticket) does their work for up to
-// CELL_TAIL_MAX cells: the per-cell adaptive bookkeeping (collisions_methods.py:357-374), the end
-// of the working range (adaptive_sdm_end, :313-328), and - if the time step goes on and nobody
-// died - what opens the next sub-step: cell_idx.sort_by_key(dt_left) (collision.py:183) by rank
-// counting out of LDS and the per-cell init.  It then writes the word the next sub-step's launch
-// is gated on and publishes the control block.  A death leaves the gate closed: the host runs the
-// compaction and the counting sort (which must see the cell order of THIS sub-step) and opens the
-// next sub-step with k_cells_begin as before.
-#define CELL_TAIL_MAX 2048
-__device__ __forceinline__ void cells_tail(const sdm_step_cfg &cfg, const FusedArgs &A,
-                                           const CellArgs &X, char *smem) {
-  __shared__ int s_top[CELL2_THREADS / SDM_WAVE];
-  __shared__ int s_go;
-  const int C = (int)cfg.n_cell, tid = threadIdx.x;
-  double *key = (double *)smem;  // dt_left of every cell after this sub-step
-  int top = 0;
-  for (int c = tid; c < C; c += CELL2_THREADS) {
-    double left = A.dt_left[c];
-    // (cell_min: written by the cells' own workgroups in this kernel - read past the L1)
-    const double m = __hip_atomic_load(&A.cell_min[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    double t = A.dt_todo[c];
-    if (m < t) t = m;
-    A.dt_todo[c] = t;
-    const double smin = A.stats_dt_min[c];
-    const double s_new = m < smin ? m : smin;  // Python min(s, m): NaN-sticky
-    A.stats_dt_min[c] = s_new;
-    note_dt_min(A.ctl, s_new, cfg.dt_min);
-    left -= t;
-    A.dt_left[c] = left;
-    if (t > 0) A.stats_n_substep[c] += 1;
-    key[c] = left;
-    if (left != 0 && c + 1 > top) top = c + 1;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const int other = __shfl_xor(top, o, 64);
-    top = other > top ? other : top;
-  }
-  if (lane_id() == 0) s_top[tid / SDM_WAVE] = top;
-  __syncthreads();
-  if (tid == 0) {
-    for (int w = 1; w < CELL2_THREADS / SDM_WAVE; ++w) top = s_top[w] > top ? s_top[w] : top;
-    const int64_t end = top == 0 ? 0 : A.cell_start[top];
-    X.tail_end2[1] = end;
-    X.tail_end2[2] = 0;
-    A.ctl[CTL_WORK] = end;
-    const int64_t healthy =
-        __hip_atomic_load(&A.ctl[CTL_HEALTHY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_go = end != 0 && healthy != 0;
-    X.tail_gate_next[0] = s_go;
-  }
-  __syncthreads();
-  if (s_go) {  // k_cells_begin of the next sub-step (never the first of a time step)
-    for (int c = tid; c < C; c += CELL2_THREADS) {
-      const double ki = key[c];
-      int rank = 0;
-      for (int j = 0; j < C; ++j) {
-        const double kj = key[j];
-        rank += (kj < ki) || (kj == ki && j < c);
-      }
-      X.tail_cell_idx[C - 1 - rank] = c;
-      A.dt_todo[c] = cfg.dt_max < ki ? cfg.dt_max : ki;  // Python min(l, dt_max)
-      A.cell_min[c] = INFINITY;
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    __threadfence();
-    publish_ctl(A.ctl, X.tail_box, X.tail_seq, A.ctl[CTL_WORK]);
-  }
-}
-
 __device__ __forceinline__ int lds_exch16(uint32_t *words, int i, int v) {
   uint32_t *w = words + (i >> 1);
   const int sh = (i & 1) * 16;
@@ -1692,15 +1604,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     const int w0 = sub * (T / SDM_WAVE);  // this cell's wavefronts
     double bmin = red[w0];
     for (int w = 1; w < T / SDM_WAVE; ++w) bmin = red[w0 + w] < bmin ? red[w0 + w] : bmin;
-    if (tid == 0 && n > 0) {  // k_cells_end / cells_tail do the per-cell bookkeeping
-      if (X.tail_end2) {
-        const unsigned long long was = atomicExch((unsigned long long *)&A.cell_min[cid],
-                                                  (unsigned long long)__double_as_longlong(bmin));
-        asm volatile("" ::"v"(was));  // (wait for it: see the ticket at the end of the kernel)
-      } else {
-        A.cell_min[cid] = bmin;
-      }
-    }
+    if (tid == 0 && n > 0) A.cell_min[cid] = bmin;  // k_cells_end does the per-cell bookkeeping
     const double l = A.dt_left[cid];
     double todo = cfg.dt_max < l ? cfg.dt_max : l;
     if (bmin < todo) todo = bmin;
@@ -1789,20 +1693,6 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   __syncthreads();
   CELL_MARK(6);
   for (int li = tid; li < n; li += T) X.idx_out[lo + li] = out[li];
-  if (X.tail_end2) {  // this kernel ends the sub-step: the workgroup that finishes last does it
-    // No fences here: on this part an agent-scope fence writes back and invalidates the XCD's
-    // whole L2 - a thousand of them per launch cost three times the kernel (measured).  What the
-    // last workgroup needs from the others are two words per cell, and those travel as atomics:
-    // the cell minimum and a death's health word are RETURNING atomic exchanges (complete at the
-    // memory side before the wave goes on to the barrier below), read back with atomic loads
-    __shared__ bool tail_mine;
-    __syncthreads();
-    if (threadIdx.x == 0)
-      tail_mine = atomicAdd((unsigned long long *)&X.tail_end2[2], 1ull) ==
-                  (unsigned long long)(n_cell_groups - 1);
-    __syncthreads();
-    if (tail_mine) cells_tail(cfg, A, X, smem);
-  }
 #ifdef CELL_PROFILE
   __syncthreads();
   if (blockIdx.x == 7 && threadIdx.x == 0) {
@@ -2468,14 +2358,6 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   if (cell_path && cfg->adaptive && work_host != 0) {
     int64_t launched = 0;  // sub-steps launched in this time step (the draw window shifts by it)
     bool shard_resorted = false;
-    // The cell kernel ends the sub-step itself (cells_tail): coalescence on k_cell_step2, one
-    // process, a grid of at most CELL_TAIL_MAX cells; not in timing mode, whose per-phase events
-    // describe the three-launch form (SDM_CELL_TAIL=0 switches it off: A/B measurements)
-    static const bool tail_enabled = !(getenv("SDM_CELL_TAIL") && getenv("SDM_CELL_TAIL")[0] == '0');
-    const bool tail_mode = tail_enabled && cell2 && !sharded && !cfg->enable_breakup &&
-                           !ctx->timing && C <= CELL_TAIL_MAX;
-    bool need_begin = true;  // tail mode: the next sub-step is opened by k_cells_begin (first of a
-                             // time step, after a compaction), else by the previous one's tail
     auto launch_substep = [&](bool gated, int64_t *seq_out) -> int {
       if (!cfg->optimized_random || launched == 0) {  // (c), as in the loop below
         draw_off = off;
@@ -2486,7 +2368,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       A.s_rand = sdm_pcg_advance_host(rng_state, rng_inc, draw_off + (uint64_t)(N + shift));
       A.s_rand_b = sdm_pcg_advance_host(rng_state, rng_inc, draw_off_b);
       const uint64_t u01_off = draw_off + (uint64_t)(cfg->optimized_random ? launched : 0);
-      if (!tail_mode || need_begin) {
+      {
         PhaseScope ph(ctx, SDM_PHASE_CELLS_PRE);
         hipLaunchKernelGGL(k_cells_begin, dim3((unsigned)C), blk, 0, s, *cfg, A, st->cell_idx,
                            S.end2, fill_pending ? 1 : 0, gated ? 1 : 0);
@@ -2494,24 +2376,11 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         fill_pending = false;
       }
       CellArgs X;
-      memset(&X, 0, sizeof(X));
       X.idx_in = cur;
       X.idx_out = alt;
       X.s_u01 = sdm_pcg_advance_host(rng_state, rng_inc, u01_off);
       X.n_tail_blocks = 64;
       X.gate = S.end2 + 3;
-      if (tail_mode) {
-        // two gate words, by the parity of the sub-step: the tail of sub-step n writes the word
-        // of n + 1 while blocks of n's own grid (the dead-tail copies) may still be about to
-        // read theirs
-        X.gate = (gated && !need_begin) ? S.end2 + 5 + (launched & 1) : nullptr;
-        X.tail_end2 = S.end2;
-        X.tail_gate_next = S.end2 + 5 + ((launched + 1) & 1);
-        X.tail_cell_idx = st->cell_idx;
-        X.tail_box = ctx->box_dev;
-        X.tail_seq = *seq_out = ++ctx->poll_seq;
-        need_begin = false;
-      }
       X.copy_others = sharded && launched == 0;  // (see CellArgs; once per time step suffices...
       if (sharded && shard_resorted) { X.copy_others = 1; shard_resorted = false; }  // ...or sort)
       A.idx = alt;
@@ -2537,10 +2406,6 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         const int r = shard_cells(cur, alt, gated ? S.end2 + 3 : nullptr);
         if (r) return r;
         HIP_TRY(hipMemsetAsync(S.end2, 0, sizeof(int64_t), s));
-      }
-      if (tail_mode) {  // the cell kernel has ended the sub-step and published under tail_seq
-        ++launched;
-        return SDM_OK;
       }
       *seq_out = ++ctx->poll_seq;
       if (!sharded) {  // (sharded: after the read-back, and only if a super-droplet died)
@@ -2609,15 +2474,13 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         take_back();
         break;
       }
-      if ((sharded || tail_mode) && last_ctl[CTL_HEALTHY] == 0) {
-        // a super-droplet died (sharded: somewhere - every process flags the dead positions in
-        // its own permutation): the compaction runs now; the sub-step launched ahead fell through
-        // (k_cells_begin's gate / the gate word of the cell kernel's tail)
+      if (sharded && last_ctl[CTL_HEALTHY] == 0) {
+        // a super-droplet died somewhere: every process flags the dead positions in its own
+        // permutation, then runs the compaction (the sub-step launched ahead fell through:
+        // k_cells_begin's gate)
         take_back();
-        if (sharded) {
-          rc = shard_dead(cur);
-          if (rc) return rc;
-        }
+        rc = shard_dead(cur);
+        if (rc) return rc;
         PhaseScope ph(ctx, SDM_PHASE_SANITIZE);
         rc = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl, S.cctl,
                                      nullptr, true);
@@ -2630,7 +2493,6 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         take_back();
         sorted_host = 0;
         shard_resorted = true;
-        need_begin = true;  // (tail mode: a closed gate means nothing opened the next sub-step)
         hipLaunchKernelGGL(k_reset_work, one, one, 0, s, st->ctl);  // sanitize left work = valid
         LAUNCH_CHECK();
         rc = cond_sort(ctx, cfg, st, cur, S, &sorted_host);
