@@ -633,18 +633,22 @@ __device__ __forceinline__ void cells_end_body(const CellsEnd &E) {
       nz = left != 0;
     }
     const unsigned long long mask = __ballot(nz);
-    if (mask && lane_id() == 0)
-      atomicMax((long long *)&E.end2[0], (long long)((c - lane_id()) + (63 - __clzll(mask)) + 1));
+    if (mask && lane_id() == 0) {
+      // (returning: complete at the memory side before this wave goes on to the ticket - what the
+      // last workgroup reads of the others travels in atomics alone, so no fence is needed: on
+      // this part an agent-scope fence writes back and invalidates the XCD's L2, 129 times per
+      // sub-step here)
+      const long long was = atomicMax((long long *)&E.end2[0],
+                                      (long long)((c - lane_id()) + (63 - __clzll(mask)) + 1));
+      asm volatile("" ::"v"(was));
+    }
   }
   __shared__ bool last_cells;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
+  if (threadIdx.x == 0)
     last_cells = atomicAdd((unsigned long long *)&E.end2[2], 1ull) == gridDim.x - 1;
-  }
   __syncthreads();
   if (last_cells && threadIdx.x == 0) {
-    __threadfence();
     const int64_t top = __hip_atomic_load(&E.end2[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int64_t end = top == 0 ? 0 : E.cell_start[top];
     E.end2[1] = end;
