@@ -714,6 +714,52 @@ def gen_traj():
         save(f"traj_multicell_{name}", **out)
 
 
+def gen_global_multicell():
+    """multi-cell domains with the GLOBAL croupier (shuffle_global over the whole permutation, then
+    the counting sort by cell before pairing, particle_attributes.py:98-105 - every sub-step):
+    no golden of the earlier rounds covered this combination; found untested by tests/fuzz_parity.py"""
+    rng = np.random.default_rng(2025)
+    for name, grid, n_sd, kern, adaptive, dt, optrand in (
+        ("golovin_4x4_global", (4, 4), 2**10, "golovin", True, 100.0, False),
+        ("geometric_4x4_global", (4, 4), 2**11, "geometric", True, 5.0, True),
+        ("geometric_8x8_global_small_cells", (8, 8), 256, "geometric", True, 5.0, True),
+        ("golovin_3x5_global_na", (3, 5), 1500, "golovin", False, 100.0, False),
+    ):
+        n_cell = int(np.prod(grid))
+        cell_id = rng.integers(0, n_cell, size=n_sd).astype(np.int64)
+        if kern == "golovin":
+            volume, mult = shima_init(n_sd, n_part=2**23 / n_cell * 4)
+            dv = 1e6
+            make = lambda a=adaptive, o=optrand: Coalescence(
+                collision_kernel=Golovin(b=1.5e3), adaptive=a, optimized_random=o,
+                croupier="global",
+            )
+            fk = None
+        else:
+            dv = 10.0 * n_sd / 2**13 / n_cell * 16
+            x0 = Formulae().trivia.volume(radius=15e-6)
+            spectrum = spectra.Exponential(norm_factor=239e6 * dv * n_cell, scale=x0)
+            volume, mult = ConstantMultiplicity(spectrum).sample(n_sd)
+            make = lambda a=adaptive, o=optrand: Coalescence(
+                collision_kernel=Geometric(collection_efficiency=1), adaptive=a,
+                optimized_random=o, croupier="global",
+            )
+            fk = {"terminal_velocity": "GunnKinzer1949"}
+        perm = rng.permutation(n_sd)
+        volume, mult = volume[perm], mult[perm]
+        out = run_traj(
+            n_sd=n_sd, seed=44, dt=dt, dv=dv, volume=volume, multiplicity=mult,
+            make_dynamic=make, record_steps=(1, 3, 10), formulae_kwargs=fk,
+            grid=grid, cell_id=cell_id,
+        )
+        out["init/volume"] = volume
+        out["init/multiplicity"] = mult
+        out["init/cell_id"] = cell_id
+        out["cfg"] = np.asarray([n_sd, 44, int(adaptive), dt, dv, n_cell, int(optrand)])
+        out["grid"] = np.asarray(grid)
+        save(f"traj_multicell_{name}", **out)
+
+
 def gen_breakup():
     # ---- config 3 family: Geometric + Berry1967 Ec + ConstEb(1) + Exponential fragmentation
     #      (deJong_Mackay_et_al_2023/settings_0D.py:21-52)
@@ -1204,6 +1250,8 @@ if __name__ == "__main__":
         sys.exit(0)
     what = sys.argv[1:] or ["micro", "frag", "traj", "breakup", "shards", "moments", "displacement",
                             "kernels", "breakup_more"]
+    if "global_multicell" in what:
+        gen_global_multicell()
     if "displacement" in what:
         gen_displacement()
     if "moments" in what:

@@ -75,6 +75,8 @@ def setup_from_golden(name, engine, route="fused"):
         grid = tuple(int(g) for g in gold["grid"])
         cell_id = gold["init/cell_id"]
         kernel = R.Golovin(b=1.5e3) if "golovin" in name else R.Geometric(collection_efficiency=1)
+        if "global" in name:
+            options["croupier"] = "global"
         setup = R.CollisionSetup.coalescence(kernel, optimized_random=bool(cfg[6]), **options)
     elif name.startswith("traj_breakup"):
         ec, frag, hab = breakup_parts(name[len("traj_breakup_"):])
