@@ -2542,9 +2542,15 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       rc = sdm_sort_by_key_async(ctx, st->cell_idx, st->dt_left, C);
       if (rc) return rc;
     }
-    // (b) cell_start getter: counting sort if unsorted (particle_attributes.py:51-55)
-    rc = cond_sort(ctx, cfg, st, cur, S, &sorted_host);
-    if (rc) return rc;
+    // (b) cell_start getter: counting sort if unsorted (particle_attributes.py:51-55) - asked
+    // for by the LOCAL shuffle only (`permutation`, :98-105: `idx.shuffle(u01, parts=cell_start)`);
+    // the global shuffle permutes the state as it stands, sorted or not, and the sort follows it
+    // (found by tests/fuzz_parity.py: an unsorted state from the host, several cells, global
+    // croupier - no golden had covered the combination)
+    if (cfg->croupier_local) {
+      rc = cond_sort(ctx, cfg, st, cur, S, &sorted_host);
+      if (rc) return rc;
+    }
     // (c) random numbers (random_generator_optimizer.py:37-48): a draw = pairs_rand (N + shift)
     // then rand (P) from the collision generator, P from each breakup generator
     if (!cfg->optimized_random || n_sub == 0) {
@@ -2799,7 +2805,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       LAUNCH_CHECK();
     }
     if (C > 1) {
-      const bool grouped = sorted_host == 1;  // by the cell_idx of the last counting sort
+      // by the cell_idx of the last counting sort.  (Local croupier only: under the global one
+      // every sub-step sorts just its working range again, so after a cut cell_start describes
+      // that range and not the whole state - the full counting sort it is, as in the reference)
+      const bool grouped = sorted_host == 1 && cfg->croupier_local;
       hipLaunchKernelGGL(k_step_close, dim3(grid_for(C)), blk, 0, s, st->ctl, st->cell_idx, C,
                          S.gate_len, S.seg_size);
       LAUNCH_CHECK();
