@@ -34,7 +34,10 @@ for case in range(n_cases):
         options["substeps"] = int(rng.choice([1, 2, 3]))
     if rng.random() < 0.3 and name != "kinematic2d":  # (that configuration sets it itself)
         options["optimized_random"] = True
-    if grid is None and rng.random() < 0.2:
+    # (the global croupier over several cells only without adaptive sub-stepping: with it the
+    # reference duplicates ids once a working length is cut - tests/test_hip_parity.py says why -
+    # and a serial and a parallel run then differ legitimately; "kinematic2d" brings its own grid)
+    if (grid is None and name != "kinematic2d" or not adaptive) and rng.random() < 0.25:
         options["croupier"] = "global"
     dt = float(rng.choice([1.0, 5.0, 50.0, 200.0])) if name in ("shima", "kinematic2d") else None
     chunks = [int(c) for c in rng.choice([1, 2, 3, 5, 8], size=int(rng.integers(1, 4)))]
