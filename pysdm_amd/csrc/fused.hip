@@ -1457,7 +1457,11 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   // run instead of sitting on the critical path of the probability phase (20 of a cell's 52 us).
   // (not with the parameterized kernels: their efficiency polynomial leaves no registers to
   // carry six more doubles through the shuffle)
+#ifdef SDM_NO_NORM_AHEAD  // (A/B build)
+  constexpr bool NORM_AHEAD = false;
+#else
   constexpr bool NORM_AHEAD = KERNEL != SDM_KERNEL_PARAMETERIZED;
+#endif
   const int lp0 = (int)((lo - s_base) & 1);
   double pnorm[NORM_AHEAD ? CELL2_MAXPAIR : 1];
   if (NORM_AHEAD) {

@@ -609,7 +609,11 @@ __device__ __forceinline__ void compact_epilogue(const CompactEpilogue &E,
 // bookkeeping (collisions_methods.py:357-374), end2[0] = 1 + largest c with dt_left[c] != 0
 // (adaptive_sdm_end, :313-328), and by the workgroup that finishes last the working length and
 // the publication of the control block (as the compaction left it)
-__device__ __forceinline__ void cells_end_body(const CellsEnd &E) {
+// `after_compaction`: the compaction proper ran in this kernel and committed control words from
+// another workgroup - then the finish ticket is fenced as it always was.  The fence-free form is
+// for the common sub-step in which nothing but this function has written anything the publishing
+// workgroup reads (a fuzz run caught the difference: intermittently stale lengths after deaths)
+__device__ __forceinline__ void cells_end_body(const CellsEnd &E, bool after_compaction) {
   const bool ran = E.end2[3] != 0;  // (fused.hip: k_cells_begin - gated sub-steps)
   const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
   for (int64_t base = 0; base < E.n_cell; base += n_threads) {  // (uniform trip count)
@@ -645,10 +649,13 @@ __device__ __forceinline__ void cells_end_body(const CellsEnd &E) {
   }
   __shared__ bool last_cells;
   __syncthreads();
-  if (threadIdx.x == 0)
+  if (threadIdx.x == 0) {
+    if (after_compaction) __threadfence();
     last_cells = atomicAdd((unsigned long long *)&E.end2[2], 1ull) == gridDim.x - 1;
+  }
   __syncthreads();
   if (last_cells && threadIdx.x == 0) {
+    if (after_compaction) __threadfence();
     const int64_t top = __hip_atomic_load(&E.end2[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int64_t end = top == 0 ? 0 : E.cell_start[top];
     E.end2[1] = end;
@@ -806,7 +813,7 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
   }
   if (fctl[FCTL_HEALTHY] != 0) {
     if (E.dt_left && blockIdx.x == 0) compact_epilogue(E, fctl);
-    if (E.cells.n_cell) cells_end_body(E.cells);
+    if (E.cells.n_cell) cells_end_body(E.cells, false);
     return;
   }
   int64_t new_len;
@@ -816,7 +823,7 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
                                            excl);
   if (E.cells.n_cell) {
     if (done)
-      cells_end_body(E.cells);  // (its last workgroup publishes what the commit above left)
+      cells_end_body(E.cells, true);  // (its last workgroup publishes what the commit above left)
     else if (blockIdx.x == 0 && threadIdx.x == 0)
       // a grid barrier timed out (fctl[7] = 2, set by every workgroup that gave up - this one
       // included): the host still gets its publication, carrying the error code

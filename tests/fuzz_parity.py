@@ -17,6 +17,10 @@ from pysdm_amd.engine import HipEngine  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+# optional: execute only cases [first, last) of the sequence (the others are drawn and skipped) -
+# to tell a failure that depends on what ran before in the process from one that does not
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+last = int(sys.argv[4]) if len(sys.argv) > 4 else n_cases
 hip, oracle = HipEngine.get(), OracleEngine.get()
 t_start = time.time()
 for case in range(n_cases):
@@ -44,6 +48,8 @@ for case in range(n_cases):
     seed = int(rng.integers(1, 1000))
     label = (f"case {case}: {name} n_sd={n_sd} grid={grid} adaptive={adaptive} thin={thin} "
              f"dt={dt} {options} chunks={chunks} seed={seed}")
+    if not first <= case < last:
+        continue
     snaps = []
     try:
         for engine in (hip, oracle):

@@ -3,26 +3,23 @@ import numpy as np
 sys.path.insert(0, ".")
 from oracle.engine import OracleEngine
 from pysdm_amd.engine import HipEngine
-from tests.trajectory import setup_from_golden
-name = sys.argv[1] if len(sys.argv) > 1 else "traj_multicell_geometric_4x4_global"
-route = sys.argv[2] if len(sys.argv) > 2 else "chain"
-runs = []
-for engine in (HipEngine.get(), OracleEngine.get()):
-    runner, gold, steps = setup_from_golden(name, engine, route=route)
-    runs.append(runner)
-for step in range(1, 11):
+from pysdm_amd.cases import make_box
+cases = {"a": dict(n_sd=65536, grid=(3, 8), dt=5.0, seed=205, opts={}),
+         "b": dict(n_sd=40000, grid=(8, 5), dt=200.0, seed=535, opts={"optimized_random": True})}
+c = cases[sys.argv[1]]
+runs = [make_box(e, "shima", n_sd=c["n_sd"], adaptive=True, dt=c["dt"], thin=0.02, grid=c["grid"], seed=c["seed"], **c["opts"])
+        for e in (HipEngine.get(), OracleEngine.get())]
+chunks = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1] * 6
+for step, chunk in enumerate(chunks, 1):
     snaps = []
     for r in runs:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            r.run(1)
-        pop = r.population
-        snaps.append((r.engine.download(pop.perm), r.engine.download(pop.perm_spare), pop.live, pop.working, r.sub_steps_done,
-                      r.engine.download(pop.multiplicity)))
-    a, b = snaps
-    d = np.nonzero(a[0] != b[0])[0]
-    d2 = np.nonzero(a[1] != b[1])[0]
-    print("step", step, "live", a[2], b[2], "substeps", a[4], b[4], "perm diffs", len(d), d[:12], "spare diffs", len(d2), d2[:12],
-          "mult equal", np.array_equal(a[5], b[5]), flush=True)
-    if len(d):
-        print("  hip", a[0][d[:12]], "oracle", b[0][d[:12]])
+            r.run(chunk)
+        s = r.snapshot()
+        snaps.append((s, r.sub_steps_done, r.offset))
+    (a, na, oa), (b, nb, ob) = snaps
+    L = int(b["length"])
+    print("step", step, "length", int(a["length"]), L, "substeps", na, nb, "offsets", oa == ob,
+          {k: bool(np.array_equal(a[k][:L] if k == "idx" else a[k], b[k][:L] if k == "idx" else b[k], equal_nan=True)) for k in b}, flush=True)
+    sizes = np.diff(b["cell_start"]); print("   max cell", sizes.max(), "cells", len(sizes))
