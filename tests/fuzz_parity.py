@@ -43,6 +43,14 @@ for case in range(n_cases):
     # and a serial and a parallel run then differ legitimately; "kinematic2d" brings its own grid)
     if (grid is None and name != "kinematic2d" or not adaptive) and rng.random() < 0.25:
         options["croupier"] = "global"
+    if name in ("berry_breakup", "straub", "straub_rain"):
+        if rng.random() < 0.3:
+            options["handle_all_breakups"] = True
+        if rng.random() < 0.2:
+            options["max_multiplicity"] = int(rng.choice([10**7, 10**9, 10**12]))
+    if adaptive and rng.random() < 0.3:
+        options["dt_range"] = tuple(float(v) for v in rng.choice([(0.1, 100.0), (0.5, 2.0), (1.0, 1.0),
+                                                                   (0.01, 0.5)]))
     dt = float(rng.choice([1.0, 5.0, 50.0, 200.0])) if name in ("shima", "kinematic2d") else None
     chunks = [int(c) for c in rng.choice([1, 2, 3, 5, 8], size=int(rng.integers(1, 4)))]
     seed = int(rng.integers(1, 1000))
