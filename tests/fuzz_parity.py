@@ -52,17 +52,19 @@ for case in range(n_cases):
         options["dt_range"] = tuple(float(v) for v in rng.choice([(0.1, 100.0), (0.5, 2.0), (1.0, 1.0),
                                                                    (0.01, 0.5)]))
     dt = float(rng.choice([1.0, 5.0, 50.0, 200.0])) if name in ("shima", "kinematic2d") else None
+    # (the stage-by-stage route - one ABI symbol per backend method - on the smaller set-ups)
+    route = "chain" if (n_sd <= 4096 and rng.random() < 0.35) else "fused"
     chunks = [int(c) for c in rng.choice([1, 2, 3, 5, 8], size=int(rng.integers(1, 4)))]
     seed = int(rng.integers(1, 1000))
     label = (f"case {case}: {name} n_sd={n_sd} grid={grid} adaptive={adaptive} thin={thin} "
-             f"dt={dt} {options} chunks={chunks} seed={seed}")
+             f"dt={dt} {options} chunks={chunks} seed={seed} route={route}")
     if not first <= case < last:
         continue
     snaps = []
     try:
         for engine in (hip, oracle):
             runner = make_box(engine, name, n_sd=n_sd, adaptive=adaptive, dt=dt, thin=thin,
-                              grid=grid, seed=seed, **options)
+                              grid=grid, seed=seed, route=route, **options)
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 for steps in chunks:
@@ -70,6 +72,8 @@ for case in range(n_cases):
             snaps.append((runner.snapshot(), runner.offset, runner.offset_breakup,
                           runner.sub_steps_done))
     except (ValueError, NotImplementedError) as refused:  # a combination the set-up refuses
+        if "Radii can be interpolated" not in str(refused) and "dt_range" not in str(refused):
+            raise
         print(label, "-> refused:", refused, flush=True)
         continue
     a, b = snaps
