@@ -66,6 +66,31 @@ def _worker(rank, world, port, errors):
                         value, mine = value[:length], mine[:length]
                     np.testing.assert_array_equal(mine, value, err_msg=f"{adaptive} {key}")
             assert shard.shard.calls[2] > 0
+        # the same with other grids / cell sizes / seeds, several steps per call (launch-ahead with
+        # the gate closing on a death, the working copy under sharding, exchanges of dead positions)
+        for k, (grid, n_sd, chunks) in enumerate((((8, 5), 40000, (5,)), ((3, 8), 2**16, (2, 2, 1)),
+                                                  ((5, 4), 20000, (5, 8, 2)), ((4, 4), 2**13, (3, 4)),
+                                                  ((8, 5), 40000, (4, 4)), ((5, 4), 20000, (7,)))):
+            stage(f"deaths, grid {grid}, {n_sd} super-droplets, steps {chunks}")
+            options = dict(n_sd=n_sd, adaptive=True, dt=200.0, thin=0.02, grid=grid,
+                           seed=3000 + k, optimized_random=bool(k % 2))
+            single, shard = cases.make_box(engine, "shima", **options), cases.make_box(
+                engine, "shima", **options)
+            sharding.attach(shard, rank, world)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for steps in chunks:
+                    single.run(steps)
+                    shard.run(steps)
+            got, ref = sharding.gather(shard), single.snapshot()
+            length = int(ref["length"])
+            assert int(got["length"]) == length < n_sd
+            for key, value in ref.items():
+                mine = got[key]
+                if key == "idx":
+                    value, mine = value[:length], mine[:length]
+                np.testing.assert_array_equal(mine, value, err_msg=f"{grid} {key}")
+            assert shard.sub_steps_done == single.sub_steps_done and shard.offset == single.offset
         # replicated displacement on the completed state + sharded collisions (migration between
         # the processes' cells every step) against the reference's golden
         from . import displacement_cases  # pylint: disable=import-outside-toplevel
