@@ -73,11 +73,25 @@ class Checkpoint:
               "collision_rate_deficit", "coalescence_rate", "breakup_rate", "breakup_rate_deficit")
     SCALARS = ("offset", "offset_breakup", "sub_steps_done", "pairs_done", "steps_done")
 
+    # (cell_start belongs to the permutation: a sorted state restored without it is a state whose
+    # segments hold other cells' droplets as soon as one droplet has died since the snapshot)
+    COLUMNS = ("perm", "multiplicity", "extensive", "cell_order", "cell_start")
+
+    @staticmethod
+    def _copy(array):  # torch tensors on the GPU, numpy arrays under the CPU checker
+        return array.clone() if hasattr(array, "clone") else array.copy()
+
+    @staticmethod
+    def _assign(target, saved):
+        if hasattr(target, "copy_"):
+            target.copy_(saved)
+        else:
+            target[...] = saved
+
     def __init__(self, runner):
         pop = runner.population
-        self.columns = {name: getattr(pop, name).clone()
-                        for name in ("perm", "multiplicity", "extensive", "cell_order")}
-        self.diagnostics = {name: getattr(runner, name).clone() for name in self.RUNNER
+        self.columns = {name: self._copy(getattr(pop, name)) for name in self.COLUMNS}
+        self.diagnostics = {name: self._copy(getattr(runner, name)) for name in self.RUNNER
                             if getattr(runner, name) is not None}
         self.scalars = {name: getattr(runner, name) for name in self.SCALARS}
         self.live, self.ordered = pop.live, pop.ordered
@@ -85,9 +99,9 @@ class Checkpoint:
     def restore(self, runner):
         pop = runner.population
         for name, saved in self.columns.items():
-            getattr(pop, name).copy_(saved)
+            self._assign(getattr(pop, name), saved)
         for name, saved in self.diagnostics.items():
-            getattr(runner, name).copy_(saved)
+            self._assign(getattr(runner, name), saved)
         for name, value in self.scalars.items():
             setattr(runner, name, value)
         pop.live = pop.working = self.live
@@ -174,6 +188,14 @@ def phase_timing(engine):
     return {name(i).decode(): (ms[i], count[i]) for i in range(n) if count[i] > 0}
 
 
+_T0 = time.perf_counter()
+
+
+def progress(stage):
+    """one line per stage on stderr (stdout carries the JSON line alone)"""
+    print(f"[bench {time.perf_counter() - _T0:7.1f} s] {stage}", file=sys.stderr, flush=True)
+
+
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
@@ -233,6 +255,7 @@ def main():
                             ids_by_cell=args.ids_by_cell, grid=args.grid)
     pop, setup = runner.population, runner.setup
     n_sd = pop.n_sd
+    progress(f"{args.workload}: state built (n_sd = {n_sd}), rank {rank} of {world}")
     runner.run(1)  # allocates scratch, builds the mirror
     # non-adaptive: no host read-back inside the timed loop
     runner.read_back = bool(setup.adaptive) or world > 1
@@ -245,6 +268,7 @@ def main():
 
     runner.run(args.warmup)
     runner.sync()
+    progress("warm-up done")
     evolving = bool(setup.adaptive) or pop.n_cell > 1
     checkpoint = Checkpoint(runner) if evolving and args.reps > 1 else None
     reps, rep_substeps, comm = [], [], None
@@ -278,6 +302,7 @@ def main():
                 dist.all_reduce(p, op=dist.ReduceOp.SUM)
         reps.append((float(p.item()) / float(t.item()), float(t.item()), float(p.item())))
         rep_substeps.append(runner.sub_steps_done - substeps_before)
+        progress(f"repetition {rep}: {reps[-1][0]:.4g} pairs/s")
         if runner.shard is not None:
             shard = runner.shard
             comm = {"f64_calls": shard.calls[1] - comm_before[0],
@@ -323,6 +348,7 @@ def main():
         shima_box_live = box.population.live
         del box
 
+    progress("timed region done; per-kernel timing pass")
     roofline = None
     baseline = None
     sharded_run = runner.shard is not None
@@ -359,6 +385,7 @@ def main():
         # peak - both fractions are reported, the HBM one stays the contract figure
         wide = setup.breakup or args.workload in ("kinematic2d", "berry_breakup", "straub",
                                                   "straub_rain")
+        progress("kernel timing done; random-sector calibration")
         ceiling = random_sector_ceiling(engine, n_sd, wide)
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -384,6 +411,7 @@ def main():
             "timed_mode_ms_per_step": round(timed_wall_ms, 5),
         }
         if not args.no_cpu_baseline and world == 1:  # the CPU leg: rank 0 at N=1 only
+            progress("CPU baseline (the oracle on the host cores, bounded sample)")
             baseline = cpu_baseline(args.workload, args.n_sd, adaptive)
 
     if world > 1:

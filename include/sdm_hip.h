@@ -388,7 +388,10 @@ typedef struct sdm_step_state {
   const double *gk_a, *gk_b;  /* Gunn-Kinzer table (or NULL) */
   /* device control block, int64[8]: {valid_n_sd, working_length, sorted, healthy, n_overflow,
    * candidate pairs processed so far (single-cell non-adaptive steps), largest cell, events};
-   * kept device-resident between calls.  Word 7: low byte = device-side error code (0 = none),
+   * kept device-resident between calls.  Word 7: low byte = device-side error code (0 = none;
+   * 1 = a cell larger than the per-cell kernel's capacity, 2 = the compaction kernel's grid
+   * barrier timed out; 4 is used inside the library: `sorted` was claimed but cell_start
+   * does not span exactly the live super-droplets - the call returns SDM_E_ARG, nothing computed),
    * bit 8 = "a cell's stats_dt_min became equal to dt_min" - the data-level event behind the
    * reference's warning "adaptive time-step reached dt_min" (collision.py:276-277): the caller
    * evaluates `amin(stats_dt_min) == dt_min`, warns, and clears the bit; n_overflow likewise

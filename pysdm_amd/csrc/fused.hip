@@ -1709,11 +1709,19 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
 #endif
 }
 
-// largest cell of a sorted state -> ctl[6]
+// largest cell of a sorted state -> ctl[6].  The one place a caller's claim "sorted" is checked,
+// for what four loads can tell: cell_start must be non-decreasing and span exactly the live
+// super-droplets.  A cell_start left over from another state (a restored snapshot that forgot it,
+// say) puts droplets into other cells' segments; the sub-step loop then never ends, because the
+// cells whose time is charged are not the cells that are waited for -> ctl[7] |= 4, the host
+// returns SDM_E_ARG before anything is computed
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_max_cell(const int64_t *__restrict__ cell_start, int64_t n_cell, int64_t *ctl) {
   const int64_t c = TID();
   const int64_t sz = c < n_cell ? cell_start[c + 1] - cell_start[c] : 0;
+  if (sz < 0 || (c == 0 && ctl[CTL_SORTED] != 0 &&
+                 (cell_start[0] != 0 || cell_start[n_cell] != ctl[CTL_VALID])))
+    atomicOr((unsigned long long *)&ctl[7], 4ull);
   int64_t m = sz;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -2133,6 +2141,12 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     HIP_TRY(hipMemcpyAsync(ctx->mailbox + 8, st->ctl, sizeof(int64_t) * 8, hipMemcpyDeviceToHost,
                            s));
     HIP_TRY(hipStreamSynchronize(s));
+    if ((ctx->mailbox[8 + 7] & SDM_CTL7_ERROR_MASK) == 4) {  // (k_max_cell)
+      HIP_TRY(hipMemsetAsync(st->ctl + 7, 0, sizeof(int64_t), s));
+      sdm_set_error("the state was handed over as sorted by cell, but cell_start does not span "
+                    "the live super-droplets (a cell_start of another state?): nothing computed");
+      return SDM_E_ARG;
+    }
     work_host = ctx->mailbox[8 + CTL_WORK];
     sorted_host = (int)ctx->mailbox[8 + CTL_SORTED];
     if (C == 1 && (flags & 2)) sorted_host = 1;

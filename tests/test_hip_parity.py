@@ -425,3 +425,21 @@ def test_long_breakup_loops_equal_the_checker(handle_all_breakups, hip_engine, o
     for round_got, round_want in zip(got, want):
         for value, ref in zip(round_got, round_want):
             np.testing.assert_array_equal(value, ref)
+
+
+def test_a_stale_cell_start_is_refused_not_computed_on(hip_engine):
+    """`sorted` handed over with a cell_start that belongs to another state (here: a state one
+    super-droplet shorter) must end in an error, not in a run over segments that hold other cells'
+    droplets (control block word 7, code 4; found the hard way: bench.py's checkpoint once forgot
+    cell_start and the repetition after the first death never came back)"""
+    runner = make_box(hip_engine, "kinematic2d", n_sd=2**14, grid=(4, 4))
+    runner.run(2)
+    pop = runner.population
+    assert pop.ordered
+    starts = hip_engine.download(pop.cell_start)
+    starts[5:] -= 1  # what cell_start looks like after a death in cell 4
+    pop.cell_start.copy_(hip_engine.upload(starts))
+    pop.touch_state()
+    pop.ordered = True
+    with pytest.raises(RuntimeError, match="cell_start does not span"):
+        runner.run(3)

@@ -134,3 +134,31 @@ def test_bench_cpu_baseline_leg_runs():
         result = bench.cpu_baseline(workload, n_sd, adaptive, seconds_budget=0.3)
         assert result["kind"] == "port" and result["value"] > 0
         assert result["value_1_thread"] > 0 and result["cores"] >= 1
+
+
+def test_bench_checkpoint_brings_back_the_same_steps_after_deaths(oracle_engine):
+    """bench.py restores one snapshot before every timed repetition: the K steps that follow must
+    be the same K steps each time, also when super-droplets died in between (the permutation is
+    then shorter and cell_start has moved: both belong to the snapshot)"""
+    import importlib.util  # pylint: disable=import-outside-toplevel
+
+    from pysdm_amd.cases import make_box  # pylint: disable=import-outside-toplevel
+
+    spec = importlib.util.spec_from_file_location(
+        "bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                              "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    runner = make_box(oracle_engine, "shima", n_sd=2**12, adaptive=True, dt=200.0, thin=0.02,
+                      grid=(4, 4))
+    runner.run(2)
+    start = bench.Checkpoint(runner)
+    seen = []
+    for _ in range(3):
+        start.restore(runner)
+        runner.run(4)
+        snap = runner.snapshot()
+        seen.append((int(snap["length"]), runner.sub_steps_done, runner.offset,
+                     {k: np.asarray(v).tobytes() for k, v in snap.items()}))
+    assert seen[0][0] < start.live  # droplets died inside the repetition
+    assert seen[1] == seen[0] and seen[2] == seen[0]
