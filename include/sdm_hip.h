@@ -417,6 +417,11 @@ typedef struct sdm_step_state {
   double *xchg_cells;         /* [n_cell + 1 + shard_world] scratch for the per-cell exchange */
   int64_t *xchg_idx;          /* [n_sd] scratch for the exchange of dead positions */
   int32_t shard_rank, shard_world; /* this process's place among the processes (slices above) */
+  /* sharded run with a sharded displacement step (sdm_disp_shard below): `cell_id` then holds, for
+   * ids that stand in other processes' positions, the cell of the super-droplet truly there; the
+   * one place the reference reads a cell id by RAW id - `normalize` indexes cell_id with the pair
+   * number (collisions_methods.py:430-442) - needs every id's own cell: this column.  NULL = cell_id */
+  const int64_t *cell_id_by_id;
 } sdm_step_state;
 
 typedef struct sdm_step_result {
@@ -481,6 +486,65 @@ typedef struct sdm_disp_state {
  * sub-steps, in sub-step order), *valid_n_sd = surviving super-droplets; synchronises once.      */
 int sdm_displacement_step(sdm_ctx *ctx, const sdm_disp_cfg *cfg, const sdm_disp_state *state,
                           double *rainfall_mass, int64_t *valid_n_sd);
+
+/* ---- the displacement step of a sharded run ------------------------------------------------------
+ * Between two sharded collision steps (see "sharding" above) a process holds exact data only for
+ * the super-droplets of its own cells: their rows in the columns, and their POSITIONS in the
+ * permutation.  Every other position holds a placeholder - some id that is not one of its own,
+ * whose cell_id entry is the cell of the super-droplet that is truly there (all the replicated
+ * compaction and counting sort read of it).  This entry point keeps exactly that:
+ *   - a super-droplet is moved (all n_substeps of it: displacement depends on nothing but the
+ *     droplet and the replicated Courant field) by the process that owns its cell when the call
+ *     begins; rows of other super-droplets are not touched;
+ *   - removal (precipitation, out of the column): the owners' dead POSITIONS are summed as
+ *     rank-disjoint slices, exactly as in the collision step, and every process runs the
+ *     reference's compaction on its own permutation.  Positions are the global names: a filler
+ *     taken from the tail lands in the same hole on every process;
+ *   - at the end, per super-droplet whose cell changed: {position, id, new cell} to everybody
+ *     (cell_id_by_id[id] takes the new cell, and so does the cell_id entry of the placeholder at
+ *     that position), and for those that changed OWNER the row itself - {position, id, new cell,
+ *     multiplicity, cell origin; attributes and position in cell as bit patterns} - which the new
+ *     owner stores under the true id, at the true position (the placeholders involved trade
+ *     places among themselves).  One sum of 2 * world doubles (the counts) and one of exactly the
+ *     int64 words listed; nothing the size of a column.
+ *   - removed super-droplets keep moving in the reference (the displacement kernels run over the
+ *     raw columns, and `normalize` reads cell ids by raw id, dead or alive): the process that
+ *     owned one when it was removed keeps moving it, wherever it goes, and announces its cells
+ *     like the others' (position -1 in the list).  `role` records who is whose.
+ * The rainfall is the sum of the owners' partial sums (within 1e-15 relative of the one-process
+ * value, not bit-identical: the order of the additions differs).  Everything else - ids,
+ * multiplicities, attributes, positions, cells of the owned super-droplets; the permutation after
+ * the next sharded collision step - is the one-process result bit for bit.
+ * The reference has no counterpart (PySDM is a one-process code); the step computed is
+ * PySDM/dynamics/displacement.py:100-153 as above. */
+typedef struct sdm_disp_shard {
+  const uint8_t *cell_owned;  /* [n_cell] by cell id: 1 = this process's cell */
+  int64_t n_cell;
+  sdm_exchange_fn exchange;
+  void *exchange_user;
+  int32_t shard_rank, shard_world;
+  double *xchg_counts;        /* [2 * shard_world + 2] scratch for the counts */
+  int64_t *xchg_words;        /* [word_capacity] scratch for positions / rows */
+  int64_t word_capacity;      /* SDM_E_ARG if a step needs more (n_sd * (7 + 2 * n_dims + n_attr)
+                                 always suffices) */
+  int64_t *cell_id_by_id;     /* [n_sd] every id's own cell (see sdm_step_state); initially a
+                                 copy of cell_id */
+  /* [n_sd] kept by the caller between calls, written by the library: 0 = not this process's,
+   * 1 = alive and in one of its cells, 2 = removed while it was (kept moving here).  role_ready = 0:
+   * the library fills it from cell_id_by_id and the permutation first (and sets role_ready) */
+  uint8_t *role;
+  int32_t role_ready;
+  int64_t *multiplicity;      /* [n_sd] writable: rows of arriving super-droplets */
+  double *attributes;         /* [n_attr, n_sd] */
+  int32_t n_attr;
+  /* out, this call: super-droplets of this process whose cell changed; of those, how many changed
+   * owner; rows received; int64 words handed to `exchange`; super-droplets removed (all ranks) */
+  int64_t n_moved, n_left, n_arrived, n_words, n_removed;
+} sdm_disp_shard;
+
+int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
+                                  const sdm_disp_state *state, sdm_disp_shard *shard,
+                                  double *rainfall_mass, int64_t *valid_n_sd);
 
 #ifdef __cplusplus
 }

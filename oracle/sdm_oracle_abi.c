@@ -929,7 +929,8 @@ static int box_step(Box *B, int64_t shift_len) {
   if (box_kernel(B, B->kernel_temp)) return SDM_E_ARG;
   oracle_pair_op_i64(SDM_PAIR_MAX, prob, B->P, st->multiplicity, B->flag, B->idx, B->work);
   pw_mul(B, prob, B->kernel_temp);
-  oracle_normalize(prob, B->P, st->cell_id, st->cell_idx, box_cell_start(B), B->norm, B->C,
+  oracle_normalize(prob, B->P, st->cell_id_by_id ? st->cell_id_by_id : st->cell_id, st->cell_idx,
+                   box_cell_start(B), B->norm, B->C,
                    c->dt, c->dv);
   if (c->enable_breakup) {
     if (box_ec(B, B->Ec)) return SDM_E_ARG;
@@ -1181,6 +1182,273 @@ API int sdm_displacement_step(sdm_ctx *ctx, const sdm_disp_cfg *cfg, const sdm_d
     oracle_cell_id(st->cell_id, st->cell_origin, cfg->strides, D, N);
   }
   free(whole);
+  st->ctl[0] = length;
+  st->ctl[1] = length;
+  st->ctl[2] = 0;
+  st->ctl[3] = 1;
+  *rainfall_mass = rain;
+  *valid_n_sd = length;
+  return SDM_OK;
+}
+
+/* ---- the displacement step of a sharded run (include/sdm_hip.h: sdm_disp_shard) ------------------
+ * The checker's statement of the protocol: serial loops, the same exchanges, the same words. */
+static int disp_exchange_dead(const sdm_disp_state *st, sdm_disp_shard *sh, const int64_t *dead,
+                              int64_t n_mine, double rain_mine, int64_t N, int64_t *length,
+                              double *rain) {
+  const int W = sh->shard_world, R = sh->shard_rank;
+  double *x = sh->xchg_counts;
+  for (int r = 0; r < W; ++r) x[r] = r == R ? (double)n_mine : 0.0;
+  x[W] = rain_mine;
+  if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_F64, x, W + 1))
+    FAIL(SDM_E_HIP, "exchange callback failed (displacement: counts of the removed)");
+  *rain += x[W];
+  int64_t total = 0, before = 0;
+  for (int r = 0; r < W; ++r) {
+    if (r < R) before += (int64_t)x[r];
+    total += (int64_t)x[r];
+  }
+  if (total == 0) return SDM_OK;
+  if (total > sh->word_capacity) FAIL(SDM_E_ARG, "sharded displacement: word_capacity too small");
+  int64_t *y = sh->xchg_words;
+  for (int64_t i = 0; i < total; ++i) y[i] = 0;
+  for (int64_t i = 0; i < n_mine; ++i) y[before + i] = dead[i];
+  if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_I64, y, total))
+    FAIL(SDM_E_HIP, "exchange callback failed (displacement: positions of the removed)");
+  sh->n_words += total;
+  sh->n_removed += total;
+  for (int64_t i = 0; i < total; ++i) st->idx[y[i]] = N;
+  *length = oracle_remove_zero_n_or_flagged(st->multiplicity, st->idx, *length, N);
+  return SDM_OK;
+}
+
+API int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
+                                      const sdm_disp_state *st, sdm_disp_shard *sh,
+                                      double *rainfall_mass, int64_t *valid_n_sd) {
+  (void)ctx;
+  if (!cfg || !st || !sh || !rainfall_mass || !valid_n_sd) FAIL(SDM_E_ARG, "null argument");
+  if (!sh->cell_owned || !sh->exchange || !sh->xchg_counts || !sh->xchg_words ||
+      !sh->multiplicity || !sh->attributes || !sh->cell_id_by_id || !sh->role || sh->n_attr < 1 || sh->shard_world < 1 ||
+      sh->shard_rank < 0 || sh->shard_rank >= sh->shard_world)
+    FAIL(SDM_E_ARG, "sharded displacement: incomplete sdm_disp_shard");
+  const int64_t N = cfg->n_sd;
+  const int D = cfg->n_dims, W = sh->shard_world, R = sh->shard_rank, A = sh->n_attr;
+  int64_t length = st->ctl[0];
+  sh->n_moved = sh->n_left = sh->n_arrived = sh->n_words = sh->n_removed = 0;
+  uint8_t *mine = (uint8_t *)malloc((size_t)N);
+  int64_t *cell0 = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+  int64_t *dead = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+  int64_t *inv = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+  uint8_t *mark = (uint8_t *)calloc((size_t)(2 * N), 1);
+  int rc = SDM_OK;
+  if (!mine || !cell0 || !dead || !inv || !mark) {
+    free(mine); free(cell0); free(dead); free(inv); free(mark);
+    FAIL(SDM_E_NOMEM, "oracle scratch allocation failed");
+  }
+  uint8_t *role = sh->role;
+  if (!sh->role_ready) { /* alive: in the permutation; the removed stay where their cell is */
+    for (int64_t k = 0; k < N; ++k) role[k] = sh->cell_owned[sh->cell_id_by_id[k]] ? 2 : 0;
+    for (int64_t i = 0; i < length; ++i)
+      if (role[st->idx[i]]) role[st->idx[i]] = 1;
+    sh->role_ready = 1;
+  }
+  for (int64_t k = 0; k < N; ++k) {
+    /* removed by a collision step since (the owner sees the zero; its compaction took it out) */
+    if (role[k] == 1 && sh->multiplicity[k] == 0) role[k] = 2;
+    cell0[k] = sh->cell_id_by_id[k];
+    mine[k] = role[k] != 0;
+  }
+  double rain = 0.0;
+  const int64_t last = (int64_t)(D - 1) * N;
+  for (int s = 0; s < cfg->n_substeps && rc == SDM_OK; ++s) {
+    /* the owner moves its super-droplets: displacement_methods.py:14-129, displacement.py:123-137 */
+    for (int64_t k = 0; k < N; ++k) {
+      if (!mine[k]) continue;
+      for (int dim = 0; dim < D; ++dim) {
+        int64_t l = 0, r = 0;
+        for (int d = 0; d < D; ++d) {
+          const int64_t o = st->cell_origin[d * N + k], extent = cfg->grid[d] + (d == dim);
+          l = l * extent + o;
+          r = r * extent + o + (d == dim);
+        }
+        const double x = st->position_in_cell[dim * N + k];
+        const double c_l = st->courant[dim][l] / (double)cfg->n_substeps;
+        const double c_r = st->courant[dim][r] / (double)cfg->n_substeps;
+        double v = c_l * (1 - x) + c_r * x;
+        if (cfg->scheme == 0) v = v / (1 - c_r + c_l);
+        if (cfg->enable_sedimentation && dim == D - 1) {
+          v = v * (1 / cfg->dt_over_dz);
+          v = v - st->fall_velocity[k];
+          v = v * cfg->dt_over_dz;
+        }
+        st->displacement[dim * N + k] = v;
+        st->position_in_cell[dim * N + k] = x + v;
+      }
+    }
+    if (cfg->enable_sedimentation) { /* displacement_methods.py:131-166 */
+      int64_t n_mine = 0;
+      double rain_mine = 0.0;
+      for (int64_t i = 0; i < length; ++i) {
+        const int64_t k = st->idx[i];
+        if (role[k] != 1) continue;
+        const double z = (double)st->cell_origin[last + k] + st->position_in_cell[last + k];
+        if (st->displacement[last + k] < 0 && z < cfg->level) {
+          role[k] = 2;
+          rain_mine += fabs(st->water_mass[k]) * (double)st->multiplicity[k];
+          dead[n_mine++] = i;
+        }
+      }
+      rc = disp_exchange_dead(st, sh, dead, n_mine, rain_mine, N, &length, &rain);
+      if (rc) break;
+    }
+    { /* displacement_methods.py:168-190 */
+      int64_t n_mine = 0;
+      for (int64_t i = 0; i < length; ++i) {
+        const int64_t k = st->idx[i];
+        if (role[k] != 1) continue;
+        const double z = (double)st->cell_origin[last + k] + st->position_in_cell[last + k];
+        if (z < 0 || z > (double)cfg->grid[D - 1]) {
+          role[k] = 2;
+          dead[n_mine++] = i;
+        }
+      }
+      double none = 0.0;
+      rc = disp_exchange_dead(st, sh, dead, n_mine, 0.0, N, &length, &none);
+      if (rc) break;
+    }
+    for (int64_t k = 0; k < N; ++k) { /* displacement.py:143-153 */
+      if (!mine[k]) continue;
+      int64_t id = 0;
+      for (int d = 0; d < D; ++d) {
+        const double x = st->position_in_cell[d * N + k];
+        const int64_t whole = (int64_t)floor(x);
+        st->position_in_cell[d * N + k] = x - (double)whole;
+        int64_t o = (st->cell_origin[d * N + k] + whole) % cfg->grid[d];
+        if (o != 0 && ((o < 0) != (cfg->grid[d] < 0))) o += cfg->grid[d];
+        st->cell_origin[d * N + k] = o;
+        id += o * cfg->strides[d];
+      }
+      sh->cell_id_by_id[k] = id;
+      if (role[k] == 1) st->cell_id[k] = id;
+    }
+  }
+  /* ---- who changed cell, who changed owner (over the raw ids: the removed keep moving in the
+   * reference, and `normalize` reads their cell ids too) ----------------------------------------- */
+  const int64_t row = 4 + D + A + D; /* {position, id, new cell, multiplicity, origin; bits} */
+  if (rc == SDM_OK) {
+    for (int64_t k = 0; k < N; ++k) inv[k] = -1;
+    for (int64_t i = 0; i < length; ++i) inv[st->idx[i]] = i;
+    int64_t n_a = 0, n_b = 0;
+    for (int64_t k = 0; k < N; ++k) {
+      if (!mine[k] || sh->cell_id_by_id[k] == cell0[k]) continue;
+      ++n_a;
+      if (role[k] == 1 && !sh->cell_owned[sh->cell_id_by_id[k]]) ++n_b;
+    }
+    sh->n_moved = n_a;
+    sh->n_left = n_b;
+    double *x = sh->xchg_counts;
+    for (int r = 0; r < 2 * W; ++r) x[r] = 0.0;
+    x[R] = (double)n_a;
+    x[W + R] = (double)n_b;
+    if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_F64, x, 2 * W)) {
+      rc = SDM_E_HIP;
+      snprintf(g_err, sizeof(g_err), "exchange callback failed (displacement: counts)");
+    }
+    int64_t tot_a = 0, tot_b = 0, at_a = 0, at_b = 0;
+    for (int r = 0; r < W && rc == SDM_OK; ++r) {
+      if (r < R) { at_a += (int64_t)x[r]; at_b += (int64_t)x[W + r]; }
+      tot_a += (int64_t)x[r];
+      tot_b += (int64_t)x[W + r];
+    }
+    const int64_t words = 3 * tot_a + row * tot_b;
+    if (rc == SDM_OK && words > sh->word_capacity) {
+      rc = SDM_E_ARG;
+      snprintf(g_err, sizeof(g_err), "sharded displacement: word_capacity too small");
+    }
+    if (rc == SDM_OK && words > 0) {
+      int64_t *y = sh->xchg_words, *b = y + 3 * tot_a;
+      for (int64_t i = 0; i < words; ++i) y[i] = 0;
+      for (int64_t k = 0; k < N; ++k) {
+        const int64_t to = sh->cell_id_by_id[k];
+        if (!mine[k] || to == cell0[k]) continue;
+        y[3 * at_a] = role[k] == 1 ? inv[k] : -1;
+        y[3 * at_a + 1] = k;
+        y[3 * at_a + 2] = to;
+        ++at_a;
+        if (role[k] != 1 || sh->cell_owned[to]) continue;
+        role[k] = 0; /* it goes on as a placeholder here */
+        int64_t *w = b + row * at_b++;
+        w[0] = inv[k]; w[1] = k; w[2] = to; w[3] = sh->multiplicity[k];
+        for (int d = 0; d < D; ++d) w[4 + d] = st->cell_origin[d * N + k];
+        for (int a = 0; a < A; ++a) memcpy(&w[4 + D + a], &sh->attributes[a * N + k], 8);
+        for (int d = 0; d < D; ++d) memcpy(&w[4 + D + A + d], &st->position_in_cell[d * N + k], 8);
+      }
+      if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_I64, y, words)) {
+        rc = SDM_E_HIP;
+        snprintf(g_err, sizeof(g_err), "exchange callback failed (displacement: rows)");
+      }
+      sh->n_words += words;
+      if (rc == SDM_OK) {
+        /* arrivals: rows whose new cell is this process's (never its own rows: those it sent
+         * left its cells).  A live one's true id goes to its true position; the placeholders
+         * involved trade places, each taking the cell id of the position it moves to */
+        uint8_t *is_p = mark, *is_x = mark + N;
+        int64_t n_arr = 0;
+        for (int64_t j = 0; j < tot_b; ++j) {
+          const int64_t *w = b + row * j;
+          if (!sh->cell_owned[w[2]]) continue;
+          ++n_arr;
+          is_p[w[0]] = 1;
+          is_x[w[1]] = 1;
+        }
+        sh->n_arrived = n_arr;
+        int64_t *tmp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(3 * n_arr + 3));
+        if (!tmp) { rc = SDM_E_NOMEM; snprintf(g_err, sizeof(g_err), "oracle scratch"); }
+        else {
+          int64_t *free_slot = tmp, *free_cell = tmp + n_arr + 1, *homeless = tmp + 2 * n_arr + 2;
+          int64_t n_free = 0, n_home = 0;
+          for (int64_t j = 0; j < tot_b; ++j) {
+            const int64_t *w = b + row * j;
+            if (!sh->cell_owned[w[2]]) continue;
+            const int64_t at = inv[w[1]];
+            if (at >= 0 && !is_p[at]) {
+              free_slot[n_free] = at;
+              free_cell[n_free++] = st->cell_id[w[1]];
+            }
+            const int64_t there = st->idx[w[0]];
+            if (!is_x[there]) homeless[n_home++] = there;
+          }
+          for (int64_t j = 0; j < tot_b; ++j) {
+            const int64_t *w = b + row * j;
+            if (sh->cell_owned[w[2]]) st->idx[w[0]] = w[1];
+          }
+          for (int64_t j = 0; j < n_free; ++j) { /* (n_home - n_free ids leave the live set) */
+            st->idx[free_slot[j]] = homeless[j];
+            st->cell_id[homeless[j]] = free_cell[j];
+          }
+          free(tmp);
+        }
+        /* everybody's list of changed cells: the id's own cell, and the cell id of whatever id
+         * stands at that position here */
+        for (int64_t j = 0; j < tot_a && rc == SDM_OK; ++j) {
+          sh->cell_id_by_id[y[3 * j + 1]] = y[3 * j + 2];
+          if (y[3 * j] >= 0) st->cell_id[st->idx[y[3 * j]]] = y[3 * j + 2];
+        }
+        for (int64_t j = 0; j < tot_b && rc == SDM_OK; ++j) {
+          const int64_t *w = b + row * j;
+          if (!sh->cell_owned[w[2]]) continue;
+          const int64_t k = w[1];
+          role[k] = 1;
+          sh->multiplicity[k] = w[3];
+          for (int d = 0; d < D; ++d) st->cell_origin[d * N + k] = w[4 + d];
+          for (int a = 0; a < A; ++a) memcpy(&sh->attributes[a * N + k], &w[4 + D + a], 8);
+          for (int d = 0; d < D; ++d) memcpy(&st->position_in_cell[d * N + k], &w[4 + D + A + d], 8);
+        }
+      }
+    }
+  }
+  free(mine); free(cell0); free(dead); free(inv); free(mark);
+  if (rc) return rc;
   st->ctl[0] = length;
   st->ctl[1] = length;
   st->ctl[2] = 0;

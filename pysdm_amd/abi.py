@@ -59,6 +59,7 @@ class StepState(ctypes.Structure):  # == sdm_step_state
         ("cell_owned", c_ptr), ("exchange", c_ptr), ("exchange_user", c_ptr),
         ("xchg_cells", c_ptr), ("xchg_idx", c_ptr),
         ("shard_rank", ctypes.c_int32), ("shard_world", ctypes.c_int32),
+        ("cell_id_by_id", c_ptr),
     ]
 
 
@@ -87,6 +88,18 @@ class DispState(ctypes.Structure):  # == sdm_disp_state
         ("courant", c_ptr * 3), ("displacement", c_ptr), ("position_in_cell", c_ptr),
         ("cell_origin", c_ptr), ("cell_id", c_ptr), ("fall_velocity", c_ptr),
         ("water_mass", c_ptr), ("multiplicity", c_ptr), ("idx", c_ptr), ("ctl", c_ptr),
+    ]
+
+
+class DispShard(ctypes.Structure):  # == sdm_disp_shard
+    _fields_ = [
+        ("cell_owned", c_ptr), ("n_cell", c_i64), ("exchange", c_ptr), ("exchange_user", c_ptr),
+        ("shard_rank", ctypes.c_int32), ("shard_world", ctypes.c_int32),
+        ("xchg_counts", c_ptr), ("xchg_words", c_ptr), ("word_capacity", c_i64),
+        ("cell_id_by_id", c_ptr), ("role", c_ptr), ("role_ready", ctypes.c_int32),
+        ("multiplicity", c_ptr), ("attributes", c_ptr), ("n_attr", ctypes.c_int32),
+        ("n_moved", c_i64), ("n_left", c_i64), ("n_arrived", c_i64), ("n_words", c_i64),
+        ("n_removed", c_i64),
     ]
 
 

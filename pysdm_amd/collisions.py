@@ -141,6 +141,8 @@ class CollisionRunner:  # pylint: disable=too-many-instance-attributes
                 self.shard.fill(state, address)
             self._address = address
             self._state = state
+        # (sharded run with a sharded displacement step: every id's own cell, see sdm_hip.h)
+        state.cell_id_by_id = self._address(getattr(pop, "cell_id_by_id", None))
         state.idx = self._address(pop.perm)
         state.tmp_idx = self._address(pop.perm_spare)
         state.rng_offset = self.offset

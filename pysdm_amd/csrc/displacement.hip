@@ -206,6 +206,13 @@ struct DispArgs {
   uint8_t *cls;     // per raw super-droplet after the move: 0 stays, 1 precipitates, 2 left the
                     // column -- so that the position-indexed kernels gather one byte, not three
                     // doubles, through idx
+  // sharded run (sdm_displacement_step_sharded; all NULL otherwise): who is whose (sdm_hip.h:
+  // sdm_disp_shard.role), every id's own cell, and where the positions of this process's
+  // removed super-droplets are listed
+  uint8_t *role;
+  int64_t *cell_by_id;
+  int64_t *dead;
+  unsigned long long *n_dead;
 };
 
 // A: over raw super-droplets: displacement of every dimension (Arakawa-C interpolation),
@@ -214,6 +221,10 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_disp_move(DispArgs X) {
   const sdm_disp_cfg &c = X.cfg;
   const int64_t k = TID();
   if (k >= c.n_sd) return;
+  if (X.role && X.role[k] == 0) {  // another process's row (sharded run): not touched
+    X.cls[k] = 0;
+    return;
+  }
   int64_t origin[3] = {0, 0, 0};
   for (int d = 0; d < c.n_dims; ++d) origin[d] = X.st.cell_origin[d * c.n_sd + k];
   const double n_sub = (double)c.n_substeps;
@@ -258,10 +269,15 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_disp_precip(DispArgs X) {
   double mass = 0.0;
   for (int64_t i = TID(); i < length; i += (int64_t)gridDim.x * SDM_BLOCK) {
     const int64_t k = X.st.idx[i];
-    if (X.cls[k] == 1) {
+    if (X.cls[k] == 1 && (!X.role || X.role[k] == 1)) {
       mass += fabs(X.st.water_mass[k]) * (double)X.st.multiplicity[k];
-      X.st.idx[i] = c.n_sd;
-      X.st.ctl[3] = 0;
+      if (X.role) {  // sharded: the position is announced first (every process flags it)
+        X.role[k] = 2;
+        X.dead[atomicAdd(X.n_dead, 1ull)] = i;
+      } else {
+        X.st.idx[i] = c.n_sd;
+        X.st.ctl[3] = 0;
+      }
     }
   }
 #pragma unroll
@@ -281,9 +297,14 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_disp_column(DispArgs X) {
   const int64_t i = TID();
   if (i >= X.st.ctl[0]) return;
   const int64_t k = X.st.idx[i];
-  if (X.cls[k] == 2) {
-    X.st.idx[i] = c.n_sd;
-    X.st.ctl[3] = 0;
+  if (X.cls[k] == 2 && (!X.role || X.role[k] == 1)) {
+    if (X.role) {
+      X.role[k] = 2;
+      X.dead[atomicAdd(X.n_dead, 1ull)] = i;
+    } else {
+      X.st.idx[i] = c.n_sd;
+      X.st.ctl[3] = 0;
+    }
   }
 }
 
@@ -293,6 +314,7 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_disp_cells(DispArgs X) {
   const sdm_disp_cfg &c = X.cfg;
   const int64_t k = TID();
   if (k >= c.n_sd) return;
+  if (X.role && X.role[k] == 0) return;
   int64_t id = 0;
   for (int d = 0; d < c.n_dims; ++d) {
     const double x = X.st.position_in_cell[d * c.n_sd + k];
@@ -303,6 +325,12 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_disp_cells(DispArgs X) {
     if (m != 0 && ((m < 0) != (c.grid[d] < 0))) m += c.grid[d];  // Python's %
     X.st.cell_origin[d * c.n_sd + k] = m;
     id += m * c.strides[d];
+  }
+  if (X.role) {
+    // (a removed one, role 2, may stand in the permutation as a placeholder for somebody else's
+    // super-droplet: its cell_id entry then belongs to that position)
+    X.cell_by_id[k] = id;
+    if (X.role[k] != 1) return;
   }
   X.st.cell_id[k] = id;
 }
@@ -330,6 +358,10 @@ extern "C" int sdm_displacement_step(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
   X.partial = cv.take<double>(nb);
   X.rain = cv.take<double>(1);
   X.cls = cv.take<uint8_t>(N);
+  X.role = nullptr;
+  X.cell_by_id = nullptr;
+  X.dead = nullptr;
+  X.n_dead = nullptr;
   int64_t *cctl = cv.take<int64_t>(8);
   char *compact = cv.take<char>(sdm_compact_scratch(N));
   const unsigned n_precip = nb < DISP_PRECIP_GRID ? nb : DISP_PRECIP_GRID;
@@ -358,6 +390,429 @@ extern "C" int sdm_displacement_step(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
                          hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   memcpy(rainfall_mass, ctx->mailbox, sizeof(double));
+  *valid_n_sd = ctx->mailbox[1];
+  if (ctx->mailbox[1 + 7] != 0) {
+    sdm_set_error("displacement: grid barrier of the compaction kernel timed out");
+    return SDM_E_HIP;
+  }
+  return SDM_OK;
+}
+
+// ---- the displacement step of a sharded run (include/sdm_hip.h: sdm_disp_shard) ----------------
+// The kernels above with `role` set, and what crosses the processes in between.  Every list is
+// filled through an atomic counter: its order differs from run to run and does not matter (the
+// positions of the removed are a set; the placeholders that trade places are interchangeable).
+struct ShardLists {
+  int64_t *words;      // the exchange buffer: [3 x all movers][row x all that changed owner]
+  int64_t row;         // words per row
+  int64_t tot_a, tot_b;
+  int n_dims, n_attr;
+  int64_t n_sd;
+};
+
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_role_init(uint8_t *__restrict__ role, const uint8_t *__restrict__ owned,
+            const int64_t *__restrict__ cell_by_id, int64_t n_sd) {
+  const int64_t k = TID();
+  if (k < n_sd) role[k] = owned[cell_by_id[k]] ? 2 : 0;  // (2: not in the permutation = removed)
+}
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_role_alive(uint8_t *__restrict__ role, const int64_t *__restrict__ idx,
+             const int64_t *__restrict__ ctl) {
+  const int64_t i = TID();
+  if (i < ctl[0] && role[idx[i]]) role[idx[i]] = 1;
+}
+// what a collision step removed since the last call (the owner sees the zero multiplicity; its
+// compaction took the id out of the permutation), and the cells the call begins with
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_shard_begin(uint8_t *__restrict__ role, const int64_t *__restrict__ multiplicity,
+              const int64_t *__restrict__ cell_by_id, int64_t *__restrict__ cell0, int64_t n_sd) {
+  const int64_t k = TID();
+  if (k >= n_sd) return;
+  if (role[k] == 1 && multiplicity[k] == 0) role[k] = 2;
+  cell0[k] = cell_by_id[k];
+}
+// counts[0 .. world) = how many this process lists (its own slot only), counts[world] = value
+__global__ void k_pack_counts(double *__restrict__ counts, int world, int rank,
+                              const unsigned long long *__restrict__ n, const double *value) {
+  const int r = threadIdx.x;
+  if (r < world) counts[r] = r == rank ? (double)*n : 0.0;
+  if (r == world) counts[world] = value ? *value : 0.0;
+}
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_copy_i64(int64_t *__restrict__ out, const int64_t *__restrict__ in, int64_t n) {
+  const int64_t i = TID();
+  if (i < n) out[i] = in[i];
+}
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_flag_positions(int64_t *__restrict__ idx, const int64_t *__restrict__ dead, int64_t n,
+                 int64_t n_sd, int64_t *__restrict__ ctl) {
+  const int64_t i = TID();
+  if (i >= n) return;
+  idx[dead[i]] = n_sd;
+  if (i == 0) ctl[3] = 0;
+}
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_inverse(int32_t *__restrict__ inv, const int64_t *__restrict__ idx,
+          const int64_t *__restrict__ ctl) {
+  const int64_t i = TID();
+  if (i < ctl[0]) inv[idx[i]] = (int32_t)i;
+}
+// movers: this process's rows (alive or removed) whose cell changed; of the alive ones, those
+// whose new cell is another process's.  n[0], n[1]: the two counts
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_count_movers(const uint8_t *__restrict__ role, const uint8_t *__restrict__ owned,
+               const int64_t *__restrict__ cell_by_id, const int64_t *__restrict__ cell0,
+               int64_t n_sd, unsigned long long *__restrict__ n) {
+  const int64_t k = TID();
+  bool a = false, b = false;
+  if (k < n_sd && role[k] != 0 && cell_by_id[k] != cell0[k]) {
+    a = true;
+    b = role[k] == 1 && !owned[cell_by_id[k]];
+  }
+  const unsigned long long ma = __ballot(a), mb = __ballot(b);
+  if (lane_id() == 0) {
+    if (ma) atomicAdd(&n[0], (unsigned long long)__popcll(ma));
+    if (mb) atomicAdd(&n[1], (unsigned long long)__popcll(mb));
+  }
+}
+__global__ void k_pack_counts2(double *__restrict__ counts, int world, int rank,
+                               const unsigned long long *__restrict__ n) {
+  const int r = threadIdx.x;
+  if (r < 2 * world) counts[r] = 0.0;
+  __syncthreads();
+  if (r == 0) {
+    counts[rank] = (double)n[0];
+    counts[world + rank] = (double)n[1];
+  }
+}
+// at[0], at[1]: where this process's slices begin (in entries), advanced atomically
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_list_movers(ShardLists L, uint8_t *__restrict__ role, const uint8_t *__restrict__ owned,
+              const int64_t *__restrict__ cell_by_id, const int64_t *__restrict__ cell0,
+              const int32_t *__restrict__ inv, const int64_t *__restrict__ multiplicity,
+              const double *__restrict__ attributes, const int64_t *__restrict__ cell_origin,
+              const double *__restrict__ position_in_cell, unsigned long long *__restrict__ at) {
+  const int64_t k = TID();
+  if (k >= L.n_sd || role[k] == 0) return;
+  const int64_t to = cell_by_id[k];
+  if (to == cell0[k]) return;
+  const bool alive = role[k] == 1;
+  const int64_t p = alive ? (int64_t)inv[k] : -1;
+  int64_t *a = L.words + 3 * (int64_t)atomicAdd(&at[0], 1ull);
+  a[0] = p;
+  a[1] = k;
+  a[2] = to;
+  if (!alive || owned[to]) return;
+  role[k] = 0;  // it goes on as a placeholder here
+  int64_t *w = L.words + 3 * L.tot_a + L.row * (int64_t)atomicAdd(&at[1], 1ull);
+  w[0] = p;
+  w[1] = k;
+  w[2] = to;
+  w[3] = multiplicity[k];
+  for (int d = 0; d < L.n_dims; ++d) w[4 + d] = cell_origin[d * L.n_sd + k];
+  for (int x = 0; x < L.n_attr; ++x)
+    w[4 + L.n_dims + x] = __double_as_longlong(attributes[x * L.n_sd + k]);
+  for (int d = 0; d < L.n_dims; ++d)
+    w[4 + L.n_dims + L.n_attr + d] = __double_as_longlong(position_in_cell[d * L.n_sd + k]);
+}
+// arrivals: rows whose new cell is this process's.  The true id goes to the true position; the
+// placeholders involved trade places, each taking the cell id of the position it moves to
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_arrivals_mark(ShardLists L, const uint8_t *__restrict__ owned, uint8_t *__restrict__ is_p,
+                uint8_t *__restrict__ is_x, unsigned long long *__restrict__ n_arrived) {
+  const int64_t j = TID();
+  if (j >= L.tot_b) return;
+  const int64_t *w = L.words + 3 * L.tot_a + L.row * j;
+  if (!owned[w[2]]) return;
+  is_p[w[0]] = 1;
+  is_x[w[1]] = 1;
+  atomicAdd(n_arrived, 1ull);
+}
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_arrivals_lists(ShardLists L, const uint8_t *__restrict__ owned,
+                 const uint8_t *__restrict__ is_p, const uint8_t *__restrict__ is_x,
+                 const int32_t *__restrict__ inv, const int64_t *__restrict__ idx,
+                 const int64_t *__restrict__ cell_id, int32_t *__restrict__ free_slot,
+                 int64_t *__restrict__ free_cell, int32_t *__restrict__ homeless,
+                 unsigned long long *__restrict__ n) {  // n[0] free slots, n[1] homeless ids
+  const int64_t j = TID();
+  if (j >= L.tot_b) return;
+  const int64_t *w = L.words + 3 * L.tot_a + L.row * j;
+  if (!owned[w[2]]) return;
+  const int32_t at = inv[w[1]];
+  if (at >= 0 && !is_p[at]) {
+    const unsigned long long f = atomicAdd(&n[0], 1ull);
+    free_slot[f] = at;
+    free_cell[f] = cell_id[w[1]];
+  }
+  const int64_t there = idx[w[0]];
+  if (!is_x[there]) homeless[atomicAdd(&n[1], 1ull)] = (int32_t)there;
+}
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_arrivals_place(ShardLists L, const uint8_t *__restrict__ owned, int64_t *__restrict__ idx) {
+  const int64_t j = TID();
+  if (j >= L.tot_b) return;
+  const int64_t *w = L.words + 3 * L.tot_a + L.row * j;
+  if (owned[w[2]]) idx[w[0]] = w[1];
+}
+// (the homeless beyond the free slots leave the live set of this process: their places went to
+// arrivals that were not among its placeholders)
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_arrivals_fill(int64_t bound, const unsigned long long *__restrict__ n,
+                const int32_t *__restrict__ free_slot, const int64_t *__restrict__ free_cell,
+                const int32_t *__restrict__ homeless, int64_t *__restrict__ idx,
+                int64_t *__restrict__ cell_id) {
+  const int64_t j = TID();
+  if (j >= bound || j >= (int64_t)n[0]) return;
+  idx[free_slot[j]] = homeless[j];
+  cell_id[homeless[j]] = free_cell[j];
+}
+// everybody's list of changed cells: the id's own cell, and the cell id of whatever id stands at
+// that position here
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_apply_cells(ShardLists L, const int64_t *__restrict__ idx, int64_t *__restrict__ cell_id,
+              int64_t *__restrict__ cell_by_id) {
+  const int64_t j = TID();
+  if (j >= L.tot_a) return;
+  const int64_t *a = L.words + 3 * j;
+  cell_by_id[a[1]] = a[2];
+  if (a[0] >= 0) cell_id[idx[a[0]]] = a[2];
+}
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_apply_rows(ShardLists L, const uint8_t *__restrict__ owned, uint8_t *__restrict__ role,
+             int64_t *__restrict__ multiplicity, double *__restrict__ attributes,
+             int64_t *__restrict__ cell_origin, double *__restrict__ position_in_cell) {
+  const int64_t j = TID();
+  if (j >= L.tot_b) return;
+  const int64_t *w = L.words + 3 * L.tot_a + L.row * j;
+  if (!owned[w[2]]) return;
+  const int64_t k = w[1];
+  role[k] = 1;
+  multiplicity[k] = w[3];
+  for (int d = 0; d < L.n_dims; ++d) cell_origin[d * L.n_sd + k] = w[4 + d];
+  for (int x = 0; x < L.n_attr; ++x)
+    attributes[x * L.n_sd + k] = __longlong_as_double(w[4 + L.n_dims + x]);
+  for (int d = 0; d < L.n_dims; ++d)
+    position_in_cell[d * L.n_sd + k] = __longlong_as_double(w[4 + L.n_dims + L.n_attr + d]);
+}
+
+extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
+                                             const sdm_disp_state *state, sdm_disp_shard *sh,
+                                             double *rainfall_mass, int64_t *valid_n_sd) {
+  ARG_TRY(ctx && cfg && state && sh && rainfall_mass && valid_n_sd);
+  ARG_TRY(cfg->n_sd >= 1 && cfg->n_sd < INT32_MAX && cfg->n_dims >= 1 && cfg->n_dims <= 3);
+  ARG_TRY((cfg->scheme == 0 || cfg->scheme == 1) && cfg->n_substeps >= 1);
+  for (int d = 0; d < cfg->n_dims; ++d) ARG_TRY(cfg->grid[d] >= 1 && state->courant[d]);
+  ARG_TRY(state->displacement && state->position_in_cell && state->cell_origin &&
+          state->cell_id && state->water_mass && state->multiplicity && state->idx && state->ctl);
+  ARG_TRY(!cfg->enable_sedimentation || (state->fall_velocity && cfg->dt_over_dz != 0));
+  ARG_TRY(sh->cell_owned && sh->exchange && sh->xchg_counts && sh->xchg_words &&
+          sh->cell_id_by_id && sh->role && sh->multiplicity && sh->attributes);
+  ARG_TRY(sh->n_attr >= 1 && sh->shard_world >= 1 && sh->shard_world <= 256 &&
+          sh->shard_rank >= 0 && sh->shard_rank < sh->shard_world && sh->word_capacity >= 0);
+  const int64_t N = cfg->n_sd;
+  const int D = cfg->n_dims, W = sh->shard_world, R = sh->shard_rank;
+  const unsigned nb = grid_for(N);
+  const size_t need = carve_size(sizeof(double) * nb) + 256 + 256 + carve_size((size_t)N) +
+                      sdm_compact_scratch(N) + 2 * carve_size(sizeof(int64_t) * (size_t)N) +
+                      carve_size(sizeof(int32_t) * (size_t)N) + carve_size(2 * (size_t)N) +
+                      2 * carve_size(sizeof(int32_t) * (size_t)N) +
+                      carve_size(sizeof(int64_t) * (size_t)N) + 1024;
+  int rc = sdm_reserve(ctx, need);
+  if (rc) return rc;
+  Carver cv(ctx->arena);
+  DispArgs X;
+  X.cfg = *cfg;
+  X.st = *state;
+  X.partial = cv.take<double>(nb);
+  X.rain = cv.take<double>(1);
+  X.cls = cv.take<uint8_t>(N);
+  int64_t *cctl = cv.take<int64_t>(8);
+  char *compact = cv.take<char>(sdm_compact_scratch(N));
+  int64_t *cell0 = cv.take<int64_t>(N);
+  X.dead = cv.take<int64_t>(N);
+  int32_t *inv = cv.take<int32_t>(N);
+  uint8_t *mark = cv.take<uint8_t>(2 * (size_t)N);
+  int32_t *free_slot = cv.take<int32_t>(N), *homeless = cv.take<int32_t>(N);
+  int64_t *free_cell = cv.take<int64_t>(N);
+  unsigned long long *counters = cv.take<unsigned long long>(8);
+  double *part_rain = cv.take<double>(1);
+  X.n_dead = counters;  // [0]; [2], [3]: movers; [4], [5]: slices; [6]: arrivals; then [0], [1] again
+  X.role = sh->role;
+  X.cell_by_id = sh->cell_id_by_id;
+  const unsigned n_precip = nb < DISP_PRECIP_GRID ? nb : DISP_PRECIP_GRID;
+  hipStream_t s = ctx->stream;
+  const dim3 grid(nb), blk(SDM_BLOCK), one(1);
+  sh->n_moved = sh->n_left = sh->n_arrived = sh->n_words = sh->n_removed = 0;
+  if (!sh->role_ready) {
+    hipLaunchKernelGGL(k_role_init, grid, blk, 0, s, sh->role, sh->cell_owned, sh->cell_id_by_id, N);
+    hipLaunchKernelGGL(k_role_alive, grid, blk, 0, s, sh->role, state->idx, state->ctl);
+    LAUNCH_CHECK();
+    sh->role_ready = 1;
+  }
+  hipLaunchKernelGGL(k_shard_begin, grid, blk, 0, s, sh->role, (const int64_t *)sh->multiplicity,
+                     (const int64_t *)sh->cell_id_by_id, cell0, N);
+  LAUNCH_CHECK();
+  double rain = 0.0;
+  double host_counts[2 * 256 + 2];
+  // the positions listed by k_disp_precip / k_disp_column on every process -> flagged on every
+  // process -> the reference's compaction on every process's own permutation
+  auto remove_listed = [&](bool with_rain) -> int {
+    hipLaunchKernelGGL(k_pack_counts, one, dim3(320), 0, s, sh->xchg_counts, W, R,
+                       (const unsigned long long *)X.n_dead,
+                       (const double *)(with_rain ? part_rain : nullptr));
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemcpyAsync(ctx->mailbox, X.n_dead, sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, s));
+    if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_F64, sh->xchg_counts, W + 1) != 0) {
+      sdm_set_error("sharded displacement: the exchange callback failed (counts of the removed)");
+      return SDM_E_HIP;
+    }
+    HIP_TRY(hipMemcpyAsync(host_counts, sh->xchg_counts, sizeof(double) * (size_t)(W + 1),
+                           hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const int64_t mine = ctx->mailbox[0];
+    if (with_rain) rain += host_counts[W];
+    int64_t total = 0, before = 0;
+    for (int r = 0; r < W; ++r) {
+      if (r < R) before += (int64_t)host_counts[r];
+      total += (int64_t)host_counts[r];
+    }
+    HIP_TRY(hipMemsetAsync(X.n_dead, 0, sizeof(unsigned long long), s));
+    if (total == 0) return SDM_OK;
+    if (total > sh->word_capacity || total > N || before + mine > total) {
+      sdm_set_error("sharded displacement: word_capacity too small for %lld removed",
+                    (long long)total);
+      return SDM_E_ARG;
+    }
+    HIP_TRY(hipMemsetAsync(sh->xchg_words, 0, sizeof(int64_t) * (size_t)total, s));
+    if (mine > 0) {
+      hipLaunchKernelGGL(k_copy_i64, dim3(grid_for(mine)), blk, 0, s, sh->xchg_words + before,
+                         (const int64_t *)X.dead, mine);
+      LAUNCH_CHECK();
+    }
+    if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_I64, sh->xchg_words, total) != 0) {
+      sdm_set_error("sharded displacement: the exchange callback failed (positions of the removed)");
+      return SDM_E_HIP;
+    }
+    sh->n_words += total;
+    sh->n_removed += total;
+    hipLaunchKernelGGL(k_flag_positions, dim3(grid_for(total)), blk, 0, s, state->idx,
+                       (const int64_t *)sh->xchg_words, total, N, state->ctl);
+    LAUNCH_CHECK();
+    return sdm_compact_fused_async(ctx, compact, state->multiplicity, state->idx, N, N,
+                                   state->ctl, cctl, nullptr, true);
+  };
+  HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 8, s));
+  for (int sub = 0; sub < cfg->n_substeps; ++sub) {
+    hipLaunchKernelGGL(k_disp_move, grid, blk, 0, s, X);
+    if (cfg->enable_sedimentation) {
+      hipLaunchKernelGGL(k_disp_precip, dim3(n_precip), blk, 0, s, X);
+      hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(1024), 0, s, X.partial,
+                         (int64_t)n_precip, part_rain, 0);
+      LAUNCH_CHECK();
+      rc = remove_listed(true);
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_disp_column, grid, blk, 0, s, X);
+    LAUNCH_CHECK();
+    rc = remove_listed(false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_disp_cells, grid, blk, 0, s, X);
+    LAUNCH_CHECK();
+  }
+  // ---- who changed cell, who changed owner ----------------------------------------------------
+  ShardLists L;
+  L.words = sh->xchg_words;
+  L.row = 4 + D + sh->n_attr + D;
+  L.n_dims = D;
+  L.n_attr = sh->n_attr;
+  L.n_sd = N;
+  HIP_TRY(hipMemsetAsync(inv, 0xff, sizeof(int32_t) * (size_t)N, s));
+  hipLaunchKernelGGL(k_inverse, grid, blk, 0, s, inv, (const int64_t *)state->idx,
+                     (const int64_t *)state->ctl);
+  hipLaunchKernelGGL(k_count_movers, grid, blk, 0, s, (const uint8_t *)sh->role, sh->cell_owned,
+                     (const int64_t *)sh->cell_id_by_id, (const int64_t *)cell0, N, counters + 2);
+  hipLaunchKernelGGL(k_pack_counts2, one, dim3(512), 0, s, sh->xchg_counts, W, R,
+                     (const unsigned long long *)(counters + 2));
+  LAUNCH_CHECK();
+  HIP_TRY(hipMemcpyAsync(ctx->mailbox, counters + 2, 2 * sizeof(unsigned long long),
+                         hipMemcpyDeviceToHost, s));
+  if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_F64, sh->xchg_counts, 2 * W) != 0) {
+    sdm_set_error("sharded displacement: the exchange callback failed (counts of the movers)");
+    return SDM_E_HIP;
+  }
+  HIP_TRY(hipMemcpyAsync(host_counts, sh->xchg_counts, sizeof(double) * (size_t)(2 * W),
+                         hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  sh->n_moved = ctx->mailbox[0];
+  sh->n_left = ctx->mailbox[1];
+  int64_t tot_a = 0, tot_b = 0, at_a = 0, at_b = 0;
+  for (int r = 0; r < W; ++r) {
+    if (r < R) { at_a += (int64_t)host_counts[r]; at_b += (int64_t)host_counts[W + r]; }
+    tot_a += (int64_t)host_counts[r];
+    tot_b += (int64_t)host_counts[W + r];
+  }
+  L.tot_a = tot_a;
+  L.tot_b = tot_b;
+  const int64_t words = 3 * tot_a + L.row * tot_b;
+  if (words > sh->word_capacity || tot_a > 2 * N || tot_b > N) {
+    sdm_set_error("sharded displacement: word_capacity too small (%lld words needed)",
+                  (long long)words);
+    return SDM_E_ARG;
+  }
+  if (words > 0) {
+    HIP_TRY(hipMemsetAsync(sh->xchg_words, 0, sizeof(int64_t) * (size_t)words, s));
+    const unsigned long long begin[2] = {(unsigned long long)at_a, (unsigned long long)at_b};
+    HIP_TRY(hipMemcpyAsync(counters + 4, begin, sizeof(begin), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_list_movers, grid, blk, 0, s, L, sh->role, sh->cell_owned,
+                       (const int64_t *)sh->cell_id_by_id, (const int64_t *)cell0,
+                       (const int32_t *)inv, (const int64_t *)sh->multiplicity,
+                       (const double *)sh->attributes, (const int64_t *)state->cell_origin,
+                       (const double *)state->position_in_cell, counters + 4);
+    LAUNCH_CHECK();
+    HIP_TRY(hipStreamSynchronize(s));  // (`begin` is on this frame)
+    if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_I64, sh->xchg_words, words) != 0) {
+      sdm_set_error("sharded displacement: the exchange callback failed (rows)");
+      return SDM_E_HIP;
+    }
+    sh->n_words += words;
+    if (tot_b > 0) {
+      const dim3 gb(grid_for(tot_b));
+      HIP_TRY(hipMemsetAsync(mark, 0, 2 * (size_t)N, s));
+      HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 2, s));
+      HIP_TRY(hipMemsetAsync(counters + 6, 0, sizeof(unsigned long long), s));
+      hipLaunchKernelGGL(k_arrivals_mark, gb, blk, 0, s, L, sh->cell_owned, mark, mark + N,
+                         counters + 6);
+      hipLaunchKernelGGL(k_arrivals_lists, gb, blk, 0, s, L, sh->cell_owned,
+                         (const uint8_t *)mark, (const uint8_t *)(mark + N), (const int32_t *)inv,
+                         (const int64_t *)state->idx, (const int64_t *)state->cell_id, free_slot,
+                         free_cell, homeless, counters);
+      hipLaunchKernelGGL(k_arrivals_place, gb, blk, 0, s, L, sh->cell_owned, state->idx);
+      hipLaunchKernelGGL(k_arrivals_fill, gb, blk, 0, s, tot_b,
+                         (const unsigned long long *)counters, (const int32_t *)free_slot,
+                         (const int64_t *)free_cell, (const int32_t *)homeless, state->idx,
+                         state->cell_id);
+      LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_apply_cells, dim3(grid_for(tot_a)), blk, 0, s, L,
+                       (const int64_t *)state->idx, state->cell_id, sh->cell_id_by_id);
+    LAUNCH_CHECK();
+    if (tot_b > 0) {
+      hipLaunchKernelGGL(k_apply_rows, dim3(grid_for(tot_b)), blk, 0, s, L, sh->cell_owned,
+                         sh->role, sh->multiplicity, sh->attributes, state->cell_origin,
+                         state->position_in_cell);
+      LAUNCH_CHECK();
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->mailbox, counters + 6, sizeof(unsigned long long),
+                         hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(ctx->mailbox + 1, state->ctl, sizeof(int64_t) * 8,
+                         hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  sh->n_arrived = tot_b > 0 ? ctx->mailbox[0] : 0;
+  *rainfall_mass = rain;
   *valid_n_sd = ctx->mailbox[1];
   if (ctx->mailbox[1 + 7] != 0) {
     sdm_set_error("displacement: grid barrier of the compaction kernel timed out");

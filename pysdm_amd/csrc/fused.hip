@@ -2032,7 +2032,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   A.multiplicity = st->multiplicity;
   A.attributes = st->attributes;
   A.cell_id = st->cell_id;
-  A.cell_id_raw = ctx->cell_id_raw ? ctx->cell_id_raw : st->cell_id;
+  // (a sharded run with a sharded displacement step keeps every id's own cell apart from the
+  // column the permutation is sorted by: sdm_hip.h, sdm_step_state.cell_id_by_id)
+  A.cell_id_raw = ctx->cell_id_raw ? ctx->cell_id_raw
+                                   : (st->cell_id_by_id ? st->cell_id_by_id : st->cell_id);
   A.cell_idx = st->cell_idx;
   A.cell_start = st->cell_start;
   A.dt_left = st->dt_left;
@@ -3127,7 +3130,7 @@ static int relabel_enter(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *
   R->inner.attributes = R->attributes;
   R->inner.cell_id = R->cell_id;
   R->inner.nm = R->nm;
-  ctx->cell_id_raw = st->cell_id;
+  ctx->cell_id_raw = st->cell_id_by_id ? st->cell_id_by_id : st->cell_id;
   // what the step just done left for the next one is as true of the copy
   ctx->carry.owner = &R->inner;
   if (ctx->lists.active) ctx->lists.owner = &R->inner;

@@ -69,6 +69,11 @@ class DisplacementRunner:  # pylint: disable=too-many-instance-attributes
         self.strides = eng.upload(grid_strides(self.grid))
         self.ctl = eng.zeros(8, INT)
         self.law = LAWS[terminal_velocity](eng) if enable_sedimentation else None
+        # a sharded run (pysdm_amd.sharding.attach_displacement): this process moves the
+        # super-droplets of its own cells, `sdm_displacement_step_sharded`
+        self.shard = None
+        self.shard_stats = {"moved": 0, "left": 0, "arrived": 0, "words": 0, "removed": 0,
+                            "calls": 0}
 
     def set_courant(self, courant_field):
         """component d on the cell faces normal to d: grid shape with one more point along d"""
@@ -126,7 +131,37 @@ class DisplacementRunner:  # pylint: disable=too-many-instance-attributes
                                                    dtype=np.int64)))
         state.ctl = address(self.ctl)
         rainfall, survivors = ctypes.c_double(), ctypes.c_int64()
-        eng.call("sdm_displacement_step", cfg, state, rainfall, survivors)
+        if self.shard is None:
+            eng.call("sdm_displacement_step", cfg, state, rainfall, survivors)
+        else:
+            shard = self.shard
+            n_attr = int(pop.extensive.shape[0])
+            counts, words = shard.displacement_buffers(
+                pop.n_sd * (7 + 2 * self.n_dims + n_attr))
+            if pop.cell_id_by_id is None:  # until now every id's cell_id entry was its own cell
+                pop.cell_id_by_id = (pop.cell_id.clone() if hasattr(pop.cell_id, "clone")
+                                     else pop.cell_id.copy())
+            part = abi.DispShard()
+            part.cell_owned, part.n_cell = address(shard.owned), pop.n_cell
+            part.exchange = ctypes.cast(shard.callback, ctypes.c_void_p)
+            part.exchange_user = None
+            part.shard_rank, part.shard_world = shard.rank, shard.world
+            part.xchg_counts, part.xchg_words = address(counts), address(words)
+            part.word_capacity = int(words.shape[0])
+            part.cell_id_by_id = address(pop.cell_id_by_id)
+            part.role, part.role_ready = address(shard.role), int(shard.role_ready)
+            part.multiplicity, part.attributes = address(pop.multiplicity), address(pop.extensive)
+            part.n_attr = n_attr
+            shard.error = None
+            try:
+                eng.call("sdm_displacement_step_sharded", cfg, state, part, rainfall, survivors)
+            except RuntimeError as error:
+                raise (shard.error or error) from error
+            for key in ("moved", "left", "arrived", "words", "removed"):
+                self.shard_stats[key] += int(getattr(part, "n_" + key))
+            self.shard_stats["calls"] += 1
+            shard.role_ready = True
+            pop.touch_state()  # rows of arriving super-droplets: the collision step's mirror
         pop.live = pop.working = survivors.value
         self.precipitation_mass_in_last_step = rainfall.value
 

@@ -121,6 +121,7 @@ class Population:  # pylint: disable=too-many-instance-attributes
         # `host_dirty`, and the next fused call starts from the host's view again
         self.host_dirty = True
         self.bookkeeping_stale = False  # see refresh_bookkeeping
+        self.cell_id_by_id = None  # sharded runs with a sharded displacement step (displacement.py)
         self.mirror_version = None   # state_version the mirror records were built from
         if (multiplicity == 0).any():  # unused slots: compact them away before the first step
             self.compact(assume_unhealthy=True)
@@ -150,6 +151,7 @@ class Population:  # pylint: disable=too-many-instance-attributes
         self._derived = {}
         self.host_dirty = True
         self.bookkeeping_stale = False
+        self.cell_id_by_id = None
         self.mirror_version = None
         return self
 

@@ -48,6 +48,9 @@ class Shard:  # pylint: disable=too-many-instance-attributes
         self.owned = engine.upload(mask)
         self.x_cells = engine.zeros(n_cell + 1 + world, np.float64)
         self.x_idx = engine.zeros(n_sd, np.int64)
+        self.d_counts = self.d_words = None  # (displacement_buffers)
+        self.role = engine.zeros(n_sd, np.uint8)  # sdm_disp_shard.role, filled by the library
+        self.role_ready = False
         self.calls = {abi.XCHG_SUM_F64: 0, abi.XCHG_SUM_I64: 0}
         self.bytes = {abi.XCHG_SUM_F64: 0, abi.XCHG_SUM_I64: 0}  # payload handed to collectives
         self.error = None
@@ -56,11 +59,26 @@ class Shard:  # pylint: disable=too-many-instance-attributes
     def _as_tensor(self, array):
         return array if hasattr(array, "data_ptr") else self.torch.from_numpy(array)
 
+    @staticmethod
+    def _address(buffer):
+        return buffer.data_ptr() if hasattr(buffer, "data_ptr") else buffer.ctypes.data
+
+    def displacement_buffers(self, n_words):
+        """scratch of the sharded displacement step (sdm_disp_shard): counts, and `n_words` int64
+        for positions and rows; allocated on first use, kept"""
+        if self.d_counts is None:
+            self.d_counts = self.engine.zeros(2 * self.world + 2, np.float64)
+        if self.d_words is None or int(self.d_words.shape[0]) < n_words:
+            self.d_words = self.engine.zeros(n_words, np.int64)
+        return self.d_counts, self.d_words
+
     def _exchange(self, _user, what, pointer, count):
         try:
-            buffer = self.x_cells if what == abi.XCHG_SUM_F64 else self.x_idx
-            address = buffer.data_ptr() if hasattr(buffer, "data_ptr") else buffer.ctypes.data
-            if address != pointer:
+            candidates = ((self.x_cells, self.d_counts) if what == abi.XCHG_SUM_F64
+                          else (self.x_idx, self.d_words))
+            buffer = next((b for b in candidates
+                           if b is not None and self._address(b) == pointer), None)
+            if buffer is None:
                 raise RuntimeError("exchange called with a foreign buffer")
             self.calls[what] += 1
             self.bytes[what] += 8 * int(count)
@@ -112,25 +130,55 @@ def attach(runner, rank, world, group=None):
 
 def owned_droplets(runner):
     """boolean mask over the global super-droplet ids: those living in this process's cells"""
-    cell_id = runner.engine.download(runner.population.cell_id)
+    pop = runner.population
+    cell_id = runner.engine.download(pop.cell_id if pop.cell_id_by_id is None
+                                     else pop.cell_id_by_id)
     return runner.shard.owned_host[cell_id]
 
 
-def gather(runner):
-    """the global snapshot put together from the owners: multiplicities / attributes of every
-    super-droplet from the process owning its cell, per-cell diagnostics from the cell's owner;
-    permutation and cell_start are global already.  Identical on every process."""
-    shard = runner.shard
-    snap = runner.snapshot()
-    mine = owned_droplets(runner)
-    snap["multiplicity"] = shard.sum(np.where(mine, snap["multiplicity"], 0))
-    snap["attributes"] = shard.sum(np.where(mine[None, :], snap["attributes"], 0.0))
-    # the permutation: each owner's segments (the other segments hold the right members in an
-    # arbitrary order on this process)
+def gather_population(shard, population):
+    """the global population put together from the owners, identical on every process: rows
+    (multiplicity, attributes, cell id and - where the population has them - cell origin and
+    position in cell) of every super-droplet from the process owning its cell, the permutation
+    from the owners of its positions.  (Rows of super-droplets that are no longer alive hold
+    whatever their last owner left there.)"""
+    down = population.engine.download
+    # (not population.snapshot(): that one sorts by cell first, and the state is gathered as it is)
+    snap = {"idx": down(population.perm), "length": np.asarray(population.live)}
+    cells = down(population.cell_id if population.cell_id_by_id is None
+                 else population.cell_id_by_id)
+    if shard.role_ready:
+        # after a sharded displacement step ownership is a record, not a look-up: an id may stand
+        # in this process's permutation as a placeholder while its own (removed) self drifts
+        # through this process's cells.  role 1 = alive here, 2 = removed here, still moved here
+        role = down(shard.role)
+        mine, alive = role != 0, role == 1
+    else:
+        mine = alive = shard.owned_host[cells]
+    snap["multiplicity"] = shard.sum(np.where(mine, down(population.multiplicity), 0))
+    snap["attributes"] = shard.sum(np.where(mine[None, :], down(population.extensive), 0.0))
+    snap["cell_id"] = cells  # (every id's own cell: the same column on every process)
+    if population.cell_origin is not None:
+        snap["cell_origin"] = shard.sum(np.where(mine[None, :], down(population.cell_origin), 0))
+        snap["position_in_cell"] = shard.sum(
+            np.where(mine[None, :], down(population.position_in_cell), 0.0))
+    # the permutation: each owner's positions (the others hold placeholders on this process)
     length = int(snap["length"])
     idx = snap["idx"][:length]
-    live_mine = mine[idx]
+    live_mine = alive[idx]
     snap["idx"] = np.concatenate([shard.sum(np.where(live_mine, idx, 0)), snap["idx"][length:]])
+    return snap
+
+
+def gather(runner):
+    """the global snapshot put together from the owners: the population (gather_population),
+    per-cell diagnostics from the cell's owner.  Identical on every process."""
+    shard = runner.shard
+    # (the population first: `snapshot` reads the permutation, then sorts for its cell_start)
+    whole = gather_population(shard, runner.population)
+    snap = runner.snapshot()
+    for key in ("idx", "length", "multiplicity", "attributes"):  # (cells, positions: see there)
+        snap[key] = whole[key]
     for key in ("collision_rate", "collision_rate_deficit", "coalescence_rate", "breakup_rate",
                 "breakup_rate_deficit"):
         if key in snap:
@@ -140,6 +188,16 @@ def gather(runner):
         owned_min = np.where(shard.owned_host, snap["stats_dt_min"], 0.0)
         snap["stats_dt_min"] = shard.sum(owned_min)
     return snap
+
+
+def attach_displacement(displacement, shard):
+    """the displacement step of a sharded run: this process moves the super-droplets of its own
+    cells and hands over those that leave them (sdm_displacement_step_sharded); `shard`: the
+    collision runner's (`runner.shard`), or a Shard of its own for a run without collisions"""
+    if displacement.route != "fused":
+        raise ValueError("sharding drives the fused route")
+    displacement.shard = shard
+    return displacement
 
 
 def make_sharded_box(engine, name, *, rank, world, n_sd=None, adaptive=None, seed=44, dt=None,

@@ -18,9 +18,12 @@ CASES = ("disp1d_implicit_sed", "disp2d_implicit_sed", "disp2d_explicit", "disp3
          "disp2d_collide")
 
 
-def run_case(name, engine, route="fused", shard=None):
-    """`shard` = (rank, world): the collision step sharded over the processes, the displacement
-    step replicated on the state completed from the owners (pysdm_amd.sharding)"""
+def run_case(name, engine, route="fused", shard=None, owner_moves=False, group=None):
+    """`shard` = (rank, world): the collision step sharded over the processes; the displacement
+    step either replicated on the state completed from the owners (`complete_state`), or - with
+    `owner_moves` - sharded as well: every process moves the super-droplets of its own cells and
+    hands over those that leave them (sdm_displacement_step_sharded), and the state compared with
+    the golden is the one gathered from the owners.  Returns the displacement runner."""
     gold = np.load(os.path.join(GOLDEN, f"traj_{name}.npz"))
     n_sd, dt, explicit, sed, adaptive, collide, steps = gold["cfg"]
     steps = int(steps)
@@ -41,10 +44,16 @@ def run_case(name, engine, route="fused", shard=None):
         collisions = CollisionRunner(
             population, R.CollisionSetup.coalescence(R.Geometric(), adaptive=True, seed=44),
             dt=float(dt), dv=dv, route=route)
+    part = None
     if shard is not None:
         from pysdm_amd import sharding  # pylint: disable=import-outside-toplevel
 
-        sharding.attach(collisions, *shard)
+        if collisions is not None:
+            part = sharding.attach(collisions, *shard, group=group).shard
+        else:
+            part = sharding.Shard(engine, population.n_sd, population.n_cell, *shard, group=group)
+        if owner_moves:
+            sharding.attach_displacement(displacement, part)
     displacement.set_courant(tuple(gold[f"courant/{d}"] for d in range(len(grid))))
     assert displacement.n_substeps == int(gold["n_substeps"])
     down = engine.download
@@ -54,12 +63,16 @@ def run_case(name, engine, route="fused", shard=None):
             displacement.run()
             if collisions is not None:
                 collisions.run(1)
-                if shard is not None:
+                if shard is not None and not owner_moves:
                     sharding.complete_state(collisions)
         population.compact()
         tag = f"{name} step {step}"
         length = population.live
         assert length == int(gold[f"step{step}/length"]), tag
+        if owner_moves:
+            whole = sharding.gather_population(part, population)
+            _compare(whole, length, displacement.precipitation_mass_in_last_step, gold, step, tag)
+            continue
         live = down(population.perm)[:length]
         np.testing.assert_array_equal(live, gold[f"step{step}/idx"][:length], err_msg=tag)
         np.testing.assert_allclose(displacement.precipitation_mass_in_last_step,
@@ -77,3 +90,24 @@ def run_case(name, engine, route="fused", shard=None):
             else:
                 np.testing.assert_allclose(actual, expected, rtol=1e-12, atol=1e-13,
                                            err_msg=f"{tag} {short}")
+    return displacement
+
+
+def _compare(whole, length, precipitation, gold, step, tag):
+    """the state gathered from the owners of a sharded run against the golden"""
+    live = whole["idx"][:length]
+    np.testing.assert_array_equal(live, gold[f"step{step}/idx"][:length], err_msg=tag)
+    np.testing.assert_allclose(precipitation, float(gold[f"step{step}/precipitation"]),
+                               rtol=1e-12, err_msg=tag)
+    for key, short, exact in (("cell_origin", "cell_origin", True), ("cell_id", "cell_id", True),
+                              ("multiplicity", "multiplicity", True),
+                              ("position_in_cell", "position", False)):
+        actual, expected = whole[key][..., live], gold[f"step{step}/{short}"][..., live]
+        if exact:
+            np.testing.assert_array_equal(actual, expected, err_msg=f"{tag} {short}")
+        else:
+            np.testing.assert_allclose(actual, expected, rtol=1e-12, atol=1e-13,
+                                       err_msg=f"{tag} {short}")
+    np.testing.assert_allclose(whole["attributes"][0][live], gold[f"step{step}/mass"][live],
+                               rtol=1e-12, atol=1e-13, err_msg=f"{tag} mass")
+

@@ -26,8 +26,9 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     source = (
         '#include "include/sdm_hip.h"\n#include <stdio.h>\n'
-        'int main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(sdm_step_cfg), sizeof(sdm_step_state),'
-        " sizeof(sdm_step_result), sizeof(sdm_disp_cfg), sizeof(sdm_disp_state));return 0;}\n"
+        'int main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(sdm_step_cfg), sizeof(sdm_step_state),'
+        " sizeof(sdm_step_result), sizeof(sdm_disp_cfg), sizeof(sdm_disp_state),"
+        " sizeof(sdm_disp_shard));return 0;}\n"
     )
     with tempfile.TemporaryDirectory() as tmp:
         src, exe = os.path.join(tmp, "sz.c"), os.path.join(tmp, "sz")
@@ -36,7 +37,7 @@ def test_struct_layouts_match_the_header():
         subprocess.check_call(["gcc", "-I", ROOT, src, "-o", exe], cwd=ROOT)
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
     assert sizes == [ctypes.sizeof(t) for t in (abi.StepCfg, abi.StepState, abi.StepResult,
-                                                abi.DispCfg, abi.DispState)]
+                                                abi.DispCfg, abi.DispState, abi.DispShard)]
 
 
 def test_error_reporting_without_a_gpu_call():

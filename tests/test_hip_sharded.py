@@ -97,6 +97,17 @@ def _worker(rank, world, port, errors):
 
         stage("displacement + collisions")
         displacement_cases.run_case("disp2d_collide", engine, shard=(rank, world))
+        # the displacement step sharded as well (sdm_displacement_step_sharded): every process
+        # moves its own super-droplets, rows and positions of those that change owner cross the
+        # processes, nothing the size of a column does
+        for name in displacement_cases.CASES:
+            stage(f"sharded displacement: {name}")
+            moved = displacement_cases.run_case(name, engine, shard=(rank, world),
+                                                owner_moves=True)
+            stats = moved.shard_stats
+            assert stats["moved"] > 0 and stats["calls"] > 0, stats
+            if name != "disp1d_implicit_sed":
+                assert stats["removed"] > 0 and stats["left"] + stats["arrived"] > 0, stats
         stage("done")
         dist.barrier()
         dist.destroy_process_group()

@@ -95,6 +95,14 @@ def _worker(rank, world, port, errors):
         from . import displacement_cases  # pylint: disable=import-outside-toplevel
 
         displacement_cases.run_case("disp2d_collide", engine, shard=(rank, world))
+        # the displacement step sharded as well (sdm_displacement_step_sharded)
+        for name in displacement_cases.CASES:
+            moved = displacement_cases.run_case(name, engine, shard=(rank, world),
+                                                owner_moves=True)
+            stats = moved.shard_stats
+            assert stats["moved"] > 0 and stats["calls"] > 0, stats
+            if name != "disp1d_implicit_sed":
+                assert stats["removed"] > 0 and stats["left"] + stats["arrived"] > 0, stats
         dist.barrier()
         dist.destroy_process_group()
     except Exception as exc:  # pylint: disable=broad-except
