@@ -111,3 +111,43 @@ def _compare(whole, length, precipitation, gold, step, tag):
     np.testing.assert_allclose(whole["attributes"][0][live], gold[f"step{step}/mass"][live],
                                rtol=1e-12, atol=1e-13, err_msg=f"{tag} mass")
 
+
+
+def sharded_flow_equals_single(engine, rank, world, *, n_sd, grid, steps, group=None):
+    """the 2-D kinematic set-up (single-eddy flow + sedimentation, then adaptive Geometric
+    coalescence: pysdm_amd.cases.make_kinematic_flow) with BOTH steps sharded, beside the
+    one-process run on the same engine: after every step the state gathered from the owners must
+    be the one-process state - ids, positions in the permutation, multiplicities, attributes,
+    cells and positions to the bit; the rainfall within 1e-12.  Returns the exchange statistics."""
+    from pysdm_amd import cases, sharding  # pylint: disable=import-outside-toplevel
+
+    size = (1500.0, 1500.0)
+    single_d, single_c = cases.make_kinematic_flow(engine, n_sd=n_sd, grid=grid, size=size)
+    shard_d, shard_c = cases.make_kinematic_flow(engine, n_sd=n_sd, grid=grid, size=size)
+    part = sharding.attach(shard_c, rank, world, group=group).shard
+    sharding.attach_displacement(shard_d, part)
+    down = engine.download
+    for step in range(1, steps + 1):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rain = (single_d.run(), shard_d.run())
+            single_c.run(1)
+            shard_c.run(1)
+        np.testing.assert_allclose(rain[1], rain[0], rtol=1e-12, err_msg=f"step {step} rain")
+        pop = single_c.population
+        whole = sharding.gather_population(part, shard_c.population)
+        length = pop.live
+        assert int(whole["length"]) == length, f"step {step}"
+        live = down(pop.perm)[:length]
+        np.testing.assert_array_equal(whole["idx"][:length], live, err_msg=f"step {step} idx")
+        np.testing.assert_array_equal(whole["cell_id"], down(pop.cell_id),
+                                      err_msg=f"step {step} cells of all ids")
+        for key, column in (("multiplicity", pop.multiplicity), ("attributes", pop.extensive),
+                            ("cell_origin", pop.cell_origin),
+                            ("position_in_cell", pop.position_in_cell)):
+            np.testing.assert_array_equal(whole[key][..., live], down(column)[..., live],
+                                          err_msg=f"step {step} {key}")
+        assert shard_c.sub_steps_done == single_c.sub_steps_done, f"step {step}"
+    stats = dict(shard_d.shard_stats)
+    stats["collision_exchange_bytes"] = sum(part.bytes.values())
+    return stats

@@ -108,7 +108,11 @@ def _worker(rank, world, port, errors):
             assert stats["moved"] > 0 and stats["calls"] > 0, stats
             if name != "disp1d_implicit_sed":
                 assert stats["removed"] > 0 and stats["left"] + stats["arrived"] > 0, stats
-        stage("done")
+        stage("sharded flow at 2^18 beside the one-process run")
+        stats = displacement_cases.sharded_flow_equals_single(engine, rank, world, n_sd=2**18,
+                                                              grid=(16, 16), steps=5)
+        assert stats["left"] > 0 and stats["arrived"] > 0 and stats["removed"] > 0, stats
+        stage(f"done {stats}")
         dist.barrier()
         dist.destroy_process_group()
     except Exception as exc:  # pylint: disable=broad-except

@@ -103,6 +103,10 @@ def _worker(rank, world, port, errors):
             assert stats["moved"] > 0 and stats["calls"] > 0, stats
             if name != "disp1d_implicit_sed":
                 assert stats["removed"] > 0 and stats["left"] + stats["arrived"] > 0, stats
+        # ... and beside the one-process run of the 2-D kinematic set-up (eddy + sedimentation)
+        stats = displacement_cases.sharded_flow_equals_single(engine, rank, world, n_sd=2**13,
+                                                              grid=(8, 8), steps=6)
+        assert stats["left"] > 0 and stats["arrived"] > 0 and stats["removed"] > 0, stats
         dist.barrier()
         dist.destroy_process_group()
     except Exception as exc:  # pylint: disable=broad-except
