@@ -500,9 +500,9 @@ int sdm_displacement_step(sdm_ctx *ctx, const sdm_disp_cfg *cfg, const sdm_disp_
  *     rank-disjoint slices, exactly as in the collision step, and every process runs the
  *     reference's compaction on its own permutation.  Positions are the global names: a filler
  *     taken from the tail lands in the same hole on every process;
- *   - at the end, per super-droplet whose cell changed: {position, id, new cell} to everybody
- *     (cell_id_by_id[id] takes the new cell, and so does the cell_id entry of the placeholder at
- *     that position), and for those that changed OWNER the row itself - {position, id, new cell,
+ *   - at the end, per super-droplet whose cell changed: {position and id (one word), new cell} to
+ *     everybody (cell_id_by_id[id] takes the new cell, and so does the cell_id entry of the
+ *     placeholder at that position), and for those that changed OWNER the row itself - {position, id, new cell,
  *     multiplicity, cell origin; attributes and position in cell as bit patterns} - which the new
  *     owner stores under the true id, at the true position (the placeholders involved trade
  *     places among themselves).  One sum of 2 * world doubles (the counts) and one of exactly the
@@ -525,7 +525,7 @@ typedef struct sdm_disp_shard {
   int32_t shard_rank, shard_world;
   double *xchg_counts;        /* [2 * shard_world + 2] scratch for the counts */
   int64_t *xchg_words;        /* [word_capacity] scratch for positions / rows */
-  int64_t word_capacity;      /* SDM_E_ARG if a step needs more (n_sd * (7 + 2 * n_dims + n_attr)
+  int64_t word_capacity;      /* SDM_E_ARG if a step needs more (n_sd * (6 + 2 * n_dims + n_attr)
                                  always suffices) */
   int64_t *cell_id_by_id;     /* [n_sd] every id's own cell (see sdm_step_state); initially a
                                  copy of cell_id */

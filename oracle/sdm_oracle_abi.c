@@ -1360,20 +1360,20 @@ API int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
       tot_a += (int64_t)x[r];
       tot_b += (int64_t)x[W + r];
     }
-    const int64_t words = 3 * tot_a + row * tot_b;
+    /* a changed cell travels as two words: (position + 1) << 32 | id, new cell (n_sd < 2^31) */
+    const int64_t words = 2 * tot_a + row * tot_b;
     if (rc == SDM_OK && words > sh->word_capacity) {
       rc = SDM_E_ARG;
       snprintf(g_err, sizeof(g_err), "sharded displacement: word_capacity too small");
     }
     if (rc == SDM_OK && words > 0) {
-      int64_t *y = sh->xchg_words, *b = y + 3 * tot_a;
+      int64_t *y = sh->xchg_words, *b = y + 2 * tot_a;
       for (int64_t i = 0; i < words; ++i) y[i] = 0;
       for (int64_t k = 0; k < N; ++k) {
         const int64_t to = sh->cell_id_by_id[k];
         if (!mine[k] || to == cell0[k]) continue;
-        y[3 * at_a] = role[k] == 1 ? inv[k] : -1;
-        y[3 * at_a + 1] = k;
-        y[3 * at_a + 2] = to;
+        y[2 * at_a] = (((role[k] == 1 ? inv[k] : -1) + 1) << 32) | k;
+        y[2 * at_a + 1] = to;
         ++at_a;
         if (role[k] != 1 || sh->cell_owned[to]) continue;
         role[k] = 0; /* it goes on as a placeholder here */
@@ -1431,8 +1431,9 @@ API int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
         /* everybody's list of changed cells: the id's own cell, and the cell id of whatever id
          * stands at that position here */
         for (int64_t j = 0; j < tot_a && rc == SDM_OK; ++j) {
-          sh->cell_id_by_id[y[3 * j + 1]] = y[3 * j + 2];
-          if (y[3 * j] >= 0) st->cell_id[st->idx[y[3 * j]]] = y[3 * j + 2];
+          const int64_t at = (y[2 * j] >> 32) - 1, id = y[2 * j] & 0xffffffffLL;
+          sh->cell_id_by_id[id] = y[2 * j + 1];
+          if (at >= 0) st->cell_id[st->idx[at]] = y[2 * j + 1];
         }
         for (int64_t j = 0; j < tot_b && rc == SDM_OK; ++j) {
           const int64_t *w = b + row * j;

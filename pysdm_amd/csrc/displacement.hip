@@ -403,7 +403,7 @@ extern "C" int sdm_displacement_step(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
 // filled through an atomic counter: its order differs from run to run and does not matter (the
 // positions of the removed are a set; the placeholders that trade places are interchangeable).
 struct ShardLists {
-  int64_t *words;      // the exchange buffer: [3 x all movers][row x all that changed owner]
+  int64_t *words;      // the exchange buffer: [2 x all movers][row x all that changed owner]
   int64_t row;         // words per row
   int64_t tot_a, tot_b;
   int n_dims, n_attr;
@@ -499,13 +499,13 @@ k_list_movers(ShardLists L, uint8_t *__restrict__ role, const uint8_t *__restric
   if (to == cell0[k]) return;
   const bool alive = role[k] == 1;
   const int64_t p = alive ? (int64_t)inv[k] : -1;
-  int64_t *a = L.words + 3 * (int64_t)atomicAdd(&at[0], 1ull);
-  a[0] = p;
-  a[1] = k;
-  a[2] = to;
+  // a changed cell travels as two words: (position + 1) << 32 | id, new cell (n_sd < 2^31)
+  int64_t *a = L.words + 2 * (int64_t)atomicAdd(&at[0], 1ull);
+  a[0] = ((p + 1) << 32) | k;
+  a[1] = to;
   if (!alive || owned[to]) return;
   role[k] = 0;  // it goes on as a placeholder here
-  int64_t *w = L.words + 3 * L.tot_a + L.row * (int64_t)atomicAdd(&at[1], 1ull);
+  int64_t *w = L.words + 2 * L.tot_a + L.row * (int64_t)atomicAdd(&at[1], 1ull);
   w[0] = p;
   w[1] = k;
   w[2] = to;
@@ -523,7 +523,7 @@ k_arrivals_mark(ShardLists L, const uint8_t *__restrict__ owned, uint8_t *__rest
                 uint8_t *__restrict__ is_x, unsigned long long *__restrict__ n_arrived) {
   const int64_t j = TID();
   if (j >= L.tot_b) return;
-  const int64_t *w = L.words + 3 * L.tot_a + L.row * j;
+  const int64_t *w = L.words + 2 * L.tot_a + L.row * j;
   if (!owned[w[2]]) return;
   is_p[w[0]] = 1;
   is_x[w[1]] = 1;
@@ -538,7 +538,7 @@ k_arrivals_lists(ShardLists L, const uint8_t *__restrict__ owned,
                  unsigned long long *__restrict__ n) {  // n[0] free slots, n[1] homeless ids
   const int64_t j = TID();
   if (j >= L.tot_b) return;
-  const int64_t *w = L.words + 3 * L.tot_a + L.row * j;
+  const int64_t *w = L.words + 2 * L.tot_a + L.row * j;
   if (!owned[w[2]]) return;
   const int32_t at = inv[w[1]];
   if (at >= 0 && !is_p[at]) {
@@ -553,7 +553,7 @@ __global__ void __launch_bounds__(SDM_BLOCK)
 k_arrivals_place(ShardLists L, const uint8_t *__restrict__ owned, int64_t *__restrict__ idx) {
   const int64_t j = TID();
   if (j >= L.tot_b) return;
-  const int64_t *w = L.words + 3 * L.tot_a + L.row * j;
+  const int64_t *w = L.words + 2 * L.tot_a + L.row * j;
   if (owned[w[2]]) idx[w[0]] = w[1];
 }
 // (the homeless beyond the free slots leave the live set of this process: their places went to
@@ -575,9 +575,10 @@ k_apply_cells(ShardLists L, const int64_t *__restrict__ idx, int64_t *__restrict
               int64_t *__restrict__ cell_by_id) {
   const int64_t j = TID();
   if (j >= L.tot_a) return;
-  const int64_t *a = L.words + 3 * j;
-  cell_by_id[a[1]] = a[2];
-  if (a[0] >= 0) cell_id[idx[a[0]]] = a[2];
+  const int64_t *a = L.words + 2 * j;
+  const int64_t at = (a[0] >> 32) - 1, id = a[0] & 0xffffffffLL;
+  cell_by_id[id] = a[1];
+  if (at >= 0) cell_id[idx[at]] = a[1];
 }
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_apply_rows(ShardLists L, const uint8_t *__restrict__ owned, uint8_t *__restrict__ role,
@@ -585,7 +586,7 @@ k_apply_rows(ShardLists L, const uint8_t *__restrict__ owned, uint8_t *__restric
              int64_t *__restrict__ cell_origin, double *__restrict__ position_in_cell) {
   const int64_t j = TID();
   if (j >= L.tot_b) return;
-  const int64_t *w = L.words + 3 * L.tot_a + L.row * j;
+  const int64_t *w = L.words + 2 * L.tot_a + L.row * j;
   if (!owned[w[2]]) return;
   const int64_t k = w[1];
   role[k] = 1;
@@ -756,7 +757,7 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
   }
   L.tot_a = tot_a;
   L.tot_b = tot_b;
-  const int64_t words = 3 * tot_a + L.row * tot_b;
+  const int64_t words = 2 * tot_a + L.row * tot_b;
   if (words > sh->word_capacity || tot_a > 2 * N || tot_b > N) {
     sdm_set_error("sharded displacement: word_capacity too small (%lld words needed)",
                   (long long)words);

@@ -2336,11 +2336,12 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   // does the reference's swap-from-the-end (collisions_methods.py:664-680) on every process alike.
   // (Round 2 summed the whole masked permutation here: n_sd int64 per death.)
   auto shard_dead = [&](int64_t *perm) -> int {
-    HIP_TRY(hipMemcpyAsync(ctx->mailbox, st->xchg_cells + C, sizeof(double) * (size_t)(1 + world),
+    // (straight into this frame: the pinned mailbox has 16 words before the polled control block,
+    // 1 + world doubles need up to 65)
+    double counts[1 + 64];
+    HIP_TRY(hipMemcpyAsync(counts, st->xchg_cells + C, sizeof(double) * (size_t)(1 + world),
                            hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    double counts[1 + 64];
-    memcpy(counts, ctx->mailbox, sizeof(double) * (size_t)(1 + world));
     const int64_t total = (int64_t)counts[0];
     if (total <= 0) return SDM_OK;
     int64_t before = 0;

@@ -137,7 +137,7 @@ class DisplacementRunner:  # pylint: disable=too-many-instance-attributes
             shard = self.shard
             n_attr = int(pop.extensive.shape[0])
             counts, words = shard.displacement_buffers(
-                pop.n_sd * (7 + 2 * self.n_dims + n_attr))
+                pop.n_sd * (6 + 2 * self.n_dims + n_attr))
             if pop.cell_id_by_id is None:  # until now every id's cell_id entry was its own cell
                 pop.cell_id_by_id = (pop.cell_id.clone() if hasattr(pop.cell_id, "clone")
                                      else pop.cell_id.copy())
