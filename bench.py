@@ -48,6 +48,10 @@ WORKLOADS = {
                    "n_sd=2^22 per GPU (configs[4] adaptive-substep stress variant); replicas only",
     "kinematic2d": "32x32 cells, 2^22 super-droplets, geometric kernel, adaptive, "
                    "optimized_random, dt=5 s (configs[3]); cells sharded over the ranks",
+    "kinematic2d_flow": "configs[3] with the step that precedes collisions in the 2-D kinematic "
+                        "set-up: displacement (single-eddy flow + sedimentation, removal of what "
+                        "precipitates) then adaptive geometric coalescence, 32x32 cells, 2^22 "
+                        "super-droplets, dt=5 s; both steps sharded over the ranks",
 }
 
 
@@ -55,6 +59,13 @@ def build_workload(name, engine, rank, world, n_sd=None, adaptive=None, read_bac
                    ids_by_cell=False, grid=None):
     from pysdm_amd import cases, sharding
 
+    if name == "kinematic2d_flow":
+        displacement, collisions = cases.make_kinematic_flow(
+            engine, n_sd=n_sd or 2**22, grid=tuple(grid) if grid else (32, 32))
+        if world > 1:
+            part = sharding.attach(collisions, rank, world).shard
+            sharding.attach_displacement(displacement, part)
+        return cases.FlowRunner(displacement, collisions)
     if name == "kinematic2d" and world > 1:
         return sharding.make_sharded_box(engine, name, rank=rank, world=world, n_sd=n_sd,
                                          adaptive=adaptive)
@@ -88,9 +99,17 @@ class Checkpoint:
         else:
             target[...] = saved
 
+    # (a flow: where the super-droplets are; sharded: every id's own cell, who is whose)
+    OPTIONAL = ("cell_id", "cell_origin", "position_in_cell", "cell_id_by_id")
+
     def __init__(self, runner):
         pop = runner.population
         self.columns = {name: self._copy(getattr(pop, name)) for name in self.COLUMNS}
+        moving = hasattr(runner, "displacement")
+        self.columns.update({name: self._copy(getattr(pop, name)) for name in self.OPTIONAL
+                             if moving and getattr(pop, name, None) is not None})
+        shard = getattr(runner, "shard", None)
+        self.role = (self._copy(shard.role), shard.role_ready) if moving and shard else None
         self.diagnostics = {name: self._copy(getattr(runner, name)) for name in self.RUNNER
                             if getattr(runner, name) is not None}
         self.scalars = {name: getattr(runner, name) for name in self.SCALARS}
@@ -104,6 +123,9 @@ class Checkpoint:
             self._assign(getattr(runner, name), saved)
         for name, value in self.scalars.items():
             setattr(runner, name, value)
+        if self.role is not None:
+            self._assign(runner.shard.role, self.role[0])
+            runner.shard.role_ready = self.role[1]
         pop.live = pop.working = self.live
         # (sortedness as it was: an unsorted state would be sorted again under the cell order the
         # adaptive scheme has just permuted - a different, equally valid trajectory)
@@ -383,8 +405,8 @@ def main():
         # the access-pattern ceiling, measured now on this device with the kernel's own footprint:
         # the path is random 64-B sector misses, which this part serves far below the streaming
         # peak - both fractions are reported, the HBM one stays the contract figure
-        wide = setup.breakup or args.workload in ("kinematic2d", "berry_breakup", "straub",
-                                                  "straub_rain")
+        wide = setup.breakup or args.workload in ("kinematic2d", "kinematic2d_flow",
+                                                  "berry_breakup", "straub", "straub_rain")
         progress("kernel timing done; random-sector calibration")
         ceiling = random_sector_ceiling(engine, n_sd, wide)
         roofline = {
@@ -419,7 +441,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         value = pairs_total / elapsed_max
-        sharded = args.workload == "kinematic2d" and world > 1
+        sharded = args.workload in ("kinematic2d", "kinematic2d_flow") and world > 1
+        flow = getattr(runner, "displacement", None)
         print(json.dumps({
             # BASELINE.json's metric; `value` is the aggregate over all ranks (bench contract)
             "metric": ("candidate SD-pairs/s per GPU; Shima-2009 box wall-clock at n_sd=2^20"
@@ -446,8 +469,12 @@ def main():
                                if args.grid else ""),
                 "n_sd": n_sd,
                 "seed": 44,
-                "route": "fused sdm_collision_run",
+                "route": ("fused sdm_collision_run" if flow is None else
+                          "sdm_displacement_step" + ("_sharded" if sharded else "")
+                          + " + fused sdm_collision_run, once each per time step"),
             },
+            # the flow sharded: what the displacement steps of this rank exchanged over the run
+            "displacement_exchange": (flow.shard_stats if flow is not None and sharded else None),
             "state_digest": state_digest,
             # sharded runs: what this rank handed to collectives during the LAST repetition
             # (per-sub-step sums of n_cell + 1 + world doubles; dead positions when one died)

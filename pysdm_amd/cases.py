@@ -184,3 +184,26 @@ def make_kinematic_flow(engine, *, n_sd=2**22, grid=(32, 32), size=(1500.0, 1500
     collisions = CollisionRunner(population, cfg["make"](True, seed=seed), dt=dt, dv=dv_cell,
                                  route=route)
     return displacement, collisions
+
+
+class FlowRunner:
+    """displacement + collisions as one thing that steps (`bench.py --workload kinematic2d_flow`,
+    tools): `run(k)` = k times { Displacement.__call__, Collision.__call__ } - the order the
+    reference's Particulator runs its dynamics in a kinematic set-up; everything else (population,
+    set-up, counters, diagnostics) is the collision runner's"""
+
+    def __init__(self, displacement, collisions):
+        object.__setattr__(self, "displacement", displacement)
+        object.__setattr__(self, "collisions", collisions)
+
+    def run(self, n_steps=1):
+        for _ in range(n_steps):
+            self.displacement.run()
+            self.collisions.run(1)
+
+    def __getattr__(self, name):
+        return getattr(self.collisions, name)
+
+    def __setattr__(self, name, value):
+        setattr(self.collisions, name, value)
+

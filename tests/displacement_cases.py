@@ -151,3 +151,74 @@ def sharded_flow_equals_single(engine, rank, world, *, n_sd, grid, steps, group=
     stats = dict(shard_d.shard_stats)
     stats["collision_exchange_bytes"] = sum(part.bytes.values())
     return stats
+
+
+def random_flow_pair_equal(engine, rank, world, *, grid, n_sd, seed, sedimentation, explicit,
+                           courant, steps, thin, adaptive_displacement, collisions, group=None):
+    """a random set-up (tests/fuzz_sharded_flow.py) run sharded - displacement and collisions -
+    beside the one-process run: equal after every step, as in sharded_flow_equals_single"""
+    from pysdm_amd import sharding  # pylint: disable=import-outside-toplevel
+
+    rng = np.random.default_rng(seed)
+    dims = len(grid)
+    size = tuple(100.0 * g for g in grid)
+    positions = rng.uniform(0, 1, (dims, n_sd)) * np.asarray(grid).reshape(dims, 1)
+    volume = rng.uniform(1e-15, 1e-12, n_sd) if not thin else rng.uniform(1e-13, 1e-10, n_sd)
+    multiplicity = (rng.integers(1, 4, n_sd) if thin
+                    else rng.integers(1000, 100000, n_sd)).astype(np.int64)
+    field = tuple(rng.uniform(-courant, courant, tuple(g + (1 if axis == d else 0)
+                                                       for axis, g in enumerate(grid)))
+                  for d in range(dims))
+
+    def build():
+        cell_id, cell_origin, position_in_cell = locate(positions, grid)
+        population = Population(engine, multiplicity=multiplicity, volume=volume, cell_id=cell_id,
+                                grid=grid, cell_origin=cell_origin,
+                                position_in_cell=position_in_cell)
+        displacement = DisplacementRunner(
+            population, dt=10.0, size=size, enable_sedimentation=sedimentation,
+            adaptive=adaptive_displacement, precipitation_counting_level_index=0,
+            scheme="ExplicitInSpace" if explicit else "ImplicitInSpace")
+        runner = None
+        if collisions:
+            dv = float(np.prod(np.asarray(size) / np.asarray(grid))) * (1e-6 if thin else 1.0)
+            runner = CollisionRunner(
+                population, R.CollisionSetup.coalescence(R.Geometric(), adaptive=True,
+                                                         seed=seed % 1000),
+                dt=10.0, dv=dv)
+        displacement.set_courant(field)
+        return population, displacement, runner
+
+    pop, single_d, single_c = build()
+    pop_s, shard_d, shard_c = build()
+    if shard_c is not None:
+        part = sharding.attach(shard_c, rank, world, group=group).shard
+    else:
+        part = sharding.Shard(engine, pop_s.n_sd, pop_s.n_cell, rank, world, group=group)
+    sharding.attach_displacement(shard_d, part)
+    down = engine.download
+    for step in range(1, steps + 1):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rain = (single_d.run(), shard_d.run())
+            if single_c is not None:
+                single_c.run(1)
+                shard_c.run(1)
+        np.testing.assert_allclose(rain[1], rain[0], rtol=1e-12, err_msg=f"step {step} rain")
+        pop.compact()
+        pop_s.compact()
+        whole = sharding.gather_population(part, pop_s)
+        length = pop.live
+        assert int(whole["length"]) == length, f"step {step}: {int(whole['length'])} != {length}"
+        live = down(pop.perm)[:length]
+        np.testing.assert_array_equal(whole["idx"][:length], live, err_msg=f"step {step} idx")
+        np.testing.assert_array_equal(whole["cell_id"], down(pop.cell_id),
+                                      err_msg=f"step {step} cells of all ids")
+        for key, column in (("multiplicity", pop.multiplicity), ("attributes", pop.extensive),
+                            ("cell_origin", pop.cell_origin),
+                            ("position_in_cell", pop.position_in_cell)):
+            np.testing.assert_array_equal(whole[key][..., live], down(column)[..., live],
+                                          err_msg=f"step {step} {key}")
+    stats = dict(shard_d.shard_stats)
+    stats["live"] = int(pop.live)
+    return stats

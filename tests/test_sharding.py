@@ -174,3 +174,18 @@ def test_bench_checkpoint_brings_back_the_same_steps_after_deaths(oracle_engine)
                      {k: np.asarray(v).tobytes() for k, v in snap.items()}))
     assert seen[0][0] < start.live  # droplets died inside the repetition
     assert seen[1] == seen[0] and seen[2] == seen[0]
+    # the flow workload (displacement + collisions): positions and cells belong to the snapshot
+    flow = bench.build_workload("kinematic2d_flow", oracle_engine, 0, 1, n_sd=2**12, grid=(4, 4))
+    flow.run(2)
+    start = bench.Checkpoint(flow)
+    assert {"cell_origin", "position_in_cell", "cell_id"} <= set(start.columns)
+    seen = []
+    for _ in range(2):
+        start.restore(flow)
+        flow.run(3)
+        pop = flow.population
+        seen.append((pop.live, flow.sub_steps_done, flow.offset,
+                     [np.asarray(a).tobytes() for a in (
+                         pop.perm[:pop.live], pop.multiplicity, pop.extensive, pop.cell_id,
+                         pop.cell_origin, pop.position_in_cell)]))
+    assert seen[0][0] <= start.live and seen[1] == seen[0]
