@@ -1719,8 +1719,11 @@ __global__ void __launch_bounds__(SDM_BLOCK)
 k_max_cell(const int64_t *__restrict__ cell_start, int64_t n_cell, int64_t *ctl) {
   const int64_t c = TID();
   const int64_t sz = c < n_cell ? cell_start[c + 1] - cell_start[c] : 0;
-  if (sz < 0 || (c == 0 && ctl[CTL_SORTED] != 0 &&
-                 (cell_start[0] != 0 || cell_start[n_cell] != ctl[CTL_VALID])))
+  // (an empty state is never sorted - the sort's kernels exit at once - and nothing reads its
+  // cell_start)
+  if (ctl[CTL_VALID] != 0 &&
+      (sz < 0 || (c == 0 && ctl[CTL_SORTED] != 0 &&
+                  (cell_start[0] != 0 || cell_start[n_cell] != ctl[CTL_VALID]))))
     atomicOr((unsigned long long *)&ctl[7], 4ull);
   int64_t m = sz;
 #pragma unroll
@@ -2301,7 +2304,9 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       sdm_set_error("sharded mode: shard_rank / shard_world out of range");
       return SDM_E_ARG;
     }
-    if (!cell_path || !cfg->croupier_local) {
+    // (no super-droplet left anywhere - every process sees that - is not a route question:
+    // the largest cell of an empty state is unknown, and there is nothing to do)
+    if (!cfg->croupier_local || (!cell_path && work_host != 0)) {
       sdm_set_error("sharded mode needs the local croupier and cells of at most %d "
                     "super-droplets (largest: %lld)", CELL_CAP, (long long)max_cell);
       return SDM_E_ARG;

@@ -153,6 +153,11 @@ def sharded_flow_equals_single(engine, rank, world, *, n_sd, grid, steps, group=
     return stats
 
 
+# found by tests/fuzz_sharded_flow.py on the GPU: everything precipitates or coalesces away by the
+# fifth step, and the sharded collision step refused the empty state ("largest cell unknown")
+DIES_OUT = {'grid': (2,), 'n_sd': 238, 'seed': 1293093149, 'sedimentation': True, 'explicit': True, 'courant': 0.29784313388427763, 'steps': 6, 'thin': True, 'adaptive_displacement': True, 'collisions': True}
+
+
 def random_flow_pair_equal(engine, rank, world, *, grid, n_sd, seed, sedimentation, explicit,
                            courant, steps, thin, adaptive_displacement, collisions, group=None):
     """a random set-up (tests/fuzz_sharded_flow.py) run sharded - displacement and collisions -

@@ -108,6 +108,10 @@ def _worker(rank, world, port, errors):
             assert stats["moved"] > 0 and stats["calls"] > 0, stats
             if name != "disp1d_implicit_sed":
                 assert stats["removed"] > 0 and stats["left"] + stats["arrived"] > 0, stats
+        stage("a population that dies out")
+        stats = displacement_cases.random_flow_pair_equal(engine, rank, world,
+                                                          **displacement_cases.DIES_OUT)
+        assert stats["live"] == 0, stats
         stage("sharded flow at 2^18 beside the one-process run")
         stats = displacement_cases.sharded_flow_equals_single(engine, rank, world, n_sd=2**18,
                                                               grid=(16, 16), steps=5)

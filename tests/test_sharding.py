@@ -103,6 +103,9 @@ def _worker(rank, world, port, errors):
             assert stats["moved"] > 0 and stats["calls"] > 0, stats
             if name != "disp1d_implicit_sed":
                 assert stats["removed"] > 0 and stats["left"] + stats["arrived"] > 0, stats
+        stats = displacement_cases.random_flow_pair_equal(engine, rank, world,
+                                                          **displacement_cases.DIES_OUT)
+        assert stats["live"] == 0, stats
         # ... and beside the one-process run of the 2-D kinematic set-up (eddy + sedimentation)
         stats = displacement_cases.sharded_flow_equals_single(engine, rank, world, n_sd=2**13,
                                                               grid=(8, 8), steps=6)
