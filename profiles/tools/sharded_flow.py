@@ -23,21 +23,46 @@ def main():
     parser.add_argument("--steps", type=int, default=10)
     parser.add_argument("--n-sd", type=int, default=2**22)
     parser.add_argument("--grid", type=int, default=32)
+    parser.add_argument("--backend", default="gloo", choices=("gloo", "nccl"),
+                        help="nccl with --ranks 1: the sharded code path on one GPU, collectives "
+                             "on the device (what the protocol itself costs, no host staging)")
     args = parser.parse_args()
     if not launch.launched_by_torchrun():
-        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.ranks))
+        if args.ranks == 1:  # in this very process (so that a profiler sees the kernels)
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                              MASTER_PORT=str(launch.free_port()))
+        else:
+            sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.ranks))
     import torch.distributed as dist
 
     from pysdm_amd import cases, sharding
     from pysdm_amd.engine import HipEngine
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if args.backend == "nccl":
+        import torch
+
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     engine = HipEngine.get()
     grid = (args.grid, args.grid)
     displacement, collisions = cases.make_kinematic_flow(engine, n_sd=args.n_sd, grid=grid)
     part = sharding.attach(collisions, rank, world).shard
     sharding.attach_displacement(displacement, part)
+    # the one-process displacement step on the same state, for the price of the protocol
+    plain_d, plain_c = cases.make_kinematic_flow(engine, n_sd=args.n_sd, grid=grid)
+    plain_ms = []
+    for _ in range(4):
+        engine.synchronize()
+        t0 = time.perf_counter()
+        plain_d.run()
+        engine.synchronize()
+        plain_ms.append((time.perf_counter() - t0) * 1e3)
+        plain_c.run(1)
+    del plain_d, plain_c
     rows = []
     for step in range(1, args.steps + 1):
         before = dict(displacement.shard_stats)
@@ -66,8 +91,9 @@ def main():
         n_attr = int(collisions.population.extensive.shape[0])
         print(json.dumps({
             "workload": f"kinematic flow, {args.n_sd} super-droplets, {grid[0]} x {grid[1]} cells, "
-                        f"{world} ranks (rehearsal: one card, gloo)",
+                        f"{world} ranks (one card, {args.backend})",
             "whole_column_exchange_bytes_per_step_before": args.n_sd * 8 * (2 + n_attr),
+            "one_process_displacement_ms": plain_ms,
             "rank_0_per_step": rows}, indent=1))
     dist.barrier()
     dist.destroy_process_group()

@@ -458,22 +458,74 @@ k_inverse(int32_t *__restrict__ inv, const int64_t *__restrict__ idx,
   const int64_t i = TID();
   if (i < ctl[0]) inv[idx[i]] = (int32_t)i;
 }
-// movers: this process's rows (alive or removed) whose cell changed; of the alive ones, those
-// whose new cell is another process's.  n[0], n[1]: the two counts
+// movers: this process's rows (alive or removed) whose cell changed (a); of the alive ones, those
+// whose new cell is another process's (b).  Listed by stream compaction - per-workgroup counts,
+// one scan, ranks inside the workgroup from ballots - so that the lists come out in id order and
+// nobody queues at one counter (65 k same-address atomics were 0.8 ms at 2^22)
+__device__ __forceinline__ void mover_kind(const uint8_t *__restrict__ role,
+                                           const uint8_t *__restrict__ owned,
+                                           const int64_t *__restrict__ cell_by_id,
+                                           const int64_t *__restrict__ cell0, int64_t n_sd,
+                                           int64_t k, bool *a, bool *b) {
+  *a = *b = false;
+  if (k < n_sd && role[k] != 0 && cell_by_id[k] != cell0[k]) {
+    *a = true;
+    *b = role[k] == 1 && !owned[cell_by_id[k]];
+  }
+}
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_count_movers(const uint8_t *__restrict__ role, const uint8_t *__restrict__ owned,
                const int64_t *__restrict__ cell_by_id, const int64_t *__restrict__ cell0,
-               int64_t n_sd, unsigned long long *__restrict__ n) {
-  const int64_t k = TID();
-  bool a = false, b = false;
-  if (k < n_sd && role[k] != 0 && cell_by_id[k] != cell0[k]) {
-    a = true;
-    b = role[k] == 1 && !owned[cell_by_id[k]];
-  }
+               int64_t n_sd, int32_t *__restrict__ blk_a, int32_t *__restrict__ blk_b) {
+  __shared__ int sa[SDM_BLOCK / SDM_WAVE], sb[SDM_BLOCK / SDM_WAVE];
+  bool a, b;
+  mover_kind(role, owned, cell_by_id, cell0, n_sd, TID(), &a, &b);
   const unsigned long long ma = __ballot(a), mb = __ballot(b);
   if (lane_id() == 0) {
-    if (ma) atomicAdd(&n[0], (unsigned long long)__popcll(ma));
-    if (mb) atomicAdd(&n[1], (unsigned long long)__popcll(mb));
+    sa[threadIdx.x / SDM_WAVE] = __popcll(ma);
+    sb[threadIdx.x / SDM_WAVE] = __popcll(mb);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int ta = 0, tb = 0;
+    for (int w = 0; w < SDM_BLOCK / SDM_WAVE; ++w) { ta += sa[w]; tb += sb[w]; }
+    blk_a[blockIdx.x] = ta;
+    blk_b[blockIdx.x] = tb;
+  }
+}
+// one workgroup: exclusive prefix sums of the per-workgroup counts, in place; totals -> n[0], n[1]
+__global__ void __launch_bounds__(1024)
+k_scan_movers(int32_t *__restrict__ blk_a, int32_t *__restrict__ blk_b, int64_t nb,
+              unsigned long long *__restrict__ n) {
+  __shared__ long long wa[1024 / SDM_WAVE], wb[1024 / SDM_WAVE];
+  __shared__ long long carry[2];
+  if (threadIdx.x == 0) carry[0] = carry[1] = 0;
+  __syncthreads();
+  const int lane = lane_id(), w = threadIdx.x / SDM_WAVE;
+  for (int64_t base = 0; base < nb; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const long long va = i < nb ? blk_a[i] : 0, vb = i < nb ? blk_b[i] : 0;
+    long long ia = va, ib = vb;  // inclusive scan within the wave
+#pragma unroll
+    for (int o = 1; o < SDM_WAVE; o <<= 1) {
+      const long long ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64);
+      if (lane >= o) { ia += ta; ib += tb; }
+    }
+    if (lane == SDM_WAVE - 1) { wa[w] = ia; wb[w] = ib; }
+    __syncthreads();
+    long long oa = carry[0], ob = carry[1];
+    for (int v = 0; v < w; ++v) { oa += wa[v]; ob += wb[v]; }
+    if (i < nb) {
+      blk_a[i] = (int32_t)(oa + ia - va);
+      blk_b[i] = (int32_t)(ob + ib - vb);
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) { carry[0] = oa + ia; carry[1] = ob + ib; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    n[0] = (unsigned long long)carry[0];
+    n[1] = (unsigned long long)carry[1];
   }
 }
 __global__ void k_pack_counts2(double *__restrict__ counts, int world, int rank,
@@ -486,26 +538,38 @@ __global__ void k_pack_counts2(double *__restrict__ counts, int world, int rank,
     counts[world + rank] = (double)n[1];
   }
 }
-// at[0], at[1]: where this process's slices begin (in entries), advanced atomically
+// at_a, at_b: where this process's slices begin (in entries); blk_*: the scanned counts
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_list_movers(ShardLists L, uint8_t *__restrict__ role, const uint8_t *__restrict__ owned,
               const int64_t *__restrict__ cell_by_id, const int64_t *__restrict__ cell0,
               const int32_t *__restrict__ inv, const int64_t *__restrict__ multiplicity,
               const double *__restrict__ attributes, const int64_t *__restrict__ cell_origin,
-              const double *__restrict__ position_in_cell, unsigned long long *__restrict__ at) {
+              const double *__restrict__ position_in_cell, const int32_t *__restrict__ blk_a,
+              const int32_t *__restrict__ blk_b, int64_t at_a, int64_t at_b) {
+  __shared__ int sa[SDM_BLOCK / SDM_WAVE], sb[SDM_BLOCK / SDM_WAVE];
   const int64_t k = TID();
-  if (k >= L.n_sd || role[k] == 0) return;
+  bool a, b;
+  mover_kind(role, owned, cell_by_id, cell0, L.n_sd, k, &a, &b);
+  const unsigned long long ma = __ballot(a), mb = __ballot(b);
+  const unsigned long long below = (1ull << lane_id()) - 1;
+  if (lane_id() == 0) {
+    sa[threadIdx.x / SDM_WAVE] = __popcll(ma);
+    sb[threadIdx.x / SDM_WAVE] = __popcll(mb);
+  }
+  __syncthreads();
+  if (!a) return;
+  int64_t ra = at_a + blk_a[blockIdx.x] + __popcll(ma & below);
+  int64_t rb = at_b + blk_b[blockIdx.x] + __popcll(mb & below);
+  for (int w = 0; w < (int)(threadIdx.x / SDM_WAVE); ++w) { ra += sa[w]; rb += sb[w]; }
   const int64_t to = cell_by_id[k];
-  if (to == cell0[k]) return;
-  const bool alive = role[k] == 1;
-  const int64_t p = alive ? (int64_t)inv[k] : -1;
+  const int64_t p = role[k] == 1 ? (int64_t)inv[k] : -1;
   // a changed cell travels as two words: (position + 1) << 32 | id, new cell (n_sd < 2^31)
-  int64_t *a = L.words + 2 * (int64_t)atomicAdd(&at[0], 1ull);
-  a[0] = ((p + 1) << 32) | k;
-  a[1] = to;
-  if (!alive || owned[to]) return;
+  int64_t *e = L.words + 2 * ra;
+  e[0] = ((p + 1) << 32) | k;
+  e[1] = to;
+  if (!b) return;
   role[k] = 0;  // it goes on as a placeholder here
-  int64_t *w = L.words + 2 * L.tot_a + L.row * (int64_t)atomicAdd(&at[1], 1ull);
+  int64_t *w = L.words + 2 * L.tot_a + L.row * rb;
   w[0] = p;
   w[1] = k;
   w[2] = to;
@@ -619,7 +683,8 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
                       sdm_compact_scratch(N) + 2 * carve_size(sizeof(int64_t) * (size_t)N) +
                       carve_size(sizeof(int32_t) * (size_t)N) + carve_size(2 * (size_t)N) +
                       2 * carve_size(sizeof(int32_t) * (size_t)N) +
-                      carve_size(sizeof(int64_t) * (size_t)N) + 1024;
+                      carve_size(sizeof(int64_t) * (size_t)N) +
+                      2 * carve_size(sizeof(int32_t) * (size_t)nb) + 1024;
   int rc = sdm_reserve(ctx, need);
   if (rc) return rc;
   Carver cv(ctx->arena);
@@ -637,9 +702,10 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
   uint8_t *mark = cv.take<uint8_t>(2 * (size_t)N);
   int32_t *free_slot = cv.take<int32_t>(N), *homeless = cv.take<int32_t>(N);
   int64_t *free_cell = cv.take<int64_t>(N);
+  int32_t *blk_a = cv.take<int32_t>(nb), *blk_b = cv.take<int32_t>(nb);
   unsigned long long *counters = cv.take<unsigned long long>(8);
   double *part_rain = cv.take<double>(1);
-  X.n_dead = counters;  // [0]; [2], [3]: movers; [4], [5]: slices; [6]: arrivals; then [0], [1] again
+  X.n_dead = counters;  // [0]; [2], [3]: movers; [6]: arrivals; then [0], [1] again (free / homeless)
   X.role = sh->role;
   X.cell_by_id = sh->cell_id_by_id;
   const unsigned n_precip = nb < DISP_PRECIP_GRID ? nb : DISP_PRECIP_GRID;
@@ -734,7 +800,9 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
   hipLaunchKernelGGL(k_inverse, grid, blk, 0, s, inv, (const int64_t *)state->idx,
                      (const int64_t *)state->ctl);
   hipLaunchKernelGGL(k_count_movers, grid, blk, 0, s, (const uint8_t *)sh->role, sh->cell_owned,
-                     (const int64_t *)sh->cell_id_by_id, (const int64_t *)cell0, N, counters + 2);
+                     (const int64_t *)sh->cell_id_by_id, (const int64_t *)cell0, N, blk_a, blk_b);
+  hipLaunchKernelGGL(k_scan_movers, one, dim3(1024), 0, s, blk_a, blk_b, (int64_t)nb,
+                     counters + 2);
   hipLaunchKernelGGL(k_pack_counts2, one, dim3(512), 0, s, sh->xchg_counts, W, R,
                      (const unsigned long long *)(counters + 2));
   LAUNCH_CHECK();
@@ -765,15 +833,13 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
   }
   if (words > 0) {
     HIP_TRY(hipMemsetAsync(sh->xchg_words, 0, sizeof(int64_t) * (size_t)words, s));
-    const unsigned long long begin[2] = {(unsigned long long)at_a, (unsigned long long)at_b};
-    HIP_TRY(hipMemcpyAsync(counters + 4, begin, sizeof(begin), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_list_movers, grid, blk, 0, s, L, sh->role, sh->cell_owned,
                        (const int64_t *)sh->cell_id_by_id, (const int64_t *)cell0,
                        (const int32_t *)inv, (const int64_t *)sh->multiplicity,
                        (const double *)sh->attributes, (const int64_t *)state->cell_origin,
-                       (const double *)state->position_in_cell, counters + 4);
+                       (const double *)state->position_in_cell, (const int32_t *)blk_a,
+                       (const int32_t *)blk_b, at_a, at_b);
     LAUNCH_CHECK();
-    HIP_TRY(hipStreamSynchronize(s));  // (`begin` is on this frame)
     if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_I64, sh->xchg_words, words) != 0) {
       sdm_set_error("sharded displacement: the exchange callback failed (rows)");
       return SDM_E_HIP;
