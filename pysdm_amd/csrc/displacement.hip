@@ -580,18 +580,33 @@ k_list_movers(ShardLists L, uint8_t *__restrict__ role, const uint8_t *__restric
   for (int d = 0; d < L.n_dims; ++d)
     w[4 + L.n_dims + L.n_attr + d] = __double_as_longlong(position_in_cell[d * L.n_sd + k]);
 }
+// slot of an entry appended to a list through its counter: one atomic per wavefront, not per lane
+// (every lane of the wavefront must call; `take` = this lane appends)
+__device__ __forceinline__ unsigned long long wave_append(unsigned long long *counter, bool take) {
+  const unsigned long long mask = __ballot(take);
+  if (mask == 0) return 0;
+  const int leader = __ffsll((long long)mask) - 1;
+  unsigned long long base = 0;
+  if (lane_id() == leader) base = atomicAdd(counter, (unsigned long long)__popcll(mask));
+  base = __shfl((long long)base, leader, 64);
+  return base + __popcll(mask & ((1ull << lane_id()) - 1));
+}
+
 // arrivals: rows whose new cell is this process's.  The true id goes to the true position; the
 // placeholders involved trade places, each taking the cell id of the position it moves to
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_arrivals_mark(ShardLists L, const uint8_t *__restrict__ owned, uint8_t *__restrict__ is_p,
                 uint8_t *__restrict__ is_x, unsigned long long *__restrict__ n_arrived) {
   const int64_t j = TID();
-  if (j >= L.tot_b) return;
-  const int64_t *w = L.words + 2 * L.tot_a + L.row * j;
-  if (!owned[w[2]]) return;
-  is_p[w[0]] = 1;
-  is_x[w[1]] = 1;
-  atomicAdd(n_arrived, 1ull);
+  const int64_t *w = L.words + 2 * L.tot_a + L.row * (j < L.tot_b ? j : 0);
+  const bool mine = j < L.tot_b && owned[w[2]];
+  if (mine) {
+    is_p[w[0]] = 1;
+    is_x[w[1]] = 1;
+  }
+  const unsigned long long m = __ballot(mine);
+  if (m != 0 && lane_id() == __ffsll((long long)m) - 1)
+    atomicAdd(n_arrived, (unsigned long long)__popcll(m));
 }
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_arrivals_lists(ShardLists L, const uint8_t *__restrict__ owned,
@@ -601,17 +616,19 @@ k_arrivals_lists(ShardLists L, const uint8_t *__restrict__ owned,
                  int64_t *__restrict__ free_cell, int32_t *__restrict__ homeless,
                  unsigned long long *__restrict__ n) {  // n[0] free slots, n[1] homeless ids
   const int64_t j = TID();
-  if (j >= L.tot_b) return;
-  const int64_t *w = L.words + 2 * L.tot_a + L.row * j;
-  if (!owned[w[2]]) return;
-  const int32_t at = inv[w[1]];
-  if (at >= 0 && !is_p[at]) {
-    const unsigned long long f = atomicAdd(&n[0], 1ull);
+  const int64_t *w = L.words + 2 * L.tot_a + L.row * (j < L.tot_b ? j : 0);
+  const bool mine = j < L.tot_b && owned[w[2]];
+  const int32_t at = mine ? inv[w[1]] : -1;
+  const bool frees = mine && at >= 0 && !is_p[at];
+  const unsigned long long f = wave_append(&n[0], frees);
+  if (frees) {
     free_slot[f] = at;
     free_cell[f] = cell_id[w[1]];
   }
-  const int64_t there = idx[w[0]];
-  if (!is_x[there]) homeless[atomicAdd(&n[1], 1ull)] = (int32_t)there;
+  const int64_t there = mine ? idx[w[0]] : 0;
+  const bool loses = mine && !is_x[there];
+  const unsigned long long h = wave_append(&n[1], loses);
+  if (loses) homeless[h] = (int32_t)there;
 }
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_arrivals_place(ShardLists L, const uint8_t *__restrict__ owned, int64_t *__restrict__ idx) {
