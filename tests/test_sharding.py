@@ -136,6 +136,49 @@ def test_two_process_sharded_run_equals_the_unsharded_reference():
     assert not failed and not messages, f"{failed} {messages}"
 
 
+def _worker_three(rank, world, port, errors):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from oracle.engine import OracleEngine  # pylint: disable=import-outside-toplevel
+
+        from . import displacement_cases  # pylint: disable=import-outside-toplevel
+
+        engine = OracleEngine.get()
+        for name in displacement_cases.CASES:
+            displacement_cases.run_case(name, engine, shard=(rank, world), owner_moves=True)
+        stats = displacement_cases.sharded_flow_equals_single(engine, rank, world, n_sd=2**12,
+                                                              grid=(5, 7), steps=5)
+        assert stats["left"] > 0 and stats["arrived"] > 0, stats
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as exc:  # pylint: disable=broad-except
+        errors.put(f"rank {rank}: {exc!r}")
+        raise
+
+
+@pytest.mark.timeout(600)
+def test_three_processes_with_uneven_blocks_of_cells():
+    """both steps sharded over THREE processes (blocks of 12 / 12 / 11 cells on the 5 x 7 grid, of
+    6 / 5 / 5 on the goldens' 4 x 4): the reference's displacement goldens and the kinematic flow
+    beside the one-process run"""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    errors = ctx.Queue()
+    procs = [ctx.Process(target=_worker_three, args=(r, 3, port, errors)) for r in range(3)]
+    for proc in procs:
+        proc.start()
+    for proc in procs:
+        proc.join(500)
+    failed = [p.exitcode for p in procs if p.exitcode != 0]
+    messages = []
+    while not errors.empty():
+        messages.append(errors.get())
+    assert not failed and not messages, f"{failed} {messages}"
+
+
 def test_bench_cpu_baseline_leg_runs():
     """bench.py's `cpu_baseline` (the oracle timed on the host) on a tiny box"""
     import importlib.util  # pylint: disable=import-outside-toplevel
