@@ -56,17 +56,18 @@ WORKLOADS = {
 
 
 def build_workload(name, engine, rank, world, n_sd=None, adaptive=None, read_back=True,
-                   ids_by_cell=False, grid=None):
+                   ids_by_cell=False, grid=None, sharded=None):
     from pysdm_amd import cases, sharding
 
+    sharded = world > 1 if sharded is None else sharded
     if name == "kinematic2d_flow":
         displacement, collisions = cases.make_kinematic_flow(
             engine, n_sd=n_sd or 2**22, grid=tuple(grid) if grid else (32, 32))
-        if world > 1:
+        if sharded:
             part = sharding.attach(collisions, rank, world).shard
             sharding.attach_displacement(displacement, part)
         return cases.FlowRunner(displacement, collisions)
-    if name == "kinematic2d" and world > 1:
+    if name == "kinematic2d" and sharded:
         return sharding.make_sharded_box(engine, name, rank=rank, world=world, n_sd=n_sd,
                                          adaptive=adaptive)
     # 0-D boxes: every rank an independent realisation (seed 44 + rank)
@@ -236,6 +237,9 @@ def main():
     parser.add_argument("--ids-by-cell", action="store_true")
     # another grid for the multi-cell workload (not the configuration either): e.g. 75 75
     parser.add_argument("--grid", type=int, nargs=2, default=None)
+    # measurement of the sharding protocol itself: ONE rank that owns every cell but runs the
+    # sharded code path (exchange calls, ownership masks, lists), RCCL collectives on the device
+    parser.add_argument("--sharded-on-one", action="store_true")
     args = parser.parse_args()
 
     from pysdm_amd import launch
@@ -260,6 +264,14 @@ def main():
     if os.environ.get("SDM_BENCH_ALL_ON_DEVICE0") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    if args.sharded_on_one:
+        if world != 1 or args.workload not in ("kinematic2d", "kinematic2d_flow"):
+            sys.exit("bench.py: --sharded-on-one is for --gpus 1 and the multi-cell workloads")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
+        dist.init_process_group(dist_backend, rank=0, world_size=1,
+                                **({"device_id": torch.device("cuda", local_rank)}
+                                   if dist_backend == "nccl" else {}))
     if world > 1:
         if dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -274,7 +286,8 @@ def main():
     engine = HipEngine.get(local_rank)
     adaptive = None if args.adaptive is None else bool(args.adaptive)
     runner = build_workload(args.workload, engine, rank, world, args.n_sd, adaptive,
-                            ids_by_cell=args.ids_by_cell, grid=args.grid)
+                            ids_by_cell=args.ids_by_cell, grid=args.grid,
+                            sharded=world > 1 or args.sharded_on_one)
     pop, setup = runner.population, runner.setup
     n_sd = pop.n_sd
     progress(f"{args.workload}: state built (n_sd = {n_sd}), rank {rank} of {world}")
@@ -436,12 +449,12 @@ def main():
             progress("CPU baseline (the oracle on the host cores, bounded sample)")
             baseline = cpu_baseline(args.workload, args.n_sd, adaptive)
 
-    if world > 1:
+    if world > 1 or args.sharded_on_one:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         value = pairs_total / elapsed_max
-        sharded = args.workload in ("kinematic2d", "kinematic2d_flow") and world > 1
+        sharded = runner.shard is not None
         flow = getattr(runner, "displacement", None)
         print(json.dumps({
             # BASELINE.json's metric; `value` is the aggregate over all ranks (bench contract)
@@ -466,7 +479,9 @@ def main():
                             + ("; NOT the configuration: ids ordered by cell"
                                if args.ids_by_cell else "")
                             + (f"; NOT the configuration: grid {args.grid[0]} x {args.grid[1]}"
-                               if args.grid else ""),
+                               if args.grid else "")
+                            + ("; the sharded code path on ONE rank that owns every cell"
+                               if args.sharded_on_one else ""),
                 "n_sd": n_sd,
                 "seed": 44,
                 "route": ("fused sdm_collision_run" if flow is None else
