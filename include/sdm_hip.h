@@ -510,7 +510,9 @@ int sdm_displacement_step(sdm_ctx *ctx, const sdm_disp_cfg *cfg, const sdm_disp_
  *   - removed super-droplets keep moving in the reference (the displacement kernels run over the
  *     raw columns, and `normalize` reads cell ids by raw id, dead or alive): the process that
  *     owned one when it was removed keeps moving it, wherever it goes, and announces its cells
- *     like the others' (position -1 in the list).  `role` records who is whose.
+ *     like the others' (position -1 in the list) - if its id is below (n_sd + 1) / 2: pair
+ *     numbers end there, nobody ever asks for the cell of a removed id beyond.  `role` records
+ *     who is whose.
  * The rainfall is the sum of the owners' partial sums (within 1e-15 relative of the one-process
  * value, not bit-identical: the order of the additions differs).  Everything else - ids,
  * multiplicities, attributes, positions, cells of the owned super-droplets; the permutation after
@@ -527,7 +529,8 @@ typedef struct sdm_disp_shard {
   int64_t *xchg_words;        /* [word_capacity] scratch for positions / rows */
   int64_t word_capacity;      /* SDM_E_ARG if a step needs more (n_sd * (6 + 2 * n_dims + n_attr)
                                  always suffices) */
-  int64_t *cell_id_by_id;     /* [n_sd] every id's own cell (see sdm_step_state); initially a
+  int64_t *cell_id_by_id;     /* [n_sd] every id's own cell (see sdm_step_state; kept up to date
+                                 for the alive and for ids below (n_sd + 1) / 2); initially a
                                  copy of cell_id */
   /* [n_sd] kept by the caller between calls, written by the library: 0 = not this process's,
    * 1 = alive and in one of its cells, 2 = removed while it was (kept moving here).  role_ready = 0:

@@ -1339,8 +1339,11 @@ API int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
     for (int64_t k = 0; k < N; ++k) inv[k] = -1;
     for (int64_t i = 0; i < length; ++i) inv[st->idx[i]] = i;
     int64_t n_a = 0, n_b = 0;
+    /* (a removed one's cell is read by `normalize` alone, as cell_id[pair number]: ids from
+     * (n_sd + 1) / 2 on are never asked for) */
+    const int64_t asked = (N + 1) / 2;
     for (int64_t k = 0; k < N; ++k) {
-      if (!mine[k] || sh->cell_id_by_id[k] == cell0[k]) continue;
+      if (!mine[k] || sh->cell_id_by_id[k] == cell0[k] || (role[k] != 1 && k >= asked)) continue;
       ++n_a;
       if (role[k] == 1 && !sh->cell_owned[sh->cell_id_by_id[k]]) ++n_b;
     }
@@ -1371,7 +1374,7 @@ API int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
       for (int64_t i = 0; i < words; ++i) y[i] = 0;
       for (int64_t k = 0; k < N; ++k) {
         const int64_t to = sh->cell_id_by_id[k];
-        if (!mine[k] || to == cell0[k]) continue;
+        if (!mine[k] || to == cell0[k] || (role[k] != 1 && k >= asked)) continue;
         y[2 * at_a] = (((role[k] == 1 ? inv[k] : -1) + 1) << 32) | k;
         y[2 * at_a + 1] = to;
         ++at_a;

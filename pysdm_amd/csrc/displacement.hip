@@ -468,7 +468,10 @@ __device__ __forceinline__ void mover_kind(const uint8_t *__restrict__ role,
                                            const int64_t *__restrict__ cell0, int64_t n_sd,
                                            int64_t k, bool *a, bool *b) {
   *a = *b = false;
-  if (k < n_sd && role[k] != 0 && cell_by_id[k] != cell0[k]) {
+  // (a removed one's cell is read by `normalize` alone, as cell_id[pair number]: ids from
+  // (n_sd + 1) / 2 on are never asked for, and a quarter of a long run's traffic was theirs)
+  if (k < n_sd && role[k] != 0 && cell_by_id[k] != cell0[k] &&
+      (role[k] == 1 || k < (n_sd + 1) / 2)) {
     *a = true;
     *b = role[k] == 1 && !owned[cell_by_id[k]];
   }
