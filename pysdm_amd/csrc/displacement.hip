@@ -215,8 +215,8 @@ struct DispArgs {
   unsigned long long *n_dead;
 };
 
-// A: over raw super-droplets: displacement of every dimension (Arakawa-C interpolation),
-// sedimentation, position update -- displacement.py:107-110,123-137
+// A + C: over raw super-droplets: displacement of every dimension (Arakawa-C interpolation),
+// sedimentation, position update -- displacement.py:107-110,123-137 -- and, at the end, the cells
 __global__ void __launch_bounds__(SDM_BLOCK) k_disp_move(DispArgs X) {
   const sdm_disp_cfg &c = X.cfg;
   const int64_t k = TID();
@@ -226,6 +226,8 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_disp_move(DispArgs X) {
     return;
   }
   int64_t origin[3] = {0, 0, 0};
+  double moved[3] = {0, 0, 0};
+  uint8_t cls = 0;
   for (int d = 0; d < c.n_dims; ++d) origin[d] = X.st.cell_origin[d * c.n_sd + k];
   const double n_sub = (double)c.n_substeps;
   for (int dim = 0; dim < c.n_dims; ++dim) {
@@ -245,18 +247,38 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_disp_move(DispArgs X) {
       v *= c.dt_over_dz;
     }
     X.st.displacement[dim * c.n_sd + k] = v;
-    const double moved = x + v;
-    X.st.position_in_cell[dim * c.n_sd + k] = moved;
+    moved[dim] = x + v;
     if (dim == c.n_dims - 1) {
       // displacement_methods.py:139-160 and :176-186, evaluated where the operands are at hand;
       // precipitation is tested (and removed) first in the reference, hence takes precedence
-      const double z = (double)origin[dim] + moved;
-      uint8_t cls = 0;
+      const double z = (double)origin[dim] + moved[dim];
       if (c.enable_sedimentation && v < 0 && z < c.level) cls = 1;
       else if (z < 0 || z > (double)c.grid[dim]) cls = 2;
       X.cls[k] = cls;
     }
   }
+  // C: whole cells moved into the cell origin, periodic boundary, cell id (displacement.py:143-153,
+  // collisions_methods.py:407-416).  In the reference this follows the two removals; they read
+  // nothing but what `cls` has recorded above, so it is done while the operands are in registers
+  // (a pass of its own over the raw columns was 50 us at 2^22)
+  int64_t id = 0;
+  for (int d = 0; d < c.n_dims; ++d) {
+    const double x = moved[d];
+    const int64_t whole = (int64_t)floor(x);
+    const int64_t o = origin[d] + whole;
+    X.st.position_in_cell[d * c.n_sd + k] = x - (double)whole;
+    int64_t m = o % c.grid[d];
+    if (m != 0 && ((m < 0) != (c.grid[d] < 0))) m += c.grid[d];  // Python's %
+    X.st.cell_origin[d * c.n_sd + k] = m;
+    id += m * c.strides[d];
+  }
+  if (X.role) {
+    // (a removed one, role 2 or about to be, may stand in the permutation as a placeholder for
+    // somebody else's super-droplet: its cell_id entry then belongs to that position)
+    X.cell_by_id[k] = id;
+    if (X.role[k] != 1 || cls != 0) return;
+  }
+  X.st.cell_id[k] = id;
 }
 
 // B1: over live positions (grid-stride, DISP_PRECIP_GRID workgroups): precipitation
@@ -308,33 +330,6 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_disp_column(DispArgs X) {
   }
 }
 
-// C: over raw super-droplets: whole cells moved into the cell origin, periodic boundary, cell id
-// (displacement.py:143-153, collisions_methods.py:407-416)
-__global__ void __launch_bounds__(SDM_BLOCK) k_disp_cells(DispArgs X) {
-  const sdm_disp_cfg &c = X.cfg;
-  const int64_t k = TID();
-  if (k >= c.n_sd) return;
-  if (X.role && X.role[k] == 0) return;
-  int64_t id = 0;
-  for (int d = 0; d < c.n_dims; ++d) {
-    const double x = X.st.position_in_cell[d * c.n_sd + k];
-    const int64_t whole = (int64_t)floor(x);
-    int64_t o = X.st.cell_origin[d * c.n_sd + k] + whole;
-    X.st.position_in_cell[d * c.n_sd + k] = x - (double)whole;
-    int64_t m = o % c.grid[d];
-    if (m != 0 && ((m < 0) != (c.grid[d] < 0))) m += c.grid[d];  // Python's %
-    X.st.cell_origin[d * c.n_sd + k] = m;
-    id += m * c.strides[d];
-  }
-  if (X.role) {
-    // (a removed one, role 2, may stand in the permutation as a placeholder for somebody else's
-    // super-droplet: its cell_id entry then belongs to that position)
-    X.cell_by_id[k] = id;
-    if (X.role[k] != 1) return;
-  }
-  X.st.cell_id[k] = id;
-}
-
 extern "C" int sdm_displacement_step(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
                                      const sdm_disp_state *state, double *rainfall_mass,
                                      int64_t *valid_n_sd) {
@@ -382,7 +377,6 @@ extern "C" int sdm_displacement_step(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
     rc = sdm_compact_fused_async(ctx, compact, state->multiplicity, state->idx, N, N, state->ctl,
                                  cctl, nullptr, true);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_disp_cells, grid, blk, 0, s, X);
     LAUNCH_CHECK();
   }
   HIP_TRY(hipMemcpyAsync(ctx->mailbox, X.rain, sizeof(double), hipMemcpyDeviceToHost, s));
@@ -806,7 +800,6 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
     LAUNCH_CHECK();
     rc = remove_listed(false);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_disp_cells, grid, blk, 0, s, X);
     LAUNCH_CHECK();
   }
   // ---- who changed cell, who changed owner ----------------------------------------------------
