@@ -968,27 +968,38 @@ k_cells_begin(sdm_step_cfg cfg, FusedArgs A, int64_t *__restrict__ cell_idx,
 // adaptive_sdm_end (collisions_methods.py:313-328): end2[0] = 1 + largest c with dt_left[c] != 0,
 // and by the workgroup that finishes last: working length = cell_start[that], control block
 // published for the host (end2[2]: finish ticket - a handful of workgroups)
+// the per-cell adaptive bookkeeping of cell c (collisions_methods.py:357-374); returns dt_left[c]
+__device__ __forceinline__ double cell_bookkeeping(const sdm_step_cfg &cfg, const FusedArgs &A,
+                                                   int64_t c, double left) {
+  const double m = A.cell_min[c];
+  double t = A.dt_todo[c];
+  if (m < t) t = m;
+  A.dt_todo[c] = t;
+  const double smin = A.stats_dt_min[c];
+  const double s_new = m < smin ? m : smin;  // Python min(s, m): NaN-sticky
+  A.stats_dt_min[c] = s_new;
+  note_dt_min(A.ctl, s_new, cfg.dt_min);
+  left -= t;
+  A.dt_left[c] = left;
+  if (t > 0) A.stats_n_substep[c] += 1;
+  return left;
+}
+
+// `summed` (sharded runs, after the exchange; k_shard_book_pack filled it): dt_left of every cell
+// from its owner, [n_cell] = how many super-droplets died anywhere - taken over here, so that the
+// un-packing is not a launch of its own
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_cells_end(sdm_step_cfg cfg, FusedArgs A, int bookkeeping, int64_t *__restrict__ end2,
-            int64_t *box, int64_t seq) {
+            int64_t *box, int64_t seq, const double *__restrict__ summed) {
   const int64_t c = TID();
   const bool ran = !bookkeeping || end2[3] != 0;  // (see k_cells_begin: gated sub-steps)
   bool nz = false;
+  if (summed && c == 0 && summed[cfg.n_cell] > 0) A.ctl[CTL_HEALTHY] = 0;
   if (c < cfg.n_cell) {
-    double left = A.dt_left[c];
-    if (bookkeeping && ran && (!A.cell_owned || A.cell_owned[c])) {
-      const double m = A.cell_min[c];
-      double t = A.dt_todo[c];
-      if (m < t) t = m;
-      A.dt_todo[c] = t;
-      const double smin = A.stats_dt_min[c];
-      const double s_new = m < smin ? m : smin;  // Python min(s, m): NaN-sticky
-      A.stats_dt_min[c] = s_new;
-      note_dt_min(A.ctl, s_new, cfg.dt_min);
-      left -= t;
-      A.dt_left[c] = left;
-      if (t > 0) A.stats_n_substep[c] += 1;
-    }
+    double left = summed && cfg.adaptive ? summed[c] : A.dt_left[c];
+    if (summed && cfg.adaptive) A.dt_left[c] = left;
+    if (bookkeeping && ran && (!A.cell_owned || A.cell_owned[c]))
+      left = cell_bookkeeping(cfg, A, c, left);
     nz = left != 0;
   }
   const unsigned long long mask = __ballot(nz);
@@ -1839,6 +1850,22 @@ k_shard_pack(FusedArgs A, int64_t n_cell, int adaptive, double *__restrict__ x,
   if (c == n_cell) x[c] = (double)n_dead[0];
   if (c > n_cell && c <= n_cell + world) x[c] = (c - n_cell - 1 == rank) ? (double)n_dead[0] : 0.0;
 }
+// per-cell adaptive route: the bookkeeping of the owned cells (what k_cells_end does in a
+// one-process run) and k_shard_pack in one launch; `ran`: see k_cells_begin (gated sub-steps)
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_shard_book_pack(sdm_step_cfg cfg, FusedArgs A, const int64_t *__restrict__ end2,
+                  double *__restrict__ x, const unsigned long long *__restrict__ n_dead, int rank,
+                  int world) {
+  const int64_t c = TID(), n_cell = cfg.n_cell;
+  if (c < n_cell) {
+    double left = A.dt_left[c];
+    const bool mine = A.cell_owned[c] != 0;
+    if (mine && end2[3] != 0) left = cell_bookkeeping(cfg, A, c, left);
+    x[c] = (cfg.adaptive && mine) ? left : 0.0;
+  }
+  if (c == n_cell) x[c] = (double)n_dead[0];
+  if (c > n_cell && c <= n_cell + world) x[c] = (c - n_cell - 1 == rank) ? (double)n_dead[0] : 0.0;
+}
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_shard_unpack(FusedArgs A, int64_t n_cell, int adaptive, const double *__restrict__ x) {
   const int64_t c = TID();
@@ -2426,13 +2453,22 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         std::swap(A.list_count, A.list_count_next);
       }
       if (sharded) {
-        // bookkeeping of the owned cells first; the working length needs every cell's dt_left
-        hipLaunchKernelGGL(k_cells_end, dim3(grid_for(C)), blk, 0, s, *cfg, A, 1, S.end2,
-                           (int64_t *)nullptr, (int64_t)0);
+        // bookkeeping of the owned cells first - the working length needs every cell's dt_left -
+        // packed for the exchange by the same launch; what comes back is taken over by
+        // k_cells_end below
+        HIP_TRY(hipMemsetAsync(shard_n_dead, 0, sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(k_shard_dead_list, dim3((unsigned)C), blk, 0, s, A,
+                           (const int64_t *)cur, (const int64_t *)alt,
+                           (const int64_t *)(gated ? S.end2 + 3 : nullptr), C, N, shard_dead_pos,
+                           shard_n_dead);
+        hipLaunchKernelGGL(k_shard_book_pack, dim3((unsigned)grid_for(C + 1 + world)), blk, 0, s,
+                           *cfg, A, (const int64_t *)S.end2, st->xchg_cells,
+                           (const unsigned long long *)shard_n_dead, my_rank, world);
         LAUNCH_CHECK();
-        const int r = shard_cells(cur, alt, gated ? S.end2 + 3 : nullptr);
-        if (r) return r;
-        HIP_TRY(hipMemsetAsync(S.end2, 0, sizeof(int64_t), s));
+        if (st->exchange(st->exchange_user, SDM_XCHG_SUM_F64, st->xchg_cells, C + 1 + world) != 0) {
+          sdm_set_error("sharded mode: the exchange callback failed (per-cell sum)");
+          return SDM_E_HIP;
+        }
       }
       *seq_out = ++ctx->poll_seq;
       if (!sharded) {  // (sharded: after the read-back, and only if a super-droplet died)
@@ -2457,7 +2493,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         if (r) return r;
       } else {
         hipLaunchKernelGGL(k_cells_end, dim3(grid_for(C)), blk, 0, s, *cfg, A, 0, S.end2,
-                           ctx->box_dev, *seq_out);
+                           ctx->box_dev, *seq_out, (const double *)st->xchg_cells);
         LAUNCH_CHECK();
       }
       ++launched;
