@@ -496,8 +496,8 @@ int sdm_displacement_step(sdm_ctx *ctx, const sdm_disp_cfg *cfg, const sdm_disp_
  *   - a super-droplet is moved (all n_substeps of it: displacement depends on nothing but the
  *     droplet and the replicated Courant field) by the process that owns its cell when the call
  *     begins; rows of other super-droplets are not touched;
- *   - removal (precipitation, out of the column): the owners' dead POSITIONS are summed as
- *     rank-disjoint slices, exactly as in the collision step, and every process runs the
+ *   - removal (precipitation, out of the column): the owners' dead POSITIONS (for precipitation
+ *     also the masses, as bit patterns) are summed as rank-disjoint slices, as in the collision step, and every process runs the
  *     reference's compaction on its own permutation.  Positions are the global names: a filler
  *     taken from the tail lands in the same hole on every process;
  *   - at the end, per super-droplet whose cell changed: {position and id (one word), new cell} to
@@ -513,10 +513,10 @@ int sdm_displacement_step(sdm_ctx *ctx, const sdm_disp_cfg *cfg, const sdm_disp_
  *     like the others' (position -1 in the list) - if its id is below (n_sd + 1) / 2: pair
  *     numbers end there, nobody ever asks for the cell of a removed id beyond.  `role` records
  *     who is whose.
- * The rainfall is the sum of the owners' partial sums (within 1e-15 relative of the one-process
- * value, not bit-identical: the order of the additions differs).  Everything else - ids,
- * multiplicities, attributes, positions, cells of the owned super-droplets; the permutation after
- * the next sharded collision step - is the one-process result bit for bit.
+ * Everything - ids, multiplicities, attributes, positions, cells of the owned super-droplets; the
+ * permutation after the next sharded collision step; the rainfall (the masses of the precipitated
+ * travel with their positions, and every process adds them up in the one-process order) - is the
+ * one-process result bit for bit.
  * The reference has no counterpart (PySDM is a one-process code); the step computed is
  * PySDM/dynamics/displacement.py:100-153 as above. */
 typedef struct sdm_disp_shard {

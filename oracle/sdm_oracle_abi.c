@@ -1193,30 +1193,56 @@ API int sdm_displacement_step(sdm_ctx *ctx, const sdm_disp_cfg *cfg, const sdm_d
 
 /* ---- the displacement step of a sharded run (include/sdm_hip.h: sdm_disp_shard) ------------------
  * The checker's statement of the protocol: serial loops, the same exchanges, the same words. */
+/* positions of the removed from their owners to everybody; with `mass` (precipitation) also what
+ * each carried, so that every process adds the rainfall up in the one-process order - by
+ * position, displacement_methods.py:131-166 - and gets the one-process bits */
+static int by_position(const void *a, const void *b) {
+  const int64_t x = ((const int64_t *)a)[0], y = ((const int64_t *)b)[0];
+  return x < y ? -1 : x > y;
+}
 static int disp_exchange_dead(const sdm_disp_state *st, sdm_disp_shard *sh, const int64_t *dead,
-                              int64_t n_mine, double rain_mine, int64_t N, int64_t *length,
+                              const double *mass, int64_t n_mine, int64_t N, int64_t *length,
                               double *rain) {
   const int W = sh->shard_world, R = sh->shard_rank;
   double *x = sh->xchg_counts;
   for (int r = 0; r < W; ++r) x[r] = r == R ? (double)n_mine : 0.0;
-  x[W] = rain_mine;
-  if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_F64, x, W + 1))
+  if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_F64, x, W))
     FAIL(SDM_E_HIP, "exchange callback failed (displacement: counts of the removed)");
-  *rain += x[W];
   int64_t total = 0, before = 0;
   for (int r = 0; r < W; ++r) {
     if (r < R) before += (int64_t)x[r];
     total += (int64_t)x[r];
   }
   if (total == 0) return SDM_OK;
-  if (total > sh->word_capacity) FAIL(SDM_E_ARG, "sharded displacement: word_capacity too small");
+  const int64_t words = mass ? 2 * total : total;
+  if (words > sh->word_capacity) FAIL(SDM_E_ARG, "sharded displacement: word_capacity too small");
   int64_t *y = sh->xchg_words;
-  for (int64_t i = 0; i < total; ++i) y[i] = 0;
-  for (int64_t i = 0; i < n_mine; ++i) y[before + i] = dead[i];
-  if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_I64, y, total))
+  for (int64_t i = 0; i < words; ++i) y[i] = 0;
+  for (int64_t i = 0; i < n_mine; ++i) {
+    y[before + i] = dead[i];
+    if (mass) memcpy(&y[total + before + i], &mass[i], 8);
+  }
+  if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_I64, y, words))
     FAIL(SDM_E_HIP, "exchange callback failed (displacement: positions of the removed)");
-  sh->n_words += total;
+  sh->n_words += words;
   sh->n_removed += total;
+  if (mass) {
+    int64_t *pairs = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)total);
+    if (!pairs) FAIL(SDM_E_NOMEM, "oracle scratch allocation failed");
+    for (int64_t i = 0; i < total; ++i) {
+      pairs[2 * i] = y[i];
+      pairs[2 * i + 1] = y[total + i];
+    }
+    qsort(pairs, (size_t)total, 2 * sizeof(int64_t), by_position);
+    double fell = 0.0;
+    for (int64_t i = 0; i < total; ++i) {
+      double m;
+      memcpy(&m, &pairs[2 * i + 1], 8);
+      fell += m;
+    }
+    free(pairs);
+    *rain += fell;
+  }
   for (int64_t i = 0; i < total; ++i) st->idx[y[i]] = N;
   *length = oracle_remove_zero_n_or_flagged(st->multiplicity, st->idx, *length, N);
   return SDM_OK;
@@ -1287,18 +1313,18 @@ API int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
     }
     if (cfg->enable_sedimentation) { /* displacement_methods.py:131-166 */
       int64_t n_mine = 0;
-      double rain_mine = 0.0;
+      double *fell = (double *)inv; /* (scratch: the inverse map is built at the end) */
       for (int64_t i = 0; i < length; ++i) {
         const int64_t k = st->idx[i];
         if (role[k] != 1) continue;
         const double z = (double)st->cell_origin[last + k] + st->position_in_cell[last + k];
         if (st->displacement[last + k] < 0 && z < cfg->level) {
           role[k] = 2;
-          rain_mine += fabs(st->water_mass[k]) * (double)st->multiplicity[k];
+          fell[n_mine] = fabs(st->water_mass[k]) * (double)st->multiplicity[k];
           dead[n_mine++] = i;
         }
       }
-      rc = disp_exchange_dead(st, sh, dead, n_mine, rain_mine, N, &length, &rain);
+      rc = disp_exchange_dead(st, sh, dead, fell, n_mine, N, &length, &rain);
       if (rc) break;
     }
     { /* displacement_methods.py:168-190 */
@@ -1312,8 +1338,7 @@ API int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
           dead[n_mine++] = i;
         }
       }
-      double none = 0.0;
-      rc = disp_exchange_dead(st, sh, dead, n_mine, 0.0, N, &length, &none);
+      rc = disp_exchange_dead(st, sh, dead, NULL, n_mine, N, &length, &rain);
       if (rc) break;
     }
     for (int64_t k = 0; k < N; ++k) { /* displacement.py:143-153 */

@@ -212,6 +212,7 @@ struct DispArgs {
   uint8_t *role;
   int64_t *cell_by_id;
   int64_t *dead;
+  double *dead_mass;  // what each listed (precipitated) super-droplet carried
   unsigned long long *n_dead;
 };
 
@@ -292,11 +293,16 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_disp_precip(DispArgs X) {
   for (int64_t i = TID(); i < length; i += (int64_t)gridDim.x * SDM_BLOCK) {
     const int64_t k = X.st.idx[i];
     if (X.cls[k] == 1 && (!X.role || X.role[k] == 1)) {
-      mass += fabs(X.st.water_mass[k]) * (double)X.st.multiplicity[k];
-      if (X.role) {  // sharded: the position is announced first (every process flags it)
+      const double carried = fabs(X.st.water_mass[k]) * (double)X.st.multiplicity[k];
+      if (X.role) {
+        // sharded: position and mass are announced first; every process flags the position and
+        // adds the masses up in the one-process order (k_disp_rain below)
         X.role[k] = 2;
-        X.dead[atomicAdd(X.n_dead, 1ull)] = i;
+        const unsigned long long at = atomicAdd(X.n_dead, 1ull);
+        X.dead[at] = i;
+        X.dead_mass[at] = carried;
       } else {
+        mass += carried;
         X.st.idx[i] = c.n_sd;
         X.st.ctl[3] = 0;
       }
@@ -356,6 +362,7 @@ extern "C" int sdm_displacement_step(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
   X.role = nullptr;
   X.cell_by_id = nullptr;
   X.dead = nullptr;
+  X.dead_mass = nullptr;
   X.n_dead = nullptr;
   int64_t *cctl = cv.take<int64_t>(8);
   char *compact = cv.take<char>(sdm_compact_scratch(N));
@@ -445,6 +452,31 @@ k_flag_positions(int64_t *__restrict__ idx, const int64_t *__restrict__ dead, in
   if (i >= n) return;
   idx[dead[i]] = n_sd;
   if (i == 0) ctl[3] = 0;
+}
+// the rainfall of a sharded sub-step, to the bits of the one-process run: the masses of the
+// precipitated (from all processes) scattered to their positions in an otherwise zero array, then
+// summed exactly as k_disp_precip sums them - same grid, same strides, same trees; x + 0.0 = x
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_rain_scatter(double *__restrict__ carried, const int64_t *__restrict__ words, int64_t total) {
+  const int64_t j = TID();
+  if (j < total) carried[words[j]] = __longlong_as_double(words[total + j]);
+}
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_disp_rain(const double *__restrict__ carried, const int64_t *__restrict__ ctl,
+            double *__restrict__ partial) {
+  __shared__ double sm[SDM_BLOCK / SDM_WAVE];
+  const int64_t length = ctl[0];
+  double mass = 0.0;
+  for (int64_t i = TID(); i < length; i += (int64_t)gridDim.x * SDM_BLOCK) mass += carried[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mass += __shfl_xor(mass, o, 64);
+  if (lane_id() == 0) sm[threadIdx.x / SDM_WAVE] = mass;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < SDM_BLOCK / SDM_WAVE; ++w) t += sm[w];
+    partial[blockIdx.x] = t;
+  }
 }
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_inverse(int32_t *__restrict__ inv, const int64_t *__restrict__ idx,
@@ -697,7 +729,7 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
                       sdm_compact_scratch(N) + 2 * carve_size(sizeof(int64_t) * (size_t)N) +
                       carve_size(sizeof(int32_t) * (size_t)N) + carve_size(2 * (size_t)N) +
                       2 * carve_size(sizeof(int32_t) * (size_t)N) +
-                      carve_size(sizeof(int64_t) * (size_t)N) +
+                      2 * carve_size(sizeof(int64_t) * (size_t)N) +
                       2 * carve_size(sizeof(int32_t) * (size_t)nb) + 1024;
   int rc = sdm_reserve(ctx, need);
   if (rc) return rc;
@@ -712,13 +744,13 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
   char *compact = cv.take<char>(sdm_compact_scratch(N));
   int64_t *cell0 = cv.take<int64_t>(N);
   X.dead = cv.take<int64_t>(N);
+  X.dead_mass = cv.take<double>(N);
   int32_t *inv = cv.take<int32_t>(N);
   uint8_t *mark = cv.take<uint8_t>(2 * (size_t)N);
   int32_t *free_slot = cv.take<int32_t>(N), *homeless = cv.take<int32_t>(N);
   int64_t *free_cell = cv.take<int64_t>(N);
   int32_t *blk_a = cv.take<int32_t>(nb), *blk_b = cv.take<int32_t>(nb);
   unsigned long long *counters = cv.take<unsigned long long>(8);
-  double *part_rain = cv.take<double>(1);
   X.n_dead = counters;  // [0]; [2], [3]: movers; [6]: arrivals; then [0], [1] again (free / homeless)
   X.role = sh->role;
   X.cell_by_id = sh->cell_id_by_id;
@@ -735,63 +767,82 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
   hipLaunchKernelGGL(k_shard_begin, grid, blk, 0, s, sh->role, (const int64_t *)sh->multiplicity,
                      (const int64_t *)sh->cell_id_by_id, cell0, N);
   LAUNCH_CHECK();
-  double rain = 0.0;
   double host_counts[2 * 256 + 2];
+  double *carried = (double *)free_cell;  // (scratch of the arrivals, free until the end)
   // the positions listed by k_disp_precip / k_disp_column on every process -> flagged on every
   // process -> the reference's compaction on every process's own permutation
   auto remove_listed = [&](bool with_rain) -> int {
     hipLaunchKernelGGL(k_pack_counts, one, dim3(320), 0, s, sh->xchg_counts, W, R,
-                       (const unsigned long long *)X.n_dead,
-                       (const double *)(with_rain ? part_rain : nullptr));
+                       (const unsigned long long *)X.n_dead, (const double *)nullptr);
     LAUNCH_CHECK();
     HIP_TRY(hipMemcpyAsync(ctx->mailbox, X.n_dead, sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, s));
-    if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_F64, sh->xchg_counts, W + 1) != 0) {
+    if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_F64, sh->xchg_counts, W) != 0) {
       sdm_set_error("sharded displacement: the exchange callback failed (counts of the removed)");
       return SDM_E_HIP;
     }
-    HIP_TRY(hipMemcpyAsync(host_counts, sh->xchg_counts, sizeof(double) * (size_t)(W + 1),
+    HIP_TRY(hipMemcpyAsync(host_counts, sh->xchg_counts, sizeof(double) * (size_t)W,
                            hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     const int64_t mine = ctx->mailbox[0];
-    if (with_rain) rain += host_counts[W];
     int64_t total = 0, before = 0;
     for (int r = 0; r < W; ++r) {
       if (r < R) before += (int64_t)host_counts[r];
       total += (int64_t)host_counts[r];
     }
     HIP_TRY(hipMemsetAsync(X.n_dead, 0, sizeof(unsigned long long), s));
-    if (total == 0) return SDM_OK;
-    if (total > sh->word_capacity || total > N || before + mine > total) {
+    if (total == 0) {
+      if (with_rain) {  // (the one-process step adds this sub-step's 0.0 too)
+        HIP_TRY(hipMemsetAsync(X.partial, 0, sizeof(double) * n_precip, s));
+        hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(1024), 0, s, X.partial,
+                           (int64_t)n_precip, X.rain, 1);
+        LAUNCH_CHECK();
+      }
+      return SDM_OK;
+    }
+    const int64_t words = with_rain ? 2 * total : total;
+    if (words > sh->word_capacity || total > N || before + mine > total) {
       sdm_set_error("sharded displacement: word_capacity too small for %lld removed",
                     (long long)total);
       return SDM_E_ARG;
     }
-    HIP_TRY(hipMemsetAsync(sh->xchg_words, 0, sizeof(int64_t) * (size_t)total, s));
+    HIP_TRY(hipMemsetAsync(sh->xchg_words, 0, sizeof(int64_t) * (size_t)words, s));
     if (mine > 0) {
       hipLaunchKernelGGL(k_copy_i64, dim3(grid_for(mine)), blk, 0, s, sh->xchg_words + before,
                          (const int64_t *)X.dead, mine);
+      if (with_rain)  // (bit patterns: a sum with zeros leaves them as they are)
+        hipLaunchKernelGGL(k_copy_i64, dim3(grid_for(mine)), blk, 0, s,
+                           sh->xchg_words + total + before, (const int64_t *)X.dead_mass, mine);
       LAUNCH_CHECK();
     }
-    if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_I64, sh->xchg_words, total) != 0) {
+    if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_I64, sh->xchg_words, words) != 0) {
       sdm_set_error("sharded displacement: the exchange callback failed (positions of the removed)");
       return SDM_E_HIP;
     }
-    sh->n_words += total;
+    sh->n_words += words;
     sh->n_removed += total;
+    if (with_rain) {
+      HIP_TRY(hipMemsetAsync(carried, 0, sizeof(double) * (size_t)N, s));
+      hipLaunchKernelGGL(k_rain_scatter, dim3(grid_for(total)), blk, 0, s, carried,
+                         (const int64_t *)sh->xchg_words, total);
+      hipLaunchKernelGGL(k_disp_rain, dim3(n_precip), blk, 0, s, (const double *)carried,
+                         (const int64_t *)state->ctl, X.partial);
+      hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(1024), 0, s, X.partial,
+                         (int64_t)n_precip, X.rain, 1);
+      LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_flag_positions, dim3(grid_for(total)), blk, 0, s, state->idx,
                        (const int64_t *)sh->xchg_words, total, N, state->ctl);
     LAUNCH_CHECK();
     return sdm_compact_fused_async(ctx, compact, state->multiplicity, state->idx, N, N,
                                    state->ctl, cctl, nullptr, true);
   };
+  HIP_TRY(hipMemsetAsync(X.rain, 0, sizeof(double), s));
   HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 8, s));
   for (int sub = 0; sub < cfg->n_substeps; ++sub) {
     hipLaunchKernelGGL(k_disp_move, grid, blk, 0, s, X);
     if (cfg->enable_sedimentation) {
       hipLaunchKernelGGL(k_disp_precip, dim3(n_precip), blk, 0, s, X);
-      hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(1024), 0, s, X.partial,
-                         (int64_t)n_precip, part_rain, 0);
       LAUNCH_CHECK();
       rc = remove_listed(true);
       if (rc) return rc;
@@ -890,9 +941,10 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
                          hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(ctx->mailbox + 1, state->ctl, sizeof(int64_t) * 8,
                          hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(ctx->mailbox + 9, X.rain, sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   sh->n_arrived = tot_b > 0 ? ctx->mailbox[0] : 0;
-  *rainfall_mass = rain;
+  memcpy(rainfall_mass, ctx->mailbox + 9, sizeof(double));
   *valid_n_sd = ctx->mailbox[1];
   if (ctx->mailbox[1 + 7] != 0) {
     sdm_set_error("displacement: grid barrier of the compaction kernel timed out");

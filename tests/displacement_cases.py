@@ -118,7 +118,7 @@ def sharded_flow_equals_single(engine, rank, world, *, n_sd, grid, steps, group=
     coalescence: pysdm_amd.cases.make_kinematic_flow) with BOTH steps sharded, beside the
     one-process run on the same engine: after every step the state gathered from the owners must
     be the one-process state - ids, positions in the permutation, multiplicities, attributes,
-    cells and positions to the bit; the rainfall within 1e-12.  Returns the exchange statistics."""
+    cells, positions and the rainfall, to the bit.  Returns the exchange statistics."""
     from pysdm_amd import cases, sharding  # pylint: disable=import-outside-toplevel
 
     size = (1500.0, 1500.0)
@@ -133,7 +133,7 @@ def sharded_flow_equals_single(engine, rank, world, *, n_sd, grid, steps, group=
             rain = (single_d.run(), shard_d.run())
             single_c.run(1)
             shard_c.run(1)
-        np.testing.assert_allclose(rain[1], rain[0], rtol=1e-12, err_msg=f"step {step} rain")
+        assert rain[1] == rain[0], f"step {step} rain: {rain[1]!r} != {rain[0]!r}"  # to the bit
         pop = single_c.population
         whole = sharding.gather_population(part, shard_c.population)
         length = pop.live
@@ -212,7 +212,7 @@ def random_flow_pair_equal(engine, rank, world, *, grid, n_sd, seed, sedimentati
             if single_c is not None:
                 single_c.run(1)
                 shard_c.run(1)
-        np.testing.assert_allclose(rain[1], rain[0], rtol=1e-12, err_msg=f"step {step} rain")
+        assert rain[1] == rain[0], f"step {step} rain: {rain[1]!r} != {rain[0]!r}"  # to the bit
         pop.compact()
         pop_s.compact()
         whole = sharding.gather_population(part, pop_s)
