@@ -1200,19 +1200,28 @@ static int by_position(const void *a, const void *b) {
   const int64_t x = ((const int64_t *)a)[0], y = ((const int64_t *)b)[0];
   return x < y ? -1 : x > y;
 }
-static int disp_exchange_dead(const sdm_disp_state *st, sdm_disp_shard *sh, const int64_t *dead,
-                              const double *mass, int64_t n_mine, int64_t N, int64_t *length,
-                              double *rain) {
+/* how many each process is about to list: `lists` counts per process, filed under its rank */
+static int disp_exchange_counts(sdm_disp_shard *sh, const int64_t *mine, int lists,
+                                int64_t *total, int64_t *before) {
   const int W = sh->shard_world, R = sh->shard_rank;
   double *x = sh->xchg_counts;
-  for (int r = 0; r < W; ++r) x[r] = r == R ? (double)n_mine : 0.0;
-  if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_F64, x, W))
+  for (int l = 0; l < lists; ++l)
+    for (int r = 0; r < W; ++r) x[l * W + r] = r == R ? (double)mine[l] : 0.0;
+  if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_F64, x, lists * W))
     FAIL(SDM_E_HIP, "exchange callback failed (displacement: counts of the removed)");
-  int64_t total = 0, before = 0;
-  for (int r = 0; r < W; ++r) {
-    if (r < R) before += (int64_t)x[r];
-    total += (int64_t)x[r];
+  for (int l = 0; l < lists; ++l) {
+    total[l] = before[l] = 0;
+    for (int r = 0; r < W; ++r) {
+      if (r < R) before[l] += (int64_t)x[l * W + r];
+      total[l] += (int64_t)x[l * W + r];
+    }
   }
+  return SDM_OK;
+}
+
+static int disp_remove_listed(const sdm_disp_state *st, sdm_disp_shard *sh, const int64_t *dead,
+                              const double *mass, int64_t n_mine, int64_t total, int64_t before,
+                              int64_t N, int64_t *length, double *rain) {
   if (total == 0) return SDM_OK;
   const int64_t words = mass ? 2 * total : total;
   if (words > sh->word_capacity) FAIL(SDM_E_ARG, "sharded displacement: word_capacity too small");
@@ -1311,23 +1320,29 @@ API int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
         st->position_in_cell[dim * N + k] = x + v;
       }
     }
-    if (cfg->enable_sedimentation) { /* displacement_methods.py:131-166 */
-      int64_t n_mine = 0;
-      double *fell = (double *)inv; /* (scratch: the inverse map is built at the end) */
-      for (int64_t i = 0; i < length; ++i) {
-        const int64_t k = st->idx[i];
-        if (role[k] != 1) continue;
-        const double z = (double)st->cell_origin[last + k] + st->position_in_cell[last + k];
-        if (st->displacement[last + k] < 0 && z < cfg->level) {
-          role[k] = 2;
-          fell[n_mine] = fabs(st->water_mass[k]) * (double)st->multiplicity[k];
-          dead[n_mine++] = i;
-        }
+    /* one exchange of counts for both removals of the sub-step: who leaves the column is decided
+     * by the same positions that decide who precipitates (the latter takes precedence) */
+    int64_t mine2[2] = {0, 0}, total2[2], before2[2];
+    double *fell = (double *)inv; /* (scratch: the inverse map is built at the end) */
+    for (int64_t i = 0; i < length; ++i) {
+      const int64_t k = st->idx[i];
+      if (role[k] != 1) continue;
+      const double z = (double)st->cell_origin[last + k] + st->position_in_cell[last + k];
+      if (cfg->enable_sedimentation && st->displacement[last + k] < 0 && z < cfg->level) {
+        /* displacement_methods.py:131-166 */
+        role[k] = 2;
+        fell[mine2[0]] = fabs(st->water_mass[k]) * (double)st->multiplicity[k];
+        dead[mine2[0]++] = i;
+      } else if (z < 0 || z > (double)cfg->grid[D - 1]) {
+        ++mine2[1];
       }
-      rc = disp_exchange_dead(st, sh, dead, fell, n_mine, N, &length, &rain);
-      if (rc) break;
     }
-    { /* displacement_methods.py:168-190 */
+    rc = disp_exchange_counts(sh, mine2, 2, total2, before2);
+    if (rc) break;
+    rc = disp_remove_listed(st, sh, dead, fell, mine2[0], total2[0], before2[0], N, &length,
+                            &rain);
+    if (rc) break;
+    { /* displacement_methods.py:168-190, on the permutation the first removal left */
       int64_t n_mine = 0;
       for (int64_t i = 0; i < length; ++i) {
         const int64_t k = st->idx[i];
@@ -1338,7 +1353,8 @@ API int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
           dead[n_mine++] = i;
         }
       }
-      rc = disp_exchange_dead(st, sh, dead, NULL, n_mine, N, &length, &rain);
+      rc = disp_remove_listed(st, sh, dead, NULL, n_mine, total2[1], before2[1], N, &length,
+                              &rain);
       if (rc) break;
     }
     for (int64_t k = 0; k < N; ++k) { /* displacement.py:143-153 */

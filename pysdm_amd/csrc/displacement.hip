@@ -214,6 +214,7 @@ struct DispArgs {
   int64_t *dead;
   double *dead_mass;  // what each listed (precipitated) super-droplet carried
   unsigned long long *n_dead;
+  unsigned long long *n_column;  // counted by k_disp_count_column ahead of their listing
 };
 
 // A + C: over raw super-droplets: displacement of every dimension (Arakawa-C interpolation),
@@ -319,6 +320,16 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_disp_precip(DispArgs X) {
   }
 }
 
+// sharded: how many of this process's super-droplets k_disp_column is going to list, known as soon
+// as k_disp_move has classified them - so that ONE exchange of counts serves both removals
+__global__ void __launch_bounds__(SDM_BLOCK) k_disp_count_column(DispArgs X) {
+  const int64_t k = TID();
+  const bool leaves = k < X.cfg.n_sd && X.role[k] == 1 && X.cls[k] == 2;
+  const unsigned long long m = __ballot(leaves);
+  if (m != 0 && lane_id() == __ffsll((long long)m) - 1)
+    atomicAdd(X.n_column, (unsigned long long)__popcll(m));
+}
+
 // B2: over live positions: out of the column (displacement_methods.py:168-190)
 __global__ void __launch_bounds__(SDM_BLOCK) k_disp_column(DispArgs X) {
   const sdm_disp_cfg &c = X.cfg;
@@ -364,6 +375,7 @@ extern "C" int sdm_displacement_step(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
   X.dead = nullptr;
   X.dead_mass = nullptr;
   X.n_dead = nullptr;
+  X.n_column = nullptr;
   int64_t *cctl = cv.take<int64_t>(8);
   char *compact = cv.take<char>(sdm_compact_scratch(N));
   const unsigned n_precip = nb < DISP_PRECIP_GRID ? nb : DISP_PRECIP_GRID;
@@ -433,12 +445,13 @@ k_shard_begin(uint8_t *__restrict__ role, const int64_t *__restrict__ multiplici
   if (role[k] == 1 && multiplicity[k] == 0) role[k] = 2;
   cell0[k] = cell_by_id[k];
 }
-// counts[0 .. world) = how many this process lists (its own slot only), counts[world] = value
+// counts[l * world + r] = how many this process is about to put on list l (its own slot r only)
 __global__ void k_pack_counts(double *__restrict__ counts, int world, int rank,
-                              const unsigned long long *__restrict__ n, const double *value) {
+                              const unsigned long long *__restrict__ n0,
+                              const unsigned long long *__restrict__ n1) {
   const int r = threadIdx.x;
-  if (r < world) counts[r] = r == rank ? (double)*n : 0.0;
-  if (r == world) counts[world] = value ? *value : 0.0;
+  if (r < world) counts[r] = r == rank ? (double)*n0 : 0.0;
+  else if (r < 2 * world) counts[r] = r - world == rank ? (double)*n1 : 0.0;
 }
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_copy_i64(int64_t *__restrict__ out, const int64_t *__restrict__ in, int64_t n) {
@@ -752,6 +765,7 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
   int32_t *blk_a = cv.take<int32_t>(nb), *blk_b = cv.take<int32_t>(nb);
   unsigned long long *counters = cv.take<unsigned long long>(8);
   X.n_dead = counters;  // [0]; [2], [3]: movers; [6]: arrivals; then [0], [1] again (free / homeless)
+  X.n_column = counters + 7;
   X.role = sh->role;
   X.cell_by_id = sh->cell_id_by_id;
   const unsigned n_precip = nb < DISP_PRECIP_GRID ? nb : DISP_PRECIP_GRID;
@@ -769,27 +783,39 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
   LAUNCH_CHECK();
   double host_counts[2 * 256 + 2];
   double *carried = (double *)free_cell;  // (scratch of the arrivals, free until the end)
-  // the positions listed by k_disp_precip / k_disp_column on every process -> flagged on every
-  // process -> the reference's compaction on every process's own permutation
-  auto remove_listed = [&](bool with_rain) -> int {
-    hipLaunchKernelGGL(k_pack_counts, one, dim3(320), 0, s, sh->xchg_counts, W, R,
-                       (const unsigned long long *)X.n_dead, (const double *)nullptr);
+  // one exchange of counts for both removals of a sub-step (who leaves the column is decided by
+  // the same classification as who precipitates): totals and this process's offsets, per list
+  int64_t total2[2], before2[2], mine2[2];
+  auto exchange_counts = [&]() -> int {
+    hipLaunchKernelGGL(k_pack_counts, one, dim3(512), 0, s, sh->xchg_counts, W, R,
+                       (const unsigned long long *)X.n_dead,
+                       (const unsigned long long *)X.n_column);
     LAUNCH_CHECK();
     HIP_TRY(hipMemcpyAsync(ctx->mailbox, X.n_dead, sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, s));
-    if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_F64, sh->xchg_counts, W) != 0) {
+    HIP_TRY(hipMemcpyAsync(ctx->mailbox + 1, X.n_column, sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, s));
+    if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_F64, sh->xchg_counts, 2 * W) != 0) {
       sdm_set_error("sharded displacement: the exchange callback failed (counts of the removed)");
       return SDM_E_HIP;
     }
-    HIP_TRY(hipMemcpyAsync(host_counts, sh->xchg_counts, sizeof(double) * (size_t)W,
+    HIP_TRY(hipMemcpyAsync(host_counts, sh->xchg_counts, sizeof(double) * (size_t)(2 * W),
                            hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    const int64_t mine = ctx->mailbox[0];
-    int64_t total = 0, before = 0;
-    for (int r = 0; r < W; ++r) {
-      if (r < R) before += (int64_t)host_counts[r];
-      total += (int64_t)host_counts[r];
+    for (int l = 0; l < 2; ++l) {
+      mine2[l] = ctx->mailbox[l];
+      total2[l] = before2[l] = 0;
+      for (int r = 0; r < W; ++r) {
+        if (r < R) before2[l] += (int64_t)host_counts[l * W + r];
+        total2[l] += (int64_t)host_counts[l * W + r];
+      }
     }
+    HIP_TRY(hipMemsetAsync(X.n_column, 0, sizeof(unsigned long long), s));
+    return SDM_OK;
+  };
+  // the positions listed by k_disp_precip / k_disp_column on every process -> flagged on every
+  // process -> the reference's compaction on every process's own permutation
+  auto remove_listed = [&](bool with_rain, int64_t total, int64_t before, int64_t mine) -> int {
     HIP_TRY(hipMemsetAsync(X.n_dead, 0, sizeof(unsigned long long), s));
     if (total == 0) {
       if (with_rain) {  // (the one-process step adds this sub-step's 0.0 too)
@@ -841,17 +867,19 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
   HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 8, s));
   for (int sub = 0; sub < cfg->n_substeps; ++sub) {
     hipLaunchKernelGGL(k_disp_move, grid, blk, 0, s, X);
+    hipLaunchKernelGGL(k_disp_count_column, grid, blk, 0, s, X);
+    if (cfg->enable_sedimentation) hipLaunchKernelGGL(k_disp_precip, dim3(n_precip), blk, 0, s, X);
+    LAUNCH_CHECK();
+    rc = exchange_counts();
+    if (rc) return rc;
     if (cfg->enable_sedimentation) {
-      hipLaunchKernelGGL(k_disp_precip, dim3(n_precip), blk, 0, s, X);
-      LAUNCH_CHECK();
-      rc = remove_listed(true);
+      rc = remove_listed(true, total2[0], before2[0], mine2[0]);
       if (rc) return rc;
     }
     hipLaunchKernelGGL(k_disp_column, grid, blk, 0, s, X);
     LAUNCH_CHECK();
-    rc = remove_listed(false);
+    rc = remove_listed(false, total2[1], before2[1], mine2[1]);
     if (rc) return rc;
-    LAUNCH_CHECK();
   }
   // ---- who changed cell, who changed owner ----------------------------------------------------
   ShardLists L;
