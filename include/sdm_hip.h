@@ -505,8 +505,11 @@ int sdm_displacement_step(sdm_ctx *ctx, const sdm_disp_cfg *cfg, const sdm_disp_
  *     placeholder at that position), and for those that changed OWNER the row itself - {position, id, new cell,
  *     multiplicity, cell origin; attributes and position in cell as bit patterns} - which the new
  *     owner stores under the true id, at the true position (the placeholders involved trade
- *     places among themselves).  One sum of 2 * world doubles (the counts) and one of exactly the
- *     int64 words listed; nothing the size of a column.
+ *     places among themselves).  One sum of exactly the int64 words listed; nothing the size of
+ *     a column.  How many words: every sub-step begins with ONE sum of counts (2 * world doubles:
+ *     how many each process will list as precipitated / as out of the column - both are decided
+ *     by where the move has put the droplets; 4 * world in the last sub-step, which adds the two
+ *     lists above: the cells are known by then as well).
  *   - removed super-droplets keep moving in the reference (the displacement kernels run over the
  *     raw columns, and `normalize` reads cell ids by raw id, dead or alive): the process that
  *     owned one when it was removed keeps moving it, wherever it goes, and announces its cells
@@ -525,7 +528,7 @@ typedef struct sdm_disp_shard {
   sdm_exchange_fn exchange;
   void *exchange_user;
   int32_t shard_rank, shard_world;
-  double *xchg_counts;        /* [2 * shard_world + 2] scratch for the counts */
+  double *xchg_counts;        /* [4 * shard_world] scratch for the counts */
   int64_t *xchg_words;        /* [word_capacity] scratch for positions / rows */
   int64_t word_capacity;      /* SDM_E_ARG if a step needs more (n_sd * (6 + 2 * n_dims + n_attr)
                                  always suffices) */

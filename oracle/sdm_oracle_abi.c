@@ -1274,13 +1274,14 @@ API int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
   int64_t *cell0 = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
   int64_t *dead = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
   int64_t *inv = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
-  uint8_t *mark = (uint8_t *)calloc((size_t)(2 * N), 1);
+  uint8_t *mark = (uint8_t *)calloc((size_t)(3 * N), 1);
   int rc = SDM_OK;
   if (!mine || !cell0 || !dead || !inv || !mark) {
     free(mine); free(cell0); free(dead); free(inv); free(mark);
     FAIL(SDM_E_NOMEM, "oracle scratch allocation failed");
   }
-  uint8_t *role = sh->role;
+  uint8_t *role = sh->role, *leaving = mark + 2 * N; /* (about to leave the column) */
+  int64_t total2[4] = {0, 0, 0, 0}, before2[4] = {0, 0, 0, 0};
   if (!sh->role_ready) { /* alive: in the permutation; the removed stay where their cell is */
     for (int64_t k = 0; k < N; ++k) role[k] = sh->cell_owned[sh->cell_id_by_id[k]] ? 2 : 0;
     for (int64_t i = 0; i < length; ++i)
@@ -1322,7 +1323,8 @@ API int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
     }
     /* one exchange of counts for both removals of the sub-step: who leaves the column is decided
      * by the same positions that decide who precipitates (the latter takes precedence) */
-    int64_t mine2[2] = {0, 0}, total2[2], before2[2];
+    int64_t mine2[4] = {0, 0, 0, 0};
+    const int last_sub = s == cfg->n_substeps - 1;
     double *fell = (double *)inv; /* (scratch: the inverse map is built at the end) */
     for (int64_t i = 0; i < length; ++i) {
       const int64_t k = st->idx[i];
@@ -1334,11 +1336,37 @@ API int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
         fell[mine2[0]] = fabs(st->water_mass[k]) * (double)st->multiplicity[k];
         dead[mine2[0]++] = i;
       } else if (z < 0 || z > (double)cfg->grid[D - 1]) {
+        leaving[k] = 1;
         ++mine2[1];
       }
     }
-    rc = disp_exchange_counts(sh, mine2, 2, total2, before2);
+    if (last_sub) {
+      /* the movers of the call ride in the same exchange: where everybody ends up is known
+       * (the cells update below reads what the move above wrote), and who is removed in this
+       * sub-step counts as removed */
+      const int64_t asked = (N + 1) / 2;
+      for (int64_t k = 0; k < N; ++k) {
+        if (!mine[k]) continue;
+        int64_t to = 0;
+        for (int d = 0; d < D; ++d) {
+          const int64_t whole = (int64_t)floor(st->position_in_cell[d * N + k]);
+          int64_t o = (st->cell_origin[d * N + k] + whole) % cfg->grid[d];
+          if (o != 0 && ((o < 0) != (cfg->grid[d] < 0))) o += cfg->grid[d];
+          to += o * cfg->strides[d];
+        }
+        if (to == cell0[k]) continue;
+        const int alive = role[k] == 1 && !leaving[k];
+        if (!alive && k >= asked) continue;
+        ++mine2[2];
+        if (alive && !sh->cell_owned[to]) ++mine2[3];
+      }
+    }
+    rc = disp_exchange_counts(sh, mine2, last_sub ? 4 : 2, total2, before2);
     if (rc) break;
+    if (last_sub) {
+      sh->n_moved = mine2[2];
+      sh->n_left = mine2[3];
+    }
     rc = disp_remove_listed(st, sh, dead, fell, mine2[0], total2[0], before2[0], N, &length,
                             &rain);
     if (rc) break;
@@ -1379,32 +1407,11 @@ API int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
   if (rc == SDM_OK) {
     for (int64_t k = 0; k < N; ++k) inv[k] = -1;
     for (int64_t i = 0; i < length; ++i) inv[st->idx[i]] = i;
-    int64_t n_a = 0, n_b = 0;
     /* (a removed one's cell is read by `normalize` alone, as cell_id[pair number]: ids from
      * (n_sd + 1) / 2 on are never asked for) */
     const int64_t asked = (N + 1) / 2;
-    for (int64_t k = 0; k < N; ++k) {
-      if (!mine[k] || sh->cell_id_by_id[k] == cell0[k] || (role[k] != 1 && k >= asked)) continue;
-      ++n_a;
-      if (role[k] == 1 && !sh->cell_owned[sh->cell_id_by_id[k]]) ++n_b;
-    }
-    sh->n_moved = n_a;
-    sh->n_left = n_b;
-    double *x = sh->xchg_counts;
-    for (int r = 0; r < 2 * W; ++r) x[r] = 0.0;
-    x[R] = (double)n_a;
-    x[W + R] = (double)n_b;
-    if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_F64, x, 2 * W)) {
-      rc = SDM_E_HIP;
-      snprintf(g_err, sizeof(g_err), "exchange callback failed (displacement: counts)");
-    }
-    int64_t tot_a = 0, tot_b = 0, at_a = 0, at_b = 0;
-    for (int r = 0; r < W && rc == SDM_OK; ++r) {
-      if (r < R) { at_a += (int64_t)x[r]; at_b += (int64_t)x[W + r]; }
-      tot_a += (int64_t)x[r];
-      tot_b += (int64_t)x[W + r];
-    }
-    /* a changed cell travels as two words: (position + 1) << 32 | id, new cell (n_sd < 2^31) */
+    const int64_t tot_a = total2[2], tot_b = total2[3];
+    int64_t at_a = before2[2], at_b = before2[3];
     const int64_t words = 2 * tot_a + row * tot_b;
     if (rc == SDM_OK && words > sh->word_capacity) {
       rc = SDM_E_ARG;

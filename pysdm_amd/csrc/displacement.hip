@@ -445,13 +445,14 @@ k_shard_begin(uint8_t *__restrict__ role, const int64_t *__restrict__ multiplici
   if (role[k] == 1 && multiplicity[k] == 0) role[k] = 2;
   cell0[k] = cell_by_id[k];
 }
-// counts[l * world + r] = how many this process is about to put on list l (its own slot r only)
-__global__ void k_pack_counts(double *__restrict__ counts, int world, int rank,
-                              const unsigned long long *__restrict__ n0,
-                              const unsigned long long *__restrict__ n1) {
-  const int r = threadIdx.x;
-  if (r < world) counts[r] = r == rank ? (double)*n0 : 0.0;
-  else if (r < 2 * world) counts[r] = r - world == rank ? (double)*n1 : 0.0;
+// counts[l * world + r] = how many this process is about to put on list l (its own slot r only);
+// mine[l]: the same for the host
+struct FourCounts { const unsigned long long *n[4]; };
+__global__ void k_pack_counts(double *__restrict__ counts, int world, int rank, int lists,
+                              FourCounts C, unsigned long long *__restrict__ mine) {
+  const int t = threadIdx.x, l = t / world, r = t % world;
+  if (l < lists) counts[t] = r == rank ? (double)*C.n[l] : 0.0;
+  if (t < lists) mine[t] = *C.n[t];
 }
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_copy_i64(int64_t *__restrict__ out, const int64_t *__restrict__ in, int64_t n) {
@@ -501,27 +502,32 @@ k_inverse(int32_t *__restrict__ inv, const int64_t *__restrict__ idx,
 // whose new cell is another process's (b).  Listed by stream compaction - per-workgroup counts,
 // one scan, ranks inside the workgroup from ballots - so that the lists come out in id order and
 // nobody queues at one counter (65 k same-address atomics were 0.8 ms at 2^22)
+// `cls`: counting ahead of the removals of the last sub-step (whoever k_disp_move classified as
+// leaving will be a removed one by the time the lists are written); NULL: as things are
 __device__ __forceinline__ void mover_kind(const uint8_t *__restrict__ role,
+                                           const uint8_t *__restrict__ cls,
                                            const uint8_t *__restrict__ owned,
                                            const int64_t *__restrict__ cell_by_id,
                                            const int64_t *__restrict__ cell0, int64_t n_sd,
                                            int64_t k, bool *a, bool *b) {
   *a = *b = false;
+  if (k >= n_sd || role[k] == 0 || cell_by_id[k] == cell0[k]) return;
+  const bool alive = role[k] == 1 && (!cls || cls[k] == 0);
   // (a removed one's cell is read by `normalize` alone, as cell_id[pair number]: ids from
   // (n_sd + 1) / 2 on are never asked for, and a quarter of a long run's traffic was theirs)
-  if (k < n_sd && role[k] != 0 && cell_by_id[k] != cell0[k] &&
-      (role[k] == 1 || k < (n_sd + 1) / 2)) {
+  if (alive || k < (n_sd + 1) / 2) {
     *a = true;
-    *b = role[k] == 1 && !owned[cell_by_id[k]];
+    *b = alive && !owned[cell_by_id[k]];
   }
 }
 __global__ void __launch_bounds__(SDM_BLOCK)
-k_count_movers(const uint8_t *__restrict__ role, const uint8_t *__restrict__ owned,
-               const int64_t *__restrict__ cell_by_id, const int64_t *__restrict__ cell0,
-               int64_t n_sd, int32_t *__restrict__ blk_a, int32_t *__restrict__ blk_b) {
+k_count_movers(const uint8_t *__restrict__ role, const uint8_t *__restrict__ cls,
+               const uint8_t *__restrict__ owned, const int64_t *__restrict__ cell_by_id,
+               const int64_t *__restrict__ cell0, int64_t n_sd, int32_t *__restrict__ blk_a,
+               int32_t *__restrict__ blk_b) {
   __shared__ int sa[SDM_BLOCK / SDM_WAVE], sb[SDM_BLOCK / SDM_WAVE];
   bool a, b;
-  mover_kind(role, owned, cell_by_id, cell0, n_sd, TID(), &a, &b);
+  mover_kind(role, cls, owned, cell_by_id, cell0, n_sd, TID(), &a, &b);
   const unsigned long long ma = __ballot(a), mb = __ballot(b);
   if (lane_id() == 0) {
     sa[threadIdx.x / SDM_WAVE] = __popcll(ma);
@@ -570,16 +576,6 @@ k_scan_movers(int32_t *__restrict__ blk_a, int32_t *__restrict__ blk_b, int64_t 
     n[1] = (unsigned long long)carry[1];
   }
 }
-__global__ void k_pack_counts2(double *__restrict__ counts, int world, int rank,
-                               const unsigned long long *__restrict__ n) {
-  const int r = threadIdx.x;
-  if (r < 2 * world) counts[r] = 0.0;
-  __syncthreads();
-  if (r == 0) {
-    counts[rank] = (double)n[0];
-    counts[world + rank] = (double)n[1];
-  }
-}
 // at_a, at_b: where this process's slices begin (in entries); blk_*: the scanned counts
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_list_movers(ShardLists L, uint8_t *__restrict__ role, const uint8_t *__restrict__ owned,
@@ -591,7 +587,7 @@ k_list_movers(ShardLists L, uint8_t *__restrict__ role, const uint8_t *__restric
   __shared__ int sa[SDM_BLOCK / SDM_WAVE], sb[SDM_BLOCK / SDM_WAVE];
   const int64_t k = TID();
   bool a, b;
-  mover_kind(role, owned, cell_by_id, cell0, L.n_sd, k, &a, &b);
+  mover_kind(role, nullptr, owned, cell_by_id, cell0, L.n_sd, k, &a, &b);
   const unsigned long long ma = __ballot(a), mb = __ballot(b);
   const unsigned long long below = (1ull << lane_id()) - 1;
   if (lane_id() == 0) {
@@ -781,33 +777,33 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
   hipLaunchKernelGGL(k_shard_begin, grid, blk, 0, s, sh->role, (const int64_t *)sh->multiplicity,
                      (const int64_t *)sh->cell_id_by_id, cell0, N);
   LAUNCH_CHECK();
-  double host_counts[2 * 256 + 2];
+  double host_counts[4 * 256];
   double *carried = (double *)free_cell;  // (scratch of the arrivals, free until the end)
-  // one exchange of counts for both removals of a sub-step (who leaves the column is decided by
-  // the same classification as who precipitates): totals and this process's offsets, per list
-  int64_t total2[2], before2[2], mine2[2];
-  auto exchange_counts = [&]() -> int {
-    hipLaunchKernelGGL(k_pack_counts, one, dim3(512), 0, s, sh->xchg_counts, W, R,
-                       (const unsigned long long *)X.n_dead,
-                       (const unsigned long long *)X.n_column);
+  // ONE exchange of counts per sub-step: both removals (who leaves the column is decided by the
+  // same classification as who precipitates) and, in the last sub-step, the movers too (their
+  // cells are known as soon as k_disp_move has run).  Totals and this process's offsets, per list
+  int64_t total4[4] = {0, 0, 0, 0}, before4[4] = {0, 0, 0, 0}, mine4[4] = {0, 0, 0, 0};
+  unsigned long long *mine_dev = cv.take<unsigned long long>(4);
+  auto exchange_counts = [&](int lists) -> int {
+    FourCounts C4 = {{X.n_dead, X.n_column, counters + 2, counters + 3}};
+    hipLaunchKernelGGL(k_pack_counts, one, dim3(1024), 0, s, sh->xchg_counts, W, R, lists, C4,
+                       mine_dev);
     LAUNCH_CHECK();
-    HIP_TRY(hipMemcpyAsync(ctx->mailbox, X.n_dead, sizeof(unsigned long long),
+    HIP_TRY(hipMemcpyAsync(ctx->mailbox, mine_dev, sizeof(unsigned long long) * 4,
                            hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(ctx->mailbox + 1, X.n_column, sizeof(unsigned long long),
-                           hipMemcpyDeviceToHost, s));
-    if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_F64, sh->xchg_counts, 2 * W) != 0) {
-      sdm_set_error("sharded displacement: the exchange callback failed (counts of the removed)");
+    if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_F64, sh->xchg_counts, lists * W) != 0) {
+      sdm_set_error("sharded displacement: the exchange callback failed (counts)");
       return SDM_E_HIP;
     }
-    HIP_TRY(hipMemcpyAsync(host_counts, sh->xchg_counts, sizeof(double) * (size_t)(2 * W),
+    HIP_TRY(hipMemcpyAsync(host_counts, sh->xchg_counts, sizeof(double) * (size_t)(lists * W),
                            hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    for (int l = 0; l < 2; ++l) {
-      mine2[l] = ctx->mailbox[l];
-      total2[l] = before2[l] = 0;
+    for (int l = 0; l < lists; ++l) {
+      mine4[l] = ctx->mailbox[l];
+      total4[l] = before4[l] = 0;
       for (int r = 0; r < W; ++r) {
-        if (r < R) before2[l] += (int64_t)host_counts[l * W + r];
-        total2[l] += (int64_t)host_counts[l * W + r];
+        if (r < R) before4[l] += (int64_t)host_counts[l * W + r];
+        total4[l] += (int64_t)host_counts[l * W + r];
       }
     }
     HIP_TRY(hipMemsetAsync(X.n_column, 0, sizeof(unsigned long long), s));
@@ -866,19 +862,28 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
   HIP_TRY(hipMemsetAsync(X.rain, 0, sizeof(double), s));
   HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 8, s));
   for (int sub = 0; sub < cfg->n_substeps; ++sub) {
+    const bool last_sub = sub == cfg->n_substeps - 1;
     hipLaunchKernelGGL(k_disp_move, grid, blk, 0, s, X);
     hipLaunchKernelGGL(k_disp_count_column, grid, blk, 0, s, X);
     if (cfg->enable_sedimentation) hipLaunchKernelGGL(k_disp_precip, dim3(n_precip), blk, 0, s, X);
+    if (last_sub) {  // the movers of the call, counted ahead of this sub-step's removals
+      hipLaunchKernelGGL(k_count_movers, grid, blk, 0, s, (const uint8_t *)sh->role,
+                         (const uint8_t *)X.cls, sh->cell_owned,
+                         (const int64_t *)sh->cell_id_by_id, (const int64_t *)cell0, N, blk_a,
+                         blk_b);
+      hipLaunchKernelGGL(k_scan_movers, one, dim3(1024), 0, s, blk_a, blk_b, (int64_t)nb,
+                         counters + 2);
+    }
     LAUNCH_CHECK();
-    rc = exchange_counts();
+    rc = exchange_counts(last_sub ? 4 : 2);
     if (rc) return rc;
     if (cfg->enable_sedimentation) {
-      rc = remove_listed(true, total2[0], before2[0], mine2[0]);
+      rc = remove_listed(true, total4[0], before4[0], mine4[0]);
       if (rc) return rc;
     }
     hipLaunchKernelGGL(k_disp_column, grid, blk, 0, s, X);
     LAUNCH_CHECK();
-    rc = remove_listed(false, total2[1], before2[1], mine2[1]);
+    rc = remove_listed(false, total4[1], before4[1], mine4[1]);
     if (rc) return rc;
   }
   // ---- who changed cell, who changed owner ----------------------------------------------------
@@ -891,30 +896,9 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
   HIP_TRY(hipMemsetAsync(inv, 0xff, sizeof(int32_t) * (size_t)N, s));
   hipLaunchKernelGGL(k_inverse, grid, blk, 0, s, inv, (const int64_t *)state->idx,
                      (const int64_t *)state->ctl);
-  hipLaunchKernelGGL(k_count_movers, grid, blk, 0, s, (const uint8_t *)sh->role, sh->cell_owned,
-                     (const int64_t *)sh->cell_id_by_id, (const int64_t *)cell0, N, blk_a, blk_b);
-  hipLaunchKernelGGL(k_scan_movers, one, dim3(1024), 0, s, blk_a, blk_b, (int64_t)nb,
-                     counters + 2);
-  hipLaunchKernelGGL(k_pack_counts2, one, dim3(512), 0, s, sh->xchg_counts, W, R,
-                     (const unsigned long long *)(counters + 2));
-  LAUNCH_CHECK();
-  HIP_TRY(hipMemcpyAsync(ctx->mailbox, counters + 2, 2 * sizeof(unsigned long long),
-                         hipMemcpyDeviceToHost, s));
-  if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_F64, sh->xchg_counts, 2 * W) != 0) {
-    sdm_set_error("sharded displacement: the exchange callback failed (counts of the movers)");
-    return SDM_E_HIP;
-  }
-  HIP_TRY(hipMemcpyAsync(host_counts, sh->xchg_counts, sizeof(double) * (size_t)(2 * W),
-                         hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  sh->n_moved = ctx->mailbox[0];
-  sh->n_left = ctx->mailbox[1];
-  int64_t tot_a = 0, tot_b = 0, at_a = 0, at_b = 0;
-  for (int r = 0; r < W; ++r) {
-    if (r < R) { at_a += (int64_t)host_counts[r]; at_b += (int64_t)host_counts[W + r]; }
-    tot_a += (int64_t)host_counts[r];
-    tot_b += (int64_t)host_counts[W + r];
-  }
+  sh->n_moved = mine4[2];
+  sh->n_left = mine4[3];
+  const int64_t tot_a = total4[2], tot_b = total4[3], at_a = before4[2], at_b = before4[3];
   L.tot_a = tot_a;
   L.tot_b = tot_b;
   const int64_t words = 2 * tot_a + L.row * tot_b;

@@ -67,7 +67,7 @@ class Shard:  # pylint: disable=too-many-instance-attributes
         """scratch of the sharded displacement step (sdm_disp_shard): counts, and `n_words` int64
         for positions and rows; allocated on first use, kept"""
         if self.d_counts is None:
-            self.d_counts = self.engine.zeros(2 * self.world + 2, np.float64)
+            self.d_counts = self.engine.zeros(4 * self.world, np.float64)
         if self.d_words is None or int(self.d_words.shape[0]) < n_words:
             self.d_words = self.engine.zeros(n_words, np.int64)
         return self.d_counts, self.d_words
