@@ -2,21 +2,24 @@
 (backend "nccl" = RCCL over xGMI on GPUs, "gloo" in the CPU tests) for what crosses processes.
 
 The sharded run reproduces the ONE-process run bit for bit (same seed, same random stream): see
-include/sdm_hip.h ("sharding") for what is global in the algorithm and how the library handles it.
-In short: every process holds the columns at their global shape (ids, positions, `cell_start`,
-`cell_idx` keep their global meaning; memory is not the constraint on a 288-GB part) but runs the
-per-cell kernels only on the contiguous block of cells it owns.  Per sub-step one tiny all-reduce
-(n_cell + 1 doubles: the owned cells' `dt_left`, and whether a super-droplet died anywhere); when
-one did, one all-reduce of the permutation (n_sd int64), after which compaction and counting sort
-run replicated.  No super-droplet payload crosses processes in a collision step: a cell's
-super-droplets live, and stay, with the cell's owner.
+include/sdm_hip.h ("sharding", "sdm_disp_shard") for what is global in the algorithm and how the
+library handles it.  In short: every process holds the columns at their global shape (ids,
+positions, `cell_start`, `cell_idx` keep their global meaning; memory is not the constraint on a
+288-GB part) but computes only the contiguous block of cells it owns.
+Collision step: per sub-step one tiny all-reduce (n_cell + 1 + world doubles: the owned cells'
+`dt_left`, and how many super-droplets died where); when one did, the POSITIONS of the dead (as
+many int64 as died), after which compaction and counting sort run on every process's own
+permutation.  No super-droplet payload crosses processes in a collision step.
+Displacement step (`attach_displacement`): the owner of a super-droplet's cell moves it; the
+positions of the removed, one list {position + id, new cell} of everything that changed cell and
+the rows of what changed owner cross the processes - nothing the size of a column.
 
 `attach(runner, rank, world)` turns a CollisionRunner over the global population into this
-process's share of it; `gather(runner)` assembles the global state from the owners on the host
-(diagnostics, tests); `complete_state(runner)` does so on the device, for a replicated stage
-between sharded collision steps - the displacement step: ownership is by cell, so the
-super-droplets it moves into another process's cells change hands right there (migration needs
-no further step).
+process's share of it; `attach_displacement(displacement, shard)` does the same for the step that
+precedes it; `gather(runner)` / `gather_population(shard, population)` assemble the global state
+from the owners on the host (diagnostics, tests).  `complete_state(runner)` is the older, simpler
+hand-over for a REPLICATED displacement step (all-reduces of the masked columns: every process
+whole again); not to be mixed with `attach_displacement` in one run.
 """
 import ctypes
 
