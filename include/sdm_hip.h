@@ -497,19 +497,21 @@ int sdm_displacement_step(sdm_ctx *ctx, const sdm_disp_cfg *cfg, const sdm_disp_
  *     droplet and the replicated Courant field) by the process that owns its cell when the call
  *     begins; rows of other super-droplets are not touched;
  *   - removal (precipitation, out of the column): the owners' dead POSITIONS (for precipitation
- *     also the masses, as bit patterns) are summed as rank-disjoint slices, as in the collision step, and every process runs the
- *     reference's compaction on its own permutation.  Positions are the global names: a filler
- *     taken from the tail lands in the same hole on every process;
+ *     also the masses, as bit patterns) are summed as rank-disjoint slices, as in the collision
+ *     step, and every process runs the reference's compaction on its own permutation.  Positions
+ *     are the global names: a filler taken from the tail lands in the same hole on every process;
  *   - at the end, per super-droplet whose cell changed: {position and id (one word), new cell} to
  *     everybody (cell_id_by_id[id] takes the new cell, and so does the cell_id entry of the
- *     placeholder at that position), and for those that changed OWNER the row itself - {position, id, new cell,
- *     multiplicity, cell origin; attributes and position in cell as bit patterns} - which the new
- *     owner stores under the true id, at the true position (the placeholders involved trade
- *     places among themselves).  One sum of exactly the int64 words listed; nothing the size of
- *     a column.  How many words: every sub-step begins with ONE sum of counts (2 * world doubles:
- *     how many each process will list as precipitated / as out of the column - both are decided
- *     by where the move has put the droplets; 4 * world in the last sub-step, which adds the two
- *     lists above: the cells are known by then as well).
+ *     placeholder at that position), and for those that changed OWNER the row itself -
+ *     {position, id, new cell, multiplicity, cell origin; attributes and position in cell as bit
+ *     patterns} - which the new owner stores under the true id, at the true position (the
+ *     placeholders involved trade places among themselves).  One sum of exactly the int64 words
+ *     listed; nothing the size of a column;
+ *   - how many words each list has: every sub-step begins with ONE sum of counts (2 * world
+ *     doubles: how many each process will list as precipitated / as out of the column - both are
+ *     decided by where the move has put the droplets; 4 * world in the last sub-step, which adds
+ *     the two lists of the previous item: the cells are known by then as well).  That is the one
+ *     host round trip of a sub-step;
  *   - removed super-droplets keep moving in the reference (the displacement kernels run over the
  *     raw columns, and `normalize` reads cell ids by raw id, dead or alive): the process that
  *     owned one when it was removed keeps moving it, wherever it goes, and announces its cells
