@@ -75,6 +75,7 @@ struct sdm_ctx {
   // `normalize`'s raw look-up cell_id[pair slot] (collisions_methods.py:633-662), which keeps
   // reading the caller's column
   const int64_t *cell_id_raw;
+  int resort_backoff;  // fused.hip: death events for which the closed-form re-sort is not tried
   // fused.hip: what a multi-cell adaptive step knows at its end, for the next step of the same call
   // (valid length, an upper bound of the cell sizes; the state is sorted) - saves that step's
   // opening read-back

@@ -1917,6 +1917,7 @@ struct FusedScratch {
   uint8_t *pair_off;
   int32_t *pair_cid;
   int64_t *sorted_buf, *cs_tmp, *gate_len, *cctl, *end2, *seg_size, *seg_src;
+  int64_t *resort_plan;  // (index.hip: sdm_resort_after_compaction_async)
   char *shuffle, *sort, *compact;
   size_t total;
 };
@@ -1943,6 +1944,7 @@ static FusedScratch layout(char *base, const sdm_step_cfg *cfg) {
   S.seg_src = cv.take<int64_t>(C);
   S.gate_len = cv.take<int64_t>(4);
   S.cctl = cv.take<int64_t>(8);
+  S.resort_plan = cv.take<int64_t>(8);
   S.end2 = cv.take<int64_t>(8);  // (word 4: sharded mode's count of dead positions)
   S.shuffle = base + cv.off;
   cv.off += carve_size(sdm_shuffle_scratch(N));
@@ -2558,7 +2560,30 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         shard_resorted = true;
         hipLaunchKernelGGL(k_reset_work, one, one, 0, s, st->ctl);  // sanitize left work = valid
         LAUNCH_CHECK();
-        rc = cond_sort(ctx, cfg, st, cur, S, &sorted_host);
+        {
+          // a handful of deaths in a sorted state: the re-sort has a closed form (index.hip)
+          static const bool resort_off = getenv("SDM_NO_FAST_RESORT") != nullptr;  // (A/B runs)
+          bool closed_form = false;
+          PhaseScope ph(ctx, SDM_PHASE_SORT);
+          // (asking costs a round trip: after a refusal - too many deaths at once, a tail that
+          // spans cells - the next few deaths go straight to the counting sort)
+          if (!resort_off && ctx->resort_backoff > 0) --ctx->resort_backoff;
+          else if (!resort_off) {
+            rc = sdm_resort_plan(ctx, S.compact, N, S.cctl, st->ctl, st->cell_start, C,
+                                 S.resort_plan, &closed_form);
+            if (rc) return rc;
+            if (!closed_form) ctx->resort_backoff = 16;
+          }
+          if (closed_form) {
+            rc = sdm_resort_after_compaction_async(ctx, S.compact, N, st->ctl, cur, S.sorted_buf,
+                                                   st->cell_start, S.cs_tmp, st->cell_id,
+                                                   st->cell_idx, C, S.resort_plan, S.seg_size,
+                                                   S.seg_src);
+            if (rc) return rc;
+            sorted_host = 1;
+          }
+        }
+        rc = cond_sort(ctx, cfg, st, cur, S, &sorted_host);  // (no-op when sorted_host == 1)
         if (rc) return rc;
         const int64_t seq = ++ctx->poll_seq;
         rc = sdm_adaptive_end_async(ctx, st->dt_left, C, st->cell_start, S.end2, S.end2 + 1);

@@ -98,6 +98,15 @@ struct CompactEpilogue {
   uint64_t advance, advance_b;
   CellsEnd cells;
 };
+int sdm_resort_plan(sdm_ctx *ctx, char *scratch, int64_t length_bound, const int64_t *cctl,
+                    const int64_t *fctl, const int64_t *cell_start, int64_t n_cell, int64_t *plan,
+                    bool *applies);
+int sdm_resort_after_compaction_async(sdm_ctx *ctx, char *scratch, int64_t length_bound,
+                                      int64_t *fctl, int64_t *idx, int64_t *out,
+                                      int64_t *cell_start, int64_t *cs_new,
+                                      const int64_t *cell_id, const int64_t *cell_idx,
+                                      int64_t n_cell, const int64_t *plan, int64_t *seg_size,
+                                      int64_t *seg_key);
 int sdm_compact_fused_async(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity,
                             int64_t *idx, int64_t length_bound, int64_t flag, int64_t *fctl,
                             int64_t *ctl, int64_t *cell_start_single, bool flag_only = false,

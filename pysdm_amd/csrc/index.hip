@@ -1061,6 +1061,191 @@ int sdm_compact_rearm(sdm_ctx *ctx) {
   return SDM_OK;
 }
 
+// ---- re-sorting by cell after a compaction, without sorting ----------------------------------
+// A state that was sorted by cell when super-droplets died is, after the reference's
+// swap-from-the-end (holes filled with the live tail, compact_run above), still GROUPED by cell
+// except for the fillers; and if the whole tail lay in the last non-empty segment (a handful of
+// deaths against thousands of members: nearly always) the fillers all belong to that segment's
+// cell.  The stable counting sort that the cell_start getter would run then has a closed form:
+//   * the members of a segment keep their order; a filler standing in an EARLIER segment's hole
+//     precedes everything that stands in the last segment (it comes first in the permutation),
+//     fillers among themselves in hole order; holes inside the last segment were refilled with
+//     members of the same cell and change nothing;
+//   * the segments themselves are re-ordered: the sort runs under the cell_idx of the CURRENT
+//     sub-step (cell_idx.sort_by_key(dt_left) runs every sub-step, the permutation keeps the
+//     order of the last sort), so segment s goes where the key of its cell says.
+// Sizes per segment -> scan in key order -> one scatter pass -> copy back: streaming, no
+// histogram of 2^22 gathered keys.  Everything is decided on the device (plan[0]); when the form
+// does not apply, the counting sort that follows finds the state unsorted and runs as before.
+#define RESORT_CAP 4096
+__global__ void k_sort_cellstart(const int64_t *__restrict__ count, int64_t *__restrict__ cell_start,
+                                 int64_t n_cell, const int64_t *__restrict__ p_length);
+__global__ void k_resort_plan(const int64_t *__restrict__ fctl, const int64_t *__restrict__ cctl,
+                              const int64_t *__restrict__ cell_start, int64_t n_cell,
+                              const int32_t *__restrict__ holes, int64_t *__restrict__ plan) {
+  // (one wavefront: the count of the holes before the last segment is a reduction, not a walk)
+  const int64_t old_len = cell_start[n_cell], new_len = fctl[FCTL_VALID], n_holes = cctl[2];
+  bool ok = fctl[FCTL_SORTED] == 0 && fctl[FCTL_WORK] == new_len && old_len > new_len &&
+            new_len > 0 && n_holes >= 0 && n_holes <= RESORT_CAP && cell_start[0] == 0;
+  int64_t s_last = 0, cs_last = 0;
+  int h0 = 0;
+  if (ok) {
+    s_last = find_cell(cell_start, n_cell, old_len - 1);
+    cs_last = cell_start[s_last];
+    ok = cs_last <= new_len;  // the whole tail [new_len, old_len) lay in that segment
+    if (ok)
+      for (int k = threadIdx.x; k < (int)n_holes; k += SDM_WAVE) h0 += holes[k] < cs_last;
+  }
+  h0 = wave_sum_i32(h0);
+  if (threadIdx.x != 0) return;
+  plan[0] = ok ? 1 : 0;
+  plan[1] = s_last;
+  plan[2] = cs_last;
+  plan[3] = n_holes;
+  plan[4] = new_len;
+  plan[5] = h0;
+}
+__device__ __forceinline__ int holes_before(const int32_t *h, int n, int64_t x) {  // # holes < x
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (h[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// one thread per segment: its size after the removal, and the key of its cell under the current
+// cell_idx; seg_size (zeroed by the caller) is indexed by that key, seg_key by the segment
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_resort_segments(const int64_t *__restrict__ plan, const int64_t *__restrict__ idx,
+                  const int32_t *__restrict__ holes, const int64_t *__restrict__ cell_start,
+                  const int64_t *__restrict__ cell_id, const int64_t *__restrict__ cell_idx,
+                  int64_t n_cell, int64_t *__restrict__ seg_size, int64_t *__restrict__ seg_key) {
+  if (plan[0] == 0) return;
+  __shared__ int32_t sh[RESORT_CAP];
+  const int64_t s_last = plan[1], cs_last = plan[2], new_len = plan[4], h0 = plan[5];
+  const int n_holes = (int)plan[3];
+  for (int k = threadIdx.x; k < n_holes; k += SDM_BLOCK) sh[k] = holes[k];
+  __syncthreads();
+  const int64_t s = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+  if (s >= n_cell) return;
+  int64_t size = 0, member = -1;
+  if (s < s_last) {
+    const int64_t a = cell_start[s], b = cell_start[s + 1];
+    int hb = holes_before(sh, n_holes, a);
+    size = (b - a) - (holes_before(sh, n_holes, b) - hb);
+    if (size > 0) {  // the first position of the segment that is not a hole (= not a filler)
+      int64_t p = a;
+      while (hb < n_holes && sh[hb] == p) { ++p; ++hb; }
+      member = p;
+    }
+  } else if (s == s_last) {
+    size = new_len - cs_last + h0;
+    if (size > 0) member = new_len > cs_last ? cs_last : (int64_t)sh[0];  // (a filler: same cell)
+  }
+  int64_t key = -1;
+  if (size > 0) {
+    key = cell_idx[cell_id[idx[member]]];
+    seg_size[key] = size;
+  }
+  seg_key[s] = key;
+}
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_resort_scatter(const int64_t *__restrict__ plan, const int64_t *__restrict__ idx,
+                 const int32_t *__restrict__ holes, int64_t *__restrict__ out,
+                 const int64_t *__restrict__ cell_start, const int64_t *__restrict__ cs_new,
+                 const int64_t *__restrict__ seg_key, int64_t n_cell) {
+  if (plan[0] == 0) return;
+  __shared__ int32_t sh[RESORT_CAP];
+  const int64_t s_last = plan[1], cs_last = plan[2], new_len = plan[4], h0 = plan[5];
+  const int n_holes = (int)plan[3];
+  for (int k = threadIdx.x; k < n_holes; k += SDM_BLOCK) sh[k] = holes[k];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+  // the segment of the wavefront's first position serves all its lanes unless a boundary falls
+  // into the 64 positions (one look-up per wavefront instead of ten dependent loads per lane)
+  const int64_t w0 = i - lane_id();
+  int64_t s = 0, a = 0, b = 0;
+  if (w0 < cs_last) {
+    s = find_cell(cell_start, n_cell, w0);
+    a = cell_start[s];
+    b = cell_start[s + 1];
+  }
+  if (i >= new_len) return;
+  const int hb = holes_before(sh, n_holes, i);
+  const bool filler = hb < n_holes && sh[hb] == i;
+  int64_t dst;
+  if (i >= cs_last) {
+    dst = cs_new[seg_key[s_last]] + h0 + (i - cs_last);
+  } else if (filler) {
+    dst = cs_new[seg_key[s_last]] + hb;
+  } else {
+    if (i >= b) {  // (a boundary inside the wavefront's range)
+      s = find_cell(cell_start, n_cell, i);
+      a = cell_start[s];
+    }
+    dst = cs_new[seg_key[s]] + (i - a) - (hb - holes_before(sh, n_holes, a));
+  }
+  out[dst] = idx[i];
+}
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_resort_commit(const int64_t *__restrict__ plan, int64_t *__restrict__ idx,
+                const int64_t *__restrict__ out, int64_t *__restrict__ cell_start,
+                const int64_t *__restrict__ cs_new, int64_t n_cell, int64_t *__restrict__ fctl) {
+  if (plan[0] == 0) return;
+  const int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+  if (i < plan[4]) idx[i] = out[i];
+  if (i <= n_cell) cell_start[i] = cs_new[i];
+  if (i == 0) fctl[FCTL_SORTED] = 1;
+}
+
+// `scratch`, `cctl`: what the compaction just used (sdm_compact_fused_async); `plan`: 8 device
+// words.  *applies: whether the closed form holds (decided on the device, read back: the host is
+// about to wait for this stream anyway, and a counting sort that is launched only to find its
+// gate closed still costs 60 us of empty grids at 2^22)
+int sdm_resort_plan(sdm_ctx *ctx, char *scratch, int64_t length_bound, const int64_t *cctl,
+                    const int64_t *fctl, const int64_t *cell_start, int64_t n_cell, int64_t *plan,
+                    bool *applies) {
+  Carver cv(scratch);
+  (void)cv.take<int32_t>(COMPACT_WAVES);
+  const int32_t *holes = cv.take<int32_t>(length_bound);
+  hipLaunchKernelGGL(k_resort_plan, dim3(1), dim3(SDM_WAVE), 0, ctx->stream, fctl, cctl,
+                     cell_start, n_cell, holes, plan);
+  LAUNCH_CHECK();
+  HIP_TRY(hipMemcpyAsync(ctx->mailbox, plan, sizeof(int64_t), hipMemcpyDeviceToHost,
+                         ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  *applies = ctx->mailbox[0] != 0;
+  return SDM_OK;
+}
+
+// after sdm_resort_plan said it applies.  `seg_size`, `seg_key`: n_cell words each; `out`:
+// length_bound words; `cs_new`: n_cell + 1
+int sdm_resort_after_compaction_async(sdm_ctx *ctx, char *scratch, int64_t length_bound,
+                                      int64_t *fctl, int64_t *idx, int64_t *out,
+                                      int64_t *cell_start, int64_t *cs_new,
+                                      const int64_t *cell_id, const int64_t *cell_idx,
+                                      int64_t n_cell, const int64_t *plan, int64_t *seg_size,
+                                      int64_t *seg_key) {
+  Carver cv(scratch);
+  (void)cv.take<int32_t>(COMPACT_WAVES);
+  const int32_t *holes = cv.take<int32_t>(length_bound);
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipMemsetAsync(seg_size, 0, sizeof(int64_t) * (size_t)n_cell, s));
+  hipLaunchKernelGGL(k_resort_segments, dim3(grid_for(n_cell)), dim3(SDM_BLOCK), 0, s, plan,
+                     (const int64_t *)idx, holes, (const int64_t *)cell_start, cell_id, cell_idx,
+                     n_cell, seg_size, seg_key);
+  hipLaunchKernelGGL(k_sort_cellstart, dim3(1), dim3(1024), 0, s, (const int64_t *)seg_size,
+                     cs_new, n_cell, plan);
+  hipLaunchKernelGGL(k_resort_scatter, dim3(grid_for(length_bound)), dim3(SDM_BLOCK), 0, s, plan,
+                     (const int64_t *)idx, holes, out, (const int64_t *)cell_start,
+                     (const int64_t *)cs_new, (const int64_t *)seg_key, n_cell);
+  const int64_t n = length_bound > n_cell + 1 ? length_bound : n_cell + 1;
+  hipLaunchKernelGGL(k_resort_commit, dim3(grid_for(n)), dim3(SDM_BLOCK), 0, s, plan, idx,
+                     (const int64_t *)out, cell_start, (const int64_t *)cs_new, n_cell, fctl);
+  LAUNCH_CHECK();
+  return SDM_OK;
+}
+
 size_t sdm_compact_scratch(int64_t n) {
   return carve_size(sizeof(int32_t) * COMPACT_WAVES) + carve_size(sizeof(int32_t) * n) +
          carve_size(sizeof(int64_t) * n);
