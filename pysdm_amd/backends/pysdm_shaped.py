@@ -50,6 +50,41 @@ def backend_class_for(engine_getter, name, doc=None):  # pylint: disable=too-man
     def is_int(storage):
         return int(storage.dtype is Storage.INT)
 
+    class Typed:
+        """Storages handed over with another element type than the C parameter names.  The
+        reference's Numba bodies are duck-typed (compiled per argument types), and its own unit
+        tests use that: an int `out` for `sum_pair` (tests/unit_tests/backends/
+        test_pair_methods.py:81-101), int probabilities for `scale_prob_for_adaptive_sdm_gamma`
+        (test_collisions_methods.py:261-336), one float array as both counters of `compute_gamma`
+        (dynamics/collisions/test_sdm_single_cell.py:216-258).  The C ABI is typed, so such an
+        argument is converted into a temporary of the right type and - `with` exit - cast back into
+        the caller's array (C-style truncation = NumPy assignment).  Off the hot path: PySDM's own
+        dynamics always pass the types the ABI names, and then this is a no-op."""
+
+        def __init__(self):
+            self.pending = {}
+
+        def __call__(self, storage, tag):
+            if storage.dtype is tag:
+                return storage.data
+            key = id(storage.data)
+            if key not in self.pending:
+                eng = engine_getter()
+                temporary = eng.upload(eng.download(storage.data).astype(tag))
+                self.pending[key] = (storage, temporary)
+            return self.pending[key][1]
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, kind, value, trace):
+            if kind is None:
+                eng = engine_getter()
+                for storage, temporary in self.pending.values():
+                    eng.assign(storage.data,
+                               eng.upload(eng.download(temporary).astype(storage.dtype)))
+            return False
+
     class Random:  # pylint: disable=too-few-public-methods
         """NumPy-PCG64 stream; each call continues where the previous one stopped
         (impl_numba/random.py:13-19)"""
@@ -132,8 +167,10 @@ def backend_class_for(engine_getter, name, doc=None):  # pylint: disable=too-man
 
         @staticmethod
         def _pair(op, data_out, data_in, is_first_in_pair, idx):
-            call("sdm_pair_op", PAIR[op], data_out.data, int(data_out.shape[0]), data_in.data,
-                 is_int(data_in), flag(is_first_in_pair), idx.data, len(idx))
+            with Typed() as typed:
+                call("sdm_pair_op", PAIR[op], typed(data_out, Storage.FLOAT),
+                     int(data_out.shape[0]), data_in.data, is_int(data_in),
+                     flag(is_first_in_pair), idx.data, len(idx))
 
         def sum_pair(self, data_out, data_in, is_first_in_pair, idx):
             self._pair("sum", data_out, data_in, is_first_in_pair, idx)
@@ -166,17 +203,22 @@ def backend_class_for(engine_getter, name, doc=None):  # pylint: disable=too-man
         def scale_prob_for_adaptive_sdm_gamma(*, prob, multiplicity, cell_id, dt_left, dt,
                                               dt_range, is_first_in_pair, stats_n_substep,
                                               stats_dt_min):
-            call("sdm_scale_prob_for_adaptive_sdm_gamma", prob.data, multiplicity.idx.data,
-                 len(multiplicity), multiplicity.data, cell_id.data, dt_left.data,
-                 int(dt_left.shape[0]), float(dt), float(dt_range[0]), float(dt_range[1]),
-                 flag(is_first_in_pair), stats_n_substep.data, stats_dt_min.data)
+            with Typed() as typed:
+                call("sdm_scale_prob_for_adaptive_sdm_gamma", typed(prob, Storage.FLOAT),
+                     multiplicity.idx.data, len(multiplicity), multiplicity.data, cell_id.data,
+                     typed(dt_left, Storage.FLOAT), int(dt_left.shape[0]), float(dt),
+                     float(dt_range[0]), float(dt_range[1]), flag(is_first_in_pair),
+                     typed(stats_n_substep, Storage.INT), typed(stats_dt_min, Storage.FLOAT))
 
         @staticmethod
         def compute_gamma(*, prob, rand, multiplicity, cell_id, collision_rate_deficit,
                           collision_rate, is_first_in_pair, out):
-            call("sdm_compute_gamma", prob.data, rand.data, multiplicity.idx.data,
-                 len(multiplicity), multiplicity.data, cell_id.data, collision_rate_deficit.data,
-                 collision_rate.data, flag(is_first_in_pair), out.data)
+            with Typed() as typed:
+                call("sdm_compute_gamma", typed(prob, Storage.FLOAT), typed(rand, Storage.FLOAT),
+                     multiplicity.idx.data, len(multiplicity), multiplicity.data, cell_id.data,
+                     typed(collision_rate_deficit, Storage.INT),
+                     typed(collision_rate, Storage.INT), flag(is_first_in_pair),
+                     typed(out, Storage.FLOAT))
 
         def adaptive_sdm_end(self, dt_left, cell_start):
             return self.engine.scalar_out("sdm_adaptive_sdm_end", ctypes.c_int64, dt_left.data,
@@ -185,21 +227,27 @@ def backend_class_for(engine_getter, name, doc=None):  # pylint: disable=too-man
         @staticmethod
         def collision_coalescence(*, multiplicity, idx, attributes, gamma, healthy, cell_id,
                                   coalescence_rate, is_first_in_pair):
-            call("sdm_collision_coalescence", multiplicity.data, idx.data, len(idx),
-                 attributes.data, int(attributes.shape[0]), int(attributes.shape[1]), gamma.data,
-                 healthy.data, cell_id.data, coalescence_rate.data, flag(is_first_in_pair))
+            with Typed() as typed:
+                call("sdm_collision_coalescence", multiplicity.data, idx.data, len(idx),
+                     attributes.data, int(attributes.shape[0]), int(attributes.shape[1]),
+                     typed(gamma, Storage.FLOAT), healthy.data, cell_id.data,
+                     typed(coalescence_rate, Storage.INT), flag(is_first_in_pair))
 
         def collision_coalescence_breakup(self, *, multiplicity, idx, attributes, gamma, rand, Ec,
                                           Eb, fragment_mass, healthy, cell_id, coalescence_rate,
                                           breakup_rate, breakup_rate_deficit, is_first_in_pair,
                                           warn_overflows, particle_mass, max_multiplicity):
             overflows = self.engine.zeros(1, np.int64) if warn_overflows else None
-            call("sdm_collision_coalescence_breakup", multiplicity.data, idx.data, len(idx),
-                 attributes.data, int(attributes.shape[0]), int(attributes.shape[1]), gamma.data,
-                 rand.data, Ec.data, Eb.data, fragment_mass.data, healthy.data, cell_id.data,
-                 coalescence_rate.data, breakup_rate.data, breakup_rate_deficit.data,
-                 flag(is_first_in_pair), int(max_multiplicity), particle_mass.data,
-                 int(self.formulae.handle_all_breakups), overflows)
+            with Typed() as typed:
+                flt, cnt = Storage.FLOAT, Storage.INT
+                call("sdm_collision_coalescence_breakup", multiplicity.data, idx.data, len(idx),
+                     attributes.data, int(attributes.shape[0]), int(attributes.shape[1]),
+                     typed(gamma, flt), typed(rand, flt), typed(Ec, flt), typed(Eb, flt),
+                     typed(fragment_mass, flt), healthy.data, cell_id.data,
+                     typed(coalescence_rate, cnt), typed(breakup_rate, cnt),
+                     typed(breakup_rate_deficit, cnt), flag(is_first_in_pair),
+                     int(max_multiplicity), particle_mass.data,
+                     int(self.formulae.handle_all_breakups), overflows)
             if warn_overflows and int(self.engine.download(overflows)[0]) > 0:
                 warnings.warn("overflow")
 
@@ -317,20 +365,26 @@ def backend_class_for(engine_getter, name, doc=None):  # pylint: disable=too-man
         def moments(*, moment_0, moments, multiplicity, attr_data, cell_id, idx, length, ranks,
                     min_x, max_x, x_attr, weighting_attribute, weighting_rank,
                     skip_division_by_m0):
-            call("sdm_moments", moment_0.data, moments.data, multiplicity.data, attr_data.data,
-                 cell_id.data, idx.data, int(length), ranks.data, int(ranks.shape[0]),
-                 int(moment_0.shape[0]), float(min_x), float(max_x), x_attr.data,
-                 weighting_attribute.data, float(weighting_rank), int(skip_division_by_m0))
+            with Typed() as typed:
+                flt = Storage.FLOAT
+                call("sdm_moments", moment_0.data, moments.data, multiplicity.data,
+                     typed(attr_data, flt), cell_id.data, idx.data, int(length),
+                     typed(ranks, flt), int(ranks.shape[0]), int(moment_0.shape[0]),
+                     float(min_x), float(max_x), typed(x_attr, flt),
+                     typed(weighting_attribute, flt), float(weighting_rank),
+                     int(skip_division_by_m0))
 
         @staticmethod
         def spectrum_moments(*, moment_0, moments, multiplicity, attr_data, cell_id, idx, length,
                              rank, x_bins, x_attr, weighting_attribute, weighting_rank):
             assert moments.shape[0] == x_bins.shape[0] - 1
             assert moment_0.shape == moments.shape
-            call("sdm_spectrum_moments", moment_0.data, moments.data, multiplicity.data,
-                 attr_data.data, cell_id.data, idx.data, int(length), float(rank), x_bins.data,
-                 int(moments.shape[0]), int(moments.shape[1]), x_attr.data,
-                 weighting_attribute.data, float(weighting_rank))
+            with Typed() as typed:
+                flt = Storage.FLOAT
+                call("sdm_spectrum_moments", moment_0.data, moments.data, multiplicity.data,
+                     typed(attr_data, flt), cell_id.data, idx.data, int(length), float(rank),
+                     typed(x_bins, flt), int(moments.shape[0]), int(moments.shape[1]),
+                     typed(x_attr, flt), typed(weighting_attribute, flt), float(weighting_rank))
 
     Backend.Storage = Storage
     Backend.Random = Random

@@ -133,6 +133,10 @@ class Storage:  # pylint: disable=too-many-public-methods
         if isinstance(item, tuple) and rank == 2 and isinstance(item[1], slice):
             return self._wrap(self.data[item[0]], self.shape[1:])
         element = self.data[item]
+        if self.engine().size(element) != 1:
+            # e.g. a column `storage[:, 0]` (tests/unit_tests/dynamics/displacement/
+            # test_advection.py:84): the reference hands back `self.data[item]`, a host array there
+            return self.engine().download(element)
         return element.item() if hasattr(element, "item") else element
 
     def __setitem__(self, key, value):
@@ -149,6 +153,19 @@ class Storage:  # pylint: disable=too-many-public-methods
         """self.data = left (code) right-or-scalar"""
         eng = self.engine()
         out, n = self.data, eng.size(self.data)
+        for operand in (left, right):  # the kernels index every operand by the output's length
+            if operand is not None and eng.size(operand) != n:
+                raise ValueError(f"operand of {eng.size(operand)} elements for an output of {n}")
+        # an operand of the other numeric family (float += int storage: tests/unit_tests/backends/
+        # storage/test_basic_ops.py:9-25; NumPy casts there) is converted first - the kernels are
+        # typed.  The two mixed operations the displacement needs have kernels of their own (below)
+        mixed = not ((code == FLOOR and self.dtype is INT) or
+                     (code == SUB and self.dtype is FLOAT and right is not None and _is_int(right)))
+        if mixed and self.dtype in (FLOAT, INT):
+            want_int = self.dtype is INT
+            left, right = (operand if operand is None or _is_int(operand) == want_int
+                           else eng.upload(eng.download(operand).astype(self.dtype))
+                           for operand in (left, right))
         if code == FLOOR and self.dtype is INT:
             eng.call("sdm_floor_to_i64", out, left, n)
         elif code == SUB and self.dtype is FLOAT and right is not None and _is_int(right):
@@ -162,6 +179,20 @@ class Storage:  # pylint: disable=too-many-public-methods
 
     def _in_place(self, code, other):
         if isinstance(other, Storage):
+            # operands of another length: NumPy's rule, as in the reference, whose in-place operators
+            # are NumPy's (storage_impl.py:12-13,56-57) - a one-element array applies to every
+            # element (SimpleGeometric multiplies its n_sd-long output by the single pair value in
+            # tests/unit_tests/dynamics/collisions/test_kernels.py:33-57), anything else is an error.
+            # (Checked here: the kernels index both operands by the output's length.)
+            eng = self.engine()
+            n_out, n_other = eng.size(self.data), eng.size(other.data)
+            if n_other != n_out:
+                if n_other != 1:
+                    raise ValueError(f"operands could not be broadcast together with shapes "
+                                     f"{self.shape} {other.shape}")
+                value = other.to_ndarray().ravel()[0]
+                self._apply(code, self.data, None, value)
+                return self
             self._apply(code, self.data, other.data)
         else:
             self._apply(code, self.data, None, other)

@@ -51,8 +51,18 @@ def as_pysdm_backend(backend_class):
     base = _pysdm_backend_methods()
     if issubclass(backend_class, base):
         return backend_class
+
+    def __init__(self, formulae=None, double_precision=True, **options):
+        # next to PySDM the default formulae are PySDM's (numba.py:44: `formulae or Formulae()`):
+        # its attributes build their physics from members this package's own, smaller Formulae
+        # does not have (formulae.terminal_velocity_class, attributes/physics/terminal_velocity.py:19)
+        if formulae is None:
+            formulae = importlib.import_module("PySDM.formulae").Formulae()
+        backend_class.__init__(self, formulae, double_precision, **options)
+
     return type(backend_class.__name__, (backend_class, base), {
-        "__doc__": backend_class.__doc__, "__module__": backend_class.__module__})
+        "__init__": __init__, "__doc__": backend_class.__doc__,
+        "__module__": backend_class.__module__})
 
 
 def install():
