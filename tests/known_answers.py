@@ -628,6 +628,13 @@ def check_reference_small_backend_tests(kit):
     backend.sum_pair(out, Storage.from_ndarray(np.asarray([44.0, 666.0])), flag,
                      Storage.from_ndarray(np.asarray([0, 1])))
     np.testing.assert_array_equal(out.to_ndarray(), [44.0 + 666.0])
+    # ... as the reference's test calls it: `out` built from [0], an INT storage
+    # (test_pair_methods.py:66-101; Numba's bodies are duck-typed, the C ABI is not: pysdm_shaped.Typed)
+    out = Storage.from_ndarray(np.asarray([0]))
+    backend.sum_pair(out, Storage.from_ndarray(np.asarray([44.0, 666.0])), flag,
+                     Storage.from_ndarray(np.asarray([0, 1])))
+    assert out.dtype is Storage.INT
+    np.testing.assert_array_equal(out.to_ndarray(), [44 + 666])
     # find_pairs never flags the last position of a cut index
     for length in (1, 2, 3, 4):
         flag = kit.PairIndicator(4)

@@ -418,3 +418,20 @@ def check_storage_ops(kit):
     for bad in (lambda: sto(a) + sto(b), lambda: sto(a) * 2, lambda: sto(a) ** 2):
         with pytest.raises(TypeError):
             bad()
+    # operands of another length follow NumPy, as in the reference (its operators ARE NumPy's,
+    # storage_impl.py:12-13,56-57): one element applies to all (the reference's test_kernels.py:33-57
+    # multiplies an n_sd-long output by SimpleGeometric's single pair value), anything else is an
+    # error - and never a read past the shorter operand
+    x = sto(a); x *= sto(np.asarray([2.5])); np.testing.assert_array_equal(x.to_ndarray(), a * 2.5)
+    x = sto(a); x += sto(np.asarray([-1.0])); np.testing.assert_array_equal(x.to_ndarray(), a - 1.0)
+    for bad in (lambda: sto(a).__imul__(sto(a[:7])), lambda: sto(a).sum(sto(a), sto(b[:500])),
+                lambda: sto(a).ratio(sto(a[:3]), sto(b))):
+        with pytest.raises(ValueError):
+            bad()
+    # an operand of the other numeric family is cast (storage/test_basic_ops.py:9-25: [1.0] += [2])
+    x = sto(np.asarray([1.0, 2.0])); x += kit.Storage.from_ndarray(np.asarray([2, 3]))
+    np.testing.assert_array_equal(x.to_ndarray(), [3.0, 5.0])
+    # a column of a two-dimensional storage comes back as a host array
+    # (dynamics/displacement/test_advection.py:84: `attributes["cell origin"][:, 0]`)
+    np.testing.assert_array_equal(
+        kit.Storage.from_ndarray(np.array([[5, -1, 7], [9, 3, -2]], dtype=np.int64))[:, 1], [-1, 3])
