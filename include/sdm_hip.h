@@ -25,6 +25,8 @@ extern "C" {
 #define SDM_E_ARG (-1)    /* bad argument (null pointer, negative size, unsupported option) */
 #define SDM_E_HIP (-2)    /* a HIP runtime call failed */
 #define SDM_E_NOMEM (-3)  /* scratch arena allocation failed */
+#define SDM_E_STATE (-4)  /* the state handed over is inconsistent: a sub-step loop did not end
+                             within the bound its own arithmetic sets (see sdm_collision_step) */
 
 typedef struct sdm_ctx sdm_ctx;
 
@@ -56,6 +58,37 @@ int sdm_abi_version(void);
 int sdm_ctx_set_timing(sdm_ctx *ctx, int enable);
 int sdm_ctx_read_timing(sdm_ctx *ctx, double *ms, int64_t *count);
 const char *sdm_phase_name(int phase);
+
+/* ---- options and statistics of a context ---------------------------------------------------
+ * SDM_OPT_RESORT: how a multi-cell adaptive run re-sorts by cell after a compaction
+ * (particle_attributes.py:51-55,67-73: `sanitize` un-sorts, the `cell_start` getter sorts again):
+ *   SDM_RESORT_AUTO (default): the closed form of index.hip (sdm_sanitize_sorted below) where the
+ *     device says it applies; after a refusal the next 16 compactions OF THE SAME CALL go straight
+ *     to the counting sort (asking costs a host round trip);
+ *   SDM_RESORT_COUNTING_SORT: always the counting sort;  SDM_RESORT_ALWAYS_ASK: no back-off.
+ * The results are identical either way; the switch exists for measurements and tests.          */
+#define SDM_OPT_RESORT 0
+#define SDM_RESORT_AUTO 0
+#define SDM_RESORT_COUNTING_SORT 1
+#define SDM_RESORT_ALWAYS_ASK 2
+/* SDM_OPT_MAX_SUBSTEPS (tests): a bound on the sub-steps of one adaptive time step BELOW the one
+ * the arithmetic sets (see sdm_collision_step), so that the error path - SDM_E_STATE, the control
+ * block in the message, the context usable afterwards - can be exercised with a healthy state;
+ * 0 (default) = the arithmetic's bound alone                                                    */
+#define SDM_OPT_MAX_SUBSTEPS 1
+int sdm_ctx_set_option(sdm_ctx *ctx, int option, int64_t value);
+/* counters since the context was created / last cleared (host-side bookkeeping of the library):
+ * re-sorts after a compaction done by the closed form; asked for and refused by the device; not
+ * asked because of the back-off; done by the counting sort (= refused + skipped + switched off);
+ * sub-steps executed by the fused entry points; sub-steps launched ahead that fell through      */
+#define SDM_STAT_RESORT_CLOSED_FORM 0
+#define SDM_STAT_RESORT_REFUSED 1
+#define SDM_STAT_RESORT_SKIPPED 2
+#define SDM_STAT_RESORT_COUNTING_SORT 3
+#define SDM_STAT_SUBSTEPS 4
+#define SDM_STAT_SUBSTEPS_TAKEN_BACK 5
+#define SDM_N_STATS 8
+int sdm_ctx_read_stats(sdm_ctx *ctx, int64_t *stats, int clear);
 
 /* measurement only: the ceiling of the path's access pattern on this device.  The single-cell pair
  * kernel is bound by independent random 16-byte reads (shuffle records, {multiplicity, mass}
@@ -92,6 +125,23 @@ int sdm_sort_by_key(sdm_ctx *ctx, int64_t *idx, const double *keys, int64_t n); 
 /* :664-680 ; idx_len = len(idx) = the "removed" sentinel; *new_length out (host), syncs */
 int sdm_remove_zero_n_or_flagged(sdm_ctx *ctx, const int64_t *multiplicity, int64_t *idx,
                                  int64_t length, int64_t idx_len, int64_t *new_length);
+/* `ParticleAttributes.sanitize` (particle_attributes.py:67-73) followed by what the `cell_start`
+ * getter then does (:51-55 -> __sort_by_cell_id :106-110 -> the counting sort,
+ * collisions_methods.py:587-631,682-697) for a state that IS sorted by cell on entry (cell_start
+ * describes idx[0:length)): entries with idx[i] == idx_len (flagged) or zero multiplicity are
+ * removed the reference's way (swap from the end), the survivors stably sorted by
+ * cell_idx[cell_id[.]] again; idx[0:*new_length) and cell_start are rewritten in place, tmp_idx is
+ * scratch.  `resort`: SDM_RESORT_COUNTING_SORT, or SDM_RESORT_AUTO / _ALWAYS_ASK = the closed form
+ * where it applies: a sorted state stays grouped by cell under the swap-from-the-end except for
+ * the fillers, and if the whole removed tail lay in the last non-empty segment, members keep
+ * their order, the fillers of earlier segments' holes line up in front of the last segment in
+ * hole order and whole segments move to where the current cell_idx puts them - no histogram over
+ * gathered keys.  *path (host, may be NULL): 0 = nothing to remove (state untouched), 1 = counting
+ * sort, 2 = closed form.  The result does not depend on the path.  Synchronises.                */
+int sdm_sanitize_sorted(sdm_ctx *ctx, const int64_t *multiplicity, int64_t *idx, int64_t *tmp_idx,
+                        int64_t length, int64_t idx_len, const int64_t *cell_id,
+                        const int64_t *cell_idx, int64_t *cell_start, int64_t n_cell, int resort,
+                        int64_t *new_length, int *path);
 /* :587-631,682-697 ; writes new_idx[0:length) and cell_start[0:n_cell+1] (caller swaps buffers) */
 int sdm_counting_sort_by_cell_id(sdm_ctx *ctx, int64_t *new_idx, const int64_t *idx,
                                  const int64_t *cell_id, const int64_t *cell_idx, int64_t length,
@@ -390,8 +440,9 @@ typedef struct sdm_step_state {
    * candidate pairs processed so far (single-cell non-adaptive steps), largest cell, events};
    * kept device-resident between calls.  Word 7: low byte = device-side error code (0 = none;
    * 1 = a cell larger than the per-cell kernel's capacity, 2 = the compaction kernel's grid
-   * barrier timed out; 4 is used inside the library: `sorted` was claimed but cell_start
-   * does not span exactly the live super-droplets - the call returns SDM_E_ARG, nothing computed),
+   * barrier timed out; bit value 4 is used inside the library: `sorted` was claimed but cell_start
+   * does not span exactly the live super-droplets - the call returns SDM_E_ARG before any
+   * collision is computed),
    * bit 8 = "a cell's stats_dt_min became equal to dt_min" - the data-level event behind the
    * reference's warning "adaptive time-step reached dt_min" (collision.py:276-277): the caller
    * evaluates `amin(stats_dt_min) == dt_min`, warns, and clears the bit; n_overflow likewise
@@ -438,6 +489,12 @@ typedef struct sdm_step_result {
  *        bit 2 = with bit 1: multiplicities and attributes are untouched since the last fused call
  *                (only the permutation / cell ids changed, e.g. by a displacement), so the mirror
  *                state->nm is still current and is not rebuilt                                 */
+/* Adaptive steps: every sub-step takes at least dt_min off the dt_left of each cell still in the
+ * working range (collisions_methods.py:355-374), so a time step has at most ceil(dt / dt_min) + 1
+ * sub-steps (+ 1 for the rounding of the subtractions).  The reference's loop has no bound
+ * (collision.py:182 `while working_length != 0`) and never ends on a state whose cell_start does
+ * not belong to its permutation; here more sub-steps than that return SDM_E_STATE with the
+ * control block in sdm_last_error().                                                           */
 #define SDM_STEP_READ_BACK 1
 #define SDM_STEP_FRESH_CTL 2
 #define SDM_STEP_MIRROR_VALID 4

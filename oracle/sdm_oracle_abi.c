@@ -34,6 +34,8 @@
 struct sdm_ctx {
   char *arena; /* scratch of the fused entry points, kept between calls (first touch is slow) */
   size_t arena_bytes;
+  int64_t stats[SDM_N_STATS];
+  int64_t opt_max_substeps;
 };
 
 /* thread count of the OpenMP build (the serial build ignores it) */
@@ -67,6 +69,25 @@ API int sdm_ctx_set_stream(sdm_ctx *ctx, void *s) { (void)ctx; (void)s; return S
 API int sdm_ctx_synchronize(sdm_ctx *ctx) { (void)ctx; return SDM_OK; }
 API const char *sdm_last_error(void) { return g_err; }
 API int sdm_abi_version(void) { return 1; }
+/* the checker has one way of doing everything: options are validated and otherwise ignored */
+API int sdm_ctx_set_option(sdm_ctx *ctx, int option, int64_t value) {
+  if (!ctx) FAIL(SDM_E_ARG, "null context");
+  if (option == SDM_OPT_MAX_SUBSTEPS && value >= 0) {
+    ctx->opt_max_substeps = value;
+    return SDM_OK;
+  }
+  if (option != SDM_OPT_RESORT || value < SDM_RESORT_AUTO || value > SDM_RESORT_ALWAYS_ASK)
+    FAIL(SDM_E_ARG, "sdm_ctx_set_option: unknown option or value");
+  return SDM_OK;
+}
+API int sdm_ctx_read_stats(sdm_ctx *ctx, int64_t *stats, int clear) {
+  if (!ctx || !stats) FAIL(SDM_E_ARG, "null argument");
+  for (int k = 0; k < SDM_N_STATS; ++k) {
+    stats[k] = ctx->stats[k];
+    if (clear) ctx->stats[k] = 0;
+  }
+  return SDM_OK;
+}
 API int sdm_ctx_set_timing(sdm_ctx *ctx, int enable) { (void)ctx; (void)enable; return SDM_OK; }
 API int sdm_ctx_read_timing(sdm_ctx *ctx, double *ms, int64_t *count) {
   (void)ctx;
@@ -101,6 +122,25 @@ API int sdm_remove_zero_n_or_flagged(sdm_ctx *c, const int64_t *multiplicity, in
                                      int64_t length, int64_t idx_len, int64_t *new_length) {
   (void)c;
   *new_length = oracle_remove_zero_n_or_flagged(multiplicity, idx, length, idx_len);
+  return SDM_OK;
+}
+/* particle_attributes.py:67-73 (sanitize) + :51-55,106-110 (the cell_start getter's sort) */
+API int sdm_sanitize_sorted(sdm_ctx *c, const int64_t *multiplicity, int64_t *idx, int64_t *tmp_idx,
+                            int64_t length, int64_t idx_len, const int64_t *cell_id,
+                            const int64_t *cell_idx, int64_t *cell_start, int64_t n_cell,
+                            int resort, int64_t *new_length, int *path) {
+  (void)resort;
+  if (!c || !new_length || length < 0 || length > idx_len || n_cell < 1 || !cell_start)
+    FAIL(SDM_E_ARG, "sdm_sanitize_sorted: bad argument");
+  if (path) *path = 0;
+  if (length == 0) { *new_length = 0; return SDM_OK; }
+  const int64_t valid = oracle_remove_zero_n_or_flagged(multiplicity, idx, length, idx_len);
+  *new_length = valid;
+  if (valid == length) return SDM_OK;
+  oracle_counting_sort_by_cell_id(tmp_idx, idx, cell_id, cell_idx, valid, cell_start, n_cell + 1);
+  memcpy(idx, tmp_idx, sizeof(int64_t) * (size_t)valid);
+  ++c->stats[SDM_STAT_RESORT_COUNTING_SORT];
+  if (path) *path = 1;
   return SDM_OK;
 }
 API int sdm_counting_sort_by_cell_id(sdm_ctx *c, int64_t *new_idx, const int64_t *idx,
@@ -1061,7 +1101,18 @@ static int box_time_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *
     for (int s = 0; s < cfg->substeps && rc == SDM_OK; ++s) rc = box_step(&B, shift_len);
   } else {
     for (int64_t c = 0; c < B.C; ++c) st->dt_left[c] = cfg->dt;
+    /* (the reference's loop, collision.py:182, has no bound and never ends on a state whose
+       cell_start belongs to another permutation; product and checker both stop at the bound the
+       arithmetic sets - sdm_hip.h, SDM_E_STATE) */
+    const double ratio = cfg->dt / cfg->dt_min;
+    int64_t max_substeps = ratio < 4e18 ? (int64_t)ceil(ratio) + 2 : INT64_MAX;
+    if (ctx->opt_max_substeps > 0 && ctx->opt_max_substeps < max_substeps)
+      max_substeps = ctx->opt_max_substeps;
+    const int64_t n_sub_before = B.n_sub;
     while (B.work != 0 && rc == SDM_OK) {
+      if (B.n_sub - n_sub_before > max_substeps)
+        FAIL(SDM_E_STATE, "adaptive time step did not end within its bound of sub-steps: the "
+                          "state is inconsistent (cell_start of another permutation?)");
       oracle_sort_by_key(st->cell_idx, st->dt_left, B.C);
       rc = box_step(&B, shift_len);
       if (rc) break;
@@ -1081,6 +1132,7 @@ static int box_time_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state *
   st->rng_offset = B.off;
   st->rng_offset_breakup = B.off_b;
   st->known_valid = B.valid;
+  ctx->stats[SDM_STAT_SUBSTEPS] += B.n_sub;
   res->n_substeps = B.n_sub;
   res->n_pairs = B.n_pairs;
   res->valid_n_sd = B.valid;

@@ -75,7 +75,12 @@ struct sdm_ctx {
   // `normalize`'s raw look-up cell_id[pair slot] (collisions_methods.py:633-662), which keeps
   // reading the caller's column
   const int64_t *cell_id_raw;
-  int resort_backoff;  // fused.hip: death events for which the closed-form re-sort is not tried
+  // fused.hip: compactions of the CURRENT call for which the closed-form re-sort is not asked for
+  // (reset at every entry: which path a call takes must not depend on earlier calls)
+  int resort_backoff;
+  int opt_resort;                // SDM_OPT_RESORT
+  int64_t opt_max_substeps;      // SDM_OPT_MAX_SUBSTEPS (0: none)
+  int64_t stats[SDM_N_STATS];    // SDM_STAT_* (host-side counters, sdm_ctx_read_stats)
   // fused.hip: what a multi-cell adaptive step knows at its end, for the next step of the same call
   // (valid length, an upper bound of the cell sizes; the state is sorted) - saves that step's
   // opening read-back
@@ -125,8 +130,15 @@ int sdm_read_box(sdm_ctx *ctx, int64_t seq, int64_t out[8]);
 #define SDM_CTL7_DT_MIN 0x100
 
 #ifdef __HIPCC__
+// (returning, and the result consumed: the event must be at the memory side before this wave can
+// take a finish ticket - cells_end_body's publishing workgroup reads ctl[7] without a fence, and
+// a wave whose 64 cells all finish issues no other returning atomic before its ticket)
 __device__ __forceinline__ void note_dt_min(int64_t *ctl, double stats_value, double dt_min) {
-  if (stats_value == dt_min) atomicOr((unsigned long long *)&ctl[7], (unsigned long long)SDM_CTL7_DT_MIN);
+  if (stats_value == dt_min) {
+    const unsigned long long was =
+        atomicOr((unsigned long long *)&ctl[7], (unsigned long long)SDM_CTL7_DT_MIN);
+    asm volatile("" ::"v"(was));
+  }
 }
 
 // last act of a one-thread epilogue: control block -> host-visible box, then the sequence number

@@ -136,6 +136,32 @@ void sdm_phase_end(sdm_ctx *ctx) {
   ctx->n_ev += 1;
 }
 
+extern "C" int sdm_ctx_set_option(sdm_ctx *ctx, int option, int64_t value) {
+  ARG_TRY(ctx != nullptr);
+  if (option == SDM_OPT_RESORT) {
+    ARG_TRY(value == SDM_RESORT_AUTO || value == SDM_RESORT_COUNTING_SORT ||
+            value == SDM_RESORT_ALWAYS_ASK);
+    ctx->opt_resort = (int)value;
+    return SDM_OK;
+  }
+  if (option == SDM_OPT_MAX_SUBSTEPS) {
+    ARG_TRY(value >= 0);
+    ctx->opt_max_substeps = value;
+    return SDM_OK;
+  }
+  sdm_set_error("sdm_ctx_set_option: unknown option %d", option);
+  return SDM_E_ARG;
+}
+
+extern "C" int sdm_ctx_read_stats(sdm_ctx *ctx, int64_t *stats, int clear) {
+  ARG_TRY(ctx && stats);
+  for (int k = 0; k < SDM_N_STATS; ++k) {
+    stats[k] = ctx->stats[k];
+    if (clear) ctx->stats[k] = 0;
+  }
+  return SDM_OK;
+}
+
 extern "C" int sdm_ctx_set_timing(sdm_ctx *ctx, int enable) {
   ARG_TRY(ctx != nullptr);
   if (enable && !ctx->ev) {

@@ -2050,6 +2050,27 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     shift = (int64_t)q;
     if ((double)shift < q) shift += 1;
   }
+  // an adaptive time step ends within ceil(dt / dt_min) + 1 sub-steps (sdm_hip.h; + 1 for the
+  // rounding of the subtractions); the reference's loop has no bound and spins for ever on a state
+  // whose cell_start belongs to another permutation - here that is SDM_E_STATE
+  ARG_TRY(!cfg->adaptive || (cfg->dt_min == cfg->dt_min && cfg->dt == cfg->dt));
+  int64_t max_substeps = INT64_MAX;
+  if (cfg->adaptive) {
+    const double q = cfg->dt / cfg->dt_min;
+    max_substeps = q < 4e18 ? (int64_t)ceil(q) + 2 : INT64_MAX;
+    if (ctx->opt_max_substeps > 0 && ctx->opt_max_substeps < max_substeps)
+      max_substeps = ctx->opt_max_substeps;  // (tests: SDM_OPT_MAX_SUBSTEPS)
+  }
+  auto unbounded = [&](int64_t n_done, const int64_t *ctl8) -> int {
+    sdm_set_error("adaptive time step did not end within %lld sub-steps (dt = %g, dt_min = %g): "
+                  "the state is inconsistent - a cell_start that does not belong to the "
+                  "permutation, or dt_left edited from outside.  Control block {valid %lld, "
+                  "work %lld, sorted %lld, healthy %lld, overflow %lld, pairs %lld, max cell "
+                  "%lld, events %lld}", (long long)n_done, cfg->dt, cfg->dt_min,
+                  (long long)ctl8[0], (long long)ctl8[1], (long long)ctl8[2], (long long)ctl8[3],
+                  (long long)ctl8[4], (long long)ctl8[5], (long long)ctl8[6], (long long)ctl8[7]);
+    return SDM_E_STATE;
+  };
   FusedScratch S = layout(nullptr, cfg);
   int rc = sdm_reserve(ctx, S.total);
   if (rc) return rc;
@@ -2176,10 +2197,11 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     HIP_TRY(hipMemcpyAsync(ctx->mailbox + 8, st->ctl, sizeof(int64_t) * 8, hipMemcpyDeviceToHost,
                            s));
     HIP_TRY(hipStreamSynchronize(s));
-    if ((ctx->mailbox[8 + 7] & SDM_CTL7_ERROR_MASK) == 4) {  // (k_max_cell)
+    if (ctx->mailbox[8 + 7] & 4) {  // (k_max_cell; a bit: other codes may be set beside it)
       HIP_TRY(hipMemsetAsync(st->ctl + 7, 0, sizeof(int64_t), s));
       sdm_set_error("the state was handed over as sorted by cell, but cell_start does not span "
-                    "the live super-droplets (a cell_start of another state?): nothing computed");
+                    "the live super-droplets (a cell_start of another state?): no collision "
+                    "computed (dt_left and cell_idx were already reset for the step)");
       return SDM_E_ARG;
     }
     work_host = ctx->mailbox[8 + CTL_WORK];
@@ -2522,6 +2544,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       auto take_back = [&]() {  // the sub-step launched ahead fell through on the device
         if (taken_back) return;
         taken_back = true;
+        ++ctx->stats[SDM_STAT_SUBSTEPS_TAKEN_BACK];
         off = keep[0]; off_b = keep[1]; draw_off = keep[2]; draw_off_b = keep[3];
         { int64_t *t = cur; cur = alt; alt = t; }
         --swaps;
@@ -2538,6 +2561,13 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       if (last_ctl[7] & SDM_CTL7_ERROR_MASK) {  // device-side failure: the caller raises
         take_back();
         break;
+      }
+      if (n_sub > max_substeps) {
+        // (what was launched ahead drains by itself: every kernel of a sub-step ends; the stream
+        // positions it booked are taken back so that the state's offsets stay those of n_sub)
+        take_back();
+        HIP_TRY(hipStreamSynchronize(s));
+        return unbounded(n_sub, last_ctl);
       }
       if (sharded && last_ctl[CTL_HEALTHY] == 0) {
         // a super-droplet died somewhere: every process flags the dead positions in its own
@@ -2561,18 +2591,24 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         hipLaunchKernelGGL(k_reset_work, one, one, 0, s, st->ctl);  // sanitize left work = valid
         LAUNCH_CHECK();
         {
-          // a handful of deaths in a sorted state: the re-sort has a closed form (index.hip)
-          static const bool resort_off = getenv("SDM_NO_FAST_RESORT") != nullptr;  // (A/B runs)
+          // a handful of deaths in a sorted state: the re-sort has a closed form (index.hip;
+          // SDM_OPT_RESORT says whether to ask for it)
           bool closed_form = false;
           PhaseScope ph(ctx, SDM_PHASE_SORT);
           // (asking costs a round trip: after a refusal - too many deaths at once, a tail that
-          // spans cells - the next few deaths go straight to the counting sort)
-          if (!resort_off && ctx->resort_backoff > 0) --ctx->resort_backoff;
-          else if (!resort_off) {
+          // spans cells - the next few compactions of this call go straight to the counting sort)
+          if (ctx->opt_resort == SDM_RESORT_COUNTING_SORT) {
+          } else if (ctx->opt_resort == SDM_RESORT_AUTO && ctx->resort_backoff > 0) {
+            --ctx->resort_backoff;
+            ++ctx->stats[SDM_STAT_RESORT_SKIPPED];
+          } else {
             rc = sdm_resort_plan(ctx, S.compact, N, S.cctl, st->ctl, st->cell_start, C,
                                  S.resort_plan, &closed_form);
             if (rc) return rc;
-            if (!closed_form) ctx->resort_backoff = 16;
+            if (!closed_form) {
+              ctx->resort_backoff = 16;
+              ++ctx->stats[SDM_STAT_RESORT_REFUSED];
+            }
           }
           if (closed_form) {
             rc = sdm_resort_after_compaction_async(ctx, S.compact, N, st->ctl, cur, S.sorted_buf,
@@ -2581,6 +2617,9 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
                                                    S.seg_src);
             if (rc) return rc;
             sorted_host = 1;
+            ++ctx->stats[SDM_STAT_RESORT_CLOSED_FORM];
+          } else {
+            ++ctx->stats[SDM_STAT_RESORT_COUNTING_SORT];
           }
         }
         rc = cond_sort(ctx, cfg, st, cur, S, &sorted_host);  // (no-op when sorted_host == 1)
@@ -2831,6 +2870,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     }
     ++n_sub;
     if (!cfg->adaptive && work_host >= 0) n_pairs += work_host / 2;
+    if (cfg->adaptive && n_sub > max_substeps) {
+      HIP_TRY(hipStreamSynchronize(s));
+      return unbounded(n_sub, last_ctl);
+    }
     if (cfg->adaptive) {
       // (h) collision.py:185-187 cut_working_length(adaptive_sdm_end(dt_left))
       n_pairs += work_host / 2;
@@ -2936,6 +2979,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     ctx->lists.owner = st;
     ctx->lists.clean_set = A.list_count == S.list_count ? 0 : 1;
   }
+  ctx->stats[SDM_STAT_SUBSTEPS] += n_sub;
   res->n_substeps = n_sub;
   res->idx_swapped = swaps & 1;
   res->rng_offset = off;
@@ -2976,6 +3020,7 @@ extern "C" int sdm_collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_ste
   ctx->carry.active = false;
   ctx->lists.active = false;
   ctx->presorted.active = false;
+  ctx->resort_backoff = 0;
   return collision_step(ctx, cfg, st, res, flags, true, false);
 }
 
@@ -3228,6 +3273,7 @@ extern "C" int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step
   ctx->carry.active = false;
   ctx->lists.active = false;
   ctx->presorted.active = false;
+  ctx->resort_backoff = 0;
   sdm_step_result total;
   memset(&total, 0, sizeof(total));
   total.valid_n_sd = -1;

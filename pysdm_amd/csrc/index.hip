@@ -1538,6 +1538,87 @@ extern "C" int sdm_counting_sort_by_cell_id(sdm_ctx *ctx, int64_t *new_idx, cons
                                  length > 0 ? length : 1, cell_start, n_cell);
 }
 
+// ---- sanitize + re-sort of a sorted state in one call (sdm_hip.h: sdm_sanitize_sorted) --------
+// What the fused multi-cell step does after a sub-step in which super-droplets died, as a call of
+// its own: the compaction, then the closed-form re-sort or the counting sort.  Lets a caller (and
+// the tests) run both re-sorts on one input.
+__global__ void k_sanitize_copy_back(int64_t *__restrict__ idx, const int64_t *__restrict__ sorted,
+                                     const int64_t *__restrict__ p_length) {
+  const int64_t i = (int64_t)blockIdx.x * SDM_BLOCK + threadIdx.x;
+  if (i < *p_length) idx[i] = sorted[i];
+}
+
+extern "C" int sdm_sanitize_sorted(sdm_ctx *ctx, const int64_t *multiplicity, int64_t *idx,
+                                   int64_t *tmp_idx, int64_t length, int64_t idx_len,
+                                   const int64_t *cell_id, const int64_t *cell_idx,
+                                   int64_t *cell_start, int64_t n_cell, int resort,
+                                   int64_t *new_length, int *path) {
+  ARG_TRY(ctx && new_length && length >= 0 && length <= idx_len && idx_len < INT32_MAX &&
+          n_cell >= 1 && cell_start);
+  ARG_TRY(resort == SDM_RESORT_AUTO || resort == SDM_RESORT_COUNTING_SORT ||
+          resort == SDM_RESORT_ALWAYS_ASK);
+  if (path) *path = 0;
+  if (length == 0) { *new_length = 0; return SDM_OK; }
+  ARG_TRY(multiplicity && idx && tmp_idx && cell_id && cell_idx);
+  const size_t head = 1024, seg = carve_size(sizeof(int64_t) * (size_t)(n_cell + 1));
+  const size_t compact = carve_size(sdm_compact_scratch(length));
+  int rc = sdm_reserve(ctx, head + 3 * seg + compact + carve_size(sdm_sort_scratch(length, n_cell)));
+  if (rc) return rc;
+  Carver cv(ctx->arena);
+  int64_t *fctl = cv.take<int64_t>(8);  // {valid, work, sorted, healthy = 0: "compact now", ..}
+  int64_t *cctl = cv.take<int64_t>(8);
+  int64_t *plan = cv.take<int64_t>(8);
+  int64_t *seg_size = (int64_t *)(ctx->arena + head), *seg_key = (int64_t *)(ctx->arena + head + seg);
+  int64_t *cs_new = (int64_t *)(ctx->arena + head + 2 * seg);
+  char *compact_scratch = ctx->arena + head + 3 * seg, *sort_scratch = compact_scratch + compact;
+  hipStream_t s = ctx->stream;
+  const int64_t words[8] = {length, length, 1, 0, 0, 0, 0, 0};
+  memcpy(ctx->mailbox, words, sizeof(words));
+  HIP_TRY(hipMemcpyAsync(fctl, ctx->mailbox, sizeof(words), hipMemcpyHostToDevice, s));
+  rc = sdm_compact_fused_async(ctx, compact_scratch, multiplicity, idx, length, idx_len, fctl,
+                               cctl, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->mailbox, fctl, sizeof(words), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (ctx->mailbox[7] != 0) {
+    (void)sdm_compact_rearm(ctx);
+    sdm_set_error("sdm_sanitize_sorted: grid barrier of the compaction kernel timed out");
+    return SDM_E_HIP;
+  }
+  const int64_t valid = ctx->mailbox[FCTL_VALID];
+  *new_length = valid;
+  if (valid == length) return SDM_OK;  // nothing was removed: still sorted, cell_start stands
+  bool closed_form = false;
+  if (resort != SDM_RESORT_COUNTING_SORT) {
+    rc = sdm_resort_plan(ctx, compact_scratch, length, cctl, fctl, cell_start, n_cell, plan,
+                         &closed_form);
+    if (rc) return rc;
+  }
+  if (closed_form) {
+    rc = sdm_resort_after_compaction_async(ctx, compact_scratch, length, fctl, idx, tmp_idx,
+                                           cell_start, cs_new, cell_id, cell_idx, n_cell, plan,
+                                           seg_size, seg_key);
+    if (rc) return rc;
+    ++ctx->stats[SDM_STAT_RESORT_CLOSED_FORM];
+  } else {
+    if (resort != SDM_RESORT_COUNTING_SORT) ++ctx->stats[SDM_STAT_RESORT_REFUSED];
+    ++ctx->stats[SDM_STAT_RESORT_COUNTING_SORT];
+    if (valid == 0) {
+      HIP_TRY(hipMemsetAsync(cell_start, 0, sizeof(int64_t) * (size_t)(n_cell + 1), s));
+    } else {
+      rc = sdm_counting_sort_async(ctx, sort_scratch, tmp_idx, idx, cell_id, cell_idx,
+                                   fctl + FCTL_VALID, length, cell_start, n_cell);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_sanitize_copy_back, dim3(grid_for(length)), dim3(SDM_BLOCK), 0, s, idx,
+                         (const int64_t *)tmp_idx, (const int64_t *)(fctl + FCTL_VALID));
+      LAUNCH_CHECK();
+    }
+  }
+  if (path) *path = closed_form ? 2 : 1;
+  HIP_TRY(hipStreamSynchronize(s));
+  return SDM_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // cell_id = strides . cell_origin  (collisions_methods.py:407-416)
 // ---------------------------------------------------------------------------------------

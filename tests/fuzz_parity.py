@@ -1,19 +1,18 @@
 """randomised differential run (not collected by pytest; by hand on an MI355X:
-    python tests/fuzz_parity.py [n_cases] [seed]):
-random small-to-medium set-ups - grid or single cell, adaptive or not, thin multiplicities (deaths)
-or not, coalescence / breakup recipes, kernels, steps given as random chunks (so that the
-working copy, the launch-ahead and the step-by-step paths all get their turn) - HIP fused route
-against the checker, everything to the bit."""
+    python tests/fuzz_parity.py [n_cases] [seed] [first] [last]):
+the cases of tests/fuzz_cases.py:draw_parity_case - HIP (fused or stage-by-stage route) against
+the checker, everything to the bit.  A fixed-seed slice runs under `-m gpu`
+(tests/test_hip_fuzz.py)."""
+import os
 import sys
 import time
-import warnings
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle.engine import OracleEngine  # noqa: E402
-from pysdm_amd.cases import make_box  # noqa: E402
 from pysdm_amd.engine import HipEngine  # noqa: E402
+from tests import fuzz_cases  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
@@ -23,66 +22,9 @@ first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 last = int(sys.argv[4]) if len(sys.argv) > 4 else n_cases
 hip, oracle = HipEngine.get(), OracleEngine.get()
 t_start = time.time()
-for case in range(n_cases):
-    name = str(rng.choice(["shima", "kinematic2d", "berry_breakup", "straub", "straub_rain"]))
-    grid = None
-    if rng.random() < 0.6:
-        grid = tuple(int(g) for g in rng.choice([2, 3, 4, 5, 8], size=2))
-    cells = 1 if grid is None else grid[0] * grid[1]
-    per_cell = int(rng.choice([3, 17, 64, 300, 1000, 3000]))
-    n_sd = max(2, min(per_cell * cells, 2**16)) if grid else int(rng.choice([2, 3, 257, 4096, 2**14]))
-    adaptive = bool(rng.random() < 0.7)
-    thin = 0.02 if (name == "shima" and rng.random() < 0.5) else None
-    options = {}
-    if not adaptive:
-        options["substeps"] = int(rng.choice([1, 2, 3]))
-    if rng.random() < 0.3 and name != "kinematic2d":  # (that configuration sets it itself)
-        options["optimized_random"] = True
-    # (the global croupier over several cells only without adaptive sub-stepping: with it the
-    # reference duplicates ids once a working length is cut - tests/test_hip_parity.py says why -
-    # and a serial and a parallel run then differ legitimately; "kinematic2d" brings its own grid)
-    if (grid is None and name != "kinematic2d" or not adaptive) and rng.random() < 0.25:
-        options["croupier"] = "global"
-    if name in ("berry_breakup", "straub", "straub_rain"):
-        if rng.random() < 0.3:
-            options["handle_all_breakups"] = True
-        if rng.random() < 0.2:
-            options["max_multiplicity"] = int(rng.choice([10**7, 10**9, 10**12]))
-    if adaptive and rng.random() < 0.3:
-        options["dt_range"] = tuple(float(v) for v in rng.choice([(0.1, 100.0), (0.5, 2.0), (1.0, 1.0),
-                                                                   (0.01, 0.5)]))
-    dt = float(rng.choice([1.0, 5.0, 50.0, 200.0])) if name in ("shima", "kinematic2d") else None
-    # (the stage-by-stage route - one ABI symbol per backend method - on the smaller set-ups)
-    route = "chain" if (n_sd <= 4096 and rng.random() < 0.35) else "fused"
-    chunks = [int(c) for c in rng.choice([1, 2, 3, 5, 8], size=int(rng.integers(1, 4)))]
-    seed = int(rng.integers(1, 1000))
-    label = (f"case {case}: {name} n_sd={n_sd} grid={grid} adaptive={adaptive} thin={thin} "
-             f"dt={dt} {options} chunks={chunks} seed={seed} route={route}")
-    if not first <= case < last:
+for number in range(n_cases):
+    case = fuzz_cases.draw_parity_case(rng)
+    if not first <= number < last:
         continue
-    snaps = []
-    try:
-        for engine in (hip, oracle):
-            runner = make_box(engine, name, n_sd=n_sd, adaptive=adaptive, dt=dt, thin=thin,
-                              grid=grid, seed=seed, route=route, **options)
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore")
-                for steps in chunks:
-                    runner.run(steps)
-            snaps.append((runner.snapshot(), runner.offset, runner.offset_breakup,
-                          runner.sub_steps_done))
-    except (ValueError, NotImplementedError) as refused:  # a combination the set-up refuses
-        if "Radii can be interpolated" not in str(refused) and "dt_range" not in str(refused):
-            raise
-        print(label, "-> refused:", refused, flush=True)
-        continue
-    a, b = snaps
-    assert a[1:] == b[1:], (label, a[1:], b[1:])
-    length = int(b[0]["length"])
-    for key, ref in b[0].items():
-        value = a[0][key]
-        if key == "idx":
-            value, ref = value[:length], ref[:length]
-        assert np.array_equal(value, ref, equal_nan=True), (label, key)
-    print(label, "-> ok, length", length, "sub-steps", b[3], flush=True)
+    print(f"case {number}: {case} ->", fuzz_cases.run_parity_case(hip, oracle, case), flush=True)
 print("all cases equal the checker;", round(time.time() - t_start, 1), "s")

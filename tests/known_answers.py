@@ -804,6 +804,37 @@ def check_convergence_to_golovin_solution(kit):
     assert errors[0] > errors[1] > errors[2], errors
 
 
+def check_substep_bound(kit):
+    """an adaptive time step that does not end within its bound of sub-steps is an error
+    (SDM_E_STATE), not a hang: the reference's loop (collision.py:182) has no bound and spins for
+    ever on a state whose cell_start belongs to another permutation.  A healthy state cannot
+    exceed ceil(dt / dt_min) + 2, so the bound is lowered for the test (SDM_OPT_MAX_SUBSTEPS): the
+    error carries the control block, and the context goes on working afterwards"""
+    import pytest  # pylint: disable=import-outside-toplevel
+
+    from pysdm_amd.cases import make_box  # pylint: disable=import-outside-toplevel
+
+    eng = kit.engine
+    for kwargs in ({"grid": (4, 4), "n_sd": 2**12}, {"n_sd": 2**12}):  # per-cell route, one cell
+        reference = make_box(eng, "shima", adaptive=True, dt=200.0, dt_range=(0.5, 4.0), **kwargs)
+        reference.run(2)
+        assert reference.sub_steps_done >= 100  # (50 sub-steps per step: dt_max = 4 s)
+        bounded = make_box(eng, "shima", adaptive=True, dt=200.0, dt_range=(0.5, 4.0), **kwargs)
+        eng.call("sdm_ctx_set_option", 1, 7)
+        try:
+            with pytest.raises(RuntimeError, match="did not end within"):
+                bounded.run(1)
+        finally:
+            eng.call("sdm_ctx_set_option", 1, 0)
+        again = make_box(eng, "shima", adaptive=True, dt=200.0, dt_range=(0.5, 4.0), **kwargs)
+        again.run(2)
+        want, got = reference.snapshot(), again.snapshot()
+        for key, value in want.items():
+            np.testing.assert_array_equal(got[key], value, err_msg=key)
+    with pytest.raises(RuntimeError):
+        eng.call("sdm_ctx_set_option", 99, 0)
+
+
 ALL_CHECKS = (check_convergence_to_golovin_solution,
               check_reference_box_smoke_tests, check_reference_small_backend_tests,
               check_reference_breakup_scenarios, check_reference_breakup_dynamic_tests,
@@ -812,4 +843,4 @@ ALL_CHECKS = (check_convergence_to_golovin_solution,
               check_reference_random_reuse_and_multi_cell_call,
               check_scale_prob_known_answers, check_adaptivity_paper_diagram,
               check_gamma_formula_grid, check_same_multiplicity_split,
-              check_single_breakup_known_answers)
+              check_single_breakup_known_answers, check_substep_bound)

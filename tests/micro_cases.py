@@ -131,6 +131,166 @@ def check_remove_zero(kit):
         np.testing.assert_array_equal(idx.to_ndarray(), MICRO[f"remove/{i}/idx"], f"case {i}")
 
 
+def _sanitize_sorted_expected(idx, mult, cell_id, cell_idx, length, flag):
+    """particle_attributes.py:67-73 + :106-110 restated serially on the host: the reference's
+    swap-from-the-end (collisions_methods.py:664-680), then the stable sort by cell_idx[cell_id]"""
+    idx = idx.copy()
+    i, end = 0, length
+    while i < end:
+        if idx[i] == flag or mult[idx[i]] == 0:
+            end -= 1
+            idx[i] = idx[end]
+            idx[end] = flag
+        else:
+            i += 1
+    keys = cell_idx[cell_id[idx[:end]]]
+    idx[:end] = idx[:end][np.argsort(keys, kind="stable")]
+    n_cell = len(cell_idx)
+    cell_start = np.concatenate([[0], np.cumsum(np.bincount(keys, minlength=n_cell))])
+    return idx, end, cell_start
+
+
+def sorted_state(rng, sizes, order=None, n_extra=0):
+    """a state sorted by cell: segment k (in the order of the permutation) holds cell order[k] with
+    sizes[k] members, ids drawn at random; n_extra ids beyond the live length.  Returns idx,
+    cell_id (by id), cell_start of THAT order, and the cell_idx it is sorted under"""
+    sizes = np.asarray(sizes, dtype=np.int64)
+    n_cell, length = len(sizes), int(sizes.sum())
+    order = np.arange(n_cell) if order is None else np.asarray(order)
+    n_sd = length + n_extra
+    ids = rng.permutation(n_sd).astype(np.int64)
+    idx = np.concatenate([ids[:length], np.full(n_extra, n_sd)])
+    cell_id = np.zeros(n_sd, dtype=np.int64)
+    cell_start = np.concatenate([[0], np.cumsum(sizes)])
+    for k in range(n_cell):
+        cell_id[ids[cell_start[k]:cell_start[k + 1]]] = order[k]
+    cell_id[ids[length:]] = rng.integers(0, n_cell, n_extra)
+    cell_idx = np.empty(n_cell, dtype=np.int64)
+    cell_idx[order] = np.arange(n_cell)  # id -> position in the sorted order
+    return idx, cell_id, cell_start, cell_idx
+
+
+RESORT_AUTO, RESORT_COUNTING_SORT, RESORT_ALWAYS_ASK = 0, 1, 2
+RESORT_CAP = 4096  # index.hip: holes the closed form's kernels hold in LDS
+
+
+def _run_sanitize_sorted(kit, idx, mult, cell_id, cell_idx, cell_start, length, resort):
+    import ctypes  # pylint: disable=import-outside-toplevel
+
+    eng = kit.engine
+    d_idx, d_tmp = eng.upload(idx.copy()), eng.upload(np.zeros_like(idx))
+    d_cs = eng.upload(cell_start.copy())
+    new_length, path = ctypes.c_int64(), ctypes.c_int()
+    eng.call("sdm_sanitize_sorted", eng.upload(mult), d_idx, d_tmp, int(length), int(len(idx)),
+             eng.upload(cell_id), eng.upload(cell_idx), d_cs, int(len(cell_idx)), int(resort),
+             new_length, path)
+    return eng.download(d_idx), int(new_length.value), eng.download(d_cs), int(path.value)
+
+
+def check_sanitize_sorted(kit):  # pylint: disable=too-many-locals,too-many-statements
+    """sdm_sanitize_sorted: the compaction + re-sort a multi-cell run does after deaths, both ways
+    of re-sorting on ONE input (closed form, counting sort) against the serial restatement above -
+    the states that decide whether the closed form applies, built explicitly:
+    (a) a handful of deaths spread over the segments, current cell_idx another order than the one
+        the state is sorted under (every sub-step re-orders the cells);  (b) the removed tail spans
+        two cells: refused;  (c) the last segment is used up entirely as fillers (new length ==
+        its start, the segment's cell now known only through a filler);  (d) exactly RESORT_CAP
+        holes, and one more: refused;  (e) a segment whose leading positions are all holes;
+    (f) flagged positions instead of zero multiplicities, in a permutation whose foreign segments
+        hold placeholders (any ids of the cell, as in a sharded run);  (g) everything dies;
+    (h) nothing dies: untouched"""
+    import ctypes  # pylint: disable=import-outside-toplevel
+
+    hip = kit.engine.name == "hip"
+    rng = np.random.default_rng(2024)
+    stats = (ctypes.c_int64 * 8)()
+    kit.engine.call("sdm_ctx_read_stats", stats, 1)
+    tally = {"closed": 0, "refused": 0}
+
+    def both_ways(name, idx, mult, cell_id, cell_idx_now, cell_start, length, expect_closed):
+        flag = len(idx)
+        want_idx, want_len, want_cs = _sanitize_sorted_expected(idx, mult, cell_id, cell_idx_now,
+                                                                length, flag)
+        for resort in (RESORT_ALWAYS_ASK, RESORT_COUNTING_SORT, RESORT_AUTO):
+            got_idx, got_len, got_cs, path = _run_sanitize_sorted(
+                kit, idx, mult, cell_id, cell_idx_now, cell_start, length, resort)
+            assert got_len == want_len, (name, resort)
+            np.testing.assert_array_equal(got_idx[:got_len], want_idx[:want_len], f"{name} {resort}")
+            assert (got_idx[got_len:length] == flag).all(), name
+            if want_len != length:
+                np.testing.assert_array_equal(got_cs, want_cs, f"{name} {resort}")
+            else:
+                np.testing.assert_array_equal(got_cs, cell_start, name)  # (h): left alone
+            if want_len == length:
+                assert path == 0, (name, resort, path)
+            elif hip and resort != RESORT_COUNTING_SORT:
+                assert path == (2 if expect_closed else 1), (name, resort, path)
+                tally["closed" if expect_closed else "refused"] += 1
+            else:
+                assert path == 1, (name, resort, path)
+
+    # (a) a few deaths, cells currently in another order
+    sizes = [37, 0, 64, 129, 1, 300, 0, 250]
+    idx, cell_id, cell_start, _ = sorted_state(rng, sizes, order=[3, 0, 6, 1, 7, 2, 5, 4],
+                                               n_extra=5)
+    length = int(cell_start[-1])
+    mult = np.ones(len(idx), dtype=np.int64)
+    for p in (0, 36, 37, 100, 101, 230, 231, 400, 530, 531):  # never within 20 of the end
+        mult[idx[p]] = 0
+    now = rng.permutation(8).astype(np.int64)
+    both_ways("a", idx, mult, cell_id, now, cell_start, length, True)
+    # ... and the same deaths with holes inside the last segment too (refilled by its own members)
+    mult[idx[length - 200]] = 0
+    mult[idx[length - 3]] = 0   # in the tail itself: a dead tail element is skipped as a filler
+    both_ways("a2", idx, mult, cell_id, now, cell_start, length, True)
+    # (b) more deaths than the last segment has members: the tail spans two cells
+    sizes = [50, 40, 3]
+    idx, cell_id, cell_start, now = sorted_state(rng, sizes)
+    mult = np.ones(len(idx), dtype=np.int64)
+    mult[idx[[1, 5, 9, 13, 17]]] = 0
+    both_ways("b", idx, mult, cell_id, now, cell_start, int(cell_start[-1]), False)
+    # (c) the last segment exactly used up: new length == its start, h0 > 0
+    sizes = [50, 0, 40, 3]
+    idx, cell_id, cell_start, _ = sorted_state(rng, sizes, order=[2, 3, 0, 1])
+    mult = np.ones(len(idx), dtype=np.int64)
+    mult[idx[[4, 60, 61]]] = 0
+    both_ways("c", idx, mult, cell_id, np.asarray([1, 3, 0, 2]), cell_start, int(cell_start[-1]),
+              True)
+    # (d) RESORT_CAP holes ahead of a last segment that can fill them; one more: refused
+    for extra, closed in ((0, True), (1, False)):
+        holes = RESORT_CAP + extra
+        sizes = [3000, 2500, 1, 3000, holes + 700]
+        idx, cell_id, cell_start, now = sorted_state(rng, sizes)
+        mult = np.ones(len(idx), dtype=np.int64)
+        dead = rng.choice(int(cell_start[4]), size=holes, replace=False)
+        mult[idx[dead]] = 0
+        both_ways(f"d{extra}", idx, mult, cell_id, now, cell_start, int(cell_start[-1]), closed)
+    # (e) segments that begin with holes (one of them nothing but holes)
+    sizes = [10, 4, 12, 200]
+    idx, cell_id, cell_start, now = sorted_state(rng, sizes, order=[1, 2, 3, 0])
+    mult = np.ones(len(idx), dtype=np.int64)
+    mult[idx[[0, 1, 2, 10, 11, 12, 13, 14, 15]]] = 0
+    both_ways("e", idx, mult, cell_id, now, cell_start, int(cell_start[-1]), True)
+    # (f) flagged positions; foreign segments hold the cell's ids in some other order (placeholders)
+    sizes = [64, 64, 64, 64, 500]
+    idx, cell_id, cell_start, now = sorted_state(rng, sizes)
+    for k in (1, 3):  # "not ours": any arrangement of ids of that cell
+        seg = slice(int(cell_start[k]), int(cell_start[k + 1]))
+        idx[seg] = idx[seg][::-1]
+    mult = np.ones(len(idx), dtype=np.int64)
+    idx[[3, 70, 71, 200, 255, 300]] = len(idx)
+    both_ways("f", idx, mult, cell_id, now, cell_start, int(cell_start[-1]), True)
+    # (g) everything dies / (h) nothing dies
+    sizes = [5, 6, 7]
+    idx, cell_id, cell_start, now = sorted_state(rng, sizes)
+    both_ways("g", idx, np.zeros(len(idx), dtype=np.int64), cell_id, now, cell_start, 18, False)
+    both_ways("h", idx, np.ones(len(idx), dtype=np.int64), cell_id, now, cell_start, 18, False)
+    kit.engine.call("sdm_ctx_read_stats", stats, 0)
+    if hip:  # the library's own count of what it did agrees with the paths reported
+        assert stats[0] == tally["closed"] and stats[1] == tally["refused"], (list(stats), tally)
+    assert stats[3] > 0  # counting sorts
+
+
 def check_pair_chain(kit):  # pylint: disable=too-many-locals,too-many-statements
     for n_sd, n_cell in MICRO["pairs/cases"]:
         key = f"pairs/{n_sd}_{n_cell}"

@@ -30,7 +30,7 @@ def kit_fixture(hip_backend_class):
 
 @pytest.mark.parametrize("check", [mc.check_pcg64, mc.check_shuffle,
                                    mc.check_shuffle_known_answers, mc.check_counting_sort,
-                                   mc.check_sort_by_key_and_adaptive_end, mc.check_remove_zero,
+                                   mc.check_sort_by_key_and_adaptive_end, mc.check_remove_zero, mc.check_sanitize_sorted,
                                    mc.check_pair_chain, mc.check_moments, mc.check_moments_goldens,
                                    mc.check_storage_ops])
 def test_method_goldens(check, kit):
@@ -443,3 +443,46 @@ def test_a_stale_cell_start_is_refused_not_computed_on(hip_engine):
     pop.ordered = True
     with pytest.raises(RuntimeError, match="cell_start does not span"):
         runner.run(3)
+
+
+def test_fused_run_takes_the_closed_form_resort_and_it_equals_the_counting_sort(hip_engine,
+                                                                              oracle_engine):
+    """multi-cell adaptive runs in which super-droplets die in most steps: with SDM_OPT_RESORT =
+    ALWAYS_ASK the re-sort after a compaction is the closed form where it applies (the library's
+    own count says it was taken), with COUNTING_SORT never - and the states are the same, and the
+    checker's.  Which path a call takes does not depend on earlier calls (the back-off is reset at
+    every entry: two identical calls count the same)"""
+    import ctypes
+
+    stats = (ctypes.c_int64 * 8)()
+    runs = {}
+    try:
+        for mode in (2, 1, 0, 0):  # ALWAYS_ASK, COUNTING_SORT, AUTO, AUTO
+            hip_engine.call("sdm_ctx_set_option", 0, mode)
+            hip_engine.call("sdm_ctx_read_stats", stats, 1)
+            runner = make_box(hip_engine, "shima", n_sd=40000, adaptive=True, dt=200.0, thin=0.02,
+                              grid=(8, 5), seed=1003)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for steps in (5, 8, 2):
+                    runner.run(steps)
+            hip_engine.call("sdm_ctx_read_stats", stats, 1)
+            runs.setdefault(mode, []).append((runner.snapshot(), list(stats)))
+    finally:
+        hip_engine.call("sdm_ctx_set_option", 0, 0)
+    asked, sorted_only, (auto, auto_again) = runs[2][0], runs[1][0], runs[0]
+    assert asked[1][0] > 0 and asked[1][2] == 0          # closed form taken, nothing skipped
+    assert asked[1][0] + asked[1][1] == asked[1][0] + asked[1][3]  # refused = counting-sorted
+    assert sorted_only[1][0] == 0 and sorted_only[1][1] == 0 and sorted_only[1][3] > 0
+    assert sorted_only[1][3] == asked[1][0] + asked[1][3]  # the same compactions either way
+    assert auto[1] == auto_again[1]                        # no history between calls
+    assert auto[1][0] > 0
+    checker = make_box(oracle_engine, "shima", n_sd=40000, adaptive=True, dt=200.0, thin=0.02,
+                       grid=(8, 5), seed=1003)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for steps in (5, 8, 2):
+            checker.run(steps)
+    want = checker.snapshot()
+    for snap, _ in (asked, sorted_only, auto):
+        assert_same(snap, want)

@@ -19,7 +19,7 @@ def kit_fixture(oracle_backend_class):
 
 @pytest.mark.parametrize("check", [mc.check_pcg64, mc.check_shuffle,
                                    mc.check_shuffle_known_answers, mc.check_counting_sort,
-                                   mc.check_sort_by_key_and_adaptive_end, mc.check_remove_zero,
+                                   mc.check_sort_by_key_and_adaptive_end, mc.check_remove_zero, mc.check_sanitize_sorted,
                                    mc.check_pair_chain, mc.check_moments, mc.check_moments_goldens,
                                    mc.check_storage_ops])
 def test_method_goldens(check, kit):
