@@ -235,3 +235,56 @@ def test_bench_checkpoint_brings_back_the_same_steps_after_deaths(oracle_engine)
                          pop.perm[:pop.live], pop.multiplicity, pop.extensive, pop.cell_id,
                          pop.cell_origin, pop.position_in_cell)]))
     assert seen[0][0] <= start.live and seen[1] == seen[0]
+
+
+def _worker_eight(rank, world, port, errors):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from oracle.engine import OracleEngine  # pylint: disable=import-outside-toplevel
+
+        from . import digests, displacement_cases  # pylint: disable=import-outside-toplevel
+
+        engine = OracleEngine.get()
+        # BASELINE.json configs[3]'s grid at the process count its target names: 32 x 32 cells,
+        # blocks of 128 per process, against the digest of the REFERENCE's own run
+        runner = digests.check("kinematic2d_64percell", engine,
+                               prepare=lambda r: sharding.attach(r, rank, world),
+                               snapshot=sharding.gather)
+        first, last = runner.shard.first, runner.shard.last
+        assert last - first == 128 and runner.shard.calls[1] > 0
+        # the flow - displacement and collisions both sharded - beside the one-process run after
+        # every step: 32 x 32 cells again (128 per process), super-droplets change owner all along
+        stats = displacement_cases.sharded_flow_equals_single(engine, rank, world, n_sd=2**15,
+                                                              grid=(32, 32), steps=4)
+        assert stats["left"] > 0 and stats["arrived"] > 0, stats
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as exc:  # pylint: disable=broad-except
+        errors.put(f"rank {rank}: {exc!r}")
+        raise
+
+
+@pytest.mark.timeout(900)
+def test_eight_processes_reproduce_the_reference_digest_of_the_32x32_grid():
+    """world size 8 - the only process count BASELINE.json's target has: the 32 x 32 grid in blocks
+    of 128 cells; the state gathered from the owners equals the reference's digest (three adaptive
+    steps), and the sharded flow equals the one-process run step by step"""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    errors = ctx.Queue()
+    procs = [ctx.Process(target=_worker_eight, args=(r, 8, port, errors)) for r in range(8)]
+    for proc in procs:
+        proc.start()
+    for proc in procs:
+        proc.join(800)
+    failed = [p.exitcode for p in procs if p.exitcode != 0]
+    messages = []
+    while not errors.empty():
+        messages.append(errors.get())
+    for proc in procs:
+        if proc.is_alive():
+            proc.kill()
+    assert not failed and not messages, f"{failed} {messages}"
