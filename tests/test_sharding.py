@@ -288,3 +288,38 @@ def test_eight_processes_reproduce_the_reference_digest_of_the_32x32_grid():
         if proc.is_alive():
             proc.kill()
     assert not failed and not messages, f"{failed} {messages}"
+
+
+def test_an_emulated_rank_replayed_against_a_one_process_trace_computes_its_block(oracle_engine):
+    """bench.py --emulate-of N prices one rank of N on a single device: it owns its block of cells,
+    and what the others would have contributed to every exchange is copied in from the trace of a
+    one-process run (sharding.RecordingShard / ReplayShard).  Here on the checker: every rank of 8
+    (and of 3: uneven blocks) reproduces its block of the one-process state, deaths included, and a
+    replay against the trace of OTHER steps is refused"""
+    from pysdm_amd import cases  # pylint: disable=import-outside-toplevel
+
+    def box():
+        return cases.make_box(oracle_engine, "shima", n_sd=2**12, adaptive=True, dt=200.0,
+                              thin=0.02, grid=(8, 4))
+
+    recorded = sharding.attach_recording(box())
+    plain = box()
+    for steps in (1, 3, 2):
+        recorded.run(steps)
+        plain.run(steps)
+    whole = plain.snapshot()
+    assert int(whole["length"]) < 2**12 and recorded.shard.calls[2] > 0  # super-droplets died
+    got = recorded.snapshot()
+    for key in ("idx", "multiplicity", "attributes", "cell_start"):
+        np.testing.assert_array_equal(got[key], whole[key])
+    trace = recorded.shard.trace
+    for world in (8, 3):
+        for rank in range(world):
+            emulated = sharding.attach_replay(box(), rank, world, trace)
+            for steps in (1, 3, 2):
+                emulated.run(steps)
+            assert emulated.shard.position == len(trace)
+            assert sharding.emulated_rank_equals(emulated, whole), (rank, world)
+    other = sharding.attach_replay(box(), 0, 2, trace[3:])
+    with pytest.raises(RuntimeError):
+        other.run(6)
