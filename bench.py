@@ -424,8 +424,7 @@ def main():
             checkpoint.restore(runner)
         substeps_before = runner.sub_steps_done
         if runner.shard is not None:
-            comm_before = (runner.shard.calls[1], runner.shard.calls[2],
-                           runner.shard.bytes[1] + runner.shard.bytes[2])
+            comm_before = runner.shard.traffic()
         barrier()
         pairs_before = int(pop.ctl[5].item())  # the library's own count (control word 5)
         host_pairs_before = runner.pairs_done
@@ -452,12 +451,14 @@ def main():
         progress(f"repetition {rep}: {reps[-1][0]:.4g} pairs/s")
         if runner.shard is not None:
             shard = runner.shard
-            comm = {"f64_calls": shard.calls[1] - comm_before[0],
-                    "i64_calls": shard.calls[2] - comm_before[1],
-                    "bytes": shard.bytes[1] + shard.bytes[2] - comm_before[2],
-                    "bytes_per_step": (shard.bytes[1] + shard.bytes[2] - comm_before[2])
-                                      / args.steps,
-                    "backend": dist_backend}
+            calls, payload = shard.traffic()
+            comm = {"collectives": calls - comm_before[0], "bytes": payload - comm_before[1],
+                    "bytes_per_step": (payload - comm_before[1]) / args.steps,
+                    "backend": dist_backend,
+                    # who issues them: the library (RCCL on its own stream, no host code in the
+                    # sub-step loop) or a Python callback into torch.distributed
+                    "issued_by": "library (ncclAllReduce)" if shard.library_comm
+                                 else "python callback (torch.distributed.all_reduce)"}
     # multi-cell workload: digest of the global state (put together from the owners when sharded),
     # so that runs with different --gpus can be compared: the sharded run reproduces the
     # one-process run bit for bit

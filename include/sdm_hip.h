@@ -87,6 +87,8 @@ int sdm_ctx_set_option(sdm_ctx *ctx, int option, int64_t value);
 #define SDM_STAT_RESORT_COUNTING_SORT 3
 #define SDM_STAT_SUBSTEPS 4
 #define SDM_STAT_SUBSTEPS_TAKEN_BACK 5
+#define SDM_STAT_EXCHANGES 6       /* collectives of sharded steps (callback or RCCL) */
+#define SDM_STAT_EXCHANGE_BYTES 7  /* payload handed to them */
 #define SDM_N_STATS 8
 int sdm_ctx_read_stats(sdm_ctx *ctx, int64_t *stats, int clear);
 
@@ -418,9 +420,25 @@ typedef struct sdm_step_cfg {
  * The concatenation of the owned cells equals the one-process result bit for bit.            */
 #define SDM_XCHG_SUM_F64 1 /* buffer = device double[count]: in-place sum over all processes */
 #define SDM_XCHG_SUM_I64 2 /* buffer = device int64[count] */
+#define SDM_XCHG_MIN_F64 3 /* buffer = device double[count]: in-place minimum over all processes */
 /* must order the collective after the work already enqueued on the ctx stream and make its result
  * visible to work enqueued later on that stream; returns 0 on success */
 typedef int (*sdm_exchange_fn)(void *user, int what, void *device_buffer, int64_t count);
+
+/* The same exchanges issued by the library itself: RCCL all-reduces (xGMI between the GPUs of a
+ * node) on the context's stream, no host code inside the sub-step loop.  The host keeps the
+ * bootstrap: ONE process calls sdm_comm_unique_id, the id reaches the others by whatever the host
+ * has (torch.distributed's store, MPI, a file), EVERY process then calls sdm_comm_init (collective).
+ * While a context has a communicator, `exchange` of sdm_step_state / sdm_disp_shard is not called
+ * and may be NULL.  sdm_shard_set_comm adopts a communicator (ncclComm_t) the caller created; NULL
+ * returns to the callback.  RCCL is looked up at run time (the copy the process has loaded, else
+ * librccl.so.1): the library neither links against it nor needs it otherwise.
+ * (The reference has no counterpart: PySDM is a one-process code.)                              */
+#define SDM_COMM_ID_BYTES 128
+int sdm_comm_unique_id(uint8_t *id);  /* [SDM_COMM_ID_BYTES], host */
+int sdm_comm_init(sdm_ctx *ctx, const uint8_t *id, int rank, int world);
+int sdm_shard_set_comm(sdm_ctx *ctx, void *rccl_comm);
+int sdm_comm_destroy(sdm_ctx *ctx);
 
 typedef struct sdm_step_state {
   int64_t *idx;               /* [n_sd] current permutation */

@@ -88,6 +88,18 @@ API int sdm_ctx_read_stats(sdm_ctx *ctx, int64_t *stats, int clear) {
   }
   return SDM_OK;
 }
+/* RCCL belongs to the product: the checker exchanges through the callback alone */
+API int sdm_comm_unique_id(uint8_t *id) { (void)id; FAIL(SDM_E_ARG, "the checker has no RCCL"); }
+API int sdm_comm_init(sdm_ctx *ctx, const uint8_t *id, int rank, int world) {
+  (void)ctx; (void)id; (void)rank; (void)world;
+  FAIL(SDM_E_ARG, "the checker has no RCCL");
+}
+API int sdm_shard_set_comm(sdm_ctx *ctx, void *comm) {
+  (void)ctx;
+  if (comm) FAIL(SDM_E_ARG, "the checker has no RCCL");
+  return SDM_OK;
+}
+API int sdm_comm_destroy(sdm_ctx *ctx) { (void)ctx; return SDM_OK; }
 API int sdm_ctx_set_timing(sdm_ctx *ctx, int enable) { (void)ctx; (void)enable; return SDM_OK; }
 API int sdm_ctx_read_timing(sdm_ctx *ctx, double *ms, int64_t *count) {
   (void)ctx;

@@ -65,7 +65,8 @@ class StepState(ctypes.Structure):  # == sdm_step_state
 
 # sdm_exchange_fn
 ExchangeFn = ctypes.CFUNCTYPE(c_int, c_ptr, c_int, c_ptr, c_i64)
-XCHG_SUM_F64, XCHG_SUM_I64 = 1, 2
+XCHG_SUM_F64, XCHG_SUM_I64, XCHG_MIN_F64 = 1, 2, 3
+COMM_ID_BYTES = 128
 
 
 class StepResult(ctypes.Structure):  # == sdm_step_result

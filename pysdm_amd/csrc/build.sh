@@ -10,7 +10,7 @@ FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-ma
 [ "${1:-}" = "--force" ] && rm -f ./*.o
 objs=()
 pids=()
-for f in ctx index collisions fused displacement calib; do
+for f in ctx index collisions fused displacement calib comm; do
   stale=0
   [ -f $f.o ] || stale=1
   for dep in $f.hip common.h sdm_math.h sdm_math_tables.h physics.h index.h shuffle_device.h shuffle_build.h ../../include/sdm_hip.h; do
@@ -27,7 +27,7 @@ for pid in "${pids[@]:-}"; do
   [ -z "$pid" ] || wait "$pid"
 done
 rm -f $OUT
-$HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined -o $OUT "${objs[@]}"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined -o $OUT "${objs[@]}" -ldl
 echo "built $(realpath $OUT)"
 # the C-ABI example embeds the header's struct layouts: rebuild it with the library
 bash ../../examples/build.sh

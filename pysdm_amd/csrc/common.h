@@ -79,6 +79,10 @@ struct sdm_ctx {
   // fused.hip: compactions of the CURRENT call for which the closed-form re-sort is not asked for
   // (reset at every entry: which path a call takes must not depend on earlier calls)
   int resort_backoff;
+  // comm.hip: RCCL communicator of sharded runs (NULL: the host's exchange callback)
+  void *comm;
+  bool comm_owned;
+  int comm_rank, comm_world;
   int opt_resort;                // SDM_OPT_RESORT
   int64_t opt_max_substeps;      // SDM_OPT_MAX_SUBSTEPS (0: none)
   int64_t stats[SDM_N_STATS];    // SDM_STAT_* (host-side counters, sdm_ctx_read_stats)
@@ -166,6 +170,9 @@ struct PhaseScope {
 };
 
 void sdm_set_error(const char *fmt, ...);
+// comm.hip: one exchange of a sharded step - RCCL if the context has a communicator, else the callback
+int sdm_exchange(sdm_ctx *ctx, sdm_exchange_fn callback, void *user, int what, void *buffer,
+                 int64_t count);
 int sdm_reserve(sdm_ctx *ctx, size_t bytes);
 
 #define HIP_TRY(expr)                                                                  \

@@ -87,6 +87,7 @@ extern "C" int sdm_ctx_destroy(sdm_ctx *ctx) {
   if (!ctx) return SDM_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  (void)sdm_comm_destroy(ctx);
   if (ctx->arena) (void)hipFree(ctx->arena);
   if (ctx->pcg_tab) (void)hipFree(ctx->pcg_tab);
   if (ctx->pcg_aff) (void)hipFree(ctx->pcg_aff);

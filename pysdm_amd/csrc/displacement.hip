@@ -727,7 +727,7 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
   ARG_TRY(state->displacement && state->position_in_cell && state->cell_origin &&
           state->cell_id && state->water_mass && state->multiplicity && state->idx && state->ctl);
   ARG_TRY(!cfg->enable_sedimentation || (state->fall_velocity && cfg->dt_over_dz != 0));
-  ARG_TRY(sh->cell_owned && sh->exchange && sh->xchg_counts && sh->xchg_words &&
+  ARG_TRY(sh->cell_owned && (sh->exchange || ctx->comm) && sh->xchg_counts && sh->xchg_words &&
           sh->cell_id_by_id && sh->role && sh->multiplicity && sh->attributes);
   ARG_TRY(sh->n_attr >= 1 && sh->shard_world >= 1 && sh->shard_world <= 256 &&
           sh->shard_rank >= 0 && sh->shard_rank < sh->shard_world && sh->word_capacity >= 0);
@@ -791,8 +791,8 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
     LAUNCH_CHECK();
     HIP_TRY(hipMemcpyAsync(ctx->mailbox, mine_dev, sizeof(unsigned long long) * 4,
                            hipMemcpyDeviceToHost, s));
-    if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_F64, sh->xchg_counts, lists * W) != 0) {
-      sdm_set_error("sharded displacement: the exchange callback failed (counts)");
+    if (sdm_exchange(ctx, sh->exchange, sh->exchange_user, SDM_XCHG_SUM_F64, sh->xchg_counts,
+                     lists * W) != 0) {
       return SDM_E_HIP;
     }
     HIP_TRY(hipMemcpyAsync(host_counts, sh->xchg_counts, sizeof(double) * (size_t)(lists * W),
@@ -837,8 +837,8 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
                            sh->xchg_words + total + before, (const int64_t *)X.dead_mass, mine);
       LAUNCH_CHECK();
     }
-    if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_I64, sh->xchg_words, words) != 0) {
-      sdm_set_error("sharded displacement: the exchange callback failed (positions of the removed)");
+    if (sdm_exchange(ctx, sh->exchange, sh->exchange_user, SDM_XCHG_SUM_I64, sh->xchg_words,
+                     words) != 0) {
       return SDM_E_HIP;
     }
     sh->n_words += words;
@@ -916,8 +916,8 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
                        (const double *)state->position_in_cell, (const int32_t *)blk_a,
                        (const int32_t *)blk_b, at_a, at_b);
     LAUNCH_CHECK();
-    if (sh->exchange(sh->exchange_user, SDM_XCHG_SUM_I64, sh->xchg_words, words) != 0) {
-      sdm_set_error("sharded displacement: the exchange callback failed (rows)");
+    if (sdm_exchange(ctx, sh->exchange, sh->exchange_user, SDM_XCHG_SUM_I64, sh->xchg_words,
+                     words) != 0) {
       return SDM_E_HIP;
     }
     sh->n_words += words;

@@ -2399,8 +2399,9 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   // on identical, complete data everywhere.
   const bool sharded = st->cell_owned != nullptr;
   if (sharded) {
-    if (!st->exchange || !st->xchg_cells || !st->xchg_idx) {
-      sdm_set_error("sharded mode: exchange callback and its two buffers are required");
+    if ((!st->exchange && !ctx->comm) || !st->xchg_cells || !st->xchg_idx) {
+      sdm_set_error("sharded mode: an exchange callback (or a communicator: sdm_comm_init) and "
+                    "the two exchange buffers are required");
       return SDM_E_ARG;
     }
     if (st->shard_world < 1 || st->shard_world > 64 || st->shard_rank < 0 ||
@@ -2428,9 +2429,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     hipLaunchKernelGGL(k_shard_pack, g, blk, 0, s, A, C, cfg->adaptive, st->xchg_cells,
                        shard_n_dead, my_rank, world);
     LAUNCH_CHECK();
-    if (st->exchange(st->exchange_user, SDM_XCHG_SUM_F64, st->xchg_cells, C + 1 + world) != 0) {
-      sdm_set_error("sharded mode: the exchange callback failed (per-cell sum)");
-      return SDM_E_HIP;
+    {
+      const int r = sdm_exchange(ctx, st->exchange, st->exchange_user, SDM_XCHG_SUM_F64,
+                                 st->xchg_cells, C + 1 + world);
+      if (r) return r;
     }
     hipLaunchKernelGGL(k_shard_unpack, g, blk, 0, s, A, C, cfg->adaptive, st->xchg_cells);
     LAUNCH_CHECK();
@@ -2469,9 +2471,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
                          st->xchg_idx + before);
       LAUNCH_CHECK();
     }
-    if (st->exchange(st->exchange_user, SDM_XCHG_SUM_I64, st->xchg_idx, total) != 0) {
-      sdm_set_error("sharded mode: the exchange callback failed (dead positions)");
-      return SDM_E_HIP;
+    {
+      const int r = sdm_exchange(ctx, st->exchange, st->exchange_user, SDM_XCHG_SUM_I64,
+                                 st->xchg_idx, total);
+      if (r) return r;
     }
     hipLaunchKernelGGL(k_shard_flag, dim3(grid_for(total)), blk, 0, s, perm, st->xchg_idx, total,
                        N);
@@ -2539,9 +2542,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
                            *cfg, A, (const int64_t *)S.end2, st->xchg_cells,
                            (const unsigned long long *)shard_n_dead, my_rank, world);
         LAUNCH_CHECK();
-        if (st->exchange(st->exchange_user, SDM_XCHG_SUM_F64, st->xchg_cells, C + 1 + world) != 0) {
-          sdm_set_error("sharded mode: the exchange callback failed (per-cell sum)");
-          return SDM_E_HIP;
+        {
+          const int r = sdm_exchange(ctx, st->exchange, st->exchange_user, SDM_XCHG_SUM_F64,
+                                     st->xchg_cells, C + 1 + world);
+          if (r) return r;
         }
       }
       *seq_out = ++ctx->poll_seq;

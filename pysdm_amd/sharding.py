@@ -54,10 +54,50 @@ class Shard:  # pylint: disable=too-many-instance-attributes
         self.d_counts = self.d_words = None  # (displacement_buffers)
         self.role = engine.zeros(n_sd, np.uint8)  # sdm_disp_shard.role, filled by the library
         self.role_ready = False
-        self.calls = {abi.XCHG_SUM_F64: 0, abi.XCHG_SUM_I64: 0}
-        self.bytes = {abi.XCHG_SUM_F64: 0, abi.XCHG_SUM_I64: 0}  # payload handed to collectives
+        self.calls = {abi.XCHG_SUM_F64: 0, abi.XCHG_SUM_I64: 0, abi.XCHG_MIN_F64: 0}
+        self.bytes = dict(self.calls)  # payload handed to collectives
         self.error = None
         self.callback = abi.ExchangeFn(self._exchange)  # keep alive as long as the shard
+        self.library_comm = False
+        self._connect()
+
+    def _connect(self):
+        """GPUs + RCCL: the library issues the collectives itself (sdm_comm_init; no Python inside
+        the sub-step loop) - torch.distributed is the bootstrap that carries the unique id from
+        rank 0 to the others.  Anything else (gloo; the CPU checker; SDM_PYTHON_EXCHANGE=1 for
+        A/B measurements) goes through the callback below."""
+        import os  # pylint: disable=import-outside-toplevel
+
+        dist = self.dist
+        if (type(self) is not Shard or self.engine.name != "hip" or not dist.is_initialized()
+                or dist.get_backend(self.group) != "nccl"
+                or os.environ.get("SDM_PYTHON_EXCHANGE") == "1"):
+            return
+        ident = np.zeros(abi.COMM_ID_BYTES, dtype=np.uint8)
+        if dist.get_rank(self.group) == 0:
+            self.engine.call("sdm_comm_unique_id", ident)
+        carrier = self.torch.from_numpy(ident).to(self.x_cells.device)
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        dist.broadcast(carrier, src=src, group=self.group)
+        self.engine.call("sdm_comm_init", np.ascontiguousarray(carrier.cpu().numpy()),
+                         dist.get_rank(self.group), dist.get_world_size(self.group))
+        self.library_comm = True
+
+    def close(self):
+        if self.library_comm:
+            self.engine.call("sdm_comm_destroy")
+            self.library_comm = False
+
+    def traffic(self):
+        """(collectives, bytes handed to them) so far: counted by the library when it issues them
+        itself, by the callback otherwise"""
+        if self.library_comm:
+            import ctypes  # pylint: disable=import-outside-toplevel
+
+            stats = (ctypes.c_int64 * 8)()
+            self.engine.call("sdm_ctx_read_stats", stats, 0)
+            return int(stats[6]), int(stats[7])
+        return sum(self.calls.values()), sum(self.bytes.values())
 
     def _as_tensor(self, array):
         return array if hasattr(array, "data_ptr") else self.torch.from_numpy(array)
@@ -77,8 +117,8 @@ class Shard:  # pylint: disable=too-many-instance-attributes
 
     def _exchange(self, _user, what, pointer, count):
         try:
-            candidates = ((self.x_cells, self.d_counts) if what == abi.XCHG_SUM_F64
-                          else (self.x_idx, self.d_words))
+            candidates = ((self.x_idx, self.d_words) if what == abi.XCHG_SUM_I64
+                          else (self.x_cells, self.d_counts))
             buffer = next((b for b in candidates
                            if b is not None and self._address(b) == pointer), None)
             if buffer is None:
@@ -86,16 +126,17 @@ class Shard:  # pylint: disable=too-many-instance-attributes
             self.calls[what] += 1
             self.bytes[what] += 8 * int(count)
             tensor = self._as_tensor(buffer)[:count]
+            op = self.dist.ReduceOp.MIN if what == abi.XCHG_MIN_F64 else self.dist.ReduceOp.SUM
             if tensor.is_cuda and self.dist.get_backend(self.group) != "nccl":
                 # rehearsal on one card (several processes, gloo): through the host.  `.cpu()`
                 # waits for the library's stream, `copy_` is enqueued on it
                 host = tensor.cpu()
-                self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group)
+                self.dist.all_reduce(host, op=op, group=self.group)
                 tensor.copy_(host)
             else:
                 # RCCL: enqueued behind the work already on the current (= the library's) stream,
                 # and later work on that stream waits for it
-                self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM, group=self.group)
+                self.dist.all_reduce(tensor, op=op, group=self.group)
             return 0
         except Exception as error:  # pylint: disable=broad-except
             self.error = error  # (exceptions cannot cross the C frame: reported by the runner)

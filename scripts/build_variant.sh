@@ -9,11 +9,11 @@ tmp=$(mktemp -d)
 mkdir -p "$root/build_variants"
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function"
 pids=()
-for f in ctx index collisions fused displacement calib; do
+for f in ctx index collisions fused displacement calib comm; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c "$root/pysdm_amd/csrc/$f.hip" -o "$tmp/$f.o" 2>/dev/null &
   pids+=($!)
 done
 for pid in "${pids[@]}"; do wait "$pid"; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined -o "$out" "$tmp"/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined -o "$out" "$tmp"/*.o -ldl
 rm -rf "$tmp"
 echo "built $out"

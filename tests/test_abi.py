@@ -53,7 +53,7 @@ def test_every_prototype_is_understood_by_the_binding():
     assert kinds == {"ctx", "scalar", "pointer", "host_array"}
     first = {name: params[0].kind for name, (_, params) in table.items() if params}
     not_ctx_first = {n for n, kind in first.items() if kind != "ctx"}
-    assert not_ctx_first == {"sdm_ctx_create", "sdm_phase_name"}
+    assert not_ctx_first == {"sdm_ctx_create", "sdm_phase_name", "sdm_comm_unique_id"}
     cfg = dict((p.name, p) for p in table["sdm_collision_step"][1])
     assert cfg["cfg"].base == "sdm_step_cfg" and cfg["flags"].kind == "scalar"
 

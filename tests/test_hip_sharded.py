@@ -141,3 +141,58 @@ def test_two_processes_sharded_on_hip_equal_the_unsharded_reference(hip_engine):
     while not errors.empty():
         messages.append(errors.get())
     assert not failed and not messages, f"{failed} {messages}"
+
+
+def test_the_library_issues_the_collectives_itself_over_rccl(hip_engine):
+    """sdm_comm_unique_id / sdm_comm_init: with a communicator the exchanges of a sharded step are
+    ncclAllReduce calls on the library's stream - the host's callback is not called (here it would
+    fail the step if it were).  World size 1 (a box of this pool has one GPU): no peer, but the
+    whole device path; the run equals the unsharded one, deaths included."""
+    import ctypes
+
+    from pysdm_amd import abi, cases
+
+    def box():
+        return cases.make_box(hip_engine, "shima", n_sd=2**13, adaptive=True, dt=200.0, thin=0.02,
+                              grid=(4, 4))
+
+    ident = np.zeros(abi.COMM_ID_BYTES, dtype=np.uint8)
+    hip_engine.call("sdm_comm_unique_id", ident)
+    assert ident.any()
+    hip_engine.call("sdm_comm_init", ident, 0, 1)
+    stats = (ctypes.c_int64 * 8)()
+    hip_engine.call("sdm_ctx_read_stats", stats, 1)
+    try:
+        plain, sharded = box(), box()
+        sharded.shard = sharding.RecordingShard(hip_engine, 2**13, 16)  # (no process group needed)
+        sharded.read_back = True
+        sharded.counts_global_pairs = True
+
+        def refuse(*_):
+            return 1
+
+        sharded.shard.callback = abi.ExchangeFn(refuse)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for steps in (1, 4, 3):
+                plain.run(steps)
+                sharded.run(steps)
+        hip_engine.call("sdm_ctx_read_stats", stats, 0)
+        assert stats[6] > 0 and stats[7] >= 8 * stats[6]  # collectives issued by the library
+        want, got = plain.snapshot(), sharded.snapshot()
+        length = int(want["length"])
+        assert length < 2**13
+        for key, value in want.items():
+            mine = got[key]
+            if key == "idx":
+                value, mine = value[:length], mine[:length]
+            np.testing.assert_array_equal(mine, value, err_msg=key)
+    finally:
+        hip_engine.call("sdm_comm_destroy")
+    # without a communicator and with a callback that refuses, the step fails loudly
+    again = box()
+    again.shard = sharding.RecordingShard(hip_engine, 2**13, 16)
+    again.read_back = True
+    again.shard.callback = abi.ExchangeFn(refuse)
+    with pytest.raises(RuntimeError):
+        again.run(1)
