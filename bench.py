@@ -233,7 +233,7 @@ def emulate_ranks(args, engine, adaptive, torch, dist, launch):
     assert (pairs_r, substeps_r) == (pairs, substeps)
     whole = recorded.snapshot()
     trace = recorded.shard.trace
-    timed_exchanges = recorded.shard.calls[1] + recorded.shard.calls[2]
+    timed_exchanges = sum(recorded.shard.calls.values())
     n_cell, n_sd = recorded.population.n_cell, recorded.population.n_sd
     del recorded
     per_rank = {}

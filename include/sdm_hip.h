@@ -483,7 +483,9 @@ typedef struct sdm_step_state {
   const uint8_t *cell_owned;  /* [n_cell] by cell id: 1 = computed by this process */
   sdm_exchange_fn exchange;
   void *exchange_user;
-  double *xchg_cells;         /* [n_cell + 1 + shard_world] scratch for the per-cell exchange */
+  double *xchg_cells;         /* [max(4 n_cell, n_cell + 1 + shard_world)] scratch for the per-cell
+                                 exchanges (adaptive steps of the per-cell kernels: two buffers of
+                                 {cell minima, minus the deaths per segment}, reduced with MIN) */
   int64_t *xchg_idx;          /* [n_sd] scratch for the exchange of dead positions */
   int32_t shard_rank, shard_world; /* this process's place among the processes (slices above) */
   /* sharded run with a sharded displacement step (sdm_disp_shard below): `cell_id` then holds, for

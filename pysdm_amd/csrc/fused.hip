@@ -61,6 +61,9 @@ struct FusedArgs {
   // where they are flagged (the list of their positions is built only once the exchange of the
   // counts has shown that somebody's did: k_shard_dead_list); NULL otherwise
   unsigned long long *n_dead;
+  // sharded adaptive per-cell route: minus the deaths per SEGMENT of the permutation (k_cells_turn's
+  // min_out + n_cell: completed over the processes by the same all-reduce MIN as the cell minima)
+  double *seg_deaths;
   // graph replay (common.h: gwords): s_rand / s_rand_b are then the generators' initial states and
   // the stream positions come from the device ({collision stream, breakup streams}); rand_extra =
   // distance from a draw's first u01 to its first `rand` (n_sd + shift)
@@ -662,12 +665,20 @@ __device__ __forceinline__ int coalesce_known(const sdm_step_cfg &cfg, const Fus
 // the compaction of the fused route looks at the permutation only (index.hip, FLAG_ONLY): a
 // super-droplet whose multiplicity reached zero is flagged where it sits, the way the reference
 // flags precipitated ones (displacement_methods.py:157-158)
+// sharded runs: `died` (mask of a pair) counted for the exchange - per process, and per segment
+__device__ __forceinline__ void note_deaths(const FusedArgs &A, int64_t segment, int died) {
+  const int k = (died & 1) + (died >> 1);
+  if (A.n_dead) atomicAdd(A.n_dead, (unsigned long long)k);
+  if (A.seg_deaths) atomicAdd(&A.seg_deaths[segment], -(double)k);
+}
+
+// `A` (may be NULL): where a sharded run counts its dead
 __device__ __forceinline__ void flag_dead(const sdm_step_cfg &cfg, int64_t *__restrict__ idx,
-                                          int64_t pos, int died,
-                                          unsigned long long *n_dead = nullptr) {
+                                          int64_t pos, int died, const FusedArgs *A = nullptr) {
   if (died & 1) idx[pos] = cfg.n_sd;
   if (died & 2) idx[pos + 1] = cfg.n_sd;
-  if (n_dead && died) atomicAdd(n_dead, (unsigned long long)((died & 1) + (died >> 1)));
+  if (A && died && (A->n_dead || A->seg_deaths))
+    note_deaths(*A, A->seg_deaths ? find_cell(A->cell_start, cfg.n_cell, pos) : 0, died);
 }
 
 
@@ -730,7 +741,7 @@ __device__ __forceinline__ int pair_update_body(const sdm_step_cfg &cfg, const F
   } else {
     died = resolve_collision<false>(cfg, A, collide, j, k, cid, g, u_b);
   }
-  if (died && flag_here) flag_dead(cfg, A.idx, pos, died, A.n_dead);
+  if (died && flag_here) flag_dead(cfg, A.idx, pos, died, &A);
   return died;
 }
 
@@ -930,105 +941,119 @@ k_reseg_copy(int64_t *__restrict__ out, const int64_t *__restrict__ idx,
     out[i] = idx[i];
 }
 
-// ---- multi-cell per-cell route: what opens and what ends a sub-step, one launch each ----------
-// k_cells_begin, one workgroup per cell i: cell_idx.sort_by_key(dt_left) (collision.py:183; rank
-// of dt_left[i] by counting, as index.hip:k_sort_by_key) and the per-cell adaptive init
-// (collisions_methods.py:355-356); workgroup 0 clears the words k_cells_end accumulates in
-__global__ void __launch_bounds__(SDM_BLOCK)
-k_cells_begin(sdm_step_cfg cfg, FusedArgs A, int64_t *__restrict__ cell_idx,
-              int64_t *__restrict__ end2, int fresh, int gated) {
-  __shared__ int sm[SDM_BLOCK / SDM_WAVE];
+// ---- multi-cell per-cell route: what ends one sub-step and opens the next, in ONE launch ---------
+// k_cells_turn, one workgroup per cell id i.  Between two cell kernels an adaptive step needs: the
+// per-cell bookkeeping of the sub-step just done (collisions_methods.py:357-374: dt_left, stats),
+// adaptive_sdm_end (:313-328: the working length), the decision whether another sub-step runs, and
+// for that one cell_idx.sort_by_key(dt_left) (collision.py:183) and the per-cell init (:355-356).
+// Rounds 2-3 did this in two launches around a finish ticket (per-cell bookkeeping + an atomicMax
+// in the compaction kernel's workgroups, the ranking in a kernel of its own).  Here EVERY workgroup
+// recomputes what is global - all cells' new dt_left (n_cell values: four per thread at 1024
+// cells), from which it takes the rank of its own cell, the end of the working range and the
+// events - from inputs nobody writes in this launch, and writes its own cell's results only: no
+// atomics, no ticket, no fence, one launch; workgroup 0 also writes the control words and
+// publishes the control block of the sub-step that ended.  Hence the ping-pong: dt_left is read
+// from `left_in` and written to `left_out`, the cell minima are read from `min_in` (filled by the
+// previous cell kernel and - sharded runs - completed by the exchange) and this sub-step's are
+// reset in `min_out`.
+// min_*[c]: the minimum of the optimal sub-step over cell c's pairs (+inf: none / not this
+// process's cell); min_*[n_cell + k]: minus the number of super-droplets that died in segment k
+// (sharded runs; an all-reduce MIN over the processes completes both halves at once).
+// gate[(turn) & 1]: whether the sub-step this launch opens runs (read by its cell kernel);
+// gate[(turn - 1) & 1]: whether the previous one ran (then its bookkeeping is applied here).
+struct TurnArgs {
+  const double *left_in;
+  double *left_out;
+  const double *min_in;
+  double *min_out;
+  int64_t *cell_idx;
+  int64_t *gate;
+  int64_t turn;      // launch counter of the call (parity selects the gate word)
+  int32_t first;     // no previous sub-step in this call: nothing to apply
+  int32_t fresh;     // first sub-step of a time step: dt_left[:] = dt (collision.py:180)
+  int32_t gated;     // the sub-step was launched ahead: it runs only if work is left, the state is
+                     // sorted and nobody died (a death is dealt with by the host: compaction, re-sort)
+  int32_t end_only;  // only end the previous sub-step (no launch ahead: timing mode)
+  int32_t sharded;   // the death counts in min_in are meaningful
+  int64_t *box;
+  int64_t seq;       // publication number of the sub-step that ended (0: nothing to publish)
+};
+
+__global__ void __launch_bounds__(SDM_BLOCK) k_cells_turn(sdm_step_cfg cfg, FusedArgs A, TurnArgs T) {
+  __shared__ int sm_rank[SDM_BLOCK / SDM_WAVE], sm_top[SDM_BLOCK / SDM_WAVE];
+  __shared__ int sm_flags[SDM_BLOCK / SDM_WAVE];
   const int64_t i = blockIdx.x, n = cfg.n_cell;
-  // gated: the sub-step was launched ahead of the read-back of the previous one; it runs only if
-  // that one left work to do and the state sorted (no compaction).  end2[3] tells the kernels
-  // that follow (nothing they do changes the two words before this kernel has finished)
-  // (sharded: a death is dealt with by the host - exchange of the dead positions, compaction -
-  // before the next sub-step may run; the compaction of one process un-sorts by itself)
-  const bool run = !gated || (A.ctl[CTL_WORK] != 0 && A.ctl[CTL_SORTED] != 0 &&
-                              (!A.cell_owned || A.ctl[CTL_HEALTHY] != 0));
-  if (i == 0 && threadIdx.x == 0) end2[3] = run ? 1 : 0;
-  if (!run) return;
-  // fresh: first sub-step of a time step, dt_left[:] = dt (collision.py:180) happens here
-  const double ki = fresh ? cfg.dt : A.dt_left[i];
-  int rank = 0;
-  for (int64_t j = threadIdx.x; j < n; j += SDM_BLOCK) {
-    const double kj = fresh ? cfg.dt : A.dt_left[j];
-    rank += (kj < ki) || (kj == ki && j < i);
+  const bool apply = !T.first && T.gate[(T.turn - 1) & 1] != 0;
+  // new dt_left of cell c (what the bookkeeping of the sub-step just done leaves)
+  auto left_of = [&](int64_t c, double *todo, double *m_out) -> double {
+    if (T.fresh) return cfg.dt;
+    const double l = T.left_in[c];
+    if (!apply) return l;
+    const double m = T.min_in[c];
+    double t = cfg.dt_max < l ? cfg.dt_max : l;  // Python min(l, dt_max)
+    if (m < t) t = m;
+    if (todo) { *todo = t; *m_out = m; }
+    return l - t;
+  };
+  double t_i = 0.0, m_i = INFINITY;
+  const double left_i = left_of(i, &t_i, &m_i);
+  int rank = 0, top = 0, flags = 0;  // flags: 1 = somebody died, 2 = a cell minimum equals dt_min
+  for (int64_t c = threadIdx.x; c < n; c += SDM_BLOCK) {
+    const double lc = left_of(c, nullptr, nullptr);
+    rank += (lc < left_i) || (lc == left_i && c < i);
+    if (lc != 0 && (int)c + 1 > top) top = (int)c + 1;
+    if (apply) {
+      if (T.sharded && T.min_in[n + c] < 0) flags |= 1;
+      if (T.min_in[c] == cfg.dt_min) flags |= 2;
+    }
   }
   rank = wave_sum_i32(rank);
-  if (lane_id() == 0) sm[threadIdx.x / SDM_WAVE] = rank;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int total = 0;
-    for (int w = 0; w < SDM_BLOCK / SDM_WAVE; ++w) total += sm[w];
-    cell_idx[n - 1 - total] = i;
-    if (fresh) A.dt_left[i] = ki;
-    A.dt_todo[i] = cfg.dt_max < ki ? cfg.dt_max : ki;  // Python min(l, dt_max)
-    A.cell_min[i] = INFINITY;
-    // (end2[4]: sharded mode's count of this process's deaths in the sub-step - left alone by a
-    // sub-step that falls through, which then exchanges what the one before it did)
-    if (i == 0) { end2[0] = 0; end2[2] = 0; end2[4] = 0; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int t2 = __shfl_xor(top, o, 64);
+    top = t2 > top ? t2 : top;
+    flags |= __shfl_xor(flags, o, 64);
   }
-}
-
-// k_cells_end, one thread per cell, after the compaction: the per-cell adaptive bookkeeping
-// (collisions_methods.py:357-374, `bookkeeping`; k_cell_step left the cell minima), then
-// adaptive_sdm_end (collisions_methods.py:313-328): end2[0] = 1 + largest c with dt_left[c] != 0,
-// and by the workgroup that finishes last: working length = cell_start[that], control block
-// published for the host (end2[2]: finish ticket - a handful of workgroups)
-// the per-cell adaptive bookkeeping of cell c (collisions_methods.py:357-374); returns dt_left[c]
-__device__ __forceinline__ double cell_bookkeeping(const sdm_step_cfg &cfg, const FusedArgs &A,
-                                                   int64_t c, double left) {
-  const double m = A.cell_min[c];
-  double t = A.dt_todo[c];
-  if (m < t) t = m;
-  A.dt_todo[c] = t;
-  const double smin = A.stats_dt_min[c];
-  const double s_new = m < smin ? m : smin;  // Python min(s, m): NaN-sticky
-  A.stats_dt_min[c] = s_new;
-  note_dt_min(A.ctl, s_new, cfg.dt_min);
-  left -= t;
-  A.dt_left[c] = left;
-  if (t > 0) A.stats_n_substep[c] += 1;
-  return left;
-}
-
-// `summed` (sharded runs, after the exchange; k_shard_book_pack filled it): dt_left of every cell
-// from its owner, [n_cell] = how many super-droplets died anywhere - taken over here, so that the
-// un-packing is not a launch of its own
-__global__ void __launch_bounds__(SDM_BLOCK)
-k_cells_end(sdm_step_cfg cfg, FusedArgs A, int bookkeeping, int64_t *__restrict__ end2,
-            int64_t *box, int64_t seq, const double *__restrict__ summed) {
-  const int64_t c = TID();
-  const bool ran = !bookkeeping || end2[3] != 0;  // (see k_cells_begin: gated sub-steps)
-  bool nz = false;
-  if (summed && c == 0 && summed[cfg.n_cell] > 0) A.ctl[CTL_HEALTHY] = 0;
-  if (c < cfg.n_cell) {
-    double left = summed && cfg.adaptive ? summed[c] : A.dt_left[c];
-    if (summed && cfg.adaptive) A.dt_left[c] = left;
-    if (bookkeeping && ran && (!A.cell_owned || A.cell_owned[c]))
-      left = cell_bookkeeping(cfg, A, c, left);
-    nz = left != 0;
-  }
-  const unsigned long long mask = __ballot(nz);
-  if (mask && lane_id() == 0)
-    atomicMax((long long *)&end2[0], (long long)((c - lane_id()) + (63 - __clzll(mask)) + 1));
-  __shared__ bool last;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    last = atomicAdd((unsigned long long *)&end2[2], 1ull) == gridDim.x - 1;
+  if (lane_id() == 0) {
+    sm_rank[threadIdx.x / SDM_WAVE] = rank;
+    sm_top[threadIdx.x / SDM_WAVE] = top;
+    sm_flags[threadIdx.x / SDM_WAVE] = flags;
   }
   __syncthreads();
-  if (last && threadIdx.x == 0) {
-    __threadfence();
-    const int64_t top = __hip_atomic_load(&end2[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int64_t end = top == 0 ? 0 : A.cell_start[top];
-    end2[1] = end;
-    end2[2] = 0;
-    if (ran) A.ctl[CTL_WORK] = end;
-    publish_ctl(A.ctl, box, seq, ran ? end : A.ctl[CTL_WORK]);
+  if (threadIdx.x != 0) return;
+  rank = top = flags = 0;
+  for (int w = 0; w < SDM_BLOCK / SDM_WAVE; ++w) {
+    rank += sm_rank[w];
+    top = sm_top[w] > top ? sm_top[w] : top;
+    flags |= sm_flags[w];
   }
+  // adaptive_sdm_end (collisions_methods.py:313-328): dt_left is scanned by POSITION there
+  const int64_t end = top == 0 ? 0 : A.cell_start[top];
+  const int64_t work = apply ? end : A.ctl[CTL_WORK];
+  const bool healthy = A.ctl[CTL_HEALTHY] != 0 && !(flags & 1);
+  const bool run = !T.end_only &&
+                   (!T.gated || (work != 0 && A.ctl[CTL_SORTED] != 0 && healthy));
+  // this cell's own results
+  T.left_out[i] = left_i;
+  if (apply) {
+    const double smin = A.stats_dt_min[i];
+    A.stats_dt_min[i] = m_i < smin ? m_i : smin;  // Python min(s, m): NaN-sticky
+    if (t_i > 0) A.stats_n_substep[i] += 1;
+  }
+  if (run) {
+    T.cell_idx[n - 1 - rank] = i;
+    T.min_out[i] = INFINITY;
+    if (T.sharded) T.min_out[n + i] = 0.0;
+  }
+  if (i != 0) return;
+  T.gate[T.turn & 1] = run ? 1 : 0;
+  if (apply) A.ctl[CTL_WORK] = end;
+  if (flags & 1) A.ctl[CTL_HEALTHY] = 0;
+  // the reference's warning "adaptive time-step reached dt_min" (collision.py:276-277): the host
+  // evaluates amin(stats_dt_min) == dt_min when this bit is set.  A minimum equal to dt_min is
+  // what can make it so (the optimal sub-step is clamped to dt_min from below)
+  if (flags & 2) A.ctl[7] |= SDM_CTL7_DT_MIN;
+  if (T.seq) publish_ctl(A.ctl, T.box, T.seq, work);
 }
 
 template <bool BREAKUP>
@@ -1248,7 +1273,7 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     __syncthreads();
     double bmin = red[0];
     for (int w = 1; w < CELL_THREADS / SDM_WAVE; ++w) bmin = red[w] < bmin ? red[w] : bmin;
-    if (tid == 0) A.cell_min[cid] = bmin;  // k_cells_adaptive does the per-cell bookkeeping
+    if (tid == 0) A.cell_min[cid] = bmin;  // (k_cells_turn does the per-cell bookkeeping)
     const double l = A.dt_left[cid];
     double todo = cfg.dt_max < l ? cfg.dt_max : l;
     if (bmin < todo) todo = bmin;
@@ -1317,7 +1342,7 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
                                                pk[r], lo + lp, false, &psj[r], &psk[r]);
     if (died & 1) out[lp] = (int32_t)N;  // the permutation is still in LDS here
     if (died & 2) out[lp + 1] = (int32_t)N;
-    if (died && A.n_dead) atomicAdd(A.n_dead, (unsigned long long)((died & 1) + (died >> 1)));
+    if (died) note_deaths(A, blockIdx.x, died);
   }
   __syncthreads();
   if (dense) {
@@ -1342,7 +1367,7 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
       const int died = act ? coalesce_known(cfg, A, j, k, g, sj, sk) : 0;
       if (died & 1) out[lp] = (int32_t)N;  // the permutation is still in LDS here
       if (died & 2) out[lp + 1] = (int32_t)N;
-      if (died && A.n_dead) atomicAdd(A.n_dead, (unsigned long long)((died & 1) + (died >> 1)));
+      if (died) note_deaths(A, blockIdx.x, died);
     }
     __syncthreads();
   }
@@ -1644,7 +1669,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     const int w0 = sub * (T / SDM_WAVE);  // this cell's wavefronts
     double bmin = red[w0];
     for (int w = 1; w < T / SDM_WAVE; ++w) bmin = red[w0 + w] < bmin ? red[w0 + w] : bmin;
-    if (tid == 0 && n > 0) A.cell_min[cid] = bmin;  // k_cells_end does the per-cell bookkeeping
+    if (tid == 0 && n > 0) A.cell_min[cid] = bmin;  // (k_cells_turn does the per-cell bookkeeping)
     const double l = A.dt_left[cid];
     double todo = cfg.dt_max < l ? cfg.dt_max : l;
     if (bmin < todo) todo = bmin;
@@ -1728,7 +1753,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     const int died = coal ? coalesce_known(cfg, A, j, k, g, sj, sk) : 0;
     if (died & 1) out[lp] = (int32_t)N;  // the permutation is still in LDS here
     if (died & 2) out[lp + 1] = (int32_t)N;
-    if (died && A.n_dead) atomicAdd(A.n_dead, (unsigned long long)((died & 1) + (died >> 1)));
+    if (died) note_deaths(A, cell, died);
   }
   __syncthreads();
   CELL_MARK(6);
@@ -1791,7 +1816,7 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_resolve_dense(sdm_step_cfg cfg, F
   c.j = c.k = c.cid = c.pos = 0; c.g = 0; c.u_b = 0;
   if (active) c = A.list[l * A.list_cap + t];
   const int died = resolve_collision<true>(cfg, A, active, c.j, c.k, c.cid, c.g, c.u_b);
-  if (died) flag_dead(cfg, A.idx, c.pos, died, A.n_dead);
+  if (died) flag_dead(cfg, A.idx, c.pos, died, &A);
 }
 
 // ---- control-word kernels -------------------------------------------------------------------
@@ -1880,21 +1905,47 @@ k_shard_pack(FusedArgs A, int64_t n_cell, int adaptive, double *__restrict__ x,
   if (c == n_cell) x[c] = (double)n_dead[0];
   if (c > n_cell && c <= n_cell + world) x[c] = (c - n_cell - 1 == rank) ? (double)n_dead[0] : 0.0;
 }
-// per-cell adaptive route: the bookkeeping of the owned cells (what k_cells_end does in a
-// one-process run) and k_shard_pack in one launch; `ran`: see k_cells_begin (gated sub-steps)
-__global__ void __launch_bounds__(SDM_BLOCK)
-k_shard_book_pack(sdm_step_cfg cfg, FusedArgs A, const int64_t *__restrict__ end2,
-                  double *__restrict__ x, const unsigned long long *__restrict__ n_dead, int rank,
-                  int world) {
-  const int64_t c = TID(), n_cell = cfg.n_cell;
-  if (c < n_cell) {
-    double left = A.dt_left[c];
-    const bool mine = A.cell_owned[c] != 0;
-    if (mine && end2[3] != 0) left = cell_bookkeeping(cfg, A, c, left);
-    x[c] = (cfg.adaptive && mine) ? left : 0.0;
+// adaptive per-cell route (k_cells_turn's buffers): neg[k] = minus the number of super-droplets that
+// died in segment k, from every process (all-reduce MIN) -> off[k] = where segment k's dead go in
+// the list of positions (segment order: the same on every process), *total
+__global__ void __launch_bounds__(1024)
+k_shard_dead_offsets(const double *__restrict__ neg, int64_t n, int64_t *__restrict__ off,
+                     int64_t *__restrict__ total) {
+  __shared__ int64_t sm[1024];
+  const int64_t per = (n + 1023) / 1024, c0 = (int64_t)threadIdx.x * per;
+  const int64_t c1 = c0 + per < n ? c0 + per : n;
+  int64_t sum = 0;
+  for (int64_t c = c0; c < c1; ++c) sum += (int64_t)(-neg[c]);
+  sm[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int64_t t = (int)threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
+    __syncthreads();
+    sm[threadIdx.x] += t;
+    __syncthreads();
   }
-  if (c == n_cell) x[c] = (double)n_dead[0];
-  if (c > n_cell && c <= n_cell + world) x[c] = (c - n_cell - 1 == rank) ? (double)n_dead[0] : 0.0;
+  int64_t run = sm[threadIdx.x] - sum;
+  for (int64_t c = c0; c < c1; ++c) {
+    off[c] = run;
+    run += (int64_t)(-neg[c]);
+  }
+  if (threadIdx.x == 1023) *total = sm[1023];
+}
+// one workgroup per segment in which a super-droplet died: the positions of its flagged entries,
+// at the segment's place in the list.  Only the owner's permutation carries this sub-step's flags
+// (all earlier ones were compacted away), so the other processes find none and write nothing
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_shard_dead_list_by_segment(const int64_t *__restrict__ cell_start, const double *__restrict__ neg,
+                             const int64_t *__restrict__ off, const int64_t *__restrict__ idx,
+                             int64_t n_sd, int64_t *__restrict__ out) {
+  if (neg[blockIdx.x] == 0) return;
+  __shared__ int found;
+  if (threadIdx.x == 0) found = 0;
+  __syncthreads();
+  const int64_t lo = cell_start[blockIdx.x], hi = cell_start[blockIdx.x + 1];
+  const int64_t base = off[blockIdx.x];
+  for (int64_t i = lo + threadIdx.x; i < hi; i += SDM_BLOCK)
+    if (idx[i] >= n_sd) out[base + atomicAdd(&found, 1)] = i;
 }
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_shard_unpack(FusedArgs A, int64_t n_cell, int adaptive, const double *__restrict__ x) {
@@ -1964,7 +2015,7 @@ static FusedScratch layout(char *base, const sdm_step_cfg *cfg) {
   S.list = cv.take<Collided>(cfg->enable_breakup ? std::max<int64_t>(P, LIST_NL * S.flat_list_cap)
                                                  : 1);
   S.list_count = cv.take<unsigned long long>(2 * LIST_NL * SDM_CNT_STRIDE);
-  S.cell_min = cv.take<double>(C);
+  S.cell_min = cv.take<double>(4 * C);  // (k_cells_turn: two buffers of minima + deaths)
   S.block_min = cv.take<double>(grid_for((cfg->n_sd + 1) / 2) + 1);
   S.pair_off = cv.take<uint8_t>(split ? P : 1);
   S.pair_cid = cv.take<int32_t>(split ? P : 1);
@@ -1975,7 +2026,7 @@ static FusedScratch layout(char *base, const sdm_step_cfg *cfg) {
   S.gate_len = cv.take<int64_t>(4);
   S.cctl = cv.take<int64_t>(8);
   S.resort_plan = cv.take<int64_t>(8);
-  S.end2 = cv.take<int64_t>(8);  // (sharded mode: word 4 deaths of the sub-step, 5 owned cells, 6 listed)
+  S.end2 = cv.take<int64_t>(8);  // (words 2-3: k_cells_turn's gates; sharded mode: 4 deaths of a sub-step, 5 owned cells, 6 listed)
   S.shuffle = base + cv.off;
   cv.off += carve_size(sdm_shuffle_scratch(N));
   S.sort = base + cv.off;
@@ -2485,15 +2536,57 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     const int r = shard_cells();
     return r ? r : shard_dead(perm);
   };
-  // Multi-cell per-cell route, adaptive: the same idea with a device-side gate.  Sub-step k + 1
-  // is launched before the host waits for the control block of sub-step k; its first kernel
-  // (k_cells_begin) looks at what k left - work to do and no compaction (state still sorted) - and
-  // if not, the whole sub-step falls through (end2[3]) and the host takes back what it had booked
-  // for it (stream positions, buffer exchange).  A compaction is followed, as before, by a
-  // counting sort and a fresh working length before the next sub-step.
+  // Multi-cell per-cell route, adaptive.  A sub-step is two launches: k_cells_turn (ends the
+  // previous sub-step: bookkeeping, working length, publication of its control block; opens this
+  // one: cell order, per-cell init, the decision whether it runs at all) and the cell kernel; in
+  // sharded runs an all-reduce MIN of the cell minima (and minus the deaths per segment) follows.
+  // Sub-step k + 1 is launched before the host waits for the control block of sub-step k, which
+  // k + 1's own first kernel publishes; if k left nothing to do, un-sorted the state or killed a
+  // super-droplet, the whole of k + 1 falls through on the device (gate word) and the host takes
+  // back what it had booked for it (stream positions, buffer exchange).  A death is dealt with
+  // here: (sharded: exchange of the dead positions,) compaction, re-sort, a fresh working length.
   if (cell_path && cfg->adaptive && work_host != 0) {
     int64_t launched = 0;  // sub-steps launched in this time step (the draw window shifts by it)
+    int64_t turn = 0;      // turn kernels launched in this call of the step
     bool shard_resorted = false;
+    // ping-pong (k_cells_turn): dt_left between the caller's array and scratch, the cell minima
+    // (+ deaths per segment) between the two halves of the exchange buffer / of the scratch
+    double *left_buf[2] = {st->dt_left, S.dt_todo};
+    double *min_base = sharded ? st->xchg_cells : S.cell_min;
+    double *min_buf[2] = {min_base, min_base + 2 * C};
+    int left_cur = 0;  // left_buf[left_cur] holds the current dt_left
+    int64_t *gate_words = S.end2 + 2;  // two words (turn parity)
+    int64_t pending_seq = 0;           // publication number of the sub-step not yet ended
+    double *last_min = nullptr;        // the buffer the sub-step not yet ended reduced into
+    auto launch_turn = [&](bool gated, bool end_only) -> int {
+      PhaseScope ph(ctx, SDM_PHASE_CELLS_PRE);
+      TurnArgs T;
+      memset(&T, 0, sizeof(T));
+      T.left_in = left_buf[left_cur];
+      T.left_out = left_buf[left_cur ^ 1];
+      T.min_in = min_buf[(turn + 1) & 1];
+      T.min_out = min_buf[turn & 1];
+      T.cell_idx = st->cell_idx;
+      T.gate = gate_words;
+      T.turn = turn;
+      T.first = turn == 0;
+      T.fresh = fill_pending ? 1 : 0;
+      T.gated = gated ? 1 : 0;
+      T.end_only = end_only ? 1 : 0;
+      T.sharded = sharded ? 1 : 0;
+      T.box = ctx->box_dev;
+      T.seq = pending_seq;
+      hipLaunchKernelGGL(k_cells_turn, dim3((unsigned)C), blk, 0, s, *cfg, A, T);
+      LAUNCH_CHECK();
+      fill_pending = false;
+      left_cur ^= 1;
+      A.dt_left = left_buf[left_cur];
+      A.cell_min = T.min_out;
+      A.seg_deaths = sharded ? T.min_out + C : nullptr;
+      ++turn;
+      return SDM_OK;
+    };
+    // returns the publication number under which the sub-step's control block will appear
     auto launch_substep = [&](bool gated, int64_t *seq_out) -> int {
       if (!cfg->optimized_random || launched == 0) {  // (c), as in the loop below
         draw_off = off;
@@ -2504,26 +2597,20 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       A.s_rand = sdm_pcg_advance_host(rng_state, rng_inc, draw_off + (uint64_t)(N + shift));
       A.s_rand_b = sdm_pcg_advance_host(rng_state, rng_inc, draw_off_b);
       const uint64_t u01_off = draw_off + (uint64_t)(cfg->optimized_random ? launched : 0);
-      {
-        PhaseScope ph(ctx, SDM_PHASE_CELLS_PRE);
-        hipLaunchKernelGGL(k_cells_begin, dim3((unsigned)C), blk, 0, s, *cfg, A, st->cell_idx,
-                           S.end2, fill_pending ? 1 : 0, gated ? 1 : 0);
-        LAUNCH_CHECK();
-        fill_pending = false;
-      }
+      int r = launch_turn(gated, false);  // (publishes the control block of the sub-step before)
+      if (r) return r;
       CellArgs X;
+      memset(&X, 0, sizeof(X));
       X.idx_in = cur;
       X.idx_out = alt;
       X.s_u01 = sdm_pcg_advance_host(rng_state, rng_inc, u01_off);
       X.n_tail_blocks = 64;
-      X.gate = S.end2 + 3;
+      X.gate = gate_words + ((turn - 1) & 1);
       X.copy_others = sharded && launched == 0;  // (see CellArgs; once per time step suffices...
       if (sharded && shard_resorted) { X.copy_others = 1; shard_resorted = false; }  // ...or sort)
       A.idx = alt;
-      {
-        const int r = launch_cell_kernel(X);
-        if (r) return r;
-      }
+      r = launch_cell_kernel(X);
+      if (r) return r;
       { int64_t *t = cur; cur = alt; alt = t; }
       ++swaps;
       if (cfg->enable_breakup) {
@@ -2534,47 +2621,46 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         LAUNCH_CHECK();
         std::swap(A.list_count, A.list_count_next);
       }
+      last_min = A.cell_min;
       if (sharded) {
-        // bookkeeping of the owned cells first - the working length needs every cell's dt_left -
-        // packed for the exchange by the same launch; what comes back is taken over by
-        // k_cells_end below
-        hipLaunchKernelGGL(k_shard_book_pack, dim3((unsigned)grid_for(C + 1 + world)), blk, 0, s,
-                           *cfg, A, (const int64_t *)S.end2, st->xchg_cells,
-                           (const unsigned long long *)shard_n_dead, my_rank, world);
-        LAUNCH_CHECK();
-        {
-          const int r = sdm_exchange(ctx, st->exchange, st->exchange_user, SDM_XCHG_SUM_F64,
-                                     st->xchg_cells, C + 1 + world);
-          if (r) return r;
-        }
-      }
-      *seq_out = ++ctx->poll_seq;
-      if (!sharded) {  // (sharded: after the read-back, and only if a super-droplet died)
-        // the compaction kernel's workgroups end the sub-step as well (index.hip: cells_end_body)
-        PhaseScope ph(ctx, SDM_PHASE_SANITIZE);
-        CompactEpilogue E;
-        memset(&E, 0, sizeof(E));
-        E.cells.n_cell = C;
-        E.cells.dt_left = st->dt_left;
-        E.cells.dt_todo = A.dt_todo;
-        E.cells.stats_dt_min = st->stats_dt_min;
-        E.cells.cell_min = A.cell_min;
-        E.cells.stats_n_substep = st->stats_n_substep;
-        E.cells.cell_start = st->cell_start;
-        E.cells.end2 = S.end2;
-        E.cells.ctl = st->ctl;
-        E.cells.box = ctx->box_dev;
-        E.cells.seq = *seq_out;
-        E.cells.dt_min = cfg->dt_min;
-        const int r = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl,
-                                              S.cctl, nullptr, true, &E);
+        // every process's cell minima and deaths per segment in one reduction (a sub-step that
+        // fell through reduces stale words nobody reads: the number of collectives of a step
+        // does not depend on what the device decided)
+        r = sdm_exchange(ctx, st->exchange, st->exchange_user, SDM_XCHG_MIN_F64, A.cell_min, 2 * C);
         if (r) return r;
-      } else {
-        hipLaunchKernelGGL(k_cells_end, dim3(grid_for(C)), blk, 0, s, *cfg, A, 0, S.end2,
-                           ctx->box_dev, *seq_out, (const double *)st->xchg_cells);
-        LAUNCH_CHECK();
       }
+      *seq_out = pending_seq = ++ctx->poll_seq;
       ++launched;
+      return SDM_OK;
+    };
+    // A super-droplet died in sub-step k (sharded: somewhere): the positions of all the dead reach
+    // every process - one all-gather, as a sum of segment-ordered disjoint slices of exactly their
+    // number - and are flagged in its permutation (in a segment of another process that removes
+    // SOME member of the cell: the invariant of sdm_hip.h); the compaction follows
+    auto shard_dead_by_segment = [&](int64_t *perm, const double *mins) -> int {
+      int64_t *offsets = S.seg_src, *total_dev = S.end2 + 6;
+      hipLaunchKernelGGL(k_shard_dead_offsets, one, dim3(1024), 0, s, mins + C, C, offsets,
+                         total_dev);
+      LAUNCH_CHECK();
+      HIP_TRY(hipMemcpyAsync(ctx->mailbox, total_dev, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      const int64_t total = ctx->mailbox[0];
+      if (total <= 0) return SDM_OK;
+      if (total > N) {
+        sdm_set_error("sharded mode: inconsistent death counts (%lld)", (long long)total);
+        return SDM_E_HIP;
+      }
+      HIP_TRY(hipMemsetAsync(st->xchg_idx, 0, sizeof(int64_t) * (size_t)total, s));
+      hipLaunchKernelGGL(k_shard_dead_list_by_segment, dim3((unsigned)C), blk, 0, s,
+                         (const int64_t *)st->cell_start, mins + C, (const int64_t *)offsets,
+                         (const int64_t *)perm, N, st->xchg_idx);
+      LAUNCH_CHECK();
+      const int r = sdm_exchange(ctx, st->exchange, st->exchange_user, SDM_XCHG_SUM_I64,
+                                 st->xchg_idx, total);
+      if (r) return r;
+      hipLaunchKernelGGL(k_shard_flag, dim3(grid_for(total)), blk, 0, s, perm, st->xchg_idx, total,
+                         N);
+      LAUNCH_CHECK();
       return SDM_OK;
     };
     int64_t seq_k = 0;
@@ -2583,17 +2669,18 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     for (;;) {
       const uint64_t keep[4] = {off, off_b, draw_off, draw_off_b};
       int64_t seq_next = 0;
-      // (not in timing mode: a sub-step that falls through would count as a launch)
-      // Sharded runs launch ahead as well: the exchange of a sub-step is one more piece of work
-      // on the stream (an RCCL collective enqueued by the callback); a sub-step that falls through
-      // exchanges what the one before it did (same dt_left, same deaths), which changes nothing
-      // (and they do so in timing mode too: the number of exchanges of a step must not depend on
-      // a switch that one process may have set and another not)
+      double *min_k = last_min;  // what sub-step k reduced into
+      // (not in timing mode: a sub-step that falls through would count as a launch; there the
+      // sub-step is ended by a turn kernel of its own.  Sharded runs always launch ahead: the
+      // number of collectives of a step must not depend on a switch one process may have set
+      // and another not)
       const bool ahead = !ctx->timing || sharded;
       if (ahead) {
         rc = launch_substep(true, &seq_next);
-        if (rc) return rc;
+      } else {
+        rc = launch_turn(false, true);
       }
+      if (rc) return rc;
       bool taken_back = !ahead;
       auto take_back = [&]() {  // the sub-step launched ahead fell through on the device
         if (taken_back) return;
@@ -2609,6 +2696,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         rc = sdm_read_box(ctx, seq_k, last_ctl);
         if (rc) return rc;
       }
+      pending_seq = ahead ? seq_next : 0;
       have_ctl = true;
       ++n_sub;
       n_pairs += work_host / 2;
@@ -2623,23 +2711,23 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         HIP_TRY(hipStreamSynchronize(s));
         return unbounded(n_sub, last_ctl);
       }
-      if (sharded && last_ctl[CTL_HEALTHY] == 0) {
-        // a super-droplet died somewhere: every process flags the dead positions in its own
-        // permutation, then runs the compaction (the sub-step launched ahead fell through:
-        // k_cells_begin's gate)
+      if (last_ctl[CTL_HEALTHY] == 0) {
+        // a super-droplet died (the sub-step launched ahead fell through: k_cells_turn's gate).
+        // Sharded: every process flags the dead positions in its own permutation first
         take_back();
-        rc = shard_dead(cur);
-        if (rc) return rc;
-        PhaseScope ph(ctx, SDM_PHASE_SANITIZE);
-        rc = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl, S.cctl,
-                                     nullptr, true);
-        if (rc) return rc;
-        last_ctl[CTL_SORTED] = 0;
-      }
-      if (last_ctl[CTL_SORTED] == 0) {
-        // a compaction happened in sub-step k: sort by cell, then the end of the working range
-        // from the new cell_start (particle_attributes.py cell_start getter)
-        take_back();
+        pending_seq = 0;  // (the fallen-through sub-step has nothing to publish)
+        if (sharded) {
+          rc = shard_dead_by_segment(cur, min_k);
+          if (rc) return rc;
+        }
+        {
+          PhaseScope ph(ctx, SDM_PHASE_SANITIZE);
+          rc = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl,
+                                       S.cctl, nullptr, true);
+          if (rc) return rc;
+        }
+        // sort by cell, then the end of the working range from the new cell_start
+        // (particle_attributes.py cell_start getter)
         sorted_host = 0;
         shard_resorted = true;
         hipLaunchKernelGGL(k_reset_work, one, one, 0, s, st->ctl);  // sanitize left work = valid
@@ -2679,7 +2767,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         rc = cond_sort(ctx, cfg, st, cur, S, &sorted_host);  // (no-op when sorted_host == 1)
         if (rc) return rc;
         const int64_t seq = ++ctx->poll_seq;
-        rc = sdm_adaptive_end_async(ctx, st->dt_left, C, st->cell_start, S.end2, S.end2 + 1);
+        rc = sdm_adaptive_end_async(ctx, left_buf[left_cur], C, st->cell_start, S.end2,
+                                    S.end2 + 1);
         if (rc) return rc;
         hipLaunchKernelGGL(k_set_work, one, one, 0, s, st->ctl, S.end2 + 1, ctx->box_dev, seq);
         LAUNCH_CHECK();
@@ -2704,6 +2793,11 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         if (rc) return rc;
       }
     }
+    A.dt_left = st->dt_left;
+    A.seg_deaths = nullptr;
+    if (left_cur != 0)  // the step's last dt_left stands in the scratch half of the ping-pong
+      HIP_TRY(hipMemcpyAsync(st->dt_left, left_buf[1], sizeof(double) * (size_t)C,
+                             hipMemcpyDeviceToDevice, s));
   }
   // one cell whose shuffle is left to the pair kernels (records only, see (d))
   const bool split_one = C == 1 && cfg->croupier_local && sdm_shuffle_can_split(N, false);

@@ -49,7 +49,9 @@ class Shard:  # pylint: disable=too-many-instance-attributes
         mask[self.first:self.last] = 1
         self.owned_host = mask.astype(bool)
         self.owned = engine.upload(mask)
-        self.x_cells = engine.zeros(n_cell + 1 + world, np.float64)
+        # (the largest layout a library asks for: two buffers of {cell minima, deaths per segment}
+        # of the adaptive per-cell route, sdm_hip.h; n_cell + 1 + world on the other routes)
+        self.x_cells = engine.zeros(max(4 * n_cell, n_cell + 1 + world), np.float64)
         self.x_idx = engine.zeros(n_sd, np.int64)
         self.d_counts = self.d_words = None  # (displacement_buffers)
         self.role = engine.zeros(n_sd, np.uint8)  # sdm_disp_shard.role, filled by the library
@@ -106,6 +108,16 @@ class Shard:  # pylint: disable=too-many-instance-attributes
     def _address(buffer):
         return buffer.data_ptr() if hasattr(buffer, "data_ptr") else buffer.ctypes.data
 
+    def _view(self, candidates, pointer, count):
+        """the `count` words at `pointer` as a view of the exchange buffer they lie in"""
+        for buffer in candidates:
+            if buffer is None:
+                continue
+            first = (pointer - self._address(buffer)) // 8
+            if 0 <= first and first + count <= int(buffer.shape[0]):
+                return self._as_tensor(buffer)[first:first + count]
+        raise RuntimeError("exchange called with a foreign buffer")
+
     def displacement_buffers(self, n_words):
         """scratch of the sharded displacement step (sdm_disp_shard): counts, and `n_words` int64
         for positions and rows; allocated on first use, kept"""
@@ -119,13 +131,9 @@ class Shard:  # pylint: disable=too-many-instance-attributes
         try:
             candidates = ((self.x_idx, self.d_words) if what == abi.XCHG_SUM_I64
                           else (self.x_cells, self.d_counts))
-            buffer = next((b for b in candidates
-                           if b is not None and self._address(b) == pointer), None)
-            if buffer is None:
-                raise RuntimeError("exchange called with a foreign buffer")
+            tensor = self._view(candidates, pointer, int(count))
             self.calls[what] += 1
             self.bytes[what] += 8 * int(count)
-            tensor = self._as_tensor(buffer)[:count]
             op = self.dist.ReduceOp.MIN if what == abi.XCHG_MIN_F64 else self.dist.ReduceOp.SUM
             if tensor.is_cuda and self.dist.get_backend(self.group) != "nccl":
                 # rehearsal on one card (several processes, gloo): through the host.  `.cpu()`
@@ -171,15 +179,14 @@ class RecordingShard(Shard):
 
     def _exchange(self, _user, what, pointer, count):
         try:
-            buffer = self.x_cells if what == abi.XCHG_SUM_F64 else self.x_idx
-            if self._address(buffer) != pointer:
-                raise RuntimeError("exchange called with a foreign buffer")
             self.calls[what] += 1
             self.bytes[what] += 8 * int(count)
             # per-cell sum: dt_left of every cell + the number of deaths (the per-process counts
-            # behind them depend on the process count); dead positions: all of them
+            # behind them depend on the process count); cell minima + deaths per segment, dead
+            # positions: all of them
             keep = self.n_cell + 1 if what == abi.XCHG_SUM_F64 else int(count)
-            tensor = self._as_tensor(buffer)[:keep]
+            tensor = self._view((self.x_idx,) if what == abi.XCHG_SUM_I64 else (self.x_cells,),
+                                pointer, keep)
             self.trace.append((what, tensor.clone() if hasattr(tensor, "clone") else tensor.copy()))
             return 0
         except Exception as error:  # pylint: disable=broad-except
@@ -204,9 +211,6 @@ class ReplayShard(Shard):
 
     def _exchange(self, _user, what, pointer, count):
         try:
-            buffer = self.x_cells if what == abi.XCHG_SUM_F64 else self.x_idx
-            if self._address(buffer) != pointer:
-                raise RuntimeError("exchange called with a foreign buffer")
             if self.position >= len(self.trace):
                 raise RuntimeError("more exchanges than the recorded run had")
             recorded_what, words = self.trace[self.position]
@@ -217,7 +221,8 @@ class ReplayShard(Shard):
                                    f"kind {what} / {recorded_what}, {keep} / {words.shape[0]} words")
             self.calls[what] += 1
             self.bytes[what] += 8 * int(count)
-            target = self._as_tensor(buffer)[:keep]
+            target = self._view((self.x_idx,) if what == abi.XCHG_SUM_I64 else (self.x_cells,),
+                                pointer, keep)
             if hasattr(target, "copy_"):
                 target.copy_(words)  # (the own count in the per-process tail stays as computed)
             else:
