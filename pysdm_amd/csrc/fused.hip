@@ -2143,6 +2143,11 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       max_substeps = ctx->opt_max_substeps;  // (tests: SDM_OPT_MAX_SUBSTEPS)
   }
   auto unbounded = [&](int64_t n_done, const int64_t *ctl8) -> int {
+    // (the context goes on working: what this call left half-done in it - the single cell's
+    // counter slots, which are folded into the counters only at a call's end - is dropped)
+    if (ctx->cnt_slots)
+      (void)hipMemsetAsync(ctx->cnt_slots, 0, sizeof(int64_t) * SDM_CNT_SLOTS * SDM_CNT_STRIDE,
+                           ctx->stream);
     sdm_set_error("adaptive time step did not end within %lld sub-steps (dt = %g, dt_min = %g): "
                   "the state is inconsistent - a cell_start that does not belong to the "
                   "permutation, or dt_left edited from outside.  Control block {valid %lld, "

@@ -77,5 +77,5 @@ def test_bench_with_two_self_started_ranks_reproduces_the_one_rank_state(hip_eng
         lines[gpus] = found[0]
     assert lines[1]["n_gpus"] == 1 and lines[2]["n_gpus"] == 2
     assert lines[2]["state_digest"] == lines[1]["state_digest"]
-    assert lines[2]["scaling"] == "strong" and lines[2]["comm"]["f64_calls"] > 0
+    assert lines[2]["scaling"] == "strong" and lines[2]["comm"]["collectives"] > 0
     assert lines[2]["comm"]["bytes_per_step"] < 8 * 2**17  # (no n_sd-wide exchange)
