@@ -35,6 +35,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_PAIR = 136   # 24 u01 + 32 idx + 32 multiplicity + 16 cell id + 32*A, A=1
 BYTES_PER_PAIR_BREAKUP = 152  # + proc_rand, rand_frag
+# n_sd of BASELINE.json's configurations (offline counters apply to these sizes only)
+CONFIG_N_SD = {"shima": 2**20, "berry_breakup": 2**20, "kinematic2d": 2**22,
+               "kinematic2d_flow": 2**22, "straub": 2**22, "straub_rain": 2**22}
 
 
 WORKLOADS = {
@@ -506,6 +509,7 @@ def main():
         # ---- per-kernel durations, HIP events on the library's own stream (separate pass)
         engine.call("sdm_ctx_set_timing", 1)
         runner.read_back = True  # events are resolved per call
+        pairs_before_pass = runner.pairs_done
         t0 = time.perf_counter()
         runner.run(args.roofline_steps)
         torch.cuda.synchronize()
@@ -516,18 +520,26 @@ def main():
         per_step = {k: v[0] / args.roofline_steps for k, v in phases.items()}
         dominant = max(per_step, key=per_step.get)
         dom_ms = per_launch[dominant]
-        # one launch of the dominant kernel covers one sub-step over the working population
-        launch_pairs = n_sd // 2
+        # one launch of the dominant kernel covers one sub-step over the WORKING population: the
+        # candidate pairs of this pass over its launches (an adaptive multi-cell step cuts the
+        # working length as cells finish: n_sd // 2 would overstate the average launch)
+        pass_pairs = runner.pairs_done - pairs_before_pass
+        launch_pairs = (pass_pairs / phases[dominant][1] if pass_pairs > 0 else n_sd // 2)
         bytes_per_pair = BYTES_PER_PAIR_BREAKUP if setup.breakup else BYTES_PER_PAIR
         achieved = bytes_per_pair * launch_pairs / (dom_ms * 1e-3) / 1e9
-        traffic = misses = None
+        # fabric traffic and L2 counters of the dominant kernel: rocprofv3 --pmc passes of this very
+        # workload, run offline and tracked in profiles/traffic.json ("r04": per workload and bench
+        # phase {fetch_kb, write_kb, tcc_req, tcc_miss, bytes}; "r04_calibration": the same
+        # counters for k_calib_random per read) - NOT collected in this run
+        offline, counters, calibration = {}, {}, {}
         traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(traffic_file):
             with open(traffic_file, encoding="utf-8") as f:
-                # measured offline with rocprofv3 --pmc (see profiles/README.md); per workload
                 offline = json.load(f)
-            traffic = offline.get(args.workload, {}).get(dominant)
-            misses = offline.get("_tcc_miss_per_launch", {}).get(args.workload, {}).get(dominant)
+            counters = offline.get("r04", {}).get(args.workload, {}).get(dominant, {})
+            calibration = offline.get("r04_calibration", {})
+        full_size = n_sd == CONFIG_N_SD.get(args.workload)
+        traffic = counters.get("bytes") if full_size else None
         # the access-pattern ceiling, measured now on this device with the kernel's own footprint:
         # the path is random 64-B sector misses, which this part serves far below the streaming
         # peak - both fractions are reported, the HBM one stays the contract figure
@@ -535,21 +547,37 @@ def main():
                                                   "berry_breakup", "straub", "straub_rain")
         progress("kernel timing done; random-sector calibration")
         ceiling = random_sector_ceiling(engine, n_sd, wide)
+        # like for like: the kernel's L2 misses per second against the calibration's MISSES per
+        # second, its L2 requests against the calibration's REQUESTS (the calibration's reads are
+        # not all misses: profiles/traffic.json has its counters per read)
+        l2 = None
+        if full_size and counters.get("tcc_miss") and calibration.get("tcc_miss_per_read"):
+            seconds = dom_ms * 1e-3
+            calib_reads_per_s = ceiling["sector_misses_per_s"]  # (reads per second, measured now)
+            l2 = {
+                "kernel_requests_per_launch": counters["tcc_req"],
+                "kernel_misses_per_launch": counters["tcc_miss"],
+                "kernel_requests_per_pair": counters["tcc_req"] / launch_pairs,
+                "kernel_misses_per_pair": counters["tcc_miss"] / launch_pairs,
+                "kernel_misses_per_s": counters["tcc_miss"] / seconds,
+                "kernel_requests_per_s": counters["tcc_req"] / seconds,
+                "calibration_misses_per_s": calib_reads_per_s * calibration["tcc_miss_per_read"],
+                "calibration_requests_per_s": calib_reads_per_s * calibration["tcc_req_per_read"],
+            }
+            l2["frac_of_ceiling_misses"] = l2["kernel_misses_per_s"] / l2["calibration_misses_per_s"]
+            l2["frac_of_ceiling_requests"] = (l2["kernel_requests_per_s"]
+                                              / l2["calibration_requests_per_s"])
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": "offline PMC (profiles/traffic.json, rocprofv3 --pmc FETCH_SIZE / "
+                              "WRITE_SIZE passes of this workload; not collected in this run)",
             "kernel": dominant, "kernel_ms": dom_ms,
+            "pairs_per_launch": launch_pairs,
             # 64-B sectors under independent random access, same table footprint, same run
             "random_sector_ceiling_gbs": ceiling["gbs"],
             "random_sector_calibration": ceiling,
-            # the kernel's own sector traffic (L2 misses per launch x 64 B, offline PMC pass,
-            # profiles/traffic.json) over its duration, against that ceiling
-            "sector_traffic_gbs": (misses * 64 / (dom_ms * 1e-3) / 1e9
-                                   if misses and n_sd == 2**20 * (4 if args.workload == "kinematic2d" else 1)
-                                   else None),
-            "frac_of_ceiling": (misses * 64 / (dom_ms * 1e-3) / 1e9 / ceiling["gbs"]
-                                if misses and n_sd == 2**20 * (4 if args.workload == "kinematic2d" else 1)
-                                else None),
+            "l2": l2,
             "algorithmic_bytes_per_launch": bytes_per_pair * launch_pairs,
             # the same bytes against the wall-clock time of a whole time step (all kernels)
             "whole_step_frac": bytes_per_pair * pairs_total / world / elapsed_max / 1e9

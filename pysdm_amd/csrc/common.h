@@ -135,9 +135,11 @@ int sdm_read_box(sdm_ctx *ctx, int64_t seq, int64_t out[8]);
 #define SDM_CTL7_DT_MIN 0x100
 
 #ifdef __HIPCC__
-// (returning, and the result consumed: the event must be at the memory side before this wave can
-// take a finish ticket - cells_end_body's publishing workgroup reads ctl[7] without a fence, and
-// a wave whose 64 cells all finish issues no other returning atomic before its ticket)
+// (k_cells_adaptive: any thread of the launch may raise the bit; the multi-cell per-cell route has
+// no use for it any more - k_cells_turn's workgroup 0 derives the event from the minima it reads
+// anyway and writes the word itself, so that the publication it makes cannot overtake it.  The
+// atomic is a returning one with its result consumed: complete at the memory side before the wave
+// goes on - round 3's fence-free finish ticket needed that, and it costs nothing to keep)
 __device__ __forceinline__ void note_dt_min(int64_t *ctl, double stats_value, double dt_min) {
   if (stats_value == dt_min) {
     const unsigned long long was =

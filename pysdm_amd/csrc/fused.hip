@@ -10,9 +10,10 @@
 //      optimal sub-step is the one global dependency) -> k_pair_update [-> k_resolve_dense with
 //      breakup] -> compaction, whose epilogue closes the sub-step and publishes the control block;
 //      the head of the next sub-step (build + k_pair_prob) is launched ahead of the read-back
-//   many cells of at most 6144 super-droplets:  k_cells_begin -> k_cell_step2 / k_cell_step (one
-//      workgroup per cell: shuffle in LDS, pairs, probabilities, update) -> compaction ->
-//      k_cells_end; the next sub-step is launched ahead, gated on the device
+//   many cells of at most 6144 super-droplets:  k_cells_turn (ends the previous sub-step, opens
+//      this one) -> k_cell_step2 / k_cell_step (one workgroup per cell: shuffle in LDS, pairs,
+//      probabilities, update) [-> all-reduce MIN in sharded runs]; the next sub-step is launched
+//      ahead, gated on the device; a compaction only when the host has learnt of a death
 //   larger cells / global croupier:  generic kernels (per-position cell look-ups, counting sort)
 #include <algorithm>
 #include "common.h"
@@ -775,7 +776,7 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_all(sdm_step_cfg cfg, FusedA
 // breakup route are sized for SDM_BLOCK-thread workgroups).
 struct SortAhead {
   int2 *events;
-  int32_t *toff, *jarr;
+  int32_t *toff, *jarr, *loc;
   int n_bins, n_tiles;
   const int64_t *p_length;
   u128 s_off;  // generator state at the next sub-step's first u01
@@ -796,8 +797,8 @@ k_pair_all_sort(sdm_step_cfg cfg, FusedArgs A, SortAhead X) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x < X.n_tiles) {
     const int64_t length = *X.p_length;
-    bin_sort_body<true>(smem, X.events, X.toff, X.jarr, X.n_bins, nullptr, nullptr, 1, length,
-                        length, X.s_off, A.rng_inc, A.rng_tab, nullptr, A.rng_aff);
+    bin_sort_body<true>(smem, X.events, X.toff, X.jarr, X.loc, X.n_bins, nullptr, nullptr, 1,
+                        length, length, X.s_off, A.rng_inc, A.rng_tab, nullptr, A.rng_aff);
     return;
   }
   const int64_t W = A.ctl[CTL_WORK];
@@ -2935,6 +2936,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         X.events = B.events;
         X.toff = B.toff;
         X.jarr = B.jarr;
+        X.loc = B.loc;
         X.n_bins = B.n_bins;
         X.n_tiles = B.n_tiles;
         X.p_length = st->cell_start + C;

@@ -43,6 +43,10 @@ struct SortPrologue {
 // the re-sort it has to do itself when a super-droplet died in between
 struct BuildPrologue {
   SortPrologue compact;  // compact.fctl == NULL: none
+  // SDM_REC_CHAIN: the overflow links of the hit lists (scratch of the build); per event its place
+  // in the sorted array (from the tile sort); the S words, by that place
+  int32_t *chain_links, *loc;
+  uint32_t *ssucc;
   int2 *events;
   int32_t *toff, *jarr;
   u128 s_off, inc;
@@ -51,7 +55,7 @@ struct BuildPrologue {
 // the buffers of a build, for a tile sort done elsewhere (same scratch, same size)
 struct SortBuffers {
   int2 *events;
-  int32_t *toff, *jarr;
+  int32_t *toff, *jarr, *loc;  // (loc: NULL unless the build makes successor words)
   int n_bins, n_tiles;
   size_t lds_bytes;
 };
@@ -75,19 +79,6 @@ int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
 // kernel's last act instead of a launch of its own: refused-breakup count of the counter slots
 // into fctl[4] (slots may be NULL), working length = dt_left[0] != 0 ? valid length : 0, control
 // block published to the polled host box with sequence number `seq` (common.h:publish_ctl)
-// multi-cell per-cell route: what ends a sub-step after the compaction (fused.hip: k_cells_end -
-// per-cell adaptive bookkeeping, adaptive_sdm_end, publication of the control block), run by the
-// compaction kernel's own workgroups: one launch less per sub-step
-struct CellsEnd {
-  int64_t n_cell;  // 0: none
-  double *dt_left, *dt_todo, *stats_dt_min;
-  const double *cell_min;
-  int64_t *stats_n_substep;
-  const int64_t *cell_start;
-  int64_t *end2, *ctl, *box;
-  int64_t seq;
-  double dt_min;
-};
 struct CompactEpilogue {
   const double *dt_left;  // NULL: no epilogue
   int64_t *slots;
@@ -96,7 +87,6 @@ struct CompactEpilogue {
   // graph replay (common.h: gwords): stream positions advanced by these at the kernel's start
   uint64_t *gwords;
   uint64_t advance, advance_b;
-  CellsEnd cells;
 };
 int sdm_resort_plan(sdm_ctx *ctx, char *scratch, int64_t length_bound, const int64_t *cctl,
                     const int64_t *fctl, const int64_t *cell_start, int64_t n_cell, int64_t *plan,

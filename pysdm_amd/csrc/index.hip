@@ -245,7 +245,7 @@ extern "C" int sdm_debug_bin_profile(long long *out) {
 #endif
 
 template <bool RNG>
-__global__ void k_bin_sort(int2 *events, int32_t *toff, int32_t *jarr, int n_bins,
+__global__ void k_bin_sort(int2 *events, int32_t *toff, int32_t *jarr, int32_t *loc, int n_bins,
                            const double *u01, const int64_t *cell_start, int64_t n_cell,
                            const int64_t *p_length, int64_t length_arg, u128 s_off, u128 inc,
                            const u128 *tab, const uint64_t *dev_off, const u128 *aff);
@@ -279,13 +279,19 @@ static int ev_tile_count(int64_t n) { return (int)((n + EV_TILE - 1) / EV_TILE);
 
 static size_t binned_scratch_bytes(int64_t n) {
   const size_t nb = (size_t)bin_count(n), nt = (size_t)ev_tile_count(n);
-  return carve_size(sizeof(PackRec) * n) + 3 * carve_size(sizeof(int32_t) * n) +
+  return carve_size(sizeof(PackRec) * (n + EV_TILE)) + 3 * carve_size(sizeof(int32_t) * n) +
          carve_size(sizeof(int2) * (nt * EV_TILE)) + carve_size(sizeof(int32_t) * (nb + 1) * nt);
 }
 
 // usable while the count matrix stays small and LDS holds the per-bin arrays of K3
 // (8192 bins = 2^25 positions: K3 then holds 3 x 8193 + 3 x 4096 ints = 146 KB of the CU's 160 KB)
 static bool binned_ok(int64_t n, bool global) { return !global && n >= 2 && bin_count(n) <= 8192; }
+
+// SDM_REC_FORMAT=records: the round-1..3 records also where the successor words would be built
+static bool chain_enabled() {
+  static const bool off = getenv("SDM_REC_FORMAT") && !strcmp(getenv("SDM_REC_FORMAT"), "records");
+  return !off;
+}
 
 static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *idx0,
                                 const double *u01, const int64_t *cell_start, int64_t n_cell,
@@ -294,23 +300,32 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
                                 const uint64_t *dev_off, const SortPrologue *presorted) {
   // id_bound: the ids in idx0 are below it (-1: unknown); decides the record layout
   const int64_t both = id_bound > length_bound ? id_bound : length_bound;
-  const int fmt = id_bound < 0 ? SDM_REC_PLAIN
+  // SDM_REC_CHAIN where the caller's kernels do the walk (`views`); SDM_REC_FORMAT=records keeps
+  // the round-1..3 records there as well (A/B measurements)
+  const int fmt = (views && id_bound >= 0 && both <= CHAIN_MAX && chain_enabled()) ? SDM_REC_CHAIN
+                  : id_bound < 0 ? SDM_REC_PLAIN
                   : both <= P21_MAX ? SDM_REC_P21 : (both <= P24_MAX ? SDM_REC_P24 : SDM_REC_PLAIN);
-  const int slots = fmt == SDM_REC_P21 ? 4 : (fmt == SDM_REC_P24 ? 3 : 2);
+  const int slots = (fmt == SDM_REC_P21 || fmt == SDM_REC_CHAIN) ? 4 : (fmt == SDM_REC_P24 ? 3 : 2);
   Carver cv(scratch);
   const int nb = bin_count(length_bound), nt = ev_tile_count(length_bound);
-  PackRec *rec = cv.take<PackRec>(length_bound);
+  PackRec *rec = cv.take<PackRec>(length_bound + EV_TILE);
   int32_t *ovf_head = cv.take<int32_t>(length_bound);
   int32_t *ovf_next = cv.take<int32_t>(length_bound);
   int32_t *jarr = cv.take<int32_t>(length_bound);
   int2 *events = cv.take<int2>((size_t)nt * EV_TILE);
   int32_t *toff = cv.take<int32_t>((size_t)(nb + 1) * nt);
+  // SDM_REC_CHAIN: the record buffer's 16 B per position hold four int32 arrays of nt * EV_TILE
+  // words instead - first | overflow links | loc (event -> place in `events`) | ssucc (by place)
+  const size_t padded = (size_t)nt * EV_TILE;
+  int32_t *chain = (int32_t *)rec;
+  int32_t *loc = fmt == SDM_REC_CHAIN ? chain + 2 * padded : nullptr;
   const dim3 block(BIN_THREADS);
   const size_t lds_sort = sizeof(int32_t) * (size_t)((nb + 1) + ((nb + 1) & ~1) + 2) +
                           sizeof(int2) * EV_TILE;
   // (64 KB with three inline slots - two workgroups per CU - 80 KB with four; the prologue of a
   // presorted build sorts in the same memory)
-  size_t lds_build = sizeof(int32_t) * (size_t)((slots + 1) * BIN_POS);
+  // (SDM_REC_CHAIN: + own target, id and place of every position of the bin)
+  size_t lds_build = sizeof(int32_t) * (size_t)((slots + 1 + (fmt == SDM_REC_CHAIN ? 3 : 0)) * BIN_POS);
   if (presorted && lds_sort > lds_build) lds_build = lds_sort;
   // gfx950 has 160 KiB of LDS per CU; > 64 KiB dynamic needs opting in (per kernel and device)
   if (lds_sort > 65536) {
@@ -320,7 +335,8 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
   }
   if (lds_build > 65536)
-    HIP_TRY(hipFuncSetAttribute(fmt == SDM_REC_P21   ? (const void *)k_bin_build2<SDM_REC_P21>
+    HIP_TRY(hipFuncSetAttribute(fmt == SDM_REC_CHAIN ? (const void *)k_bin_build2<SDM_REC_CHAIN>
+                                : fmt == SDM_REC_P21 ? (const void *)k_bin_build2<SDM_REC_P21>
                                 : fmt == SDM_REC_P24 ? (const void *)k_bin_build2<SDM_REC_P24>
                                                      : (const void *)k_bin_build2<SDM_REC_PLAIN>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
@@ -333,6 +349,7 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
       bp.events = events;
       bp.toff = toff;
       bp.jarr = jarr;
+      bp.loc = loc;
       bp.s_off = s_off;
       bp.inc = inc;
       bp.tab = ctx->pcg_tab;
@@ -340,17 +357,21 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
     } else
     if (u01)
       hipLaunchKernelGGL((k_bin_sort<false>), dim3(nt), block, lds_sort, ctx->stream, events, toff,
-                         jarr, nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc,
+                         jarr, loc, nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc,
                          ctx->pcg_tab, (const uint64_t *)nullptr, (const u128 *)nullptr);
     else
       hipLaunchKernelGGL((k_bin_sort<true>), dim3(nt), block, lds_sort, ctx->stream, events, toff,
-                         jarr, nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc,
+                         jarr, loc, nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc,
                          ctx->pcg_tab, dev_off, (const u128 *)ctx->pcg_aff);
 #define BUILD_LAUNCH(F)                                                                        \
   hipLaunchKernelGGL(k_bin_build2<F>, dim3(nb), block, lds_build, ctx->stream, (void *)rec,    \
                      ovf_head, ovf_next, events, toff, jarr, nb, nt, idx0, p_length, length_bound, \
                      bp)
-    if (fmt == SDM_REC_P21) BUILD_LAUNCH(SDM_REC_P21);
+    bp.chain_links = chain + padded;
+    bp.loc = loc;
+    bp.ssucc = (uint32_t *)(chain + 3 * padded);
+    if (fmt == SDM_REC_CHAIN) BUILD_LAUNCH(SDM_REC_CHAIN);
+    else if (fmt == SDM_REC_P21) BUILD_LAUNCH(SDM_REC_P21);
     else if (fmt == SDM_REC_P24) BUILD_LAUNCH(SDM_REC_P24);
     else BUILD_LAUNCH(SDM_REC_PLAIN);
 #undef BUILD_LAUNCH
@@ -360,7 +381,8 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
     views->rec = rec;
     views->fmt = fmt;
     views->ovf_head = ovf_head;
-    views->ovf_next = ovf_next;
+    // (SDM_REC_CHAIN: first = rec, tsucc = ovf_head, ssucc by place in the sorted array)
+    views->ovf_next = fmt == SDM_REC_CHAIN ? chain + 3 * padded : ovf_next;
     return SDM_OK;
   }
   {
@@ -395,9 +417,11 @@ int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
 void sdm_shuffle_sort_buffers(char *scratch, int64_t length_bound, SortBuffers *out) {
   Carver cv(scratch);  // (the carve of shuffle_binned_async)
   const int nb = bin_count(length_bound), nt = ev_tile_count(length_bound);
-  (void)cv.take<PackRec>(length_bound);
+  int32_t *chain = (int32_t *)cv.take<PackRec>(length_bound + EV_TILE);
   (void)cv.take<int32_t>(length_bound);
   (void)cv.take<int32_t>(length_bound);
+  out->loc = chain_enabled() && length_bound <= CHAIN_MAX ? chain + 2 * (size_t)nt * EV_TILE
+                                                          : nullptr;
   out->jarr = cv.take<int32_t>(length_bound);
   out->events = cv.take<int2>((size_t)nt * EV_TILE);
   out->toff = cv.take<int32_t>((size_t)(nb + 1) * nt);
@@ -605,66 +629,6 @@ __device__ __forceinline__ void compact_epilogue(const CompactEpilogue &E,
 
 // FLAG_ONLY: the caller guarantees that no live super-droplet has zero multiplicity (it entered
 // with a healthy state and only flags positions), so the random gather of multiplicities is skipped
-// k_cells_end (fused.hip) as a device function of this kernel's workgroups: per-cell adaptive
-// bookkeeping (collisions_methods.py:357-374), end2[0] = 1 + largest c with dt_left[c] != 0
-// (adaptive_sdm_end, :313-328), and by the workgroup that finishes last the working length and
-// the publication of the control block (as the compaction left it)
-// `after_compaction`: the compaction proper ran in this kernel and committed control words from
-// another workgroup - then the finish ticket is fenced as it always was.  The fence-free form is
-// for the common sub-step in which nothing but this function has written anything the publishing
-// workgroup reads (a fuzz run caught the difference: intermittently stale lengths after deaths)
-__device__ __forceinline__ void cells_end_body(const CellsEnd &E, bool after_compaction) {
-  const bool ran = E.end2[3] != 0;  // (fused.hip: k_cells_begin - gated sub-steps)
-  const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t base = 0; base < E.n_cell; base += n_threads) {  // (uniform trip count)
-    const int64_t c = base + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool nz = false;
-    if (c < E.n_cell) {
-      double left = E.dt_left[c];
-      if (ran) {
-        const double m = E.cell_min[c];
-        double t = E.dt_todo[c];
-        if (m < t) t = m;
-        E.dt_todo[c] = t;
-        const double smin = E.stats_dt_min[c];
-        const double s_new = m < smin ? m : smin;  // Python min(s, m): NaN-sticky
-        E.stats_dt_min[c] = s_new;
-        note_dt_min(E.ctl, s_new, E.dt_min);
-        left -= t;
-        E.dt_left[c] = left;
-        if (t > 0) E.stats_n_substep[c] += 1;
-      }
-      nz = left != 0;
-    }
-    const unsigned long long mask = __ballot(nz);
-    if (mask && lane_id() == 0) {
-      // (returning: complete at the memory side before this wave goes on to the ticket - what the
-      // last workgroup reads of the others travels in atomics alone, so no fence is needed: on
-      // this part an agent-scope fence writes back and invalidates the XCD's L2, 129 times per
-      // sub-step here)
-      const long long was = atomicMax((long long *)&E.end2[0],
-                                      (long long)((c - lane_id()) + (63 - __clzll(mask)) + 1));
-      asm volatile("" ::"v"(was));
-    }
-  }
-  __shared__ bool last_cells;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (after_compaction) __threadfence();
-    last_cells = atomicAdd((unsigned long long *)&E.end2[2], 1ull) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (last_cells && threadIdx.x == 0) {
-    if (after_compaction) __threadfence();
-    const int64_t top = __hip_atomic_load(&E.end2[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int64_t end = top == 0 ? 0 : E.cell_start[top];
-    E.end2[1] = end;
-    E.end2[2] = 0;
-    if (ran) E.ctl[1] = end;  // (CTL_WORK)
-    publish_ctl(E.ctl, E.box, E.seq, ran ? end : E.ctl[1]);
-  }
-}
-
 // the compaction proper, by every workgroup of the grid (all resident; at most COMPACT_MAX_GROUPS);
 // false: a grid barrier timed out (fctl[7] = 2).  *new_length: the length every workgroup computed
 template <bool FLAG_ONLY>
@@ -813,36 +777,27 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
   }
   if (fctl[FCTL_HEALTHY] != 0) {
     if (E.dt_left && blockIdx.x == 0) compact_epilogue(E, fctl);
-    if (E.cells.n_cell) cells_end_body(E.cells, false);
     return;
   }
   int64_t new_len;
   __shared__ int excl[COMPACT_WAVES];
-  const bool done = compact_run<FLAG_ONLY>(multiplicity, idx, flag, fctl, wave_dead, n_tiles, ctl,
-                                           holes, fillers, cell_start_single, bar, E, &new_len,
-                                           excl);
-  if (E.cells.n_cell) {
-    if (done)
-      cells_end_body(E.cells, true);  // (its last workgroup publishes what the commit above left)
-    else if (blockIdx.x == 0 && threadIdx.x == 0)
-      // a grid barrier timed out (fctl[7] = 2, set by every workgroup that gave up - this one
-      // included): the host still gets its publication, carrying the error code
-      publish_ctl(fctl, E.cells.box, E.cells.seq, 0);
-  }
+  (void)compact_run<FLAG_ONLY>(multiplicity, idx, flag, fctl, wave_dead, n_tiles, ctl, holes,
+                               fillers, cell_start_single, bar, E, &new_len, excl);
 }
 
 // k_bin_sort (declared above): the tile sort of the shuffle build
 template <bool RNG>
 __global__ void __launch_bounds__(BIN_THREADS)
 k_bin_sort(int2 *__restrict__ events, int32_t *__restrict__ toff, int32_t *__restrict__ jarr,
-           int n_bins, const double *__restrict__ u01, const int64_t *__restrict__ cell_start,
+           int32_t *__restrict__ loc, int n_bins, const double *__restrict__ u01,
+           const int64_t *__restrict__ cell_start,
            int64_t n_cell, const int64_t *__restrict__ p_length, int64_t length_arg, u128 s_off,
            u128 inc, const u128 *__restrict__ tab, const uint64_t *__restrict__ dev_off,
            const u128 *__restrict__ aff) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int64_t length = p_length ? *p_length : length_arg;
-  bin_sort_body<RNG>(smem, events, toff, jarr, n_bins, u01, cell_start, n_cell, length, -1, s_off,
-                     inc, tab, dev_off, aff);
+  bin_sort_body<RNG>(smem, events, toff, jarr, loc, n_bins, u01, cell_start, n_cell, length, -1,
+                     s_off, inc, tab, dev_off, aff);
 }
 
 template <int FMT>
@@ -853,9 +808,11 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
              int n_tiles, const int64_t *__restrict__ idx0, const int64_t *__restrict__ p_length,
              int64_t length_arg, BuildPrologue P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int SLOTS = FMT == SDM_REC_P21 ? 4 : (FMT == SDM_REC_P24 ? 3 : 2);
+  constexpr int SLOTS = (FMT == SDM_REC_P21 || FMT == SDM_REC_CHAIN) ? 4 : (FMT == SDM_REC_P24 ? 3 : 2);
   int32_t *slot = (int32_t *)smem;  // SLOTS x BIN_POS, then BIN_POS list heads
   int32_t *head = slot + SLOTS * BIN_POS;
+  // SDM_REC_CHAIN: own target / id / place in the sorted array of every position of the bin
+  int32_t *jp_l = head + BIN_POS, *id_l = jp_l + BIN_POS, *loc_l = id_l + BIN_POS;
   // P.compact.fctl: the events were sorted ahead, by the pair kernel of the previous sub-step, for
   // the length that sub-step began with.  If a super-droplet died in it (rare), the compaction
   // runs here, every workgroup sorts its tile again for the new length (n_tiles == n_bins on this
@@ -869,8 +826,8 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
                            (int *)smem))
       return;
     __syncthreads();
-    bin_sort_body<true>(smem, P.events, P.toff, P.jarr, n_bins, nullptr, nullptr, 1, length, length,
-                        P.s_off, P.inc, P.tab, nullptr, P.aff);
+    bin_sort_body<true>(smem, P.events, P.toff, P.jarr, P.loc, n_bins, nullptr, nullptr, 1, length,
+                        length, P.s_off, P.inc, P.tab, nullptr, P.aff);
     if (!grid_barrier(C.bar + 3, gridDim.x)) {
       if (threadIdx.x == 0) C.fctl[7] = 2;
       return;
@@ -885,12 +842,13 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
   constexpr int PER_POS = BIN_POS / BIN_THREADS;
   // what the records need from memory besides the hits, requested now, used at the end
   int64_t id_v[PER_POS];
-  int32_t j_v[PER_POS];
+  int32_t j_v[PER_POS], loc_v[PER_POS];
 #pragma unroll
   for (int k = 0; k < PER_POS; ++k) {
     const int64_t p = base + threadIdx.x + k * BIN_THREADS;
     id_v[k] = p < length ? idx0[p] : 0;
     j_v[k] = p < length ? jarr[p] : -1;
+    loc_v[k] = (FMT == SDM_REC_CHAIN && p < length) ? P.loc[p] : -1;
   }
   // this bin's run in every tile's segment: `tpt` threads share a tile (4 at 2^20
   // super-droplets: runs hold ~16 events), each takes every tpt-th event of the run; the first
@@ -931,15 +889,65 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
 #pragma unroll
       for (int k = 0; k < SLOTS; ++k)
         if (!placed) placed = atomicCAS(&slot[k * BIN_POS + q], -1, e.x) == -1;
-      if (!placed) ovf_next[e.x] = atomicExch(&head[q], e.x);  // -1 terminated, built entirely here
+      // (-1 terminated, built entirely here; SDM_REC_CHAIN keeps the links in scratch of their own:
+      // ovf_next is its ssucc table)
+      if (!placed)
+        (FMT == SDM_REC_CHAIN ? P.chain_links : ovf_next)[e.x] = atomicExch(&head[q], e.x);
     };
 #pragma unroll
     for (int k = 0; k < RUN_AHEAD; ++k)
       if (ev[k].x >= 0) place(ev[k]);
     for (int x = a + sub + RUN_AHEAD * tpt; x < b; x += tpt) place(run[x]);
   }
+  if (FMT == SDM_REC_CHAIN) {
+    // (the loads requested at the kernel's start have long arrived)
+#pragma unroll
+    for (int k = 0; k < PER_POS; ++k) {
+      const int q = threadIdx.x + k * BIN_THREADS;
+      jp_l[q] = j_v[k];
+      id_l[q] = (int32_t)id_v[k];
+      loc_l[q] = loc_v[k];
+    }
+  }
   __syncthreads();
   BIN_MARK(11);
+  // SDM_REC_CHAIN (shuffle_device.h): everything that touches a position of this bin is in LDS now -
+  // its own event (jp_l >= 0: it has one) and the events that hit it (inline slots, the overflow
+  // list this workgroup has just built).  F(q, e): what the content of position q is once all
+  // events above e have been applied, as a successor word
+  int32_t *links = P.chain_links;
+  auto hit_above = [&](int q, int32_t e) -> int32_t {  // smallest hit on q with index > e
+    int32_t best = INT32_MAX;
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+      const int32_t v = slot[k * BIN_POS + q];
+      if (v > e && v < best) best = v;
+    }
+    for (int32_t t = head[q]; t >= 0; t = links[t])
+      if (t > e && t < best) best = t;
+    return best;
+  };
+  auto value_after = [&](int q, int32_t e) -> uint32_t {
+    const int32_t up = hit_above(q, e);
+    const int32_t pi = (int32_t)base + q;
+    const int32_t own = (jp_l[q] >= 0 && pi > e) ? pi : INT32_MAX;
+    if (up == INT32_MAX && own == INT32_MAX) return chain_word(0, id_l[q]);
+    return own <= up ? chain_word(CHAIN_S, loc_l[q]) : chain_word(CHAIN_T, up);
+  };
+  if (FMT == SDM_REC_CHAIN) {
+    // the S word of every event that hits this bin, written where the event was read: the same
+    // runs of the tile-sorted array, the same threads
+    for (int t = t_first; t < n_tiles; t += t_step) {
+      const int32_t *row = toff + (int64_t)t * (n_bins + 1) + bin;
+      const int a = row[0], b = row[1];
+      const int2 *run = events + (int64_t)t * EV_TILE;
+      uint32_t *out = P.ssucc + (int64_t)t * EV_TILE;
+      for (int x = a + sub; x < b; x += tpt) {
+        const int2 e = run[x];
+        out[x] = value_after(e.y - (int)base, e.x);
+      }
+    }
+  }
 #pragma unroll
   for (int kq = 0; kq < PER_POS; ++kq) {
     const int q = threadIdx.x + kq * BIN_THREADS;
@@ -948,7 +956,12 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
     const int32_t h = head[q];
     const int32_t id = (int32_t)id_v[kq];
     const int32_t jp = j_v[kq];
-    if (FMT == SDM_REC_P21) {
+    if (FMT == SDM_REC_CHAIN) {
+      uint32_t *first = (uint32_t *)rec_out, *tsucc = (uint32_t *)ovf_head;
+      first[p] = value_after(q, -1);
+      const int32_t up = hit_above(q, (int32_t)p);
+      tsucc[p] = up == INT32_MAX ? chain_word(0, id) : chain_word(CHAIN_T, up);
+    } else if (FMT == SDM_REC_P21) {
       PackRec21 r;
       p21_pack(r.lo, r.hi, jp, slot[q], slot[BIN_POS + q], slot[2 * BIN_POS + q],
                slot[(SLOTS - 1) * BIN_POS + q], id, h >= 0);
@@ -965,7 +978,7 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
       r.val = id | (h >= 0 ? (int32_t)0x80000000 : 0);
       ((PackRec *)rec_out)[p] = r;
     }
-    if (h >= 0) ovf_head[p] = h;
+    if (FMT != SDM_REC_CHAIN && h >= 0) ovf_head[p] = h;
   }
   BIN_MARK(12);
 }
@@ -1017,13 +1030,14 @@ bool sdm_shuffle_presort_ok(sdm_ctx *ctx, int64_t length_bound, int64_t id_bound
   const int64_t both = id_bound > length_bound ? id_bound : length_bound;
   if (nb != nt || nb > COMPACT_MAX_GROUPS || id_bound < 0 || both > P21_MAX) return false;
   if (ctx->build_resident == 0) {
-    const size_t lds_build = sizeof(int32_t) * (size_t)(5 * BIN_POS);
+    const size_t lds_build = sizeof(int32_t) * (size_t)((chain_enabled() ? 8 : 5) * BIN_POS);
     int per_cu = 0, cus = 0;
-    if (hipFuncSetAttribute((const void *)k_bin_build2<SDM_REC_P21>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize,
+    const void *kernel = chain_enabled() ? (const void *)k_bin_build2<SDM_REC_CHAIN>
+                                         : (const void *)k_bin_build2<SDM_REC_P21>;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(lds_build > 65536 ? lds_build : 65536)) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bin_build2<SDM_REC_P21>,
-                                                     BIN_THREADS, lds_build) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BIN_THREADS, lds_build) !=
+            hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) !=
             hipSuccess) {
       (void)hipGetLastError();

@@ -120,7 +120,8 @@ extern __device__ long long bin_prof[32];
 template <bool RNG>
 __device__ __forceinline__ void
 bin_sort_body(char *smem, int2 *__restrict__ events, int32_t *__restrict__ toff,
-              int32_t *__restrict__ jarr, int n_bins, const double *__restrict__ u01,
+              int32_t *__restrict__ jarr, int32_t *__restrict__ loc, int n_bins,
+              const double *__restrict__ u01,
               const int64_t *__restrict__ cell_start, int64_t n_cell, int64_t length,
               int64_t one_cell_len, u128 s_off, u128 inc, const u128 *__restrict__ tab,
               const uint64_t *__restrict__ dev_off, const u128 *__restrict__ aff) {
@@ -198,7 +199,10 @@ bin_sort_body(char *smem, int2 *__restrict__ events, int32_t *__restrict__ toff,
   for (int e = 0; e < EV_PER_THREAD; ++e)
     if (j[e] >= 0) {
       const int b = j[e] >> BIN_SHIFT;
-      ev_buf[lstart[b] + rank[e]] = make_int2((int)(first + e), j[e]);
+      const int at = lstart[b] + rank[e];
+      ev_buf[at] = make_int2((int)(first + e), j[e]);
+      // (SDM_REC_CHAIN: where the event stands in the sorted array - its S word's address)
+      if (loc) loc[first + e] = (int32_t)(tile_first + at);
     }
   __syncthreads();
   BIN_MARK(6);

@@ -25,6 +25,33 @@ struct __align__(16) PackRec24 { uint64_t lo, hi; };
 #define SDM_REC_PLAIN 0
 #define SDM_REC_P21 1
 #define SDM_REC_P24 2
+// SDM_REC_CHAIN (round 4): no records at all - the walk's whole case analysis is done by the build,
+// which sees every event that touches a position together in LDS, and handed over as successor
+// words.  Let F(q, t) be the content of position q once all events with index > t have been applied
+// (the chain runs from the top index down: index_methods.py:32-43); the final content of p is
+// F(p, lo).  With e = the smallest event index > t that touches q (its own event q, or an event
+// that hits it): F(q, t) = idx0[q] if there is none, F(j_q, q) if e is q's own event, F(e, e) if
+// e hits q.  Only two families of arguments ever occur: T(i) = F(i, i) - the content of position
+// i just before its own event - and S(i) = F(j_i, i) - the content of i's target just before i's
+// event - and each is the other family's value further up or a terminal id:
+//   first[p] = what F(p, lo) is: T(e) / S(p) / the id              (by p's bin, coalesced)
+//   tsucc[i] = what T(i) is: T(next hit on i above i) or idx0[i]   (by i's bin, coalesced)
+//   ssucc[l] = what S(i) is: S(j_i) / T(next hit on j_i above i) / idx0[j_i]
+//              (by j_i's bin: it holds all of j_i's events) - stored where that bin READ event i:
+//              at i's place l in the tile-sorted event array, so the write is as coalesced as
+//              the read was (runs of ~16 events per tile and bin).  By event index it would be
+//              2^20 scattered 4-byte stores: measured, 14 us on top of a 14-us build
+//              (profiles/r04_chain_scattered_stores.json).  Every word that names an S carries
+//              that place (the tile sort records it per event: `loc`).
+// A word is {kind: 0 = super-droplet id, 1 = T, 2 = S} << 30 | payload (T: event index, S: place
+// in the sorted array).  The walk is then a chain of single 4-byte look-ups (no decoding, no
+// overflow lists, nothing to compare) in two 4-byte tables - 8 MB at 2^20 positions where the
+// records took 16 - and its first look-up, which the records needed a random read for, comes with
+// the coalesced read of first[p].
+#define SDM_REC_CHAIN 3
+#define CHAIN_MAX 0x3FFFFFFF  // ids and positions below 2^30
+#define CHAIN_T 1u
+#define CHAIN_S 2u
 
 struct ShuffleViews {
   const void *rec;  // array of the record type `fmt` names
@@ -148,11 +175,50 @@ __device__ __forceinline__ void walk_packed2(const REC *__restrict__ rec,
   f0 = r0;
   f1 = r1;
 }
+__device__ __forceinline__ uint32_t chain_word(uint32_t kind, int32_t payload) {
+  return (kind << 30) | (uint32_t)payload;
+}
+// SDM_REC_CHAIN: two walks in lockstep (rec = first, ovf_head = tsucc, ovf_next = ssucc)
+__device__ __forceinline__ void walk_chain2(const uint32_t *__restrict__ first,
+                                            const uint32_t *__restrict__ tsucc,
+                                            const uint32_t *__restrict__ ssucc, int32_t p0,
+                                            int32_t p1, int64_t &id0, int64_t &id1) {
+  uint32_t n0, n1;
+  if (p1 == p0 + 1 && (p0 & 1) == 0) {  // a pair slot: one 8-byte load
+    const uint2 w = *(const uint2 *)(first + p0);
+    n0 = w.x;
+    n1 = w.y;
+  } else {
+    n0 = first[p0];
+    n1 = first[p1];
+  }
+  while ((n0 | n1) >> 30) {  // both look-ups of a round are in flight together
+    const uint32_t k0 = n0 >> 30, k1 = n1 >> 30;
+    uint32_t m0 = n0, m1 = n1;
+    if (k0) m0 = (k0 == CHAIN_T ? tsucc : ssucc)[n0 & CHAIN_MAX];
+    if (k1) m1 = (k1 == CHAIN_T ? tsucc : ssucc)[n1 & CHAIN_MAX];
+    n0 = m0;
+    n1 = m1;
+  }
+  id0 = n0;
+  id1 = n1;
+}
+__device__ __forceinline__ int64_t walk_chain(const uint32_t *__restrict__ first,
+                                              const uint32_t *__restrict__ tsucc,
+                                              const uint32_t *__restrict__ ssucc, int32_t p) {
+  uint32_t n = first[p];
+  while (n >> 30) n = ((n >> 30) == CHAIN_T ? tsucc : ssucc)[n & CHAIN_MAX];
+  return n;
+}
+
 // the walks' results as super-droplet ids, for records of layout `fmt`
 __device__ __forceinline__ void walk_ids2(const void *rec, int fmt, const int32_t *ovf_head,
                                           const int32_t *ovf_next, int32_t p0, int32_t p1,
                                           int32_t lo, int64_t &id0, int64_t &id1) {
-  if (fmt == SDM_REC_P21) {
+  if (fmt == SDM_REC_CHAIN) {
+    walk_chain2((const uint32_t *)rec, (const uint32_t *)ovf_head, (const uint32_t *)ovf_next, p0,
+                p1, id0, id1);
+  } else if (fmt == SDM_REC_P21) {
     PackRec21 f0, f1;
     walk_packed2((const PackRec21 *)rec, ovf_head, ovf_next, p0, p1, lo, f0, f1);
     id0 = rec_id(f0); id1 = rec_id(f1);
@@ -168,6 +234,9 @@ __device__ __forceinline__ void walk_ids2(const void *rec, int fmt, const int32_
 }
 __device__ __forceinline__ int64_t walk_id(const void *rec, int fmt, const int32_t *ovf_head,
                                            const int32_t *ovf_next, int32_t p, int32_t lo) {
+  if (fmt == SDM_REC_CHAIN)
+    return walk_chain((const uint32_t *)rec, (const uint32_t *)ovf_head,
+                      (const uint32_t *)ovf_next, p);
   if (fmt == SDM_REC_P21)
     return rec_id(walk_packed((const PackRec21 *)rec, ovf_head, ovf_next, p, lo));
   if (fmt == SDM_REC_P24)
