@@ -104,6 +104,9 @@ struct sdm_ctx {
     int rec_fmt;
     int64_t *cur, *alt;  // permutation buffers as its kernels left them (cur: written)
   } ahead;
+  // displacement.hip (sharded step): precipitated masses by position, zero between uses
+  double *rain_carry;
+  int64_t rain_carry_len;
   // device control words for fine-grained calls (int64[16])
   int64_t *dscal;
   // single-cell collision counters, spread over SDM_CNT_SLOTS cache lines (fused.hip)

@@ -94,6 +94,7 @@ extern "C" int sdm_ctx_destroy(sdm_ctx *ctx) {
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   if (ctx->dscal) (void)hipFree(ctx->dscal);
   if (ctx->cnt_slots) (void)hipFree(ctx->cnt_slots);
+  if (ctx->rain_carry) (void)hipFree(ctx->rain_carry);
   if (ctx->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)ctx->graph_exec);
   free(ctx->graph_key);
   if (ctx->gwords) (void)hipFree(ctx->gwords);

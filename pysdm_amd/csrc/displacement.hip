@@ -439,33 +439,62 @@ k_role_alive(uint8_t *__restrict__ role, const int64_t *__restrict__ idx,
 // compaction took the id out of the permutation), and the cells the call begins with
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_shard_begin(uint8_t *__restrict__ role, const int64_t *__restrict__ multiplicity,
-              const int64_t *__restrict__ cell_by_id, int64_t *__restrict__ cell0, int64_t n_sd) {
+              const int64_t *__restrict__ cell_by_id, int64_t *__restrict__ cell0, int64_t n_sd,
+              double *__restrict__ rain, unsigned long long *__restrict__ counters) {
   const int64_t k = TID();
+  if (k == 0) *rain = 0.0;       // (the call's rainfall sum and its eight list counters start
+  if (k < 8) counters[k] = 0;    //  from zero: no fills of their own)
   if (k >= n_sd) return;
   if (role[k] == 1 && multiplicity[k] == 0) role[k] = 2;
   cell0[k] = cell_by_id[k];
 }
 // counts[l * world + r] = how many this process is about to put on list l (its own slot r only);
 // mine[l]: the same for the host
-struct FourCounts { const unsigned long long *n[4]; };
+// (the counters of the two removal lists start from zero again afterwards: the lists' lengths are
+// with the host from here on)
+struct FourCounts { unsigned long long *n[4]; };
 __global__ void k_pack_counts(double *__restrict__ counts, int world, int rank, int lists,
                               FourCounts C, unsigned long long *__restrict__ mine) {
   const int t = threadIdx.x, l = t / world, r = t % world;
-  if (l < lists) counts[t] = r == rank ? (double)*C.n[l] : 0.0;
-  if (t < lists) mine[t] = *C.n[t];
+  __shared__ unsigned long long v[4];
+  if (t < 4) v[t] = t < lists ? *C.n[t] : 0;
+  __syncthreads();
+  if (l < lists) counts[t] = r == rank ? (double)v[l] : 0.0;
+  if (t < lists) mine[t] = v[t];
+  if (t < 2) *C.n[t] = 0;
+}
+// this process's slices of an exchange of lists, the rest of the `words` zero (a sum over the
+// processes then IS the concatenation): own positions at [before, before + mine), with rain their
+// masses (bit patterns) at total + the same
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_place_slices(int64_t *__restrict__ out, int64_t words, int64_t total, int64_t before,
+               int64_t mine, const int64_t *__restrict__ dead,
+               const int64_t *__restrict__ dead_mass) {
+  const int64_t i = TID();
+  if (i >= words) return;
+  const int64_t j = i < total ? i : i - total;
+  int64_t v = 0;
+  if (j >= before && j < before + mine) v = (i < total ? dead : dead_mass)[j - before];
+  out[i] = v;
+}
+__global__ void __launch_bounds__(SDM_BLOCK)
+k_rain_unscatter(double *__restrict__ carried, const int64_t *__restrict__ words, int64_t total) {
+  const int64_t j = TID();
+  if (j < total) carried[words[j]] = 0.0;
 }
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_copy_i64(int64_t *__restrict__ out, const int64_t *__restrict__ in, int64_t n) {
   const int64_t i = TID();
   if (i < n) out[i] = in[i];
 }
+// (n_dead: the counter of the list just consumed starts from zero again)
 __global__ void __launch_bounds__(SDM_BLOCK)
 k_flag_positions(int64_t *__restrict__ idx, const int64_t *__restrict__ dead, int64_t n,
-                 int64_t n_sd, int64_t *__restrict__ ctl) {
+                 int64_t n_sd, int64_t *__restrict__ ctl, unsigned long long *__restrict__ n_dead) {
   const int64_t i = TID();
   if (i >= n) return;
   idx[dead[i]] = n_sd;
-  if (i == 0) ctl[3] = 0;
+  if (i == 0) { ctl[3] = 0; *n_dead = 0; }
 }
 // the rainfall of a sharded sub-step, to the bits of the one-process run: the masses of the
 // precipitated (from all processes) scattered to their positions in an otherwise zero array, then
@@ -542,38 +571,71 @@ k_count_movers(const uint8_t *__restrict__ role, const uint8_t *__restrict__ cls
   }
 }
 // one workgroup: exclusive prefix sums of the per-workgroup counts, in place; totals -> n[0], n[1]
+// (the counts go through LDS - read and written back coalesced -, a thread sums a run of
+// consecutive ones there, one scan over the 1024 run totals: the first version scanned 1024
+// counts per round with three barriers each, 38 us for 16 k counts)
+#define SCAN_MOVERS_CAP 16384  // counts held in LDS (2^22 super-droplets); more: in rounds
+#define SCAN_MOVERS_PER (SCAN_MOVERS_CAP / 1024)
+// (a thread's run of SCAN_MOVERS_PER counts stands at a stride of PER + 1 words: no bank conflicts)
+#define SCAN_MOVERS_AT(i) ((i) + (i) / SCAN_MOVERS_PER)
+#define SCAN_MOVERS_LDS (2 * (SCAN_MOVERS_CAP + 1024) * sizeof(int32_t))
 __global__ void __launch_bounds__(1024)
 k_scan_movers(int32_t *__restrict__ blk_a, int32_t *__restrict__ blk_b, int64_t nb,
               unsigned long long *__restrict__ n) {
-  __shared__ long long wa[1024 / SDM_WAVE], wb[1024 / SDM_WAVE];
-  __shared__ long long carry[2];
-  if (threadIdx.x == 0) carry[0] = carry[1] = 0;
-  __syncthreads();
-  const int lane = lane_id(), w = threadIdx.x / SDM_WAVE;
-  for (int64_t base = 0; base < nb; base += 1024) {
-    const int64_t i = base + threadIdx.x;
-    const long long va = i < nb ? blk_a[i] : 0, vb = i < nb ? blk_b[i] : 0;
-    long long ia = va, ib = vb;  // inclusive scan within the wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int32_t *la = (int32_t *)smem, *lb = la + SCAN_MOVERS_CAP + 1024;
+  __shared__ int sa[1024], sb[1024];
+  long long carry_a = 0, carry_b = 0;
+  for (int64_t base = 0; base < nb; base += SCAN_MOVERS_CAP) {
+    const int m = (int)(nb - base < SCAN_MOVERS_CAP ? nb - base : SCAN_MOVERS_CAP);
+    for (int i = threadIdx.x; i < SCAN_MOVERS_CAP; i += 1024) {
+      la[SCAN_MOVERS_AT(i)] = i < m ? blk_a[base + i] : 0;
+      lb[SCAN_MOVERS_AT(i)] = i < m ? blk_b[base + i] : 0;
+    }
+    __syncthreads();
+    const int i0 = threadIdx.x * SCAN_MOVERS_PER;
+    int ta = 0, tb = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_MOVERS_PER; ++k) {
+      ta += la[SCAN_MOVERS_AT(i0 + k)];
+      tb += lb[SCAN_MOVERS_AT(i0 + k)];
+    }
+    // inclusive scan of the 1024 run totals: within the wavefront by shuffles, then over the 16
+    int ia = ta, ib = tb;
 #pragma unroll
     for (int o = 1; o < SDM_WAVE; o <<= 1) {
-      const long long ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64);
-      if (lane >= o) { ia += ta; ib += tb; }
+      const int xa = __shfl_up(ia, o, 64), xb = __shfl_up(ib, o, 64);
+      if (lane_id() >= o) { ia += xa; ib += xb; }
     }
-    if (lane == SDM_WAVE - 1) { wa[w] = ia; wb[w] = ib; }
+    if (lane_id() == SDM_WAVE - 1) { sa[threadIdx.x / SDM_WAVE] = ia; sb[threadIdx.x / SDM_WAVE] = ib; }
     __syncthreads();
-    long long oa = carry[0], ob = carry[1];
-    for (int v = 0; v < w; ++v) { oa += wa[v]; ob += wb[v]; }
-    if (i < nb) {
-      blk_a[i] = (int32_t)(oa + ia - va);
-      blk_b[i] = (int32_t)(ob + ib - vb);
+    int wa = 0, wb = 0, all_a = 0, all_b = 0;
+    for (int w = 0; w < 1024 / SDM_WAVE; ++w) {
+      if (w < (int)(threadIdx.x / SDM_WAVE)) { wa += sa[w]; wb += sb[w]; }
+      all_a += sa[w];
+      all_b += sb[w];
     }
+    long long ra = carry_a + wa + ia - ta, rb = carry_b + wb + ib - tb;
+#pragma unroll
+    for (int k = 0; k < SCAN_MOVERS_PER; ++k) {
+      const int va = la[SCAN_MOVERS_AT(i0 + k)], vb = lb[SCAN_MOVERS_AT(i0 + k)];
+      la[SCAN_MOVERS_AT(i0 + k)] = (int32_t)ra;
+      lb[SCAN_MOVERS_AT(i0 + k)] = (int32_t)rb;
+      ra += va;
+      rb += vb;
+    }
+    carry_a += all_a;
+    carry_b += all_b;
     __syncthreads();
-    if (threadIdx.x == 1023) { carry[0] = oa + ia; carry[1] = ob + ib; }
+    for (int i = threadIdx.x; i < m; i += 1024) {
+      blk_a[base + i] = la[SCAN_MOVERS_AT(i)];
+      blk_b[base + i] = lb[SCAN_MOVERS_AT(i)];
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    n[0] = (unsigned long long)carry[0];
-    n[1] = (unsigned long long)carry[1];
+    n[0] = (unsigned long long)carry_a;
+    n[1] = (unsigned long long)carry_b;
   }
 }
 // at_a, at_b: where this process's slices begin (in entries); blk_*: the scanned counts
@@ -717,6 +779,14 @@ k_apply_rows(ShardLists L, const uint8_t *__restrict__ owned, uint8_t *__restric
     position_in_cell[d * L.n_sd + k] = __longlong_as_double(w[4 + L.n_dims + L.n_attr + d]);
 }
 
+__global__ void k_disp_final(const int64_t *__restrict__ arrived, const int64_t *__restrict__ ctl,
+                             const double *__restrict__ rain, int64_t *__restrict__ out) {
+  const int t = threadIdx.x;
+  if (t == 0) out[0] = arrived[0];
+  if (t >= 1 && t < 9) out[t] = ctl[t - 1];
+  if (t == 9) out[9] = __double_as_longlong(rain[0]);
+}
+
 extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *cfg,
                                              const sdm_disp_state *state, sdm_disp_shard *sh,
                                              double *rainfall_mass, int64_t *valid_n_sd) {
@@ -739,7 +809,7 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
                       carve_size(sizeof(int32_t) * (size_t)N) + carve_size(2 * (size_t)N) +
                       2 * carve_size(sizeof(int32_t) * (size_t)N) +
                       2 * carve_size(sizeof(int64_t) * (size_t)N) +
-                      2 * carve_size(sizeof(int32_t) * (size_t)nb) + 1024;
+                      2 * carve_size(sizeof(int32_t) * (size_t)nb) + 2048;
   int rc = sdm_reserve(ctx, need);
   if (rc) return rc;
   Carver cv(ctx->arena);
@@ -775,22 +845,31 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
     sh->role_ready = 1;
   }
   hipLaunchKernelGGL(k_shard_begin, grid, blk, 0, s, sh->role, (const int64_t *)sh->multiplicity,
-                     (const int64_t *)sh->cell_id_by_id, cell0, N);
+                     (const int64_t *)sh->cell_id_by_id, cell0, N, X.rain, counters);
   LAUNCH_CHECK();
   double host_counts[4 * 256];
-  double *carried = (double *)free_cell;  // (scratch of the arrivals, free until the end)
+  // the precipitated masses by position, for the rainfall sum (k_disp_rain): an array of the
+  // context's own, all zero between uses (scratch of the arena is anybody's between calls)
+  if (ctx->rain_carry_len < N) {
+    if (ctx->rain_carry) (void)hipFree(ctx->rain_carry);
+    ctx->rain_carry = nullptr;
+    ctx->rain_carry_len = 0;
+    HIP_TRY(hipMalloc((void **)&ctx->rain_carry, sizeof(double) * (size_t)N));
+    HIP_TRY(hipMemsetAsync(ctx->rain_carry, 0, sizeof(double) * (size_t)N, ctx->stream));
+    ctx->rain_carry_len = N;
+  }
+  double *carried = ctx->rain_carry;
   // ONE exchange of counts per sub-step: both removals (who leaves the column is decided by the
   // same classification as who precipitates) and, in the last sub-step, the movers too (their
   // cells are known as soon as k_disp_move has run).  Totals and this process's offsets, per list
   int64_t total4[4] = {0, 0, 0, 0}, before4[4] = {0, 0, 0, 0}, mine4[4] = {0, 0, 0, 0};
   unsigned long long *mine_dev = cv.take<unsigned long long>(4);
+  int64_t *final10 = cv.take<int64_t>(10);
   auto exchange_counts = [&](int lists) -> int {
     FourCounts C4 = {{X.n_dead, X.n_column, counters + 2, counters + 3}};
     hipLaunchKernelGGL(k_pack_counts, one, dim3(1024), 0, s, sh->xchg_counts, W, R, lists, C4,
                        mine_dev);
     LAUNCH_CHECK();
-    HIP_TRY(hipMemcpyAsync(ctx->mailbox, mine_dev, sizeof(unsigned long long) * 4,
-                           hipMemcpyDeviceToHost, s));
     if (sdm_exchange(ctx, sh->exchange, sh->exchange_user, SDM_XCHG_SUM_F64, sh->xchg_counts,
                      lists * W) != 0) {
       return SDM_E_HIP;
@@ -799,44 +878,30 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
                            hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     for (int l = 0; l < lists; ++l) {
-      mine4[l] = ctx->mailbox[l];
+      mine4[l] = (int64_t)host_counts[l * W + R];  // (slot R of the sum: this process's alone)
       total4[l] = before4[l] = 0;
       for (int r = 0; r < W; ++r) {
         if (r < R) before4[l] += (int64_t)host_counts[l * W + r];
         total4[l] += (int64_t)host_counts[l * W + r];
       }
     }
-    HIP_TRY(hipMemsetAsync(X.n_column, 0, sizeof(unsigned long long), s));
     return SDM_OK;
   };
   // the positions listed by k_disp_precip / k_disp_column on every process -> flagged on every
   // process -> the reference's compaction on every process's own permutation
   auto remove_listed = [&](bool with_rain, int64_t total, int64_t before, int64_t mine) -> int {
-    HIP_TRY(hipMemsetAsync(X.n_dead, 0, sizeof(unsigned long long), s));
-    if (total == 0) {
-      if (with_rain) {  // (the one-process step adds this sub-step's 0.0 too)
-        HIP_TRY(hipMemsetAsync(X.partial, 0, sizeof(double) * n_precip, s));
-        hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(1024), 0, s, X.partial,
-                           (int64_t)n_precip, X.rain, 1);
-        LAUNCH_CHECK();
-      }
-      return SDM_OK;
-    }
+    // (nothing to remove anywhere: nothing to launch - the one-process step adds this sub-step's
+    // rainfall of 0.0 to its sum, which changes no bit of it)
+    if (total == 0) return SDM_OK;
     const int64_t words = with_rain ? 2 * total : total;
     if (words > sh->word_capacity || total > N || before + mine > total) {
       sdm_set_error("sharded displacement: word_capacity too small for %lld removed",
                     (long long)total);
       return SDM_E_ARG;
     }
-    HIP_TRY(hipMemsetAsync(sh->xchg_words, 0, sizeof(int64_t) * (size_t)words, s));
-    if (mine > 0) {
-      hipLaunchKernelGGL(k_copy_i64, dim3(grid_for(mine)), blk, 0, s, sh->xchg_words + before,
-                         (const int64_t *)X.dead, mine);
-      if (with_rain)  // (bit patterns: a sum with zeros leaves them as they are)
-        hipLaunchKernelGGL(k_copy_i64, dim3(grid_for(mine)), blk, 0, s,
-                           sh->xchg_words + total + before, (const int64_t *)X.dead_mass, mine);
-      LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(k_place_slices, dim3(grid_for(words)), blk, 0, s, sh->xchg_words, words,
+                       total, before, mine, (const int64_t *)X.dead, (const int64_t *)X.dead_mass);
+    LAUNCH_CHECK();
     if (sdm_exchange(ctx, sh->exchange, sh->exchange_user, SDM_XCHG_SUM_I64, sh->xchg_words,
                      words) != 0) {
       return SDM_E_HIP;
@@ -844,23 +909,27 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
     sh->n_words += words;
     sh->n_removed += total;
     if (with_rain) {
-      HIP_TRY(hipMemsetAsync(carried, 0, sizeof(double) * (size_t)N, s));
+      // (`carried` is zero between uses: the entries scattered are taken back afterwards)
       hipLaunchKernelGGL(k_rain_scatter, dim3(grid_for(total)), blk, 0, s, carried,
                          (const int64_t *)sh->xchg_words, total);
       hipLaunchKernelGGL(k_disp_rain, dim3(n_precip), blk, 0, s, (const double *)carried,
                          (const int64_t *)state->ctl, X.partial);
       hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(1024), 0, s, X.partial,
                          (int64_t)n_precip, X.rain, 1);
+      hipLaunchKernelGGL(k_rain_unscatter, dim3(grid_for(total)), blk, 0, s, carried,
+                         (const int64_t *)sh->xchg_words, total);
       LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_flag_positions, dim3(grid_for(total)), blk, 0, s, state->idx,
-                       (const int64_t *)sh->xchg_words, total, N, state->ctl);
+                       (const int64_t *)sh->xchg_words, total, N, state->ctl, X.n_dead);
     LAUNCH_CHECK();
+    // the positions to remove are a list: no pass over the permutation (index.hip)
+    if (sdm_compact_listed_fits(total))
+      return sdm_compact_listed_async(ctx, compact, state->idx, sh->xchg_words, total, N, N,
+                                      state->ctl, cctl, nullptr);
     return sdm_compact_fused_async(ctx, compact, state->multiplicity, state->idx, N, N,
                                    state->ctl, cctl, nullptr, true);
   };
-  HIP_TRY(hipMemsetAsync(X.rain, 0, sizeof(double), s));
-  HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned long long) * 8, s));
   for (int sub = 0; sub < cfg->n_substeps; ++sub) {
     const bool last_sub = sub == cfg->n_substeps - 1;
     hipLaunchKernelGGL(k_disp_move, grid, blk, 0, s, X);
@@ -871,8 +940,12 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
                          (const uint8_t *)X.cls, sh->cell_owned,
                          (const int64_t *)sh->cell_id_by_id, (const int64_t *)cell0, N, blk_a,
                          blk_b);
-      hipLaunchKernelGGL(k_scan_movers, one, dim3(1024), 0, s, blk_a, blk_b, (int64_t)nb,
-                         counters + 2);
+      // (> 64 KB of dynamic LDS must be opted into)
+      HIP_TRY(hipFuncSetAttribute((const void *)k_scan_movers,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)SCAN_MOVERS_LDS));
+      hipLaunchKernelGGL(k_scan_movers, one, dim3(1024), SCAN_MOVERS_LDS, s,
+                         blk_a, blk_b, (int64_t)nb, counters + 2);
     }
     LAUNCH_CHECK();
     rc = exchange_counts(last_sub ? 4 : 2);
@@ -949,11 +1022,13 @@ extern "C" int sdm_displacement_step_sharded(sdm_ctx *ctx, const sdm_disp_cfg *c
       LAUNCH_CHECK();
     }
   }
-  HIP_TRY(hipMemcpyAsync(ctx->mailbox, counters + 6, sizeof(unsigned long long),
-                         hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(ctx->mailbox + 1, state->ctl, sizeof(int64_t) * 8,
-                         hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(ctx->mailbox + 9, X.rain, sizeof(double), hipMemcpyDeviceToHost, s));
+  // {arrivals, the control block, the rainfall} back in one copy
+  int64_t *final_words = final10;
+  hipLaunchKernelGGL(k_disp_final, one, dim3(16), 0, s, (const int64_t *)(counters + 6),
+                     (const int64_t *)state->ctl, (const double *)X.rain, final_words);
+  LAUNCH_CHECK();
+  HIP_TRY(hipMemcpyAsync(ctx->mailbox, final_words, sizeof(int64_t) * 10, hipMemcpyDeviceToHost,
+                         s));
   HIP_TRY(hipStreamSynchronize(s));
   sh->n_arrived = tot_b > 0 ? ctx->mailbox[0] : 0;
   memcpy(rainfall_mass, ctx->mailbox + 9, sizeof(double));

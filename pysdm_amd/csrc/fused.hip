@@ -1985,9 +1985,17 @@ k_step_close(int64_t *ctl, int64_t *__restrict__ cell_idx, int64_t n_cell, int64
   }
 }
 
-__global__ void __launch_bounds__(SDM_BLOCK) k_fill_f64(double *p, double v, int64_t n) {
+// (z0, z1: words cleared on the way - the largest-cell word and the owned-cell count that
+// k_max_cell accumulates into; NULL: none)
+__global__ void __launch_bounds__(SDM_BLOCK) k_fill_f64(double *p, double v, int64_t n,
+                                                        int64_t *z0 = nullptr,
+                                                        int64_t *z1 = nullptr) {
   const int64_t i = TID();
   if (i < n) p[i] = v;
+  if (i == 0) {
+    if (z0) *z0 = 0;
+    if (z1) *z1 = 0;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2270,17 +2278,19 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       // cell_idx.sort_by_key(dt_left) (collision.py:180-183; adaptive), then the cell_start
       // getter's counting sort, gated on the device by the sorted flag
       if (cfg->adaptive) {
-        hipLaunchKernelGGL(k_fill_f64, dim3(grid_for(C)), blk, 0, s, st->dt_left, cfg->dt, C);
+        hipLaunchKernelGGL(k_fill_f64, dim3(grid_for(C)), blk, 0, s, st->dt_left, cfg->dt, C,
+                           st->ctl + 6, S.end2 + 5);
         LAUNCH_CHECK();
         fill_pending = false;
         rc = sdm_sort_by_key_async(ctx, st->cell_idx, st->dt_left, C);
         if (rc) return rc;
+      } else {
+        HIP_TRY(hipMemsetAsync(st->ctl + 6, 0, sizeof(int64_t), s));
+        if (st->cell_owned) HIP_TRY(hipMemsetAsync(S.end2 + 5, 0, sizeof(int64_t), s));
       }
       rc = cond_sort(ctx, cfg, st, cur, S, &sorted_host);
       if (rc) return rc;
       sorted_now = true;
-      HIP_TRY(hipMemsetAsync(st->ctl + 6, 0, sizeof(int64_t), s));
-      if (st->cell_owned) HIP_TRY(hipMemsetAsync(S.end2 + 5, 0, sizeof(int64_t), s));
       hipLaunchKernelGGL(k_max_cell, dim3(grid_for(C)), blk, 0, s, st->cell_start, C, st->ctl,
                          st->cell_owned, S.end2 + 5);
       LAUNCH_CHECK();
@@ -2643,7 +2653,9 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     // every process - one all-gather, as a sum of segment-ordered disjoint slices of exactly their
     // number - and are flagged in its permutation (in a segment of another process that removes
     // SOME member of the cell: the invariant of sdm_hip.h); the compaction follows
+    int64_t listed_dead = 0;  // (dead positions standing in st->xchg_idx after shard_dead_by_segment)
     auto shard_dead_by_segment = [&](int64_t *perm, const double *mins) -> int {
+      listed_dead = 0;
       int64_t *offsets = S.seg_src, *total_dev = S.end2 + 6;
       hipLaunchKernelGGL(k_shard_dead_offsets, one, dim3(1024), 0, s, mins + C, C, offsets,
                          total_dev);
@@ -2667,6 +2679,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       hipLaunchKernelGGL(k_shard_flag, dim3(grid_for(total)), blk, 0, s, perm, st->xchg_idx, total,
                          N);
       LAUNCH_CHECK();
+      listed_dead = total;
       return SDM_OK;
     };
     int64_t seq_k = 0;
@@ -2728,8 +2741,13 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         }
         {
           PhaseScope ph(ctx, SDM_PHASE_SANITIZE);
-          rc = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl,
-                                       S.cctl, nullptr, true);
+          // (sharded: the positions to remove are known as a list - no pass over the permutation)
+          if (sharded && sdm_compact_listed_fits(listed_dead))
+            rc = sdm_compact_listed_async(ctx, S.compact, cur, st->xchg_idx, listed_dead, N, N,
+                                          st->ctl, S.cctl, nullptr);
+          else
+            rc = sdm_compact_fused_async(ctx, S.compact, st->multiplicity, cur, N, N, st->ctl,
+                                         S.cctl, nullptr, true);
           if (rc) return rc;
         }
         // sort by cell, then the end of the working range from the new cell_start

@@ -97,6 +97,12 @@ int sdm_resort_after_compaction_async(sdm_ctx *ctx, char *scratch, int64_t lengt
                                       const int64_t *cell_id, const int64_t *cell_idx,
                                       int64_t n_cell, const int64_t *plan, int64_t *seg_size,
                                       int64_t *seg_key);
+// the same compaction from a device list of the d positions to remove (all flagged already);
+// d within sdm_compact_listed_fits, else the full kernel
+bool sdm_compact_listed_fits(int64_t d);
+int sdm_compact_listed_async(sdm_ctx *ctx, char *scratch, int64_t *idx, const int64_t *dead,
+                             int64_t d, int64_t length_bound, int64_t flag, int64_t *fctl,
+                             int64_t *ctl, int64_t *cell_start_single);
 int sdm_compact_fused_async(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity,
                             int64_t *idx, int64_t length_bound, int64_t flag, int64_t *fctl,
                             int64_t *ctl, int64_t *cell_start_single, bool flag_only = false,
