@@ -478,8 +478,9 @@ typedef struct sdm_step_state {
   int64_t known_valid;
   uint64_t rng_offset;        /* doubles already drawn from the coll. stream (host-tracked) */
   uint64_t rng_offset_breakup;/* doubles already drawn from the proc/frag streams */
-  /* sharded mode (see above; all NULL = this process owns every cell).  Requires the local
-   * croupier and cells of at most 6144 super-droplets (the per-cell kernels). */
+  /* sharded mode (see above; all NULL = this process owns every cell).  Any croupier, any cell
+   * size: cells of at most 6144 super-droplets under the local croupier take the per-cell
+   * kernels, everything else the generic ones, as in a one-process run. */
   const uint8_t *cell_owned;  /* [n_cell] by cell id: 1 = computed by this process */
   sdm_exchange_fn exchange;
   void *exchange_user;

@@ -482,7 +482,12 @@ __device__ __forceinline__ PairInfo pair_prob_body(const sdm_step_cfg &cfg, cons
       if (p < W - 1) {
         const int64_t ca = A.cell_id[A.idx[p]], cb = A.cell_id[A.idx[p + 1]];
         const int64_t dd = p - A.cell_start[A.cell_idx[ca]];
-        if (ca == cb && (dd & 1) == 0) { R.have = true; i = p; }
+        // (sharded runs on these generic kernels - cells beyond the per-cell kernels' capacity,
+        // the global croupier: the pairs of another process's cell are that process's to collide)
+        if (ca == cb && (dd & 1) == 0 && (!A.cell_owned || A.cell_owned[ca])) {
+          R.have = true;
+          i = p;
+        }
       }
     }
   }
@@ -2476,13 +2481,12 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       sdm_set_error("sharded mode: shard_rank / shard_world out of range");
       return SDM_E_ARG;
     }
-    // (no super-droplet left anywhere - every process sees that - is not a route question:
-    // the largest cell of an empty state is unknown, and there is nothing to do)
-    if (!cfg->croupier_local || (!cell_path && work_host != 0)) {
-      sdm_set_error("sharded mode needs the local croupier and cells of at most %d "
-                    "super-droplets (largest: %lld)", CELL_CAP, (long long)max_cell);
-      return SDM_E_ARG;
-    }
+    // (cells beyond the per-cell kernels' capacity and the global croupier take the generic
+    // kernels, as in a one-process run: those skip the pairs of cells this process does not own,
+    // the per-sub-step exchange - owned cells' dt_left, deaths - is the one of sdm_hip.h.  The
+    // invariant holds under the global croupier as well: the shuffle permutes POSITIONS, a
+    // process's own super-droplets stand at their true positions, and the stable counting sort
+    // orders a cell's members by where the shuffle put them)
   }
   // dead positions of this process (scratch: the sort's output buffer is free between sorts)
   int64_t *shard_dead_pos = S.sorted_buf;

@@ -16,7 +16,8 @@ import torch.multiprocessing as mp
 from pysdm_amd import sharding
 
 from . import digests
-from .test_sharding import CASES, sharded_run_equals_golden
+from .test_sharding import (BEYOND_THE_CELL_KERNELS, CASES, sharded_box_equals_single,
+                            sharded_run_equals_golden)
 
 pytestmark = pytest.mark.gpu
 
@@ -37,6 +38,9 @@ def _worker(rank, world, port, errors):
         for name in CASES:
             stage(name)
             sharded_run_equals_golden(name, engine, rank, world)
+        for box in BEYOND_THE_CELL_KERNELS:  # (cells of 8192: the generic kernels; global croupier)
+            stage(f"beyond the per-cell kernels: {box}")
+            sharded_box_equals_single(engine, rank, world, **box)
         stage("32 x 32 digest")
         # 32 x 32 cells against the reference's digest
         digests.check("kinematic2d_64percell", engine,

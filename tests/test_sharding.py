@@ -53,6 +53,44 @@ def sharded_run_equals_golden(name, engine, rank, world, float_rtol=0.0):
     return runner
 
 
+def sharded_box_equals_single(engine, rank, world, runs=(1, 4, 3), **box):
+    """a box of pysdm_amd.cases run by `world` processes beside the one-process run on the same
+    engine: the state gathered from the owners, bit for bit, after every call"""
+    from pysdm_amd import cases  # pylint: disable=import-outside-toplevel
+
+    single = cases.make_box(engine, **box)
+    shard = cases.make_box(engine, **box)
+    sharding.attach(shard, rank, world)
+    for steps in runs:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            single.run(steps)
+            shard.run(steps)
+        got, ref = sharding.gather(shard), single.snapshot()
+        length = int(ref["length"])
+        assert int(got["length"]) == length
+        for key, value in ref.items():
+            if key == "stats_dt_min" and not box.get("adaptive", True):
+                continue
+            mine = got[key]
+            if key == "idx":
+                value, mine = value[:length], mine[:length]
+            np.testing.assert_array_equal(mine, value, err_msg=f"{box} {key}")
+    return shard, length
+
+
+# sharded runs beyond the per-cell kernels (round 4): cells larger than their capacity (8192 per
+# cell here) and the global croupier take the generic kernels, which skip other processes' pairs
+BEYOND_THE_CELL_KERNELS = (
+    dict(name="shima", n_sd=2**15, adaptive=True, dt=200.0, thin=0.02, grid=(2, 2)),
+    dict(name="shima", n_sd=2**15, adaptive=False, dt=200.0, thin=0.02, grid=(2, 2)),
+    dict(name="shima", n_sd=2**12, adaptive=False, dt=200.0, thin=0.02, grid=(4, 4),
+         croupier="global"),
+    dict(name="shima", n_sd=2**12, adaptive=False, dt=50.0, grid=(3, 5), croupier="global",
+         substeps=2),
+)
+
+
 def _worker(rank, world, port, errors):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -90,6 +128,10 @@ def _worker(rank, world, port, errors):
                         value, mine = value[:length], mine[:length]
                     np.testing.assert_array_equal(mine, value, err_msg=f"{adaptive} {key}")
             assert shard.shard.calls[2] > 0  # the permutation did cross the processes
+        for box in BEYOND_THE_CELL_KERNELS:
+            shard, length = sharded_box_equals_single(engine, rank, world, **box)
+            if box.get("thin"):
+                assert length < box["n_sd"]
         # displacement (replicated, on the completed state) + sharded collisions: super-droplets
         # migrate between the processes' cells every step; against the reference's golden
         from . import displacement_cases  # pylint: disable=import-outside-toplevel
