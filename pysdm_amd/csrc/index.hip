@@ -302,7 +302,13 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
   const int64_t both = id_bound > length_bound ? id_bound : length_bound;
   // SDM_REC_CHAIN where the caller's kernels do the walk (`views`); SDM_REC_FORMAT=records keeps
   // the round-1..3 records there as well (A/B measurements)
-  const int fmt = (views && id_bound >= 0 && both <= CHAIN_MAX && chain_enabled()) ? SDM_REC_CHAIN
+  // ... and only while a bin's run in a tile is a whole 64-byte sector of S words (16 events: at
+  // most 256 bins = 2^20 positions).  Beyond, the S words go back as quarter sectors written by
+  // different workgroups and the build loses more than the walk gains (2^22: k_bin_build2 62 ->
+  // 157 us against k_pair_prob 258 -> 195; profiles/r04_chain_at_2p22.json)
+  const bool whole_sectors = bin_count(length_bound) * 16 <= EV_TILE;
+  const int fmt = (views && id_bound >= 0 && both <= CHAIN_MAX && chain_enabled() && whole_sectors)
+                      ? SDM_REC_CHAIN
                   : id_bound < 0 ? SDM_REC_PLAIN
                   : both <= P21_MAX ? SDM_REC_P21 : (both <= P24_MAX ? SDM_REC_P24 : SDM_REC_PLAIN);
   const int slots = fmt == SDM_REC_CHAIN ? 5 : fmt == SDM_REC_P21 ? 4 : (fmt == SDM_REC_P24 ? 3 : 2);
@@ -420,8 +426,8 @@ void sdm_shuffle_sort_buffers(char *scratch, int64_t length_bound, SortBuffers *
   int32_t *chain = (int32_t *)cv.take<PackRec>(length_bound + EV_TILE);
   (void)cv.take<int32_t>(length_bound);
   (void)cv.take<int32_t>(length_bound);
-  out->loc = chain_enabled() && length_bound <= CHAIN_MAX ? chain + 2 * (size_t)nt * EV_TILE
-                                                          : nullptr;
+  out->loc = chain_enabled() && length_bound <= CHAIN_MAX && nb * 16 <= EV_TILE
+                 ? chain + 2 * (size_t)nt * EV_TILE : nullptr;
   out->jarr = cv.take<int32_t>(length_bound);
   out->events = cv.take<int2>((size_t)nt * EV_TILE);
   out->toff = cv.take<int32_t>((size_t)(nb + 1) * nt);
@@ -1120,9 +1126,10 @@ bool sdm_shuffle_presort_ok(sdm_ctx *ctx, int64_t length_bound, int64_t id_bound
   const int64_t both = id_bound > length_bound ? id_bound : length_bound;
   if (nb != nt || nb > COMPACT_MAX_GROUPS || id_bound < 0 || both > P21_MAX) return false;
   if (ctx->build_resident == 0) {
-    const size_t lds_build = sizeof(int32_t) * (size_t)((chain_enabled() ? 9 : 5) * BIN_POS);
+    const bool chain = chain_enabled() && nb * 16 <= EV_TILE;
+    const size_t lds_build = sizeof(int32_t) * (size_t)((chain ? 9 : 5) * BIN_POS);
     int per_cu = 0, cus = 0;
-    const void *kernel = chain_enabled() ? (const void *)k_bin_build2<SDM_REC_CHAIN>
+    const void *kernel = chain ? (const void *)k_bin_build2<SDM_REC_CHAIN>
                                          : (const void *)k_bin_build2<SDM_REC_P21>;
     if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(lds_build > 65536 ? lds_build : 65536)) != hipSuccess ||

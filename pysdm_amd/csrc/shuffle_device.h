@@ -41,7 +41,7 @@ struct __align__(16) PackRec24 { uint64_t lo, hi; };
 //              at i's place l in the tile-sorted event array, so the write is as coalesced as
 //              the read was (runs of ~16 events per tile and bin).  By event index it would be
 //              2^20 scattered 4-byte stores: measured, 14 us on top of a 14-us build
-//              (profiles/r04_chain_scattered_stores.json).  Every word that names an S carries
+//              (profiles/r04_chain_formats.json).  Every word that names an S carries
 //              that place (the tile sort records it per event: `loc`).
 // A word is {kind: 0 = super-droplet id, 1 = T, 2 = S} << 30 | payload (T: event index, S: place
 // in the sorted array).  The walk is then a chain of single 4-byte look-ups (no decoding, no
