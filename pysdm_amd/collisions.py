@@ -35,6 +35,15 @@ class CollisionRunner:  # pylint: disable=too-many-instance-attributes
             raise ValueError("No one to collide with!")
         if route not in ("fused", "chain"):
             raise ValueError(route)
+        if population.n_cell > 1 and setup.croupier == "global" and setup.adaptive:
+            # the one configuration in which this package does NOT reproduce the reference, by
+            # design ("Several cells, global croupier, adaptive")
+            warnings.warn(
+                "several cells + global croupier + adaptive sub-stepping: once a working length "
+                "is cut, the reference's counting sort duplicates ids beyond the cut "
+                "(collisions_methods.py:587-631) and the outcome depends on the order of "
+                "execution; this backend keeps every id exactly once instead - results agree with "
+                "the reference only up to the first cut", stacklevel=2)
         self.population = population
         self.engine = eng = population.engine
         self.setup = setup

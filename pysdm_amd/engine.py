@@ -117,7 +117,9 @@ class HipEngine(Engine):
                                 device=self.device)
 
     def upload(self, array):
-        return self.torch.from_numpy(np.ascontiguousarray(array)).to(self.device)
+        # (a writable, contiguous host copy: torch refuses to wrap read-only arrays quietly - the
+        # arrays of an .npz file are read-only)
+        return self.torch.from_numpy(np.require(array, requirements=["C", "W"])).to(self.device)
 
     @staticmethod
     def download(array):

@@ -7,6 +7,7 @@ forked into ranks), so call `spawn_ranks` before anything imports a device runti
 environment, exactly as when the script is started through torchrun by hand.
 """
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -20,6 +21,8 @@ def launched_by_torchrun(environ=None):
 
 
 def free_port():
+    """a port that was free a moment ago (for a process group of ONE rank, where nobody else
+    races for it between this call and the bind; `spawn_ranks` lets the launcher pick its own)"""
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         return sock.getsockname()[1]
@@ -36,8 +39,21 @@ def spawn_ranks(script, argv, n_ranks, *, env=None, stdout=None, timeout=None):
         environ.pop(name, None)
     environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL needs dmabuf IPC on this host
     environ.setdefault("OMP_NUM_THREADS", "1")
+    # --standalone: the launcher binds the rendezvous port itself (a port picked here could be
+    # taken by someone else before torch.distributed.run binds it); 127.0.0.1: the container's
+    # host name may not resolve
     command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-               f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
-               "--master-port", str(free_port()), script, *argv]
-    done = subprocess.run(command, env=environ, stdout=stdout, timeout=timeout, check=False)
-    return done.returncode
+               f"--nproc-per-node={n_ranks}", "--standalone", "--local-addr", "127.0.0.1",
+               script, *argv]
+    # a session of its own: on a timeout the WHOLE group goes - the launcher and the ranks it
+    # started, which would otherwise keep the GPU
+    with subprocess.Popen(command, env=environ, stdout=stdout, start_new_session=True) as child:
+        try:
+            return child.wait(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            child.wait()
+            raise

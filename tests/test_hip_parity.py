@@ -1,7 +1,9 @@
 """GPU parity tests proper: the HIP path (through the C ABI) against the goldens recorded from the
 reference and against the oracle on the same seeded inputs.  Integer state bit-exact; floating
-point bit-exact on the coalescence-only paths, 1e-12 relative where device transcendentals
-(OCML pow/log/exp...) feed attributes (breakup)."""
+point bit-exact on the coalescence-only paths and - against the checker - on the breakup paths as
+well (both sides evaluate pow / exp / log / erf with csrc/sdm_math.h); 1e-12 relative against the
+REFERENCE's values where transcendental functions feed attributes (its NumPy / libm are not
+ours)."""
 import warnings
 
 import numpy as np
@@ -486,3 +488,20 @@ def test_fused_run_takes_the_closed_form_resort_and_it_equals_the_counting_sort(
     want = checker.snapshot()
     for snap, _ in (asked, sorted_only, auto):
         assert_same(snap, want)
+
+
+def test_ids_stay_unique_where_the_reference_duplicates_them(hip_engine):
+    """several cells + global croupier + adaptive sub-stepping: the set-up warns,
+    and the permutation this backend leaves behind holds every live id exactly once, however many
+    working lengths were cut on the way - the behaviour chosen where the reference's is a race"""
+    name = "traj_multicell_geometric_4x4_global"
+    with pytest.warns(UserWarning, match="keeps every id exactly once"):
+        runner, _, steps = setup_from_golden(name, hip_engine, route="fused")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        runner.run(2 * steps[-1])
+    snap = runner.snapshot()
+    live = snap["idx"][: int(snap["length"])]
+    assert len(np.unique(live)) == len(live)
+    assert (snap["multiplicity"][live] > 0).all()
+    assert int(snap["stats_n_substep"].max()) > 1  # it did sub-step (working lengths were cut)
