@@ -76,6 +76,15 @@ const char *sdm_phase_name(int phase);
  * block in the message, the context usable afterwards - can be exercised with a healthy state;
  * 0 (default) = the arithmetic's bound alone                                                    */
 #define SDM_OPT_MAX_SUBSTEPS 1
+/* SDM_OPT_CELL_SHAPE (measurements, tests): the shape of the per-cell kernel of a multi-cell run
+ * with a local croupier.  SDM_CELL_SHAPE_AUTO (default) picks by the size of the largest cell and
+ * the number of cells this process computes; the others force one shape wherever its cell-size cap
+ * allows it (beyond the cap: the 512-thread shape or the general kernel).  Results are identical in all.       */
+#define SDM_OPT_CELL_SHAPE 2
+#define SDM_CELL_SHAPE_AUTO 0
+#define SDM_CELL_SHAPE_512 1  /* two workgroups of 512 threads per CU, cells <= 5632 */
+#define SDM_CELL_SHAPE_1024 2 /* one workgroup of 1024 per CU, cells <= 6144: fewer cells than CUs */
+#define SDM_CELL_SHAPE_256 3  /* four workgroups of 256 per CU, cells <= 2816 */
 int sdm_ctx_set_option(sdm_ctx *ctx, int option, int64_t value);
 /* counters since the context was created / last cleared (host-side bookkeeping of the library):
  * re-sorts after a compaction done by the closed form; asked for and refused by the device; not

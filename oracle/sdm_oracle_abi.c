@@ -76,6 +76,8 @@ API int sdm_ctx_set_option(sdm_ctx *ctx, int option, int64_t value) {
     ctx->opt_max_substeps = value;
     return SDM_OK;
   }
+  if (option == SDM_OPT_CELL_SHAPE && value >= SDM_CELL_SHAPE_AUTO && value <= SDM_CELL_SHAPE_256)
+    return SDM_OK;
   if (option != SDM_OPT_RESORT || value < SDM_RESORT_AUTO || value > SDM_RESORT_ALWAYS_ASK)
     FAIL(SDM_E_ARG, "sdm_ctx_set_option: unknown option or value");
   return SDM_OK;

@@ -151,6 +151,11 @@ extern "C" int sdm_ctx_set_option(sdm_ctx *ctx, int option, int64_t value) {
     ctx->opt_max_substeps = value;
     return SDM_OK;
   }
+  if (option == SDM_OPT_CELL_SHAPE) {
+    ARG_TRY(value >= SDM_CELL_SHAPE_AUTO && value <= SDM_CELL_SHAPE_256);
+    ctx->opt_cell_shape = (int)value;
+    return SDM_OK;
+  }
   sdm_set_error("sdm_ctx_set_option: unknown option %d", option);
   return SDM_E_ARG;
 }

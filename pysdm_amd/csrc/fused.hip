@@ -985,35 +985,84 @@ struct TurnArgs {
   int64_t seq;       // publication number of the sub-step that ended (0: nothing to publish)
 };
 
+// (TURN_GROUP cells per workgroup: what is read of all cells - their dt_left and minima - serves
+// the ranks of the group's cells together; 1024 workgroups reading everything for one rank each
+// took 8.6 us at 1024 cells, a seventh of a sub-step of a process that owns 128 of them)
+#ifndef TURN_GROUP
+#define TURN_GROUP 1
+#endif
 __global__ void __launch_bounds__(SDM_BLOCK) k_cells_turn(sdm_step_cfg cfg, FusedArgs A, TurnArgs T) {
-  __shared__ int sm_rank[SDM_BLOCK / SDM_WAVE], sm_top[SDM_BLOCK / SDM_WAVE];
-  __shared__ int sm_flags[SDM_BLOCK / SDM_WAVE];
-  const int64_t i = blockIdx.x, n = cfg.n_cell;
-  const bool apply = !T.first && T.gate[(T.turn - 1) & 1] != 0;
-  // new dt_left of cell c (what the bookkeeping of the sub-step just done leaves)
-  auto left_of = [&](int64_t c, double *todo, double *m_out) -> double {
+  __shared__ int sm_rank[SDM_BLOCK / SDM_WAVE][TURN_GROUP];
+  __shared__ int sm_top[SDM_BLOCK / SDM_WAVE], sm_flags[SDM_BLOCK / SDM_WAVE];
+  const int64_t n = cfg.n_cell, i0 = (int64_t)blockIdx.x * TURN_GROUP;
+  // every load the kernel needs is issued before anything depends on one: the kernel is a chain
+  // of memory round trips (gate -> inputs -> cell_start[top] -> control words), 1.5-2 us each,
+  // and nothing else; which loads are needed follows from the launch arguments alone
+  const bool may_apply = !T.first;
+  const bool read_in = !T.fresh;
+  constexpr int PER = 4;  // cells per thread and pass: SDM_BLOCK * PER >= 1024 cells at once
+  const int64_t gate_w = may_apply ? T.gate[(T.turn - 1) & 1] : 0;
+  const int64_t ctl_work = A.ctl[CTL_WORK], ctl_healthy = A.ctl[CTL_HEALTHY],
+                ctl_sorted = A.ctl[CTL_SORTED];
+  double own_l[TURN_GROUP], own_m[TURN_GROUP];
+#pragma unroll
+  for (int g = 0; g < TURN_GROUP; ++g) {
+    const bool in = i0 + g < n;
+    own_l[g] = in && read_in ? T.left_in[i0 + g] : cfg.dt;
+    own_m[g] = in && read_in && may_apply ? T.min_in[i0 + g] : INFINITY;
+  }
+  const bool apply = may_apply && gate_w != 0;
+  // new dt_left of a cell from its old one and its minimum (what the bookkeeping of the sub-step
+  // just done leaves)
+  auto left_of = [&](double l, double m, double *todo) -> double {
     if (T.fresh) return cfg.dt;
-    const double l = T.left_in[c];
     if (!apply) return l;
-    const double m = T.min_in[c];
     double t = cfg.dt_max < l ? cfg.dt_max : l;  // Python min(l, dt_max)
     if (m < t) t = m;
-    if (todo) { *todo = t; *m_out = m; }
+    if (todo) *todo = t;
     return l - t;
   };
-  double t_i = 0.0, m_i = INFINITY;
-  const double left_i = left_of(i, &t_i, &m_i);
-  int rank = 0, top = 0, flags = 0;  // flags: 1 = somebody died, 2 = a cell minimum equals dt_min
-  for (int64_t c = threadIdx.x; c < n; c += SDM_BLOCK) {
-    const double lc = left_of(c, nullptr, nullptr);
-    rank += (lc < left_i) || (lc == left_i && c < i);
-    if (lc != 0 && (int)c + 1 > top) top = (int)c + 1;
-    if (apply) {
-      if (T.sharded && T.min_in[n + c] < 0) flags |= 1;
-      if (T.min_in[c] == cfg.dt_min) flags |= 2;
+  double left_i[TURN_GROUP];
+#pragma unroll
+  for (int g = 0; g < TURN_GROUP; ++g)
+    left_i[g] = i0 + g < n ? left_of(own_l[g], own_m[g], nullptr) : 0.0;
+  int rank[TURN_GROUP];
+#pragma unroll
+  for (int g = 0; g < TURN_GROUP; ++g) rank[g] = 0;
+  int64_t end = 0;  // adaptive_sdm_end (collisions_methods.py:313-328): dt_left is scanned by
+                    // POSITION there; cell_start is monotone, so the largest cell_start[c + 1]
+                    // over the cells with time left is the one of the last such cell
+  int flags = 0;    // 1 = somebody died, 2 = a cell minimum equals dt_min
+  for (int64_t c0 = 0; c0 < n; c0 += SDM_BLOCK * PER) {
+    double l[PER], m[PER], d[PER];
+    int64_t e[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int64_t c = c0 + k * SDM_BLOCK + threadIdx.x;
+      const bool in = c < n;
+      l[k] = in && read_in ? T.left_in[c] : cfg.dt;
+      m[k] = in && read_in && may_apply ? T.min_in[c] : INFINITY;
+      d[k] = in && read_in && may_apply && T.sharded ? T.min_in[n + c] : 0.0;
+      e[k] = in ? A.cell_start[c + 1] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int64_t c = c0 + k * SDM_BLOCK + threadIdx.x;
+      if (c >= n) continue;
+      const double lc = left_of(l[k], m[k], nullptr);
+#pragma unroll
+      for (int g = 0; g < TURN_GROUP; ++g)
+        rank[g] += (lc < left_i[g]) || (lc == left_i[g] && c < i0 + g);
+      if (lc != 0 && e[k] > end) end = e[k];
+      if (apply) {
+        if (d[k] < 0) flags |= 1;
+        if (m[k] == cfg.dt_min) flags |= 2;
+      }
     }
   }
-  rank = wave_sum_i32(rank);
+#pragma unroll
+  for (int g = 0; g < TURN_GROUP; ++g) rank[g] = wave_sum_i32(rank[g]);
+  int top = (int)end;  // (positions fit 31 bits: n_sd < 2^31 is checked at the boundary)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const int t2 = __shfl_xor(top, o, 64);
@@ -1021,37 +1070,47 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_cells_turn(sdm_step_cfg cfg, Fuse
     flags |= __shfl_xor(flags, o, 64);
   }
   if (lane_id() == 0) {
-    sm_rank[threadIdx.x / SDM_WAVE] = rank;
+#pragma unroll
+    for (int g = 0; g < TURN_GROUP; ++g) sm_rank[threadIdx.x / SDM_WAVE][g] = rank[g];
     sm_top[threadIdx.x / SDM_WAVE] = top;
     sm_flags[threadIdx.x / SDM_WAVE] = flags;
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  rank = top = flags = 0;
+  top = flags = 0;
   for (int w = 0; w < SDM_BLOCK / SDM_WAVE; ++w) {
-    rank += sm_rank[w];
     top = sm_top[w] > top ? sm_top[w] : top;
     flags |= sm_flags[w];
   }
-  // adaptive_sdm_end (collisions_methods.py:313-328): dt_left is scanned by POSITION there
-  const int64_t end = top == 0 ? 0 : A.cell_start[top];
-  const int64_t work = apply ? end : A.ctl[CTL_WORK];
-  const bool healthy = A.ctl[CTL_HEALTHY] != 0 && !(flags & 1);
-  const bool run = !T.end_only &&
-                   (!T.gated || (work != 0 && A.ctl[CTL_SORTED] != 0 && healthy));
-  // this cell's own results
-  T.left_out[i] = left_i;
-  if (apply) {
-    const double smin = A.stats_dt_min[i];
-    A.stats_dt_min[i] = m_i < smin ? m_i : smin;  // Python min(s, m): NaN-sticky
-    if (t_i > 0) A.stats_n_substep[i] += 1;
+  end = top;
+  const int64_t work = apply ? end : ctl_work;
+  const bool healthy = ctl_healthy != 0 && !(flags & 1);
+  const bool run = !T.end_only && (!T.gated || (work != 0 && ctl_sorted != 0 && healthy));
+  // the group's own results: thread g writes those of cell i0 + g
+  const int g = threadIdx.x;
+  if (g < TURN_GROUP && i0 + g < n) {
+    const int64_t i = i0 + g;
+    double t_i = 0.0;
+    double l_g = own_l[0], m_i = own_m[0];  // (own_l[g] with a run-time g would spill)
+#pragma unroll
+    for (int k = 1; k < TURN_GROUP; ++k)
+      if (k == g) { l_g = own_l[k]; m_i = own_m[k]; }
+    const double mine = left_of(l_g, m_i, &t_i);
+    if (!apply) m_i = INFINITY;
+    int total = 0;
+    for (int w = 0; w < SDM_BLOCK / SDM_WAVE; ++w) total += sm_rank[w][g];
+    T.left_out[i] = mine;
+    if (apply) {
+      const double smin = A.stats_dt_min[i];
+      A.stats_dt_min[i] = m_i < smin ? m_i : smin;  // Python min(s, m): NaN-sticky
+      if (t_i > 0) A.stats_n_substep[i] += 1;
+    }
+    if (run) {
+      T.cell_idx[n - 1 - total] = i;
+      T.min_out[i] = INFINITY;
+      if (T.sharded) T.min_out[n + i] = 0.0;
+    }
   }
-  if (run) {
-    T.cell_idx[n - 1 - rank] = i;
-    T.min_out[i] = INFINITY;
-    if (T.sharded) T.min_out[n + i] = 0.0;
-  }
-  if (i != 0) return;
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
   T.gate[T.turn & 1] = run ? 1 : 0;
   if (apply) A.ctl[CTL_WORK] = end;
   if (flags & 1) A.ctl[CTL_HEALTHY] = 0;
@@ -1413,6 +1472,11 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
 #define CELL2W_CAP 6144
 #define CELL2W_THREADS 1024
 #define CELL2W_LDS_BYTES (CELL2W_CAP * 14)
+// ... and with 256 threads per cell, four workgroups per CU (cells up to 2816): a grid of 1024
+// cells of ~1024 is FOUR cells per CU - two rounds of the 512-thread shape, one of this
+#define CELL2Q_CAP 2816
+#define CELL2Q_THREADS 256
+#define CELL2Q_LDS_BYTES (CELL2Q_CAP * 14)
 
 __device__ __forceinline__ int lds_exch16(uint32_t *words, int i, int v) {
   uint32_t *w = words + (i >> 1);
@@ -1444,7 +1508,8 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
 #define CELL_MARK(k) do { __syncthreads(); if (threadIdx.x == 0) cell_t[(k) + 1] = wall_clock64(); } while (0)
 #endif
   constexpr int T = THREADS / CPW;  // threads per cell
-  constexpr int CAP = (THREADS == CELL2_THREADS ? CELL2_CAP : CELL2W_CAP) / CPW;  // positions per cell
+  constexpr int CAP = (THREADS == CELL2_THREADS ? CELL2_CAP :
+                       THREADS == CELL2W_THREADS ? CELL2W_CAP : CELL2Q_CAP) / CPW;  // positions per cell
   constexpr int MAXPOS = CAP / T, MAXPAIR = (CAP / 2 + T - 1) / T;
   static_assert(T % SDM_WAVE == 0 && CAP % 8 == 0 && CAP % T == 0, "cell slices");
   static_assert(MAXPAIR % CELL2_BATCH == 0, "pairs are taken in whole batches");
@@ -2329,9 +2394,19 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   // them on (a process of a sharded run with its 128 cells of 1024; a small grid)
   if (ctx->n_cus == 0)
     HIP_TRY(hipDeviceGetAttribute(&ctx->n_cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-  static const bool wide_off = getenv("SDM_NO_WIDE_CELLS") != nullptr;  // (A/B measurements)
-  const bool cell2w = cell_path && max_cell <= CELL2W_CAP && cfg->n_attr == 1 && !wide_off &&
-                      max_cell > CELL2_CAP / CELL2_PACK && n_active_cells <= ctx->n_cus;
+  const int shape = ctx->opt_cell_shape;  // (SDM_OPT_CELL_SHAPE: measurements, tests)
+  const bool unpacked = cell2 && max_cell > CELL2_CAP / CELL2_PACK;
+  const bool cell2w = cell_path && max_cell <= CELL2W_CAP && cfg->n_attr == 1 &&
+                      max_cell > CELL2_CAP / CELL2_PACK &&
+                      (shape == SDM_CELL_SHAPE_AUTO ? n_active_cells <= ctx->n_cus
+                                                    : shape == SDM_CELL_SHAPE_1024);
+  // ... or its 256-thread shape, four workgroups per CU, when the cells are small enough for
+  // four to fit and there are more than two per CU: +27 % at 1024 cells of 1024, +18 % at 1024 of
+  // 2048 (profiles/r04_cell_shapes.json) - the same sixteen wavefronts per CU, in four
+  // independent groups whose phases and barriers overlap instead of two
+  const bool cell2q = unpacked && !cell2w && max_cell <= CELL2Q_CAP &&
+                      (shape == SDM_CELL_SHAPE_AUTO ? n_active_cells > 2 * ctx->n_cus
+                                                    : shape == SDM_CELL_SHAPE_256);
   if (fill_pending && C > 1 && !cell_path) {  // the per-cell route's k_cells_begin does it itself
     hipLaunchKernelGGL(k_fill_f64, dim3(grid_for(C)), blk, 0, s, st->dt_left, cfg->dt, C);
     LAUNCH_CHECK();
@@ -2447,6 +2522,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     else if (packed) hipLaunchKernelGGL((k_cell_step2<K, false, CELL2_PACK, CELL2_THREADS>), grid_p, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
     else if (cell2w && brk) hipLaunchKernelGGL((k_cell_step2<K, true, 1, CELL2W_THREADS>), grid, dim3(CELL2W_THREADS), CELL2W_LDS_BYTES, s, *cfg, A, X); \
     else if (cell2w) hipLaunchKernelGGL((k_cell_step2<K, false, 1, CELL2W_THREADS>), grid, dim3(CELL2W_THREADS), CELL2W_LDS_BYTES, s, *cfg, A, X); \
+    else if (cell2q && brk) hipLaunchKernelGGL((k_cell_step2<K, true, 1, CELL2Q_THREADS>), grid, dim3(CELL2Q_THREADS), CELL2Q_LDS_BYTES, s, *cfg, A, X); \
+    else if (cell2q) hipLaunchKernelGGL((k_cell_step2<K, false, 1, CELL2Q_THREADS>), grid, dim3(CELL2Q_THREADS), CELL2Q_LDS_BYTES, s, *cfg, A, X); \
     else if (cell2 && brk) hipLaunchKernelGGL((k_cell_step2<K, true, 1, CELL2_THREADS>), grid, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
     else if (cell2) hipLaunchKernelGGL((k_cell_step2<K, false, 1, CELL2_THREADS>), grid, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
     else if (brk) hipLaunchKernelGGL((k_cell_step<K, true>), grid, dim3(CELL_THREADS), CELL_LDS_BYTES, s, *cfg, A, X); \
@@ -2596,7 +2673,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       T.sharded = sharded ? 1 : 0;
       T.box = ctx->box_dev;
       T.seq = pending_seq;
-      hipLaunchKernelGGL(k_cells_turn, dim3((unsigned)C), blk, 0, s, *cfg, A, T);
+      hipLaunchKernelGGL(k_cells_turn, dim3((unsigned)((C + TURN_GROUP - 1) / TURN_GROUP)), blk, 0,
+                         s, *cfg, A, T);
       LAUNCH_CHECK();
       fill_pending = false;
       left_cur ^= 1;

@@ -256,6 +256,31 @@ def test_both_per_cell_kernels_equal_oracle(n_sd, which, hip_engine, oracle_engi
     assert_same(snaps[0], snaps[1])
 
 
+@pytest.mark.parametrize("base", ["kinematic2d", "straub"])
+def test_every_shape_of_the_cell_kernel_equals_oracle(base, hip_engine, oracle_engine):
+    """SDM_OPT_CELL_SHAPE: 2 x 2 cells of ~2000 fit all three shapes of k_cell_step2 (512, 1024 and
+    256 threads per cell); AUTO would take the 1024-thread one here (fewer cells than CUs), so
+    the others are forced - state and counters equal the oracle's under each"""
+    def run(engine):
+        runner = make_box(engine, base, n_sd=4 * 2000, grid=(2, 2), **(
+            {} if base == "kinematic2d" else {"adaptive": True, "dt": 5.0}))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for steps in (1, 6, 2):
+                runner.run(steps)
+        return runner.snapshot()
+    expected = run(oracle_engine)
+    assert np.diff(expected["cell_start"]).max() <= 2816
+    try:
+        for shape in (1, 2, 3, 0):
+            hip_engine.call("sdm_ctx_set_option", 2, shape)
+            assert_same(run(hip_engine), expected)
+    finally:
+        hip_engine.call("sdm_ctx_set_option", 2, 0)
+    with pytest.raises(Exception):
+        hip_engine.call("sdm_ctx_set_option", 2, 4)
+
+
 def test_degenerate_sizes_and_operand_checks(kit, hip_engine):
     """empty and tiny inputs: zero-length arrays are accepted by every entry point that takes a
     length, two super-droplets form one pair, three leave one alone, a null context is refused,
