@@ -347,6 +347,9 @@ def main():
     # N emulated in turn on this one device - it owns its block of cells, the other ranks'
     # contributions to each exchange are replayed from the trace of a one-process run of the same
     # steps (pysdm_amd.sharding.ReplayShard); every field of the line is labelled "emulated"
+    parser.add_argument("--cell-shape", type=int, default=0,
+                        help="SDM_OPT_CELL_SHAPE of the context (A/B measurements; 0 = the "
+                             "library's own choice, which is what the bench line is quoted on)")
     parser.add_argument("--emulate-of", type=int, default=0)
     parser.add_argument("--emulate-ranks", type=int, nargs="*", default=None,
                         help="with --emulate-of: only these ranks (default: all)")
@@ -394,6 +397,8 @@ def main():
     from pysdm_amd.engine import HipEngine
 
     engine = HipEngine.get(local_rank)
+    if args.cell_shape:
+        engine.call("sdm_ctx_set_option", 2, args.cell_shape)
     adaptive = None if args.adaptive is None else bool(args.adaptive)
     if args.emulate_of:
         if world != 1 or args.workload != "kinematic2d":
