@@ -244,7 +244,7 @@ extern "C" int sdm_debug_bin_profile(long long *out) {
 }
 #endif
 
-template <bool RNG>
+template <bool RNG, int TILE>
 __global__ void k_bin_sort(int2 *events, int32_t *toff, int32_t *jarr, int32_t *loc, int n_bins,
                            const double *u01, const int64_t *cell_start, int64_t n_cell,
                            const int64_t *p_length, int64_t length_arg, u128 s_off, u128 inc,
@@ -254,7 +254,7 @@ __global__ void k_bin_sort(int2 *events, int32_t *toff, int32_t *jarr, int32_t *
 template <int FMT>
 __global__ void k_bin_build2(void *rec_out, int32_t *ovf_head, int32_t *ovf_next,
                              const int2 *events, const int32_t *toff, const int32_t *jarr,
-                             int n_bins, int n_tiles, const int64_t *idx0,
+                             int n_bins, int n_tiles, int ev_tile, const int64_t *idx0,
                              const int64_t *p_length, int64_t length_arg, BuildPrologue P);
 
 // backward walk over packed records; positions [length, n_total) are copied through
@@ -279,8 +279,9 @@ static int ev_tile_count(int64_t n) { return (int)((n + EV_TILE - 1) / EV_TILE);
 
 static size_t binned_scratch_bytes(int64_t n) {
   const size_t nb = (size_t)bin_count(n), nt = (size_t)ev_tile_count(n);
-  return carve_size(sizeof(PackRec) * (n + EV_TILE)) + 3 * carve_size(sizeof(int32_t) * n) +
-         carve_size(sizeof(int2) * (nt * EV_TILE)) + carve_size(sizeof(int32_t) * (nb + 1) * nt);
+  // (either tile size: the larger tile pads more, the smaller has more rows of offsets)
+  return carve_size(sizeof(PackRec) * (n + EV_TILE_BIG)) + 3 * carve_size(sizeof(int32_t) * n) +
+         carve_size(sizeof(int2) * (n + EV_TILE_BIG)) + carve_size(sizeof(int32_t) * (nb + 1) * nt);
 }
 
 // usable while the count matrix stays small and LDS holds the per-bin arrays of K3
@@ -306,28 +307,37 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
   // most 256 bins = 2^20 positions).  Beyond, the S words go back as quarter sectors written by
   // different workgroups and the build loses more than the walk gains (2^22: k_bin_build2 62 ->
   // 157 us against k_pair_prob 258 -> 195; profiles/r04_chain_at_2p22.json)
-  const bool whole_sectors = bin_count(length_bound) * 16 <= EV_TILE;
-  const int fmt = (views && id_bound >= 0 && both <= CHAIN_MAX && chain_enabled() && whole_sectors)
+  // From there to 2^22 (1024 bins) tiles of 16384 events restore the whole sectors: CHAIN with
+  // them took straub (2^22, adaptive, breakup) from 3.95 to 4.20e9 pairs/s, straub_rain from 4.42
+  // to 4.73e9 (profiles/r04_tile16k.json).  Only for these builds: the 139 KB of LDS of such a
+  // tile sort leave one workgroup per CU, which the 4096-event sort of the other routes need not pay
+  const bool chain_ok = views && id_bound >= 0 && both <= CHAIN_MAX && chain_enabled();
+  // (nor where the tile sort can ride in the previous pair kernel: that one is 4096 events)
+  const int tile = (chain_ok && !presorted && bin_count(length_bound) * 16 > EV_TILE &&
+                    bin_count(length_bound) * 16 <= EV_TILE_BIG &&
+                    !sdm_shuffle_presort_ok(ctx, length_bound, id_bound)) ? EV_TILE_BIG : EV_TILE;
+  const bool whole_sectors = bin_count(length_bound) * 16 <= tile;
+  const int fmt = (chain_ok && whole_sectors)
                       ? SDM_REC_CHAIN
                   : id_bound < 0 ? SDM_REC_PLAIN
                   : both <= P21_MAX ? SDM_REC_P21 : (both <= P24_MAX ? SDM_REC_P24 : SDM_REC_PLAIN);
   const int slots = fmt == SDM_REC_CHAIN ? 5 : fmt == SDM_REC_P21 ? 4 : (fmt == SDM_REC_P24 ? 3 : 2);
   Carver cv(scratch);
-  const int nb = bin_count(length_bound), nt = ev_tile_count(length_bound);
-  PackRec *rec = cv.take<PackRec>(length_bound + EV_TILE);
+  const int nb = bin_count(length_bound), nt = (int)((length_bound + tile - 1) / tile);
+  PackRec *rec = cv.take<PackRec>(length_bound + tile);
   int32_t *ovf_head = cv.take<int32_t>(length_bound);
   int32_t *ovf_next = cv.take<int32_t>(length_bound);
   int32_t *jarr = cv.take<int32_t>(length_bound);
-  int2 *events = cv.take<int2>((size_t)nt * EV_TILE);
+  int2 *events = cv.take<int2>((size_t)nt * tile);
   int32_t *toff = cv.take<int32_t>((size_t)(nb + 1) * nt);
   // SDM_REC_CHAIN: the record buffer's 16 B per position hold four int32 arrays of nt * EV_TILE
   // words instead - first | overflow links | loc (event -> place in `events`) | ssucc (by place)
-  const size_t padded = (size_t)nt * EV_TILE;
+  const size_t padded = (size_t)nt * tile;
   int32_t *chain = (int32_t *)rec;
   int32_t *loc = fmt == SDM_REC_CHAIN ? chain + 2 * padded : nullptr;
   const dim3 block(BIN_THREADS);
   const size_t lds_sort = sizeof(int32_t) * (size_t)((nb + 1) + ((nb + 1) & ~1) + 2) +
-                          sizeof(int2) * EV_TILE;
+                          sizeof(int2) * tile;
   // (64 KB with three inline slots - two workgroups per CU - 80 KB with four; the prologue of a
   // presorted build sorts in the same memory)
   // (SDM_REC_CHAIN: + own target, id and place of every position of the bin)
@@ -335,9 +345,10 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
   if (presorted && lds_sort > lds_build) lds_build = lds_sort;
   // gfx950 has 160 KiB of LDS per CU; > 64 KiB dynamic needs opting in (per kernel and device)
   if (lds_sort > 65536) {
-    HIP_TRY(hipFuncSetAttribute((const void *)k_bin_sort<true>,
+    HIP_TRY(hipFuncSetAttribute(tile == EV_TILE_BIG ? (const void *)k_bin_sort<true, EV_TILE_BIG>
+                                                    : (const void *)k_bin_sort<true, EV_TILE>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
-    HIP_TRY(hipFuncSetAttribute((const void *)k_bin_sort<false>,
+    HIP_TRY(hipFuncSetAttribute((const void *)k_bin_sort<false, EV_TILE>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
   }
   if (lds_build > 65536)
@@ -361,18 +372,25 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
       bp.tab = ctx->pcg_tab;
       bp.aff = ctx->pcg_aff;
     } else
-    if (u01)
-      hipLaunchKernelGGL((k_bin_sort<false>), dim3(nt), block, lds_sort, ctx->stream, events, toff,
-                         jarr, loc, nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc,
-                         ctx->pcg_tab, (const uint64_t *)nullptr, (const u128 *)nullptr);
+    if (u01)  // (never with the large tile: `views` come with the in-kernel generator)
+      hipLaunchKernelGGL((k_bin_sort<false, EV_TILE>), dim3(nt), block, lds_sort, ctx->stream,
+                         events, toff, jarr, loc, nb, u01, cell_start, n_cell, p_length,
+                         length_bound, s_off, inc, ctx->pcg_tab, (const uint64_t *)nullptr,
+                         (const u128 *)nullptr);
+    else if (tile == EV_TILE_BIG)
+      hipLaunchKernelGGL((k_bin_sort<true, EV_TILE_BIG>), dim3(nt), block, lds_sort, ctx->stream,
+                         events, toff, jarr, loc, nb, u01, cell_start, n_cell, p_length,
+                         length_bound, s_off, inc, ctx->pcg_tab, dev_off,
+                         (const u128 *)ctx->pcg_aff);
     else
-      hipLaunchKernelGGL((k_bin_sort<true>), dim3(nt), block, lds_sort, ctx->stream, events, toff,
-                         jarr, loc, nb, u01, cell_start, n_cell, p_length, length_bound, s_off, inc,
-                         ctx->pcg_tab, dev_off, (const u128 *)ctx->pcg_aff);
+      hipLaunchKernelGGL((k_bin_sort<true, EV_TILE>), dim3(nt), block, lds_sort, ctx->stream,
+                         events, toff, jarr, loc, nb, u01, cell_start, n_cell, p_length,
+                         length_bound, s_off, inc, ctx->pcg_tab, dev_off,
+                         (const u128 *)ctx->pcg_aff);
 #define BUILD_LAUNCH(F)                                                                        \
   hipLaunchKernelGGL(k_bin_build2<F>, dim3(nb), block, lds_build, ctx->stream, (void *)rec,    \
-                     ovf_head, ovf_next, events, toff, jarr, nb, nt, idx0, p_length, length_bound, \
-                     bp)
+                     ovf_head, ovf_next, events, toff, jarr, nb, nt, tile, idx0, p_length,          \
+                     length_bound, bp)
     bp.chain_links = chain + padded;
     bp.loc = loc;
     bp.ssucc = (uint32_t *)(chain + 3 * padded);
@@ -792,7 +810,7 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
 }
 
 // k_bin_sort (declared above): the tile sort of the shuffle build
-template <bool RNG>
+template <bool RNG, int TILE>
 __global__ void __launch_bounds__(BIN_THREADS)
 k_bin_sort(int2 *__restrict__ events, int32_t *__restrict__ toff, int32_t *__restrict__ jarr,
            int32_t *__restrict__ loc, int n_bins, const double *__restrict__ u01,
@@ -802,7 +820,7 @@ k_bin_sort(int2 *__restrict__ events, int32_t *__restrict__ toff, int32_t *__res
            const u128 *__restrict__ aff) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int64_t length = p_length ? *p_length : length_arg;
-  bin_sort_body<RNG>(smem, events, toff, jarr, loc, n_bins, u01, cell_start, n_cell, length, -1,
+  bin_sort_body<RNG, TILE>(smem, events, toff, jarr, loc, n_bins, u01, cell_start, n_cell, length, -1,
                      s_off, inc, tab, dev_off, aff);
 }
 
@@ -811,8 +829,8 @@ __global__ void __launch_bounds__(BIN_THREADS)
 k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
              int32_t *__restrict__ ovf_next, const int2 *__restrict__ events,
              const int32_t *__restrict__ toff, const int32_t *__restrict__ jarr, int n_bins,
-             int n_tiles, const int64_t *__restrict__ idx0, const int64_t *__restrict__ p_length,
-             int64_t length_arg, BuildPrologue P) {
+             int n_tiles, int ev_tile, const int64_t *__restrict__ idx0,
+             const int64_t *__restrict__ p_length, int64_t length_arg, BuildPrologue P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // (SDM_REC_CHAIN: five - a position with more hits than inline slots sends every thread that
   // asks about it through a list in global memory, and with four slots nearly every wavefront
@@ -885,7 +903,7 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
       a = row[0];
       b = row[1];
     }
-    const int2 *run = events + (int64_t)t * EV_TILE;  // (tile-major: the tile's own segment)
+    const int2 *run = events + (int64_t)t * ev_tile;  // (tile-major: the tile's own segment)
     int2 ev[RUN_AHEAD];
 #pragma unroll
     for (int k = 0; k < RUN_AHEAD; ++k) {
@@ -949,8 +967,8 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
     for (int t = t_first; t < n_tiles; t += t_step) {
       const int32_t *row = toff + (int64_t)t * (n_bins + 1) + bin;
       const int a = row[0], b = row[1];
-      const int2 *run = events + (int64_t)t * EV_TILE;
-      uint32_t *out = P.ssucc + (int64_t)t * EV_TILE;
+      const int2 *run = events + (int64_t)t * ev_tile;
+      uint32_t *out = P.ssucc + (int64_t)t * ev_tile;
       for (int x = a + sub; x < b; x += tpt) {
         const int2 e = run[x];
         out[x] = value_after(e.y - (int)base, e.x);

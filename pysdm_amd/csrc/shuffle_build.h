@@ -20,6 +20,9 @@
 #ifndef EV_TILE
 #define EV_TILE 4096     // events per K1 / K3 workgroup
 #endif
+// ... and 16384 where that makes a bin's run in a tile a whole 64-byte sector of successor words
+// again (2^20 < n_sd <= 2^22: 1024 bins; index.hip, shuffle_binned_async)
+#define EV_TILE_BIG 16384
 #define EV_PER_THREAD (EV_TILE / BIN_THREADS)  // K3
 #ifndef K1_PER_THREAD
 #define K1_PER_THREAD 4  // K1: sequential PCG64 steps per thread kept short
@@ -117,7 +120,7 @@ extern __device__ long long bin_prof[32];
 #endif
 
 // `one_cell_len` >= 0: the single cell [0, length) as the caller knows it (cell_start not read)
-template <bool RNG>
+template <bool RNG, int TILE = EV_TILE>
 __device__ __forceinline__ void
 bin_sort_body(char *smem, int2 *__restrict__ events, int32_t *__restrict__ toff,
               int32_t *__restrict__ jarr, int32_t *__restrict__ loc, int n_bins,
@@ -127,10 +130,12 @@ bin_sort_body(char *smem, int2 *__restrict__ events, int32_t *__restrict__ toff,
               const uint64_t *__restrict__ dev_off, const u128 *__restrict__ aff) {
   int32_t *lstart = (int32_t *)smem;                      // n_bins + 1
   int32_t *lcount = lstart + n_bins + 1;                  // n_bins
-  int2 *ev_buf = (int2 *)(lcount + ((n_bins + 1) & ~1));  // EV_TILE
+  int2 *ev_buf = (int2 *)(lcount + ((n_bins + 1) & ~1));  // TILE
   __shared__ u128 s_slot;
   BIN_MARK(0);
-  const int64_t tile_first = (int64_t)blockIdx.x * EV_TILE;
+  constexpr int PER = TILE / BIN_THREADS;  // consecutive events per thread
+  static_assert(PER * BIN_THREADS == TILE && TILE % PCG_AFF_STRIDE == 0, "tile shapes");
+  const int64_t tile_first = (int64_t)blockIdx.x * TILE;
   int32_t *my_off = toff + (int64_t)blockIdx.x * (n_bins + 1);
   if (tile_first >= length) {
     for (int b = threadIdx.x; b <= n_bins; b += BIN_THREADS) my_off[b] = 0;
@@ -141,14 +146,17 @@ bin_sort_body(char *smem, int2 *__restrict__ events, int32_t *__restrict__ toff,
   // one-workgroup-per-CU kernel.  Ready affine maps (ctx->pcg_aff) make them two 128-bit
   // multiply-adds per thread and nothing to wait for (4.6 + 1.2 us of this kernel's 12.5 were
   // the bit-by-bit jumps, `profiles/r02_bin_profile.txt`); otherwise bit by bit, the table in LDS
-  const bool ready = RNG && aff && !dev_off && EV_TILE == PCG_AFF_STRIDE &&
-                     (int64_t)blockIdx.x < PCG_AFF_TILES &&
-                     (BIN_THREADS - 1) * EV_PER_THREAD < PCG_AFF_SMALL;
+  // (a thread's run starts tid * PER draws into the tile: whole strides of the table + a rest)
+  constexpr int STRIDES = TILE / PCG_AFF_STRIDE;
+  const bool ready = RNG && aff && !dev_off &&
+                     ((int64_t)blockIdx.x + 1) * STRIDES <= PCG_AFF_TILES;
   __shared__ u128 ltab[128];
   u128 s_tile = 0;
   if (ready) {
-    s_tile = pcg_apply(pcg_apply(s_off, aff, PCG_AFF_SMALL + (int64_t)blockIdx.x), aff,
-                       (int64_t)threadIdx.x * EV_PER_THREAD);
+    const int into = (int)threadIdx.x * PER;
+    s_tile = pcg_apply(pcg_apply(s_off, aff, PCG_AFF_SMALL + (int64_t)blockIdx.x * STRIDES +
+                                                 into / PCG_AFF_STRIDE),
+                       aff, (int64_t)(into % PCG_AFF_STRIDE));
     __syncthreads();  // lcount is zero before anyone counts
   } else if (RNG) {
     if (threadIdx.x < 128) ltab[threadIdx.x] = tab[threadIdx.x];
@@ -157,7 +165,7 @@ bin_sort_body(char *smem, int2 *__restrict__ events, int32_t *__restrict__ toff,
     // dev_off (graph replay): s_off is the generator's initial state, the stream position comes
     // from the device
     if (threadIdx.x == 0)
-      s_slot = pcg_jump(s_off, tab, (uint64_t)blockIdx.x * EV_TILE + (dev_off ? dev_off[0] : 0));
+      s_slot = pcg_jump(s_off, tab, (uint64_t)blockIdx.x * TILE + (dev_off ? dev_off[0] : 0));
     __syncthreads();
     s_tile = s_slot;
   } else {
@@ -165,14 +173,14 @@ bin_sort_body(char *smem, int2 *__restrict__ events, int32_t *__restrict__ toff,
   }
   BIN_MARK(1);
   BIN_MARK(2);
-  const int64_t first = tile_first + (int64_t)threadIdx.x * EV_PER_THREAD;
-  int32_t j[EV_PER_THREAD];
-  targets_run<RNG, EV_PER_THREAD>(first, length, u01, cell_start, n_cell, s_tile, inc, tab, j,
+  const int64_t first = tile_first + (int64_t)threadIdx.x * PER;
+  int32_t j[PER];
+  targets_run<RNG, PER>(first, length, u01, cell_start, n_cell, s_tile, inc, tab, j,
                                   one_cell_len, ready);
   BIN_MARK(3);
-  int rank[EV_PER_THREAD];  // arrival number of the event in its bin: its place in the bin's run
+  int rank[PER];  // arrival number of the event in its bin: its place in the bin's run
 #pragma unroll
-  for (int e = 0; e < EV_PER_THREAD; ++e) {
+  for (int e = 0; e < PER; ++e) {
     rank[e] = j[e] >= 0 ? atomicAdd(&lcount[j[e] >> BIN_SHIFT], 1) : 0;
     if (first + e < length) jarr[first + e] = j[e];
   }
@@ -196,7 +204,7 @@ bin_sort_body(char *smem, int2 *__restrict__ events, int32_t *__restrict__ toff,
   __syncthreads();
   BIN_MARK(5);
 #pragma unroll
-  for (int e = 0; e < EV_PER_THREAD; ++e)
+  for (int e = 0; e < PER; ++e)
     if (j[e] >= 0) {
       const int b = j[e] >> BIN_SHIFT;
       const int at = lstart[b] + rank[e];

@@ -201,14 +201,18 @@ def test_adaptive_steps_in_one_call_equal_oracle(name, n_sd, steps, dt, thin, hi
         assert int(snaps[0]["length"]) < n_sd
 
 
-@pytest.mark.parametrize("n_sd", [2**21 - 2, 2**21 - 1, 2**20 - 3])
-def test_record_layouts_at_their_size_limits(n_sd, hip_engine, oracle_engine):
-    """the shuffle records switch layout with the size (21-bit fields with four inline hits up to
-    2^21 - 2 positions, 24-bit fields with three above): same permutation and state either side
-    of the limit, and for an odd count (an unpaired last position)"""
+@pytest.mark.parametrize("n_sd,adaptive", [
+    (2**21 - 2, False), (2**21 - 1, False), (2**20 - 3, False),
+    (2**20 + 1, True), (2**22 - 1, True), (2**22 + 1, True)])
+def test_record_layouts_at_their_size_limits(n_sd, adaptive, hip_engine, oracle_engine):
+    """the shuffle's hand-over switches layout with the size - successor words up to 2^20 positions
+    (event tiles of 4096) and, where no tile sort rides in a pair kernel, up to 2^22 (tiles of
+    16384: the adaptive cases); records with 21-bit fields and four inline hits up to 2^21 - 2,
+    with 24-bit fields and three above: same permutation and state either side of each limit, and
+    for an odd count (an unpaired last position)"""
     snaps = []
     for engine in (hip_engine, oracle_engine):
-        runner = make_box(engine, "shima", n_sd=n_sd, adaptive=False)
+        runner = make_box(engine, "shima", n_sd=n_sd, adaptive=adaptive)
         run(runner, 3)
         snaps.append(runner.snapshot())
     assert_same(snaps[0], snaps[1])
