@@ -3033,6 +3033,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         SortBuffers B;
         sdm_shuffle_sort_buffers(S.shuffle, N, &B);
         SortAhead X;
+        memset(&X, 0, sizeof(X));
         X.events = B.events;
         X.toff = B.toff;
         X.jarr = B.jarr;
