@@ -21,6 +21,7 @@ typedef unsigned __int128 u128;
 struct ShufRec;  // shuffle.hip
 
 // ---- context ---------------------------------------------------------------------------
+#define SDM_DEAD_LIST_CAP 4096  // = index.hip's COMPACT_WAVES: the list is sorted in that much LDS
 struct sdm_ctx {
   int device;
   hipStream_t stream;
@@ -112,6 +113,12 @@ struct sdm_ctx {
   int64_t *dscal;
   // single-cell collision counters, spread over SDM_CNT_SLOTS cache lines (fused.hip)
   int64_t *cnt_slots;
+  // adaptive steps of one cell: the positions of a sub-step's dead (SDM_DEAD_LIST_CAP words), two
+  // counters on lines of their own, used in turn by sub-step number `dead_seq` (index.h:
+  // CompactEpilogue)
+  int64_t *dead_pos;
+  unsigned long long *dead_ctr;
+  uint64_t dead_seq;
   // optional per-phase timing with HIP events on the ctx stream (bench / profiling only)
   bool timing;
   hipEvent_t *ev;      // pool of SDM_MAX_EVENTS events

@@ -29,6 +29,9 @@ static int ctx_allocate(sdm_ctx *ctx) {
   HIP_TRY(hipMemset(ctx->dscal, 0, sizeof(int64_t) * 16));
   HIP_TRY(hipMalloc((void **)&ctx->cnt_slots, sizeof(int64_t) * SDM_CNT_SLOTS * SDM_CNT_STRIDE));
   HIP_TRY(hipMemset(ctx->cnt_slots, 0, sizeof(int64_t) * SDM_CNT_SLOTS * SDM_CNT_STRIDE));
+  HIP_TRY(hipMalloc((void **)&ctx->dead_pos, sizeof(int64_t) * SDM_DEAD_LIST_CAP));
+  HIP_TRY(hipMalloc((void **)&ctx->dead_ctr, sizeof(unsigned long long) * 32));
+  HIP_TRY(hipMemset(ctx->dead_ctr, 0, sizeof(unsigned long long) * 32));
   return SDM_OK;
 }
 
@@ -94,6 +97,8 @@ extern "C" int sdm_ctx_destroy(sdm_ctx *ctx) {
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   if (ctx->dscal) (void)hipFree(ctx->dscal);
   if (ctx->cnt_slots) (void)hipFree(ctx->cnt_slots);
+  if (ctx->dead_pos) (void)hipFree(ctx->dead_pos);
+  if (ctx->dead_ctr) (void)hipFree(ctx->dead_ctr);
   if (ctx->rain_carry) (void)hipFree(ctx->rain_carry);
   if (ctx->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)ctx->graph_exec);
   free(ctx->graph_key);

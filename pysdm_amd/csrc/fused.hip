@@ -62,6 +62,11 @@ struct FusedArgs {
   // where they are flagged (the list of their positions is built only once the exchange of the
   // counts has shown that somebody's did: k_shard_dead_list); NULL otherwise
   unsigned long long *n_dead;
+  // adaptive steps of one cell: the positions of the dead are listed as they are flagged (at most
+  // SDM_DEAD_LIST_CAP are kept; the count goes on), for a compaction without a pass over the
+  // permutation (index.hip: compact_listed_body); NULL otherwise
+  int64_t *dead_pos;
+  unsigned long long *dead_count;
   // sharded adaptive per-cell route: minus the deaths per SEGMENT of the permutation (k_cells_turn's
   // min_out + n_cell: completed over the processes by the same all-reduce MIN as the cell minima)
   double *seg_deaths;
@@ -683,6 +688,14 @@ __device__ __forceinline__ void flag_dead(const sdm_step_cfg &cfg, int64_t *__re
                                           int64_t pos, int died, const FusedArgs *A = nullptr) {
   if (died & 1) idx[pos] = cfg.n_sd;
   if (died & 2) idx[pos + 1] = cfg.n_sd;
+  if (A && died && A->dead_count) {
+    const int k = (died & 1) + (died >> 1);
+    const unsigned long long at = atomicAdd(A->dead_count, (unsigned long long)k);
+    if (at + k <= SDM_DEAD_LIST_CAP) {
+      if (died & 1) A->dead_pos[at] = pos;
+      if (died & 2) A->dead_pos[at + (died & 1)] = pos + 1;
+    }
+  }
   if (A && died && (A->n_dead || A->seg_deaths))
     note_deaths(*A, A->seg_deaths ? find_cell(A->cell_start, cfg.n_cell, pos) : 0, died);
 }
@@ -2227,6 +2240,8 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     if (ctx->cnt_slots)
       (void)hipMemsetAsync(ctx->cnt_slots, 0, sizeof(int64_t) * SDM_CNT_SLOTS * SDM_CNT_STRIDE,
                            ctx->stream);
+    if (ctx->dead_ctr)
+      (void)hipMemsetAsync(ctx->dead_ctr, 0, sizeof(unsigned long long) * 32, ctx->stream);
     sdm_set_error("adaptive time step did not end within %lld sub-steps (dt = %g, dt_min = %g): "
                   "the state is inconsistent - a cell_start that does not belong to the "
                   "permutation, or dt_left edited from outside.  Control block {valid %lld, "
@@ -3017,6 +3032,12 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       A.list_cap = S.flat_list_cap;
     }
     }  // !head_ok
+    // one adaptive cell: the kernels below list the positions of the dead for the compaction
+    const bool list_dead = C == 1 && cfg->adaptive && !sharded && !ctx->graph_capture;
+    if (list_dead) {
+      A.dead_pos = ctx->dead_pos;
+      A.dead_count = ctx->dead_ctr + (ctx->dead_seq & 1) * 16;
+    }
     // (e)+(f) probabilities, gamma, update
     if (cell_path) {
       // done by k_cell_step above
@@ -3116,6 +3137,12 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         epilogue.slots = cfg->enable_breakup ? A.slots : nullptr;  // refused-breakup count
         epilogue.box = ctx->box_dev;
         epilogue.seq = box_seq;
+      }
+      if (list_dead) {
+        epilogue.dead_pos = A.dead_pos;
+        epilogue.dead_count = A.dead_count;
+        epilogue.dead_count_next = ctx->dead_ctr + ((ctx->dead_seq & 1) ^ 1) * 16;
+        ctx->dead_seq += 1;
       }
       if (sort_ahead) {
         // the next build runs the compaction itself if a super-droplet died (k_bin_build2)

@@ -87,6 +87,14 @@ struct CompactEpilogue {
   // graph replay (common.h: gwords): stream positions advanced by these at the kernel's start
   uint64_t *gwords;
   uint64_t advance, advance_b;
+  // the positions of this sub-step's dead as a list (fused.hip: flag_dead appends them): up to
+  // COMPACT_WAVES of them are removed by ONE workgroup without a pass over the permutation
+  // (compact_listed_body).  `dead_count` is read-only in the kernel - every workgroup must see the
+  // same number - and the counter of the NEXT sub-step is cleared instead (two counters, used in
+  // turn).  NULL: no list
+  const int64_t *dead_pos;
+  const unsigned long long *dead_count;
+  unsigned long long *dead_count_next;
 };
 int sdm_resort_plan(sdm_ctx *ctx, char *scratch, int64_t length_bound, const int64_t *cctl,
                     const int64_t *fctl, const int64_t *cell_start, int64_t n_cell, int64_t *plan,

@@ -598,6 +598,75 @@ __device__ __forceinline__ bool grid_barrier(unsigned int *bar, unsigned int tar
   return ok;
 }
 
+// ---- compaction from a LIST of the positions to remove ---------------------------------------
+// Where the positions of the dead are known as a list (sharded steps: they were exchanged; adaptive
+// steps of one cell: the kernels that flag them also list them) the reference's swap-from-the-end
+// (collisions_methods.py:664-680; compact_run below) needs no pass over the permutation - the r-th
+// hole of the surviving prefix (ascending) takes the r-th live element of the tail (from the end
+// backwards), and only the d tail positions and the d listed ones are touched.  One workgroup of
+// 1024; p: LDS for the next power of two >= d positions.  Leaves what compact_run leaves: holes[]
+// (ascending) and ctl[2] = their number for the closed-form re-sort, the control words committed.
+// 41-47 us -> ~10 us per removal at 2^22 positions.
+__device__ __forceinline__ void
+compact_listed_body(int32_t *p, int64_t *__restrict__ idx, const int64_t *__restrict__ dead,
+                    int64_t d, int64_t flag, int64_t *__restrict__ fctl, int64_t *__restrict__ ctl,
+                    int32_t *__restrict__ holes, int64_t *__restrict__ cell_start_single) {
+  const int64_t length = fctl[FCTL_VALID], new_len = length - d;
+  int n2 = 1;
+  while (n2 < d) n2 <<= 1;
+  for (int t = threadIdx.x; t < n2; t += 1024) p[t] = t < d ? (int32_t)dead[t] : INT32_MAX;
+  __syncthreads();
+  for (int k = 2; k <= n2; k <<= 1)  // bitonic sort, ascending
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < n2; t += 1024) {
+        const int o = t ^ j;
+        if (o > t) {
+          const int32_t a = p[t], b = p[o];
+          if (((t & k) == 0) == (a > b)) { p[t] = b; p[o] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  // number of listed positions below x (the list is sorted)
+  auto below = [&](int64_t x) -> int {
+    int lo = 0, hi = (int)d;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (p[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  const int h = below(new_len);  // holes: the listed positions of the surviving prefix
+  for (int t = threadIdx.x; t < d; t += 1024) {
+    const int64_t x = length - 1 - t;  // the tail, from the end backwards
+    const int b = below(x);
+    const bool is_dead = b < d && p[b] == x;
+    if (!is_dead) {
+      const int r = t - ((int)d - below(x + 1));  // live tail elements above x
+      const int64_t filler = idx[x];
+      idx[p[r]] = filler;
+    }
+    if (t < h) holes[t] = p[t];
+  }
+  __syncthreads();  // (every filler was read before its tail slot takes the flag)
+  for (int t = threadIdx.x; t < d; t += 1024) idx[new_len + t] = flag;
+  if (threadIdx.x == 0) {
+    ctl[0] = length;
+    ctl[1] = new_len;
+    ctl[2] = h;
+    ctl[3] = d;
+    fctl[FCTL_VALID] = new_len;
+    fctl[FCTL_WORK] = new_len;
+    fctl[FCTL_HEALTHY] = 1;
+    if (cell_start_single) {
+      cell_start_single[0] = 0;
+      cell_start_single[1] = new_len;
+    } else {
+      fctl[FCTL_SORTED] = 0;
+    }
+  }
+}
+
 #define COMPACT_UNROLL 8
 // "dead" of lane's position in COMPACT_UNROLL consecutive tiles (false beyond tile_end / length);
 // val (optional): the idx values read
@@ -799,12 +868,25 @@ k_compact_persistent(const int64_t *__restrict__ multiplicity, int64_t *__restri
     E.gwords[0] += E.advance;
     E.gwords[1] += E.advance_b;
   }
+  // (the other counter: nobody reads it in this launch, the next sub-step's kernels add to it)
+  if (E.dead_count_next && blockIdx.x == 0 && threadIdx.x == 0) *E.dead_count_next = 0;
   if (fctl[FCTL_HEALTHY] != 0) {
     if (E.dt_left && blockIdx.x == 0) compact_epilogue(E, fctl);
     return;
   }
   int64_t new_len;
   __shared__ int excl[COMPACT_WAVES];
+  if (E.dead_count) {
+    const unsigned long long d = *E.dead_count;  // the same for every workgroup: written before
+    if (d >= 1 && d <= COMPACT_WAVES) {          // this launch, cleared by the next one
+      if (blockIdx.x != 0) return;
+      compact_listed_body((int32_t *)excl, idx, E.dead_pos, (int64_t)d, flag, fctl, ctl, holes,
+                          cell_start_single);
+      __syncthreads();
+      if (E.dt_left) compact_epilogue(E, fctl);
+      return;
+    }
+  }
   (void)compact_run<FLAG_ONLY>(multiplicity, idx, flag, fctl, wave_dead, n_tiles, ctl, holes,
                                fillers, cell_start_single, bar, E, &new_len, excl);
 }
@@ -1052,74 +1134,14 @@ int sdm_compact_fused_async(sdm_ctx *ctx, char *scratch, const int64_t *multipli
   return SDM_OK;
 }
 
-// ---- compaction from a LIST of the positions to remove ---------------------------------------
-// Sharded steps know the positions of the dead as a list (they were exchanged): the reference's
-// swap-from-the-end (collisions_methods.py:664-680; compact_run above) then needs no pass over the
-// permutation - the r-th hole of the surviving prefix (ascending) takes the r-th live element of
-// the tail (from the end backwards), and only the d tail positions and the d listed ones are
-// touched.  One workgroup; d <= COMPACT_LIST_CAP (more: the full kernel).  Leaves what compact_run
-// leaves: holes[] (ascending) and ctl[2] = their number for the closed-form re-sort, the control
-// words committed.  41-47 us -> a few us per removal at 2^22 positions.
+// the list handed over by the host: d <= COMPACT_LIST_CAP (more: the full kernel)
 #define COMPACT_LIST_CAP 8192
 __global__ void __launch_bounds__(1024)
 k_compact_listed(int64_t *__restrict__ idx, const int64_t *__restrict__ dead, int64_t d,
                  int64_t flag, int64_t *__restrict__ fctl, int64_t *__restrict__ ctl,
                  int32_t *__restrict__ holes, int64_t *__restrict__ cell_start_single) {
   __shared__ int32_t p[COMPACT_LIST_CAP];
-  const int64_t length = fctl[FCTL_VALID], new_len = length - d;
-  int n2 = 1;
-  while (n2 < d) n2 <<= 1;
-  for (int t = threadIdx.x; t < n2; t += 1024) p[t] = t < d ? (int32_t)dead[t] : INT32_MAX;
-  __syncthreads();
-  for (int k = 2; k <= n2; k <<= 1)  // bitonic sort, ascending
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = threadIdx.x; t < n2; t += 1024) {
-        const int o = t ^ j;
-        if (o > t) {
-          const int32_t a = p[t], b = p[o];
-          if (((t & k) == 0) == (a > b)) { p[t] = b; p[o] = a; }
-        }
-      }
-      __syncthreads();
-    }
-  // number of listed positions below x (the list is sorted)
-  auto below = [&](int64_t x) -> int {
-    int lo = 0, hi = (int)d;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (p[mid] < x) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-  };
-  const int h = below(new_len);  // holes: the listed positions of the surviving prefix
-  for (int t = threadIdx.x; t < d; t += 1024) {
-    const int64_t x = length - 1 - t;  // the tail, from the end backwards
-    const int b = below(x);
-    const bool is_dead = b < d && p[b] == x;
-    if (!is_dead) {
-      const int r = t - ((int)d - below(x + 1));  // live tail elements above x
-      const int64_t filler = idx[x];
-      idx[p[r]] = filler;
-    }
-    if (t < h) holes[t] = p[t];
-  }
-  __syncthreads();  // (every filler was read before its tail slot takes the flag)
-  for (int t = threadIdx.x; t < d; t += 1024) idx[new_len + t] = flag;
-  if (threadIdx.x == 0) {
-    ctl[0] = length;
-    ctl[1] = new_len;
-    ctl[2] = h;
-    ctl[3] = d;
-    fctl[FCTL_VALID] = new_len;
-    fctl[FCTL_WORK] = new_len;
-    fctl[FCTL_HEALTHY] = 1;
-    if (cell_start_single) {
-      cell_start_single[0] = 0;
-      cell_start_single[1] = new_len;
-    } else {
-      fctl[FCTL_SORTED] = 0;
-    }
-  }
+  compact_listed_body(p, idx, dead, d, flag, fctl, ctl, holes, cell_start_single);
 }
 
 // `dead`: d distinct positions < fctl[0], all flagged in idx already (device list); scratch and
