@@ -998,12 +998,13 @@ struct TurnArgs {
   int64_t seq;       // publication number of the sub-step that ended (0: nothing to publish)
 };
 
-// (TURN_GROUP cells per workgroup: what is read of all cells - their dt_left and minima - serves
-// the ranks of the group's cells together; 1024 workgroups reading everything for one rank each
-// took 8.6 us at 1024 cells, a seventh of a sub-step of a process that owns 128 of them)
-#ifndef TURN_GROUP
-#define TURN_GROUP 1
-#endif
+// TURN_GROUP cells per workgroup: what is read of all cells - their dt_left and minima - serves
+// the ranks of the group's cells together.  One cell per workgroup is fastest at 1024 cells (7.9
+// against 10.6 us with eight: the kernel is a chain of latencies there, and the eight-fold compare
+// lengthens it), but the work grows with the SQUARE of the number of cells: 45 us at 75 x 75 =
+// 5625 cells, more than that grid's cell kernel (40 us) - eight per workgroup there, sixteen beyond
+// 8192 cells
+template <int TURN_GROUP>
 __global__ void __launch_bounds__(SDM_BLOCK) k_cells_turn(sdm_step_cfg cfg, FusedArgs A, TurnArgs T) {
   __shared__ int sm_rank[SDM_BLOCK / SDM_WAVE][TURN_GROUP];
   __shared__ int sm_top[SDM_BLOCK / SDM_WAVE], sm_flags[SDM_BLOCK / SDM_WAVE];
@@ -2688,8 +2689,13 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       T.sharded = sharded ? 1 : 0;
       T.box = ctx->box_dev;
       T.seq = pending_seq;
-      hipLaunchKernelGGL(k_cells_turn, dim3((unsigned)((C + TURN_GROUP - 1) / TURN_GROUP)), blk, 0,
-                         s, *cfg, A, T);
+      if (C <= 2048)
+        hipLaunchKernelGGL(k_cells_turn<1>, dim3((unsigned)C), blk, 0, s, *cfg, A, T);
+      else if (C <= 8192)
+        hipLaunchKernelGGL(k_cells_turn<8>, dim3((unsigned)((C + 7) / 8)), blk, 0, s, *cfg, A, T);
+      else
+        hipLaunchKernelGGL(k_cells_turn<16>, dim3((unsigned)((C + 15) / 16)), blk, 0, s, *cfg, A,
+                           T);
       LAUNCH_CHECK();
       fill_pending = false;
       left_cur ^= 1;

@@ -256,6 +256,21 @@ def test_both_per_cell_kernels_equal_oracle(n_sd, which, hip_engine, oracle_engi
     assert_same(snaps[0], snaps[1])
 
 
+@pytest.mark.parametrize("grid,n_sd", [((48, 48), 2304 * 24), ((96, 96), 9216 * 10)])
+def test_grids_of_thousands_of_cells_equal_oracle(grid, n_sd, hip_engine, oracle_engine):
+    """k_cells_turn ranks the cells' dt_left eight cells per workgroup above 2048 cells and sixteen
+    above 8192 (one below): adaptive geometric coalescence on 2304 and 9216 small cells (the packed
+    shape of the cell kernel), state, counters and sub-step statistics equal the oracle's"""
+    snaps = []
+    for engine in (hip_engine, oracle_engine):
+        runner = make_box(engine, "kinematic2d", n_sd=n_sd, grid=grid)
+        for steps in (1, 5, 2):
+            runner.run(steps)
+        snaps.append(runner.snapshot())
+    assert snaps[1]["collision_rate"].sum() > 0 and snaps[1]["stats_n_substep"].max() > 8
+    assert_same(snaps[0], snaps[1])
+
+
 @pytest.mark.parametrize("base", ["kinematic2d", "straub"])
 def test_every_shape_of_the_cell_kernel_equals_oracle(base, hip_engine, oracle_engine):
     """SDM_OPT_CELL_SHAPE: 2 x 2 cells of ~2000 fit all three shapes of k_cell_step2 (512, 1024 and
