@@ -421,11 +421,16 @@ typedef struct sdm_step_cfg {
  * those cells are exact: every other segment holds as many ids as the cell has members, each an
  * id of that cell - all the replicated compaction and the stable counting sort need to put the
  * owned segments into the reference's order.  The library calls `exchange` where global data is
- * needed: after every sub-step a sum over processes of n_cell + 1 + shard_world doubles (masked
- * dt_left; how many super-droplets died, in total and per process), and - only when one died -
- * a sum of rank-disjoint slices holding the POSITIONS of the dead (exactly as many int64 as
- * died): every process flags those positions and runs the compaction and the counting sort on its
- * own copy.  No super-droplet payload and no permutation crosses processes in a collision step.
+ * needed.  After every sub-step ONE all-reduce: on the per-cell adaptive route (local croupier,
+ * cells of at most 6144) a MINIMUM over 2 n_cell doubles - per cell id the minimum of the optimal
+ * sub-step over the cell's pairs (+inf from everybody but the owner), per segment of the
+ * permutation minus the number of super-droplets that died in it - from which every process
+ * derives dt_left, the order of the cells and the working length by itself; on the other routes a
+ * SUM over n_cell + 1 + shard_world doubles (masked dt_left; how many died, in total and per
+ * process).  And - only when one died - a sum of rank-disjoint slices holding the POSITIONS of the
+ * dead (exactly as many int64 as died; ordered by segment on the per-cell route, by process on the
+ * others): every process flags those positions and runs the compaction and the counting sort on
+ * its own copy.  No super-droplet payload and no permutation crosses processes in a collision step.
  * The concatenation of the owned cells equals the one-process result bit for bit.            */
 #define SDM_XCHG_SUM_F64 1 /* buffer = device double[count]: in-place sum over all processes */
 #define SDM_XCHG_SUM_I64 2 /* buffer = device int64[count] */
