@@ -978,6 +978,22 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
   BIN_MARK(10);
   // hits on this bin's positions: the first SLOTS inline (claimed by compare-and-swap), rest listed
   constexpr int RUN_AHEAD = 8;
+  // (the first RUN_AHEAD events of the thread's FIRST tile - at 2^20 positions its only one - stay
+  // in registers: the S pass below needs the same events again)
+  int2 ev0[RUN_AHEAD];
+#pragma unroll
+  for (int k = 0; k < RUN_AHEAD; ++k) ev0[k] = make_int2(-1, 0);
+  auto place = [&](int2 e) {
+    const int q = e.y - (int)base;
+    bool placed = false;
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k)
+      if (!placed) placed = atomicCAS(&slot[k * BIN_POS + q], -1, e.x) == -1;
+    // (-1 terminated, built entirely here; SDM_REC_CHAIN keeps the links in scratch of their own:
+    // ovf_next is its ssucc table)
+    if (!placed)
+      (FMT == SDM_REC_CHAIN ? P.chain_links : ovf_next)[e.x] = atomicExch(&head[q], e.x);
+  };
   for (int t = t_first; t < n_tiles; t += t_step) {
     int a = a_first, b = b_first;
     if (t != t_first) {
@@ -992,17 +1008,10 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
       const int x = a + sub + k * tpt;
       ev[k] = x < b ? run[x] : make_int2(-1, 0);
     }
-    auto place = [&](int2 e) {
-      const int q = e.y - (int)base;
-      bool placed = false;
+    if (t == t_first) {
 #pragma unroll
-      for (int k = 0; k < SLOTS; ++k)
-        if (!placed) placed = atomicCAS(&slot[k * BIN_POS + q], -1, e.x) == -1;
-      // (-1 terminated, built entirely here; SDM_REC_CHAIN keeps the links in scratch of their own:
-      // ovf_next is its ssucc table)
-      if (!placed)
-        (FMT == SDM_REC_CHAIN ? P.chain_links : ovf_next)[e.x] = atomicExch(&head[q], e.x);
-    };
+      for (int k = 0; k < RUN_AHEAD; ++k) ev0[k] = ev[k];
+    }
 #pragma unroll
     for (int k = 0; k < RUN_AHEAD; ++k)
       if (ev[k].x >= 0) place(ev[k]);
@@ -1047,11 +1056,23 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
     // the S word of every event that hits this bin, written where the event was read: the same
     // runs of the tile-sorted array, the same threads
     for (int t = t_first; t < n_tiles; t += t_step) {
-      const int32_t *row = toff + (int64_t)t * (n_bins + 1) + bin;
-      const int a = row[0], b = row[1];
+      int a = a_first, b = b_first;
+      if (t != t_first) {
+        const int32_t *row = toff + (int64_t)t * (n_bins + 1) + bin;
+        a = row[0];
+        b = row[1];
+      }
       const int2 *run = events + (int64_t)t * ev_tile;
       uint32_t *out = P.ssucc + (int64_t)t * ev_tile;
-      for (int x = a + sub; x < b; x += tpt) {
+      int x = a + sub;
+      if (t == t_first) {  // from the registers of the placing pass
+#pragma unroll
+        for (int k = 0; k < RUN_AHEAD; ++k) {
+          if (ev0[k].x >= 0) out[x] = value_after(ev0[k].y - (int)base, ev0[k].x);
+          x += tpt;
+        }
+      }
+      for (; x < b; x += tpt) {
         const int2 e = run[x];
         out[x] = value_after(e.y - (int)base, e.x);
       }
