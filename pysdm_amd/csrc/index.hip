@@ -971,7 +971,9 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
     a_first = row[0];
     b_first = row[1];
   }
-  for (int q = threadIdx.x; q < (SLOTS + 1) * BIN_POS; q += BIN_THREADS) slot[q] = -1;
+  // (16 bytes per store: the slots and list heads are 96 KB with five slots)
+  for (int q = threadIdx.x; q < (SLOTS + 1) * BIN_POS / 4; q += BIN_THREADS)
+    ((int4 *)slot)[q] = make_int4(-1, -1, -1, -1);
   BIN_MARK(9);
   // LDS only: __syncthreads() would also wait for the global loads requested above
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
