@@ -949,19 +949,13 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
   BIN_MARK(8);
   const int bin = blockIdx.x;
   constexpr int PER_POS = BIN_POS / BIN_THREADS;
-  // what the records need from memory besides the hits, requested now, used at the end
-  int64_t id_v[PER_POS];
-  int32_t j_v[PER_POS], loc_v[PER_POS];
-#pragma unroll
-  for (int k = 0; k < PER_POS; ++k) {
-    const int64_t p = base + threadIdx.x + k * BIN_THREADS;
-    id_v[k] = p < length ? idx0[p] : 0;
-    j_v[k] = p < length ? jarr[p] : -1;
-    loc_v[k] = (FMT == SDM_REC_CHAIN && p < length) ? P.loc[p] : -1;
-  }
   // this bin's run in every tile's segment: `tpt` threads share a tile (4 at 2^20
   // super-droplets: runs hold ~16 events), each takes every tpt-th event of the run; the first
-  // RUN_AHEAD of them are requested before any is placed
+  // RUN_AHEAD of them are requested before any is placed.
+  // Order of the requests: the kernel is two dependent memory round trips (a run's bounds, then its
+  // events) around LDS work, and loads return in the order they were issued - so the bounds go
+  // first, the slot initialisation runs while they travel, the events of the thread's first tile
+  // are requested BEFORE the barrier, and what is only needed at the end comes last
   const int tpt = n_tiles >= BIN_THREADS ? 1 : BIN_THREADS / n_tiles;
   const int sub = threadIdx.x % tpt, t_step = BIN_THREADS / tpt;
   const int t_first = threadIdx.x / tpt;
@@ -974,17 +968,33 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
   // (16 bytes per store: the slots and list heads are 96 KB with five slots)
   for (int q = threadIdx.x; q < (SLOTS + 1) * BIN_POS / 4; q += BIN_THREADS)
     ((int4 *)slot)[q] = make_int4(-1, -1, -1, -1);
+  constexpr int RUN_AHEAD = 8;
+  // (the first RUN_AHEAD events of the thread's FIRST tile - at 2^20 positions its only one - stay
+  // in registers: the S pass below needs the same events again)
+  int2 ev0[RUN_AHEAD];
+  {
+    const int2 *run = events + (int64_t)t_first * ev_tile;
+#pragma unroll
+    for (int k = 0; k < RUN_AHEAD; ++k) {
+      const int x = a_first + sub + k * tpt;
+      ev0[k] = x < b_first ? run[x] : make_int2(-1, 0);  // (b_first = 0 beyond the last tile)
+    }
+  }
+  // what the records need from memory besides the hits, requested now, used at the end
+  int64_t id_v[PER_POS];
+  int32_t j_v[PER_POS], loc_v[PER_POS];
+#pragma unroll
+  for (int k = 0; k < PER_POS; ++k) {
+    const int64_t p = base + threadIdx.x + k * BIN_THREADS;
+    id_v[k] = p < length ? idx0[p] : 0;
+    j_v[k] = p < length ? jarr[p] : -1;
+    loc_v[k] = (FMT == SDM_REC_CHAIN && p < length) ? P.loc[p] : -1;
+  }
   BIN_MARK(9);
   // LDS only: __syncthreads() would also wait for the global loads requested above
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   BIN_MARK(10);
   // hits on this bin's positions: the first SLOTS inline (claimed by compare-and-swap), rest listed
-  constexpr int RUN_AHEAD = 8;
-  // (the first RUN_AHEAD events of the thread's FIRST tile - at 2^20 positions its only one - stay
-  // in registers: the S pass below needs the same events again)
-  int2 ev0[RUN_AHEAD];
-#pragma unroll
-  for (int k = 0; k < RUN_AHEAD; ++k) ev0[k] = make_int2(-1, 0);
   auto place = [&](int2 e) {
     const int q = e.y - (int)base;
     bool placed = false;
@@ -1008,11 +1018,7 @@ k_bin_build2(void *__restrict__ rec_out, int32_t *__restrict__ ovf_head,
 #pragma unroll
     for (int k = 0; k < RUN_AHEAD; ++k) {
       const int x = a + sub + k * tpt;
-      ev[k] = x < b ? run[x] : make_int2(-1, 0);
-    }
-    if (t == t_first) {
-#pragma unroll
-      for (int k = 0; k < RUN_AHEAD; ++k) ev0[k] = ev[k];
+      ev[k] = t == t_first ? ev0[k] : (x < b ? run[x] : make_int2(-1, 0));
     }
 #pragma unroll
     for (int k = 0; k < RUN_AHEAD; ++k)
