@@ -109,7 +109,8 @@ struct sdm_ctx {
   // displacement.hip (sharded step): precipitated masses by position, zero between uses
   double *rain_carry;
   int64_t rain_carry_len;
-  // device control words for fine-grained calls (int64[16])
+  // device control words for fine-grained calls (int64[16]; word 6: dt_left[0] of an adaptive
+  // single cell for the next sub-step, fused.hip; 8: a length; 10-11: adaptive_end; 12-15: barrier)
   int64_t *dscal;
   // single-cell collision counters, spread over SDM_CNT_SLOTS cache lines (fused.hip)
   int64_t *cnt_slots;

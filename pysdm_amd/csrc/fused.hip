@@ -88,6 +88,12 @@ struct FusedArgs {
   double *dt_todo, *cell_min;  // [C]
   double *block_min;           // single cell: per-workgroup partial minima of the optimal dt
   int n_block_min;
+  // single adaptive cell, at most 2048 partial minima: k_pair_update does k_cells_adaptive's work
+  // itself (0: no; 1: yes; 2: yes, and this is the first sub-step of the time step).  dt_left_pub:
+  // dt_left[0] as the previous sub-step left it, in a word nobody writes during this kernel (the
+  // compaction's epilogue copies it there)
+  int fold_pre;
+  const double *dt_left_pub;
   // single-cell fast path: the pair kernels do the shuffle's backward walk themselves (two
   // positions per thread) and write the permuted, pair-sorted idx once; NULL otherwise
   const void *rec;  // records of layout rec_fmt (shuffle_device.h: SDM_REC_*)
@@ -1145,6 +1151,51 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_update(sdm_step_cfg cfg, Fus
                                            A.rng_aff)
                              : 0.0;
   const bool in_range = d < W / 2;
+  // One adaptive cell: the per-cell bookkeeping of collisions_methods.py:357-374 needs the minimum
+  // over ALL pairs - a kernel boundary after k_pair_prob - but not a kernel: every workgroup folds
+  // the partial minima for itself (16 KB from L2 at 2^20 super-droplets, requested before the
+  // stored probability is), workgroup 0 writes the cell's words.  Saves the k_cells_adaptive
+  // launch (4.9 us + a boundary per sub-step)
+  double todo = 0;
+  if (A.fold_pre) {
+    __shared__ double wmin[SDM_BLOCK / SDM_WAVE];
+    __shared__ double s_todo;
+    double m = INFINITY;
+    for (int b0 = threadIdx.x; b0 < A.n_block_min; b0 += 8 * SDM_BLOCK) {
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int b = b0 + k * SDM_BLOCK;
+        v[k] = b < A.n_block_min ? A.block_min[b] : INFINITY;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m = v[k] < m ? v[k] : m;
+    }
+    m = wave_min_f64(m);
+    if (lane_id() == 0) wmin[threadIdx.x / SDM_WAVE] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < SDM_BLOCK / SDM_WAVE; ++w) m = wmin[w] < m ? wmin[w] : m;
+      const double l = A.fold_pre == 2 ? cfg.dt : A.dt_left_pub[0];
+      double t = cfg.dt_max < l ? cfg.dt_max : l;  // Python min(l, dt_max)
+      if (m < t) t = m;
+      s_todo = t;
+      if (blockIdx.x == 0) {
+        A.cell_min[0] = m;
+        if (W != 0) {
+          A.dt_todo[0] = t;
+          const double s = A.stats_dt_min[0];
+          const double s_new = m < s ? m : s;  // Python min(s, m): NaN-sticky
+          A.stats_dt_min[0] = s_new;
+          note_dt_min(A.ctl, s_new, cfg.dt_min);
+          A.dt_left[0] = l - t;
+          if (t > 0) A.stats_n_substep[0] += 1;
+        }
+      }
+    }
+    __syncthreads();
+    todo = s_todo;
+  }
   double p = 0;
   int64_t off = 2;
   if (in_range) {
@@ -1152,7 +1203,7 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_pair_update(sdm_step_cfg cfg, Fus
     off = A.pair_off[d];
     if (p != 0) {
       const int64_t cid = cfg.n_cell > 1 ? A.pair_cid[d] : 0;
-      p *= A.dt_todo[cid] / cfg.dt;  // collisions_methods.py:369-372
+      p *= (A.fold_pre ? todo : A.dt_todo[cid]) / cfg.dt;  // collisions_methods.py:369-372
     }
   }
   pair_update_body<BREAKUP>(cfg, A, d, in_range, p, u, u_b, false, off, 0, 0, 2 * d + off, true);
@@ -3098,13 +3149,17 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         DISPATCH_PAIR(k_pair_prob, dim3(grid_for((N + 1) / 2)));
         LAUNCH_CHECK();
       }
-      {
+      // (one cell with at most 2048 partial minima: k_pair_update folds them itself)
+      const bool fold = C == 1 && !sharded && !ctx->graph_capture && A.n_block_min <= 2048;
+      A.fold_pre = fold ? (fill_pending ? 2 : 1) : 0;
+      A.dt_left_pub = (const double *)(ctx->dscal + 6);
+      if (!fold) {
         PhaseScope ph(ctx, SDM_PHASE_CELLS_ADAPTIVE);
         hipLaunchKernelGGL(k_cells_adaptive, dim3(grid_for(C)), blk, 0, s, *cfg, A,
                            C > 1 ? 0 : (fill_pending ? 2 : 1));
         LAUNCH_CHECK();
-        fill_pending = false;
       }
+      fill_pending = false;
       {
         PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
         if (cfg->enable_breakup)
@@ -3143,6 +3198,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
         epilogue.slots = cfg->enable_breakup ? A.slots : nullptr;  // refused-breakup count
         epilogue.box = ctx->box_dev;
         epilogue.seq = box_seq;
+        epilogue.dt_left_pub = (double *)(ctx->dscal + 6);
       }
       if (list_dead) {
         epilogue.dead_pos = A.dead_pos;

@@ -95,6 +95,8 @@ struct CompactEpilogue {
   const int64_t *dead_pos;
   const unsigned long long *dead_count;
   unsigned long long *dead_count_next;
+  // a copy of dt_left[0] for the next sub-step's k_pair_update (fused.hip: FusedArgs::dt_left_pub)
+  double *dt_left_pub;
 };
 int sdm_resort_plan(sdm_ctx *ctx, char *scratch, int64_t length_bound, const int64_t *cctl,
                     const int64_t *fctl, const int64_t *cell_start, int64_t n_cell, int64_t *plan,

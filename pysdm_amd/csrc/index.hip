@@ -716,7 +716,9 @@ __device__ __forceinline__ void compact_epilogue(const CompactEpilogue &E,
     // device side: the working length of one cell is the valid length whether the time step goes
     // on or ends (reset_working_length, collision.py:189); only the host is told "0 = done"
     fctl[FCTL_WORK] = fctl[FCTL_VALID];
-    publish_ctl(fctl, E.box, E.seq, E.dt_left[0] != 0 ? fctl[FCTL_VALID] : 0);
+    const double left = E.dt_left[0];
+    if (E.dt_left_pub) E.dt_left_pub[0] = left;
+    publish_ctl(fctl, E.box, E.seq, left != 0 ? fctl[FCTL_VALID] : 0);
   }
 }
 
