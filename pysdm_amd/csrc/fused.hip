@@ -6,10 +6,12 @@
 //      inside a run of several steps: k_bin_build2 -> k_pair_all_sort, two launches per step - the
 //      pair kernel carries the tile sort of the next step's build, the build the compaction (and
 //      the repeated sort) after the rare step in which a super-droplet died
-//   one cell, adaptive:  build -> k_pair_prob -> k_cells_adaptive (the per-cell minimum of the
-//      optimal sub-step is the one global dependency) -> k_pair_update [-> k_resolve_dense with
-//      breakup] -> compaction, whose epilogue closes the sub-step and publishes the control block;
-//      the head of the next sub-step (build + k_pair_prob) is launched ahead of the read-back
+//   one cell, adaptive:  build -> k_pair_prob -> [k_cells_adaptive: above 2048 partial minima;
+//      else folded into] k_pair_update (the per-cell minimum of the optimal sub-step is the one
+//      global dependency) [-> k_resolve_dense with breakup] -> compaction (from the list of the
+//      dead that the kernels before it kept), whose epilogue closes the sub-step and publishes the
+//      control block; the head of the next sub-step (build + k_pair_prob) is launched ahead of
+//      the read-back
 //   many cells of at most 6144 super-droplets:  k_cells_turn (ends the previous sub-step, opens
 //      this one) -> k_cell_step2 / k_cell_step (one workgroup per cell: shuffle in LDS, pairs,
 //      probabilities, update) [-> all-reduce MIN in sharded runs]; the next sub-step is launched
@@ -1230,7 +1232,7 @@ struct CellArgs {
   int64_t *idx_out;
   u128 s_u01;  // PCG64 state at draw 0 of the sub-step's u01 window
   int n_tail_blocks;
-  const int64_t *gate;  // NULL, or a word written by k_cells_begin: 0 = this sub-step does not run
+  const int64_t *gate;  // NULL, or a word written by k_cells_turn: 0 = this sub-step does not run
   // sharded mode: segments of cells this process does not own are copied through unchanged (their
   // content is only required to hold the cell's members) - needed when idx_out is not known to
   // hold them already
@@ -2474,7 +2476,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
   const bool cell2q = unpacked && !cell2w && max_cell <= CELL2Q_CAP &&
                       (shape == SDM_CELL_SHAPE_AUTO ? n_active_cells > 2 * ctx->n_cus
                                                     : shape == SDM_CELL_SHAPE_256);
-  if (fill_pending && C > 1 && !cell_path) {  // the per-cell route's k_cells_begin does it itself
+  if (fill_pending && C > 1 && !cell_path) {  // the per-cell route's k_cells_turn does it itself
     hipLaunchKernelGGL(k_fill_f64, dim3(grid_for(C)), blk, 0, s, st->dt_left, cfg->dt, C);
     LAUNCH_CHECK();
     fill_pending = false;
@@ -2983,7 +2985,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     if (!cfg->adaptive && n_sub >= cfg->substeps) break;
     if (cfg->adaptive && work_host == 0) break;
     bool sort_ahead = false;  // this sub-step's pair kernel sorts the next one's events
-    if (sharded)  // (the per-cell adaptive route: k_cells_begin does it)
+    if (sharded)  // (the per-cell adaptive route: k_cells_turn does it)
       HIP_TRY(hipMemsetAsync(shard_n_dead, 0, sizeof(unsigned long long), s));
     if (head_ok) {
       if (!head_done) {
@@ -2993,7 +2995,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       head_done = false;
     } else {
     // (a) collision.py:183 cell_idx.sort_by_key(dt_left)
-    if (cfg->adaptive && C > 1 && !cell_path) {  // (per-cell route: k_cells_begin below)
+    if (cfg->adaptive && C > 1 && !cell_path) {  // (per-cell route: k_cells_turn, above)
       rc = sdm_sort_by_key_async(ctx, st->cell_idx, st->dt_left, C);
       if (rc) return rc;
     }
