@@ -85,6 +85,23 @@ const char *sdm_phase_name(int phase);
 #define SDM_CELL_SHAPE_512 1  /* two workgroups of 512 threads per CU, cells <= 5632 */
 #define SDM_CELL_SHAPE_1024 2 /* one workgroup of 1024 per CU, cells <= 6144: fewer cells than CUs */
 #define SDM_CELL_SHAPE_256 3  /* four workgroups of 256 per CU, cells <= 2816 */
+/* Three A/B switches (measurements, and tests that want both implementations in one process).
+ * Results are identical either way.  The defaults can also be set for a whole process through
+ * the environment, read when a context is created: SDM_REC_FORMAT=records, SDM_NO_PRESORT=1,
+ * SDM_CELL_COPY=0.
+ * SDM_OPT_REC_FORMAT: SDM_REC_FORMAT_AUTO (default) = successor words where they apply (one cell,
+ *   the shuffle left to the pair kernels, up to 2^22 positions); SDM_REC_FORMAT_RECORDS = the
+ *   packed 16-byte records of rounds 1-3 everywhere.
+ * SDM_OPT_NO_PRESORT: 1 = the tile sort of the next step's shuffle build does not ride in the
+ *   pair kernel (one cell, non-adaptive runs): k_bin_sort and the compaction as launches of
+ *   their own in every step.
+ * SDM_OPT_NO_CELL_COPY: 1 = multi-cell runs of three steps or more do not work on the
+ *   cell-ordered copy of the state.                                                             */
+#define SDM_OPT_REC_FORMAT 3
+#define SDM_REC_FORMAT_AUTO 0
+#define SDM_REC_FORMAT_RECORDS 1
+#define SDM_OPT_NO_PRESORT 4
+#define SDM_OPT_NO_CELL_COPY 5
 int sdm_ctx_set_option(sdm_ctx *ctx, int option, int64_t value);
 /* counters since the context was created / last cleared (host-side bookkeeping of the library):
  * re-sorts after a compaction done by the closed form; asked for and refused by the device; not

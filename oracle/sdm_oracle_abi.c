@@ -78,6 +78,9 @@ API int sdm_ctx_set_option(sdm_ctx *ctx, int option, int64_t value) {
   }
   if (option == SDM_OPT_CELL_SHAPE && value >= SDM_CELL_SHAPE_AUTO && value <= SDM_CELL_SHAPE_256)
     return SDM_OK;
+  if ((option == SDM_OPT_REC_FORMAT || option == SDM_OPT_NO_PRESORT ||
+       option == SDM_OPT_NO_CELL_COPY) && (value == 0 || value == 1))
+    return SDM_OK;
   if (option != SDM_OPT_RESORT || value < SDM_RESORT_AUTO || value > SDM_RESORT_ALWAYS_ASK)
     FAIL(SDM_E_ARG, "sdm_ctx_set_option: unknown option or value");
   return SDM_OK;

@@ -87,6 +87,7 @@ struct sdm_ctx {
   int opt_resort;                // SDM_OPT_RESORT
   int64_t opt_max_substeps;      // SDM_OPT_MAX_SUBSTEPS (0: none)
   int opt_cell_shape;            // SDM_OPT_CELL_SHAPE
+  int opt_records, opt_no_presort, opt_no_cell_copy;  // SDM_OPT_REC_FORMAT / _NO_PRESORT / _NO_CELL_COPY
   int64_t stats[SDM_N_STATS];    // SDM_STAT_* (host-side counters, sdm_ctx_read_stats)
   // fused.hip: what a multi-cell adaptive step knows at its end, for the next step of the same call
   // (valid length, an upper bound of the cell sizes; the state is sorted) - saves that step's

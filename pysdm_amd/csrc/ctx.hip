@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include <unistd.h>
 
+#include <cstring>
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -24,6 +25,10 @@ static int ctx_allocate(sdm_ctx *ctx) {
                         hipHostMallocMapped | hipHostMallocCoherent));
   memset(ctx->mailbox, 0, sizeof(int64_t) * SDM_MAILBOX_WORDS);
   if (const char *delay = getenv("SDM_DEBUG_BOX_DELAY_US")) ctx->debug_box_delay_us = atoi(delay);
+  // process-wide defaults of three A/B options (sdm_hip.h)
+  if (const char *fmt = getenv("SDM_REC_FORMAT")) ctx->opt_records = !strcmp(fmt, "records");
+  ctx->opt_no_presort = getenv("SDM_NO_PRESORT") != nullptr;
+  if (const char *copy = getenv("SDM_CELL_COPY")) ctx->opt_no_cell_copy = copy[0] == '0';
   HIP_TRY(hipHostGetDevicePointer((void **)&ctx->box_dev, ctx->mailbox + SDM_BOX, 0));
   HIP_TRY(hipMalloc((void **)&ctx->dscal, sizeof(int64_t) * 16));
   HIP_TRY(hipMemset(ctx->dscal, 0, sizeof(int64_t) * 16));
@@ -154,6 +159,19 @@ extern "C" int sdm_ctx_set_option(sdm_ctx *ctx, int option, int64_t value) {
   if (option == SDM_OPT_MAX_SUBSTEPS) {
     ARG_TRY(value >= 0);
     ctx->opt_max_substeps = value;
+    return SDM_OK;
+  }
+  if (option == SDM_OPT_REC_FORMAT || option == SDM_OPT_NO_PRESORT ||
+      option == SDM_OPT_NO_CELL_COPY) {
+    ARG_TRY(value == 0 || value == 1);
+    // (a tile sort that rode in the last pair kernel, a sub-step launched ahead: both belong to
+    // the format they were made for - none is pending between calls of a caller that changes it,
+    // and the entry points drop what they cannot use)
+    if (option == SDM_OPT_REC_FORMAT) ctx->opt_records = (int)value;
+    else if (option == SDM_OPT_NO_PRESORT) ctx->opt_no_presort = (int)value;
+    else ctx->opt_no_cell_copy = (int)value;
+    ctx->presorted.active = false;
+    ctx->build_resident = 0;  // (the occupancy of the build kernel depends on the format)
     return SDM_OK;
   }
   if (option == SDM_OPT_CELL_SHAPE) {

@@ -3103,7 +3103,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     } else if (!cfg->adaptive) {
       PhaseScope ph(ctx, SDM_PHASE_PAIR_UPDATE);
       // another sub-step of the same run follows: its tile sort rides along (k_pair_all_sort)
-      static const bool presort_off = getenv("SDM_NO_PRESORT") != nullptr;  // (A/B runs)
+      const bool presort_off = ctx->opt_no_presort != 0;  // (SDM_OPT_NO_PRESORT: A/B runs, tests)
       sort_ahead = split_one && !cell_path && !cfg->enable_breakup && !cfg->optimized_random &&
                    (n_sub + 1 < cfg->substeps || more_follow) && !ctx->graph_capture &&
                    A.rng_aff && !presort_off && A.rec != nullptr &&
@@ -3111,7 +3111,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
                    sdm_shuffle_presort_ok(ctx, N, N);
       if (sort_ahead) {
         SortBuffers B;
-        sdm_shuffle_sort_buffers(S.shuffle, N, &B);
+        sdm_shuffle_sort_buffers(ctx, S.shuffle, N, &B);
         SortAhead X;
         memset(&X, 0, sizeof(X));
         X.events = B.events;
@@ -3632,9 +3632,9 @@ extern "C" int sdm_collision_run(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step
   bool pairs_known = true;
   const bool replay = cfg && graph_eligible(ctx, cfg, st, n_steps);
   // cell-ordered working copy (above): multi-cell adaptive runs of three steps or more on the
-  // per-cell route (SDM_CELL_COPY=0 switches it off: measurements).  Sharded runs too: labels
+  // per-cell route (SDM_OPT_NO_CELL_COPY switches it off: measurements, tests).  Sharded runs too: labels
   // are a process's own business - only positions and per-cell numbers cross processes
-  static const bool copy_enabled = !(getenv("SDM_CELL_COPY") && getenv("SDM_CELL_COPY")[0] == '0');
+  const bool copy_enabled = !ctx->opt_no_cell_copy;
   Relabel relabel;
   const bool copy_wanted = copy_enabled && cfg && cfg->n_cell > 1 && cfg->adaptive &&
                            cfg->croupier_local && st->nm && n_steps >= 3 && !ctx->graph_capture;

@@ -62,7 +62,7 @@ struct SortBuffers {
 // true: builds over `length_bound` positions can take their tile sort from the previous pair kernel
 // (as many tiles as bins, all workgroups of the build resident at once for the rare re-sort)
 bool sdm_shuffle_presort_ok(sdm_ctx *ctx, int64_t length_bound, int64_t id_bound);
-void sdm_shuffle_sort_buffers(char *scratch, int64_t length_bound, SortBuffers *out);
+void sdm_shuffle_sort_buffers(sdm_ctx *ctx, char *scratch, int64_t length_bound, SortBuffers *out);
 void sdm_compact_as_prologue(sdm_ctx *ctx, char *scratch, const int64_t *multiplicity,
                              int64_t *idx, int64_t length_bound, int64_t flag, int64_t *fctl,
                              int64_t *ctl, int64_t *cell_start_single, SortPrologue *out);

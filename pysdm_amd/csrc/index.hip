@@ -288,11 +288,8 @@ static size_t binned_scratch_bytes(int64_t n) {
 // (8192 bins = 2^25 positions: K3 then holds 3 x 8193 + 3 x 4096 ints = 146 KB of the CU's 160 KB)
 static bool binned_ok(int64_t n, bool global) { return !global && n >= 2 && bin_count(n) <= 8192; }
 
-// SDM_REC_FORMAT=records: the round-1..3 records also where the successor words would be built
-static bool chain_enabled() {
-  static const bool off = getenv("SDM_REC_FORMAT") && !strcmp(getenv("SDM_REC_FORMAT"), "records");
-  return !off;
-}
+// SDM_OPT_REC_FORMAT = records: the round-1..3 records also where the successor words would be built
+static bool chain_enabled(const sdm_ctx *ctx) { return !ctx->opt_records; }
 
 static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const int64_t *idx0,
                                 const double *u01, const int64_t *cell_start, int64_t n_cell,
@@ -311,7 +308,7 @@ static int shuffle_binned_async(sdm_ctx *ctx, char *scratch, int64_t *out, const
   // them took straub (2^22, adaptive, breakup) from 3.95 to 4.20e9 pairs/s, straub_rain from 4.42
   // to 4.73e9 (profiles/r04_tile16k.json).  Only for these builds: the 139 KB of LDS of such a
   // tile sort leave one workgroup per CU, which the 4096-event sort of the other routes need not pay
-  const bool chain_ok = views && id_bound >= 0 && both <= CHAIN_MAX && chain_enabled();
+  const bool chain_ok = views && id_bound >= 0 && both <= CHAIN_MAX && chain_enabled(ctx);
   // (nor where the tile sort can ride in the previous pair kernel: that one is 4096 events)
   const int tile = (chain_ok && !presorted && bin_count(length_bound) * 16 > EV_TILE &&
                     bin_count(length_bound) * 16 <= EV_TILE_BIG &&
@@ -438,13 +435,13 @@ int sdm_shuffle_build_async(sdm_ctx *ctx, char *scratch, const int64_t *idx0,
                               length_bound, 0, s_off, inc, views, id_bound, dev_off, presorted);
 }
 
-void sdm_shuffle_sort_buffers(char *scratch, int64_t length_bound, SortBuffers *out) {
+void sdm_shuffle_sort_buffers(sdm_ctx *ctx, char *scratch, int64_t length_bound, SortBuffers *out) {
   Carver cv(scratch);  // (the carve of shuffle_binned_async)
   const int nb = bin_count(length_bound), nt = ev_tile_count(length_bound);
   int32_t *chain = (int32_t *)cv.take<PackRec>(length_bound + EV_TILE);
   (void)cv.take<int32_t>(length_bound);
   (void)cv.take<int32_t>(length_bound);
-  out->loc = chain_enabled() && length_bound <= CHAIN_MAX && nb * 16 <= EV_TILE
+  out->loc = chain_enabled(ctx) && length_bound <= CHAIN_MAX && nb * 16 <= EV_TILE
                  ? chain + 2 * (size_t)nt * EV_TILE : nullptr;
   out->jarr = cv.take<int32_t>(length_bound);
   out->events = cv.take<int2>((size_t)nt * EV_TILE);
@@ -1197,7 +1194,7 @@ bool sdm_shuffle_presort_ok(sdm_ctx *ctx, int64_t length_bound, int64_t id_bound
   const int64_t both = id_bound > length_bound ? id_bound : length_bound;
   if (nb != nt || nb > COMPACT_MAX_GROUPS || id_bound < 0 || both > P21_MAX) return false;
   if (ctx->build_resident == 0) {
-    const bool chain = chain_enabled() && nb * 16 <= EV_TILE;
+    const bool chain = chain_enabled(ctx) && nb * 16 <= EV_TILE;
     const size_t lds_build = sizeof(int32_t) * (size_t)((chain ? 9 : 5) * BIN_POS);
     int per_cu = 0, cus = 0;
     const void *kernel = chain ? (const void *)k_bin_build2<SDM_REC_CHAIN>

@@ -256,6 +256,42 @@ def test_both_per_cell_kernels_equal_oracle(n_sd, which, hip_engine, oracle_engi
     assert_same(snaps[0], snaps[1])
 
 
+@pytest.mark.parametrize("option,cases", [
+    # SDM_OPT_REC_FORMAT = records: the packed records where successor words are the default
+    (3, [("shima", dict(n_sd=2**15, adaptive=False), (1, 6, 2)),
+         ("shima", dict(n_sd=2**15, adaptive=True, thin=0.02, dt=50.0), (1, 6, 2)),
+         ("berry_breakup", dict(n_sd=2**14, adaptive=True), (1, 5, 2))]),
+    # SDM_OPT_NO_PRESORT: k_bin_sort and the compaction as launches of their own in every step
+    (4, [("shima", dict(n_sd=2**15, adaptive=False), (1, 6, 2)),
+         ("shima", dict(n_sd=2**15, adaptive=False, thin=0.02, dt=50.0), (1, 6, 2))]),
+    # SDM_OPT_NO_CELL_COPY: no cell-ordered working copy in runs of three steps or more
+    (5, [("kinematic2d", dict(n_sd=2**13, grid=(4, 4)), (1, 6, 4)),
+         ("shima", dict(n_sd=2**13, adaptive=True, thin=0.02, dt=200.0, grid=(4, 4)), (1, 6, 4))]),
+])
+def test_both_sides_of_the_ab_options_equal_oracle(option, cases, hip_engine, oracle_engine):
+    """the three A/B options of a context select between two implementations of the same step
+    (sdm_hip.h): both, in one process, against the oracle - also where super-droplets die"""
+    def run(engine, name, kwargs, chunks):
+        runner = make_box(engine, name, **kwargs)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for steps in chunks:
+                runner.run(steps)
+        return runner.snapshot()
+    try:
+        for name, kwargs, chunks in cases:
+            expected = run(oracle_engine, name, kwargs, chunks)
+            if "thin" in kwargs:
+                assert int(expected["length"]) < kwargs["n_sd"]
+            for value in (1, 0):
+                hip_engine.call("sdm_ctx_set_option", option, value)
+                assert_same(run(hip_engine, name, kwargs, chunks), expected)
+    finally:
+        hip_engine.call("sdm_ctx_set_option", option, 0)
+    with pytest.raises(Exception):
+        hip_engine.call("sdm_ctx_set_option", option, 2)
+
+
 @pytest.mark.parametrize("grid,n_sd", [((48, 48), 2304 * 24), ((96, 96), 9216 * 10)])
 def test_grids_of_thousands_of_cells_equal_oracle(grid, n_sd, hip_engine, oracle_engine):
     """k_cells_turn ranks the cells' dt_left eight cells per workgroup above 2048 cells and sixteen
