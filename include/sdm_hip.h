@@ -82,7 +82,9 @@ const char *sdm_phase_name(int phase);
  * allows it (beyond the cap: the 512-thread shape or the general kernel).  Results are identical in all.       */
 #define SDM_OPT_CELL_SHAPE 2
 #define SDM_CELL_SHAPE_AUTO 0
-#define SDM_CELL_SHAPE_512 1  /* two workgroups of 512 threads per CU, cells <= 5632 */
+#define SDM_CELL_SHAPE_512 1  /* two workgroups of 512 threads per CU, cells <= 5632; small cells
+                                 (eight per workgroup): the 704-position variant also where the
+                                 384-position one would be taken */
 #define SDM_CELL_SHAPE_1024 2 /* one workgroup of 1024 per CU, cells <= 6144: fewer cells than CUs */
 #define SDM_CELL_SHAPE_256 3  /* four workgroups of 256 per CU, cells <= 2816 */
 /* Three A/B switches (measurements, and tests that want both implementations in one process).

@@ -1531,6 +1531,11 @@ k_cell_step(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
 #define CELL2_BATCH 3
 #define CELL2_LDS_BYTES (CELL2_CAP * 14)
 #define CELL2_PACK 8  // cells per workgroup on the small-cell variant (one wavefront each)
+// ... and the same with 384 positions per cell instead of 704 (the reference's own 2-D example has
+// 64..128 super-droplets per cell): the per-lane loops, unrolled for the cap, shrink from 11
+// positions and 6 pair slots to 6 and 3, and so do the registers - three workgroups per CU
+#define CELL2T_CAP (384 * CELL2_PACK)
+#define CELL2T_LDS_BYTES (CELL2T_CAP * 14)
 // The same kernel with 1024 threads per cell (one workgroup per CU; cells up to 6144): for launches
 // in which FEWER cells than the device has CUs are computed - a process of a sharded run that owns
 // 128 of the 1024 cells (8 GPUs), say.  Two 512-thread workgroups per CU pay off when there are
@@ -1564,8 +1569,8 @@ __device__ __forceinline__ int lds_exch16(uint32_t *words, int i, int v) {
 // 170 us per sub-step whatever the cell size).  With CPW = 8 a cell is one wavefront with its own
 // slice of LDS (CELL2_CAP / 8 = 704 positions); the barriers stay workgroup-wide (the cells of a
 // workgroup move in lockstep), the reductions and counters are per wavefront anyway.
-template <int KERNEL, bool BREAKUP, int CPW, int THREADS>
-__global__ void __launch_bounds__(THREADS, 4)
+template <int KERNEL, bool BREAKUP, int CPW, int THREADS, bool TINY = false>
+__global__ void __launch_bounds__(THREADS, TINY ? 6 : 4)
 k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef CELL_PROFILE
@@ -1575,7 +1580,8 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
 #define CELL_MARK(k) do { __syncthreads(); if (threadIdx.x == 0) cell_t[(k) + 1] = wall_clock64(); } while (0)
 #endif
   constexpr int T = THREADS / CPW;  // threads per cell
-  constexpr int CAP = (THREADS == CELL2_THREADS ? CELL2_CAP :
+  static_assert(!TINY || (CPW == CELL2_PACK && THREADS == CELL2_THREADS), "tiny cells: packed");
+  constexpr int CAP = TINY ? CELL2T_CAP / CPW : (THREADS == CELL2_THREADS ? CELL2_CAP :
                        THREADS == CELL2W_THREADS ? CELL2W_CAP : CELL2Q_CAP) / CPW;  // positions per cell
   constexpr int MAXPOS = CAP / T, MAXPAIR = (CAP / 2 + T - 1) / T;
   static_assert(T % SDM_WAVE == 0 && CAP % 8 == 0 && CAP % T == 0, "cell slices");
@@ -2583,11 +2589,15 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     const bool brk = cfg->enable_breakup != 0;
     // small cells: CELL2_PACK of them per workgroup (k_cell_step2)
     const bool packed = cell2 && max_cell >= 0 && max_cell <= CELL2_CAP / CELL2_PACK;
+    const bool tiny = packed && max_cell <= CELL2T_CAP / CELL2_PACK &&
+                      ctx->opt_cell_shape != SDM_CELL_SHAPE_512;  // (forced 512: the 704 cap)
     const dim3 grid((unsigned)(C + X.n_tail_blocks));
     const dim3 grid_p((unsigned)((C + CELL2_PACK - 1) / CELL2_PACK + X.n_tail_blocks));
 #define CELL_LAUNCH(K)                                                                        \
   do {                                                                                        \
-    if (packed && brk) hipLaunchKernelGGL((k_cell_step2<K, true, CELL2_PACK, CELL2_THREADS>), grid_p, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
+    if (tiny && brk) hipLaunchKernelGGL((k_cell_step2<K, true, CELL2_PACK, CELL2_THREADS, true>), grid_p, dim3(CELL2_THREADS), CELL2T_LDS_BYTES, s, *cfg, A, X); \
+    else if (tiny) hipLaunchKernelGGL((k_cell_step2<K, false, CELL2_PACK, CELL2_THREADS, true>), grid_p, dim3(CELL2_THREADS), CELL2T_LDS_BYTES, s, *cfg, A, X); \
+    else if (packed && brk) hipLaunchKernelGGL((k_cell_step2<K, true, CELL2_PACK, CELL2_THREADS>), grid_p, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
     else if (packed) hipLaunchKernelGGL((k_cell_step2<K, false, CELL2_PACK, CELL2_THREADS>), grid_p, dim3(CELL2_THREADS), CELL2_LDS_BYTES, s, *cfg, A, X); \
     else if (cell2w && brk) hipLaunchKernelGGL((k_cell_step2<K, true, 1, CELL2W_THREADS>), grid, dim3(CELL2W_THREADS), CELL2W_LDS_BYTES, s, *cfg, A, X); \
     else if (cell2w) hipLaunchKernelGGL((k_cell_step2<K, false, 1, CELL2W_THREADS>), grid, dim3(CELL2W_THREADS), CELL2W_LDS_BYTES, s, *cfg, A, X); \

@@ -332,6 +332,30 @@ def test_every_shape_of_the_cell_kernel_equals_oracle(base, hip_engine, oracle_e
         hip_engine.call("sdm_ctx_set_option", 2, 4)
 
 
+@pytest.mark.parametrize("base", ["kinematic2d", "straub"])
+def test_both_packed_shapes_of_the_cell_kernel_equal_oracle(base, hip_engine, oracle_engine):
+    """eight small cells per workgroup: cells of at most 384 take the variant whose per-lane loops
+    are sized for them (AUTO), SDM_CELL_SHAPE_512 forces the 704-position one - 6 x 6 cells of
+    ~150, both against the oracle"""
+    def run(engine):
+        runner = make_box(engine, base, n_sd=36 * 150, grid=(6, 6), **(
+            {} if base == "kinematic2d" else {"adaptive": True, "dt": 5.0}))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for steps in (1, 6, 2):
+                runner.run(steps)
+        return runner.snapshot()
+    expected = run(oracle_engine)
+    sizes = np.diff(expected["cell_start"])
+    assert 64 < sizes.max() <= 384
+    try:
+        for shape in (1, 0):
+            hip_engine.call("sdm_ctx_set_option", 2, shape)
+            assert_same(run(hip_engine), expected)
+    finally:
+        hip_engine.call("sdm_ctx_set_option", 2, 0)
+
+
 def test_degenerate_sizes_and_operand_checks(kit, hip_engine):
     """empty and tiny inputs: zero-length arrays are accepted by every entry point that takes a
     length, two super-droplets form one pair, three leave one alone, a null context is refused,
