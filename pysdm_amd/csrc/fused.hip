@@ -18,6 +18,7 @@
 //      ahead, gated on the device; a compaction only when the host has learnt of a death
 //   larger cells / global croupier:  generic kernels (per-position cell look-ups, counting sort)
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 #include "index.h"
 #include "shuffle_build.h"
@@ -1010,8 +1011,8 @@ struct TurnArgs {
 // the ranks of the group's cells together.  One cell per workgroup is fastest at 1024 cells (7.9
 // against 10.6 us with eight: the kernel is a chain of latencies there, and the eight-fold compare
 // lengthens it), but the work grows with the SQUARE of the number of cells: 45 us at 75 x 75 =
-// 5625 cells, more than that grid's cell kernel (40 us) - eight per workgroup there, sixteen beyond
-// 8192 cells
+// 5625 cells, more than that grid's cell kernel (40 us) - eight per workgroup above 2048 cells,
+// sixteen above 8192 (measured at 5625: sixteen 29 us against eight 21 - fewer, fatter wavefronts)
 template <int TURN_GROUP>
 __global__ void __launch_bounds__(SDM_BLOCK) k_cells_turn(sdm_step_cfg cfg, FusedArgs A, TurnArgs T) {
   __shared__ int sm_rank[SDM_BLOCK / SDM_WAVE][TURN_GROUP];
@@ -1022,7 +1023,9 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_cells_turn(sdm_step_cfg cfg, Fuse
   // and nothing else; which loads are needed follows from the launch arguments alone
   const bool may_apply = !T.first;
   const bool read_in = !T.fresh;
-  constexpr int PER = 4;  // cells per thread and pass: SDM_BLOCK * PER >= 1024 cells at once
+  // cells per thread and pass: SDM_BLOCK * PER >= 1024 cells at once; more on large grids, where
+  // the passes' loads are what the kernel waits for
+  constexpr int PER = TURN_GROUP == 1 ? 4 : 8;
   const int64_t gate_w = may_apply ? T.gate[(T.turn - 1) & 1] : 0;
   const int64_t ctl_work = A.ctl[CTL_WORK], ctl_healthy = A.ctl[CTL_HEALTHY],
                 ctl_sorted = A.ctl[CTL_SORTED];
@@ -1055,32 +1058,53 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_cells_turn(sdm_step_cfg cfg, Fuse
                     // POSITION there; cell_start is monotone, so the largest cell_start[c + 1]
                     // over the cells with time left is the one of the last such cell
   int flags = 0;    // 1 = somebody died, 2 = a cell minimum equals dt_min
-  for (int64_t c0 = 0; c0 < n; c0 += SDM_BLOCK * PER) {
-    double l[PER], m[PER], d[PER];
-    int64_t e[PER];
+  // The ranking is n_cell^2 comparisons (31.6 M at 75 x 75 cells): it is what the kernel costs on a
+  // large grid, so a comparison has to be ONE instruction.  rank(i) = #{c: left_c < left_i} +
+  // #{c < i: left_c == left_i}; for the cells BELOW the group's own range that is `<=`, for those
+  // ABOVE it `<`, and only the group's own cells need the index - three loops over cells, each
+  // with one uniform test (MODE 0 / 1 / 2), instead of two floating-point compares, a 64-bit
+  // integer compare and the logic between them per pair (21 -> ~9 us at 5625 cells)
+  auto scan = [&](int64_t c_begin, int64_t c_end, auto mode) {
+    constexpr int MODE = decltype(mode)::value;
+    for (int64_t c0 = c_begin; c0 < c_end; c0 += SDM_BLOCK * PER) {
+      double l[PER], m[PER], d[PER];
+      int64_t e[PER];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const int64_t c = c0 + k * SDM_BLOCK + threadIdx.x;
-      const bool in = c < n;
-      l[k] = in && read_in ? T.left_in[c] : cfg.dt;
-      m[k] = in && read_in && may_apply ? T.min_in[c] : INFINITY;
-      d[k] = in && read_in && may_apply && T.sharded ? T.min_in[n + c] : 0.0;
-      e[k] = in ? A.cell_start[c + 1] : 0;
-    }
+      for (int k = 0; k < PER; ++k) {
+        const int64_t c = c0 + k * SDM_BLOCK + threadIdx.x;
+        const bool in = c < c_end;
+        l[k] = in && read_in ? T.left_in[c] : cfg.dt;
+        m[k] = in && read_in && may_apply ? T.min_in[c] : INFINITY;
+        d[k] = in && read_in && may_apply && T.sharded ? T.min_in[n + c] : 0.0;
+        // (many cells: the end of the working range is found as an INDEX and looked up once)
+        e[k] = !in ? 0 : (TURN_GROUP == 1 ? A.cell_start[c + 1] : c + 1);
+      }
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const int64_t c = c0 + k * SDM_BLOCK + threadIdx.x;
-      if (c >= n) continue;
-      const double lc = left_of(l[k], m[k], nullptr);
+      for (int k = 0; k < PER; ++k) {
+        const int64_t c = c0 + k * SDM_BLOCK + threadIdx.x;
+        if (c >= c_end) continue;
+        const double lc = left_of(l[k], m[k], nullptr);
 #pragma unroll
-      for (int g = 0; g < TURN_GROUP; ++g)
-        rank[g] += (lc < left_i[g]) || (lc == left_i[g] && c < i0 + g);
-      if (lc != 0 && e[k] > end) end = e[k];
-      if (apply) {
-        if (d[k] < 0) flags |= 1;
-        if (m[k] == cfg.dt_min) flags |= 2;
+        for (int g = 0; g < TURN_GROUP; ++g) {
+          if (MODE == 0) rank[g] += lc <= left_i[g];
+          else if (MODE == 1) rank[g] += lc < left_i[g];
+          else rank[g] += (lc < left_i[g]) || (lc == left_i[g] && c < i0 + g);
+        }
+        if (lc != 0 && e[k] > end) end = e[k];
+        if (apply) {
+          if (d[k] < 0) flags |= 1;
+          if (m[k] == cfg.dt_min) flags |= 2;
+        }
       }
     }
+  };
+  if (TURN_GROUP == 1) {  // (few cells: a chain of latencies - one pass, all loads at once)
+    scan(0, n, std::integral_constant<int, 2>());
+  } else {
+    const int64_t own_end = i0 + TURN_GROUP < n ? i0 + TURN_GROUP : n;
+    scan(0, i0, std::integral_constant<int, 0>());
+    scan(i0, own_end, std::integral_constant<int, 2>());
+    scan(own_end, n, std::integral_constant<int, 1>());
   }
 #pragma unroll
   for (int g = 0; g < TURN_GROUP; ++g) rank[g] = wave_sum_i32(rank[g]);
@@ -1103,7 +1127,7 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_cells_turn(sdm_step_cfg cfg, Fuse
     top = sm_top[w] > top ? sm_top[w] : top;
     flags |= sm_flags[w];
   }
-  end = top;
+  end = TURN_GROUP == 1 ? (int64_t)top : (top == 0 ? 0 : A.cell_start[top]);
   const int64_t work = apply ? end : ctl_work;
   const bool healthy = ctl_healthy != 0 && !(flags & 1);
   const bool run = !T.end_only && (!T.gated || (work != 0 && ctl_sorted != 0 && healthy));
