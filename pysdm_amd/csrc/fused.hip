@@ -61,6 +61,11 @@ struct FusedArgs {
   int64_t *ctl;
   // sharded mode (sdm_hip.h): by cell id, 1 = this process computes the cell; NULL = all
   const uint8_t *cell_owned;
+  // ... the same by SEGMENT of the permutation (1 = the segment's cell is this process's), written
+  // by k_cells_turn for the cell kernel it opens: a workgroup that has nothing to do learns so
+  // from one load instead of a chain of four (cell_start -> permutation -> cell id -> mask).  NULL:
+  // not available
+  const uint8_t *seg_owned;
   // sharded mode: super-droplets that died in this process's cells in the current sub-step, counted
   // where they are flagged (the list of their positions is built only once the exchange of the
   // counts has shown that somebody's did: k_shard_dead_list); NULL otherwise
@@ -1005,6 +1010,10 @@ struct TurnArgs {
   int32_t sharded;   // the death counts in min_in are meaningful
   int64_t *box;
   int64_t seq;       // publication number of the sub-step that ended (0: nothing to publish)
+  // sharded runs: the permutation the cell kernel will read, and where "this segment's cell is
+  // mine" goes (FusedArgs::seg_owned); NULL otherwise
+  const int64_t *perm;
+  uint8_t *seg_owned;
 };
 
 // TURN_GROUP cells per workgroup: what is read of all cells - their dt_left and minima - serves
@@ -1029,6 +1038,16 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_cells_turn(sdm_step_cfg cfg, Fuse
   const int64_t gate_w = may_apply ? T.gate[(T.turn - 1) & 1] : 0;
   const int64_t ctl_work = A.ctl[CTL_WORK], ctl_healthy = A.ctl[CTL_HEALTHY],
                 ctl_sorted = A.ctl[CTL_SORTED];
+  if (T.seg_owned) {  // (a chain of four loads of its own, beside everything else)
+    const int g = (int)threadIdx.x - SDM_WAVE;
+    if (g >= 0 && g < TURN_GROUP && i0 + g < n) {
+      const int64_t lo = A.cell_start[i0 + g], hi = A.cell_start[i0 + g + 1];
+      // (a sub-step launched ahead of the host's knowledge of a death finds FLAGGED entries - the
+      // id n_sd - in the permutation: its gate will close, but this look-up runs regardless)
+      const int64_t id = hi > lo && lo >= 0 && lo < cfg.n_sd ? T.perm[lo] : -1;
+      T.seg_owned[i0 + g] = id >= 0 && id < cfg.n_sd ? A.cell_owned[A.cell_id[id]] : 0;
+    }
+  }
   double own_l[TURN_GROUP], own_m[TURN_GROUP];
 #pragma unroll
   for (int g = 0; g < TURN_GROUP; ++g) {
@@ -1645,7 +1664,9 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   int64_t lo = 0, hi = 0;
   if (cell < C) { lo = A.cell_start[cell]; hi = A.cell_start[cell + 1]; }
   int n = (int)(hi - lo);
-  if (n > 0 && A.cell_owned && !A.cell_owned[A.cell_id[X.idx_in[lo]]]) {  // another process's cell
+  if (n > 0 && A.cell_owned &&
+      !(A.seg_owned ? A.seg_owned[cell] : A.cell_owned[A.cell_id[X.idx_in[lo]]])) {
+    // another process's cell
     if (X.copy_others)
       for (int li = tid; li < n; li += T) X.idx_out[lo + li] = X.idx_in[lo + li];
     n = 0;
@@ -1655,6 +1676,9 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
     for (int li = tid; li < n; li += T) X.idx_out[lo + li] = X.idx_in[lo + li];
     n = 0;
   }
+  // (one cell per workgroup and nothing to do: leave - a rank of a sharded run launches a
+  // workgroup per segment and computes an eighth of them)
+  if (CPW == 1 && n == 0) return;
   const int64_t W = A.ctl[CTL_WORK];
   for (int li = tid; li < n; li += T) {
     val[li] = (int32_t)X.idx_in[lo + li];
@@ -2174,6 +2198,7 @@ struct FusedScratch {
   uint8_t *pair_off;
   int32_t *pair_cid;
   int64_t *sorted_buf, *cs_tmp, *gate_len, *cctl, *end2, *seg_size, *seg_src;
+  uint8_t *seg_owned;
   int64_t *resort_plan;  // (index.hip: sdm_resort_after_compaction_async)
   char *shuffle, *sort, *compact;
   size_t total;
@@ -2199,6 +2224,7 @@ static FusedScratch layout(char *base, const sdm_step_cfg *cfg) {
   S.cs_tmp = cv.take<int64_t>(C + 1);
   S.seg_size = cv.take<int64_t>(C);
   S.seg_src = cv.take<int64_t>(C);
+  S.seg_owned = cv.take<uint8_t>(C);
   S.gate_len = cv.take<int64_t>(4);
   S.cctl = cv.take<int64_t>(8);
   S.resort_plan = cv.take<int64_t>(8);
@@ -2776,6 +2802,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       T.sharded = sharded ? 1 : 0;
       T.box = ctx->box_dev;
       T.seq = pending_seq;
+      if (sharded) {
+        T.perm = cur;
+        T.seg_owned = S.seg_owned;
+      }
       if (C <= 2048)
         hipLaunchKernelGGL(k_cells_turn<1>, dim3((unsigned)C), blk, 0, s, *cfg, A, T);
       else if (C <= 8192)
@@ -2789,6 +2819,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       A.dt_left = left_buf[left_cur];
       A.cell_min = T.min_out;
       A.seg_deaths = sharded ? T.min_out + C : nullptr;
+      A.seg_owned = sharded ? S.seg_owned : nullptr;
       ++turn;
       return SDM_OK;
     };
@@ -3009,6 +3040,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     }
     A.dt_left = st->dt_left;
     A.seg_deaths = nullptr;
+    A.seg_owned = nullptr;
     if (left_cur != 0)  // the step's last dt_left stands in the scratch half of the ping-pong
       HIP_TRY(hipMemcpyAsync(st->dt_left, left_buf[1], sizeof(double) * (size_t)C,
                              hipMemcpyDeviceToDevice, s));
