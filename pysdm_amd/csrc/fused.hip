@@ -1679,6 +1679,7 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   // (one cell per workgroup and nothing to do: leave - a rank of a sharded run launches a
   // workgroup per segment and computes an eighth of them)
   if (CPW == 1 && n == 0) return;
+  if (CPW > 1 && A.cell_owned && __syncthreads_or(n > 0) == 0) return;  // (none of its cells)
   const int64_t W = A.ctl[CTL_WORK];
   for (int li = tid; li < n; li += T) {
     val[li] = (int32_t)X.idx_in[lo + li];
