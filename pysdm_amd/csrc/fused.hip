@@ -2785,6 +2785,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     int64_t *gate_words = S.end2 + 2;  // two words (turn parity)
     int64_t pending_seq = 0;           // publication number of the sub-step not yet ended
     double *last_min = nullptr;        // the buffer the sub-step not yet ended reduced into
+    bool segments_changed = true;      // sharded: k_cells_turn writes FusedArgs::seg_owned anew
     auto launch_turn = [&](bool gated, bool end_only) -> int {
       PhaseScope ph(ctx, SDM_PHASE_CELLS_PRE);
       TurnArgs T;
@@ -2803,9 +2804,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       T.sharded = sharded ? 1 : 0;
       T.box = ctx->box_dev;
       T.seq = pending_seq;
-      if (sharded) {
+      if (sharded && segments_changed) {  // (which cell a segment holds changes with a sort only)
         T.perm = cur;
         T.seg_owned = S.seg_owned;
+        segments_changed = false;
       }
       if (C <= 2048)
         hipLaunchKernelGGL(k_cells_turn<1>, dim3((unsigned)C), blk, 0, s, *cfg, A, T);
@@ -2835,6 +2837,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       A.s_rand = sdm_pcg_advance_host(rng_state, rng_inc, draw_off + (uint64_t)(N + shift));
       A.s_rand_b = sdm_pcg_advance_host(rng_state, rng_inc, draw_off_b);
       const uint64_t u01_off = draw_off + (uint64_t)(cfg->optimized_random ? launched : 0);
+      if (launched == 0 || shard_resorted) segments_changed = true;
       int r = launch_turn(gated, false);  // (publishes the control block of the sub-step before)
       if (r) return r;
       CellArgs X;
