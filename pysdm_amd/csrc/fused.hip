@@ -66,6 +66,8 @@ struct FusedArgs {
   // from one load instead of a chain of four (cell_start -> permutation -> cell id -> mask).  NULL:
   // not available
   const uint8_t *seg_owned;
+  // ... and the cell id of every segment (adaptive per-cell route, sharded or not); NULL: unknown
+  const int32_t *seg_cid;
   // sharded mode: super-droplets that died in this process's cells in the current sub-step, counted
   // where they are flagged (the list of their positions is built only once the exchange of the
   // counts has shown that somebody's did: k_shard_dead_list); NULL otherwise
@@ -1014,6 +1016,7 @@ struct TurnArgs {
   // mine" goes (FusedArgs::seg_owned); NULL otherwise
   const int64_t *perm;
   uint8_t *seg_owned;
+  int32_t *seg_cid;  // (any run: FusedArgs::seg_cid)
 };
 
 // TURN_GROUP cells per workgroup: what is read of all cells - their dt_left and minima - serves
@@ -1038,14 +1041,16 @@ __global__ void __launch_bounds__(SDM_BLOCK) k_cells_turn(sdm_step_cfg cfg, Fuse
   const int64_t gate_w = may_apply ? T.gate[(T.turn - 1) & 1] : 0;
   const int64_t ctl_work = A.ctl[CTL_WORK], ctl_healthy = A.ctl[CTL_HEALTHY],
                 ctl_sorted = A.ctl[CTL_SORTED];
-  if (T.seg_owned) {  // (a chain of four loads of its own, beside everything else)
+  if (T.seg_cid) {  // (a chain of three or four loads of its own, beside everything else)
     const int g = (int)threadIdx.x - SDM_WAVE;
     if (g >= 0 && g < TURN_GROUP && i0 + g < n) {
       const int64_t lo = A.cell_start[i0 + g], hi = A.cell_start[i0 + g + 1];
       // (a sub-step launched ahead of the host's knowledge of a death finds FLAGGED entries - the
       // id n_sd - in the permutation: its gate will close, but this look-up runs regardless)
       const int64_t id = hi > lo && lo >= 0 && lo < cfg.n_sd ? T.perm[lo] : -1;
-      T.seg_owned[i0 + g] = id >= 0 && id < cfg.n_sd ? A.cell_owned[A.cell_id[id]] : 0;
+      const int64_t cid = id >= 0 && id < cfg.n_sd ? A.cell_id[id] : -1;
+      T.seg_cid[i0 + g] = (int32_t)cid;
+      if (T.seg_owned) T.seg_owned[i0 + g] = cid >= 0 ? A.cell_owned[cid] : 0;
     }
   }
   double own_l[TURN_GROUP], own_m[TURN_GROUP];
@@ -1689,13 +1694,20 @@ k_cell_step2(sdm_step_cfg cfg, FusedArgs A, CellArgs X) {
   if (tid == 0) { s_ncoll = 0; s_cid = 0; s_base = 0; }
   __syncthreads();
   if (n > 0) {
+    // four short serial jobs - the cell's id and pair parity (two or three dependent look-ups), the
+    // jump-aheads of the streams - by four threads of DIFFERENT wavefronts where the cell has
+    // several (in one wavefront the divergent branches run one after the other: 5 us of the
+    // cell's chain)
+    constexpr int ROLE = T >= 4 * SDM_WAVE ? SDM_WAVE : 1;
     if (tid == 0) {
-      s_cid = A.cell_id[val[0]];
+      // (seg_cid: written by k_cells_turn after a sort - one look-up instead of two dependent ones)
+      s_cid = A.seg_cid ? (int64_t)A.seg_cid[cell] : A.cell_id[val[0]];
       s_base = A.cell_start[A.cell_idx[s_cid]];
     }
-    if (tid == 1) s_rng[0] = pcg_jump_fast(X.s_u01, A.rng_tab, A.rng_aff, (uint64_t)lo);
-    if (tid == 2) s_rng[1] = pcg_jump_fast(A.s_rand, A.rng_tab, A.rng_aff, (uint64_t)(lo >> 1));
-    if (BREAKUP && tid == 3)
+    if (tid == ROLE) s_rng[0] = pcg_jump_fast(X.s_u01, A.rng_tab, A.rng_aff, (uint64_t)lo);
+    if (tid == 2 * ROLE)
+      s_rng[1] = pcg_jump_fast(A.s_rand, A.rng_tab, A.rng_aff, (uint64_t)(lo >> 1));
+    if (BREAKUP && tid == 3 * ROLE)
       s_rng[2] = pcg_jump_fast(A.s_rand_b, A.rng_tab, A.rng_aff, (uint64_t)(lo >> 1));
   }
   __syncthreads();
@@ -2200,6 +2212,7 @@ struct FusedScratch {
   int32_t *pair_cid;
   int64_t *sorted_buf, *cs_tmp, *gate_len, *cctl, *end2, *seg_size, *seg_src;
   uint8_t *seg_owned;
+  int32_t *seg_cid;
   int64_t *resort_plan;  // (index.hip: sdm_resort_after_compaction_async)
   char *shuffle, *sort, *compact;
   size_t total;
@@ -2226,6 +2239,7 @@ static FusedScratch layout(char *base, const sdm_step_cfg *cfg) {
   S.seg_size = cv.take<int64_t>(C);
   S.seg_src = cv.take<int64_t>(C);
   S.seg_owned = cv.take<uint8_t>(C);
+  S.seg_cid = cv.take<int32_t>(C);
   S.gate_len = cv.take<int64_t>(4);
   S.cctl = cv.take<int64_t>(8);
   S.resort_plan = cv.take<int64_t>(8);
@@ -2785,7 +2799,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     int64_t *gate_words = S.end2 + 2;  // two words (turn parity)
     int64_t pending_seq = 0;           // publication number of the sub-step not yet ended
     double *last_min = nullptr;        // the buffer the sub-step not yet ended reduced into
-    bool segments_changed = true;      // sharded: k_cells_turn writes FusedArgs::seg_owned anew
+    bool segments_changed = true;      // k_cells_turn writes FusedArgs::seg_cid / seg_owned anew
     auto launch_turn = [&](bool gated, bool end_only) -> int {
       PhaseScope ph(ctx, SDM_PHASE_CELLS_PRE);
       TurnArgs T;
@@ -2804,9 +2818,10 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       T.sharded = sharded ? 1 : 0;
       T.box = ctx->box_dev;
       T.seq = pending_seq;
-      if (sharded && segments_changed) {  // (which cell a segment holds changes with a sort only)
+      if (segments_changed) {  // (which cell a segment holds changes with a sort only)
         T.perm = cur;
-        T.seg_owned = S.seg_owned;
+        T.seg_cid = S.seg_cid;
+        T.seg_owned = sharded ? S.seg_owned : nullptr;
         segments_changed = false;
       }
       if (C <= 2048)
@@ -2823,6 +2838,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
       A.cell_min = T.min_out;
       A.seg_deaths = sharded ? T.min_out + C : nullptr;
       A.seg_owned = sharded ? S.seg_owned : nullptr;
+      A.seg_cid = S.seg_cid;
       ++turn;
       return SDM_OK;
     };
@@ -3045,6 +3061,7 @@ static int collision_step(sdm_ctx *ctx, const sdm_step_cfg *cfg, sdm_step_state 
     A.dt_left = st->dt_left;
     A.seg_deaths = nullptr;
     A.seg_owned = nullptr;
+    A.seg_cid = nullptr;
     if (left_cur != 0)  // the step's last dt_left stands in the scratch half of the ping-pong
       HIP_TRY(hipMemcpyAsync(st->dt_left, left_buf[1], sizeof(double) * (size_t)C,
                              hipMemcpyDeviceToDevice, s));
