@@ -163,15 +163,26 @@ __device__ __forceinline__ void note_dt_min(int64_t *ctl, double stats_value, do
 
 // last act of a one-thread epilogue: control block -> host-visible box, then the sequence number
 // (work: what the host is to see as working length, word 1)
+// Every word carries the low 24 bits of the sequence number above its value (40 bits: lengths,
+// flags, counts): the host accepts a block only when all eight words carry the tag it waits for.
+// The nine stores travel to host memory one by one, and nothing makes them ARRIVE in order (found
+// by tests/fuzz_sharded_flow.py with two processes on one card: the sequence word of a publication
+// was seen before its data words, the host acted on the block of two publications before - a death
+// went unnoticed and the step ended with a flagged super-droplet in the permutation)
+#define SDM_BOX_TAG_SHIFT 40
+#define SDM_BOX_VALUE_MASK ((1ull << SDM_BOX_TAG_SHIFT) - 1)
+#define SDM_BOX_TAG_MASK 0xFFFFFFull
 __device__ __forceinline__ void publish_ctl(const int64_t *ctl, int64_t *box, int64_t seq,
                                             int64_t work) {
   if (!box) return;
   box += (seq & 1) * SDM_BOX_STRIDE;
-  for (int w = 0; w < 8; ++w)
-    __hip_atomic_store(&box[w],
-                       w == 1 ? work
-                              : __hip_atomic_load(&ctl[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+  const uint64_t tag = ((uint64_t)seq & SDM_BOX_TAG_MASK) << SDM_BOX_TAG_SHIFT;
+  for (int w = 0; w < 8; ++w) {
+    const int64_t v = w == 1 ? work
+                             : __hip_atomic_load(&ctl[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&box[w], (int64_t)(tag | ((uint64_t)v & SDM_BOX_VALUE_MASK)),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   __hip_atomic_store(&box[8], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 #endif

@@ -29,6 +29,10 @@ static int ctx_allocate(sdm_ctx *ctx) {
   if (const char *fmt = getenv("SDM_REC_FORMAT")) ctx->opt_records = !strcmp(fmt, "records");
   ctx->opt_no_presort = getenv("SDM_NO_PRESORT") != nullptr;
   if (const char *copy = getenv("SDM_CELL_COPY")) ctx->opt_no_cell_copy = copy[0] == '0';
+  if (const char *shape = getenv("SDM_CELL_SHAPE")) {
+    const int v = atoi(shape);
+    if (v >= SDM_CELL_SHAPE_AUTO && v <= SDM_CELL_SHAPE_256) ctx->opt_cell_shape = v;
+  }
   HIP_TRY(hipHostGetDevicePointer((void **)&ctx->box_dev, ctx->mailbox + SDM_BOX, 0));
   HIP_TRY(hipMalloc((void **)&ctx->dscal, sizeof(int64_t) * 16));
   HIP_TRY(hipMemset(ctx->dscal, 0, sizeof(int64_t) * 16));
@@ -82,8 +86,23 @@ int sdm_read_box(sdm_ctx *ctx, int64_t seq, int64_t out[8]) {
   const int rc = sdm_wait_box(ctx, seq);
   if (rc) return rc;
   const int64_t *slot = ctx->mailbox + SDM_BOX + (seq & 1) * SDM_BOX_STRIDE;
-  for (int w = 0; w < 8; ++w) out[w] = __atomic_load_n(slot + w, __ATOMIC_RELAXED);
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  // the data words may arrive after the sequence word (common.h: publish_ctl): every word must
+  // carry this publication's tag
+  const uint64_t tag = (uint64_t)seq & SDM_BOX_TAG_MASK;
+  for (uint64_t spins = 1;; ++spins) {
+    bool whole = true;
+    for (int w = 0; w < 8; ++w) {
+      const uint64_t x = (uint64_t)__atomic_load_n(slot + w, __ATOMIC_ACQUIRE);
+      whole = whole && (x >> SDM_BOX_TAG_SHIFT) == tag;
+      out[w] = (int64_t)(x & SDM_BOX_VALUE_MASK);
+    }
+    if (whole) break;
+    if (spins > (1ull << 28)) {  // (seconds: the words of a publication are microseconds apart)
+      sdm_set_error("control block %lld: its words never became whole", (long long)seq);
+      return SDM_E_HIP;
+    }
+    __builtin_ia32_pause();
+  }
   if (__atomic_load_n(slot + 8, __ATOMIC_ACQUIRE) != seq) {
     sdm_set_error("control block %lld was overwritten while it was read", (long long)seq);
     return SDM_E_HIP;
